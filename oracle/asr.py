@@ -1,0 +1,556 @@
+"""Functional CPU restatement of the reference's ASR hot path (oracle; test-only).
+
+Everything here is plain PyTorch on CPU tensors, written as pure functions of
+``(state_dict, config, inputs)``.  The state-dict keys are the reference's
+(SURVEY.md section 8b), so a reference checkpoint drives the oracle directly.
+Autograd supplies gradients: callers set ``requires_grad`` on the entries of
+``sd`` they need and call ``.backward()`` on the returned loss.
+
+Reference files restated here (``/root/reference/openeat/...``):
+  models/asr_model.py, modules/{encoder,encoder_layer,attention,convolution,
+  subsampling,embedding,positionwise_feed_forward,swish,cmvn,ctc,
+  label_smoothing_loss,decoder,decoder_layer}.py, utils/{mask,common}.py
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field, asdict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+IGNORE_ID = -1  # utils/common.py:24
+
+
+# --------------------------------------------------------------------------- #
+# configuration (= ASRModel ctor kwargs, models/asr_model.py:37-70)
+# --------------------------------------------------------------------------- #
+@dataclass
+class Config:
+    input_size: int = 80
+    vocab_size: int = 50
+    encoder_num_blocks: int = 12
+    encoder_num_blocks_share: int = 1
+    decoder_num_blocks: int = 6
+    r_decoder_num_blocks: int = 0
+    decoder_num_blocks_share: int = 1
+    input_layer: str = "conv2d"
+    pos_enc_layer_type: str = "rel_pos"
+    d_model: int = 256
+    attention_heads: int = 4
+    linear_units: int = 1024
+    dropout_rate: float = 0.1
+    activation_type: str = "swish"
+    macaron_style: bool = True
+    use_cnn_module: bool = True
+    cnn_module_kernel: int = 15
+    causal: bool = False
+    ctc_weight: float = 0.3
+    lsm_weight: float = 0.1
+    reverse_weight: float = 0.0
+    length_normalized_loss: bool = False
+    ignore_id: int = IGNORE_ID
+    has_cmvn: bool = False
+
+    @property
+    def sos(self) -> int:  # asr_model.py:74
+        return self.vocab_size - 1
+
+    @property
+    def eos(self) -> int:  # asr_model.py:75
+        return self.vocab_size - 1
+
+    def model_kwargs(self) -> dict:
+        d = asdict(self)
+        d.pop("has_cmvn")
+        return d
+
+
+# --------------------------------------------------------------------------- #
+# small helpers (utils/mask.py, utils/common.py)
+# --------------------------------------------------------------------------- #
+def pad_mask(lengths: Tensor, max_len: int = 0) -> Tensor:
+    """True on padded positions.  utils/mask.py:43-69."""
+    n = int(max_len) if max_len > 0 else int(lengths.max())
+    return torch.arange(n, device=lengths.device)[None, :] >= lengths[:, None].long()
+
+
+def causal_mask(n: int) -> Tensor:
+    """Lower-triangular bool (n, n).  utils/mask.py:9-39."""
+    return torch.ones(n, n, dtype=torch.bool).tril()
+
+
+def with_sos_eos(ys_pad: Tensor, sos: int, eos: int, ignore_id: int) -> Tuple[Tensor, Tensor]:
+    """utils/common.py:89-132: ys_in = [sos, y...] padded with eos,
+    ys_out = [y..., eos] padded with ignore_id; both int64 (B, Lmax+1)."""
+    B, L = ys_pad.shape
+    keep = ys_pad != ignore_id
+    lens = keep.sum(1)
+    # the reference drops ignore_id entries wherever they are; targets are
+    # prefix-padded in practice, which is what the compaction below assumes.
+    ys_in = torch.full((B, int(lens.max()) + 1), eos, dtype=torch.long)
+    ys_out = torch.full((B, int(lens.max()) + 1), ignore_id, dtype=torch.long)
+    for b in range(B):
+        y = ys_pad[b][keep[b]].long()
+        n = y.numel()
+        ys_in[b, 0] = sos
+        ys_in[b, 1:n + 1] = y
+        ys_out[b, :n] = y
+        ys_out[b, n] = eos
+    return ys_in, ys_out
+
+
+def reversed_targets(ys_pad: Tensor, ys_lens: Tensor, pad_value: int) -> Tensor:
+    """utils/common.py:61-86: reverse the first len tokens of each row."""
+    B = ys_pad.shape[0]
+    Lm = int(ys_lens.max()) if B > 0 else 0
+    out = torch.full((B, Lm), pad_value, dtype=torch.int32)
+    for b in range(B):
+        n = int(ys_lens[b])
+        out[b, :n] = torch.flip(ys_pad[b, :n].int(), [0])
+    return out
+
+
+def token_accuracy(logits: Tensor, targets: Tensor, ignore_label: int) -> Tensor:
+    """utils/common.py:135-157."""
+    pred = logits.view(targets.size(0), targets.size(1), -1).argmax(-1)
+    m = targets != ignore_label
+    return torch.true_divide((pred[m] == targets[m]).sum(), m.sum())
+
+
+def collapse_ctc_path(path: List[int]) -> List[int]:
+    """utils/common.py:187-196: merge repeats, then drop blanks (id 0)."""
+    out: List[int] = []
+    prev = None
+    for tok in path:
+        if tok != prev and tok != 0:
+            out.append(tok)
+        prev = tok
+    return out
+
+
+def log_sum_exp(vals: List[float]) -> float:
+    """utils/common.py:198-206 (python floats)."""
+    if all(v == -float("inf") for v in vals):
+        return -float("inf")
+    m = max(vals)
+    return m + math.log(sum(math.exp(v - m) for v in vals))
+
+
+def _act(name: str):
+    """utils/common.py:160-173."""
+    if name == "swish":
+        return lambda x: x * torch.sigmoid(x)  # modules/swish.py:15-17
+    if name == "relu":
+        return F.relu
+    if name == "gelu":
+        return F.gelu
+    if name == "tanh":
+        return torch.tanh
+    if name == "selu":
+        return F.selu
+    if name == "hardtanh":
+        return F.hardtanh
+    raise KeyError(name)
+
+
+def _drop(x: Tensor, p: float, training: bool) -> Tensor:
+    return F.dropout(x, p, training) if (training and p > 0) else x
+
+
+def _ln(x: Tensor, sd: Dict[str, Tensor], pfx: str, eps: float) -> Tensor:
+    return F.layer_norm(x, (x.shape[-1],), sd[pfx + ".weight"], sd[pfx + ".bias"], eps)
+
+
+def _lin(x: Tensor, sd: Dict[str, Tensor], pfx: str) -> Tensor:
+    return F.linear(x, sd[pfx + ".weight"], sd.get(pfx + ".bias"))
+
+
+# --------------------------------------------------------------------------- #
+# positional table (modules/embedding.py:26-42)
+# --------------------------------------------------------------------------- #
+_PE_CACHE: Dict[Tuple[int, int], Tensor] = {}
+
+
+def sinusoid_table(d_model: int, max_len: int = 5000) -> Tensor:
+    key = (d_model, max_len)
+    if key not in _PE_CACHE:
+        pos = torch.arange(0, max_len, dtype=torch.float32).unsqueeze(1)
+        div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float32)
+                        * -(math.log(10000.0) / d_model))
+        pe = torch.zeros(max_len, d_model)
+        pe[:, 0::2] = torch.sin(pos * div)
+        pe[:, 1::2] = torch.cos(pos * div)
+        _PE_CACHE[key] = pe.unsqueeze(0)
+    return _PE_CACHE[key]
+
+
+# --------------------------------------------------------------------------- #
+# encoder pieces
+# --------------------------------------------------------------------------- #
+def subsample4(sd, cfg: Config, x: Tensor, mask: Tensor):
+    """modules/subsampling.py:65-116 (Conv2dSubsampling4) + embedding.py."""
+    p = "encoder.embed."
+    y = x.unsqueeze(1)
+    y = F.relu(F.conv2d(y, sd[p + "conv.0.weight"], sd[p + "conv.0.bias"], stride=2))
+    y = F.relu(F.conv2d(y, sd[p + "conv.2.weight"], sd[p + "conv.2.bias"], stride=2))
+    b, c, t, f = y.shape
+    y = _lin(y.transpose(1, 2).contiguous().view(b, t, c * f), sd, p + "out.0")
+    y, pos = position_encode(cfg, y)
+    return y, mask[:, :, :-2:2][:, :, :-2:2], pos
+
+
+def position_encode(cfg_or_kind, y: Tensor, d_model: Optional[int] = None):
+    """modules/embedding.py:44-60 (abs) / :75-88 (rel)."""
+    kind = cfg_or_kind if isinstance(cfg_or_kind, str) else cfg_or_kind.pos_enc_layer_type
+    d = y.shape[-1] if d_model is None else d_model
+    assert y.size(1) < 5000
+    pos = sinusoid_table(d)[:, : y.size(1)]
+    if kind == "abs_pos":
+        return y * math.sqrt(d) + pos, pos
+    if kind == "rel_pos":
+        return y * math.sqrt(d), pos
+    raise ValueError(kind)
+
+
+def feed_forward(sd, pfx: str, x: Tensor, act, p_drop: float, training: bool) -> Tensor:
+    """modules/positionwise_feed_forward.py:36-43."""
+    return _lin(_drop(act(_lin(x, sd, pfx + ".w_1")), p_drop, training), sd, pfx + ".w_2")
+
+
+def _split_heads(x: Tensor, h: int) -> Tensor:
+    b, t, d = x.shape
+    return x.view(b, t, h, d // h).transpose(1, 2)
+
+
+def _attend(sd, pfx: str, v: Tensor, scores: Tensor, mask: Optional[Tensor],
+            p_drop: float, training: bool) -> Tensor:
+    """modules/attention.py:65-97."""
+    if mask is not None:
+        m = mask.unsqueeze(1).eq(0)
+        scores = scores.masked_fill(m, -float("inf"))
+        attn = torch.softmax(scores, dim=-1).masked_fill(m, 0.0)
+    else:
+        attn = torch.softmax(scores, dim=-1)
+    attn = _drop(attn, p_drop, training)
+    ctx = torch.matmul(attn, v)
+    b, h, t, dk = ctx.shape
+    return _lin(ctx.transpose(1, 2).contiguous().view(b, t, h * dk), sd, pfx + ".linear_out")
+
+
+def mha(sd, pfx: str, h: int, q_in: Tensor, k_in: Tensor, v_in: Tensor,
+        mask: Optional[Tensor], p_drop: float = 0.0, training: bool = False) -> Tensor:
+    """modules/attention.py:99-117 (MultiHeadedAttention.forward)."""
+    q = _split_heads(_lin(q_in, sd, pfx + ".linear_q"), h)
+    k = _split_heads(_lin(k_in, sd, pfx + ".linear_k"), h)
+    v = _split_heads(_lin(v_in, sd, pfx + ".linear_v"), h)
+    scores = torch.matmul(q, k.transpose(-2, -1)) / math.sqrt(q.shape[-1])
+    return _attend(sd, pfx, v, scores, mask, p_drop, training)
+
+
+def relpos_mha(sd, pfx: str, h: int, x: Tensor, mask: Optional[Tensor], pos_emb: Tensor,
+               p_drop: float = 0.0, training: bool = False) -> Tensor:
+    """modules/attention.py:166-209; rel_shift is disabled there (:202-204)."""
+    q = _split_heads(_lin(x, sd, pfx + ".linear_q"), h)
+    k = _split_heads(_lin(x, sd, pfx + ".linear_k"), h)
+    v = _split_heads(_lin(x, sd, pfx + ".linear_v"), h)
+    p = _split_heads(F.linear(pos_emb, sd[pfx + ".linear_pos.weight"]), h)
+    u = sd[pfx + ".pos_bias_u"][None, :, None, :]
+    w = sd[pfx + ".pos_bias_v"][None, :, None, :]
+    ac = torch.matmul(q + u, k.transpose(-2, -1))
+    bd = torch.matmul(q + w, p.transpose(-2, -1))
+    scores = (ac + bd) / math.sqrt(q.shape[-1])
+    return _attend(sd, pfx, v, scores, mask, p_drop, training)
+
+
+def conv_module(sd, pfx: str, cfg: Config, x: Tensor, mask_pad: Tensor, act) -> Tensor:
+    """modules/convolution.py:72-120 (LayerNorm variant, eps 1e-5)."""
+    K = cfg.cnn_module_kernel
+    y = x.transpose(1, 2)
+    if mask_pad.size(2) > 0:
+        y = y.masked_fill(~mask_pad, 0.0)
+    if cfg.causal:
+        y = F.pad(y, (K - 1, 0), "constant", 0.0)
+    y = F.conv1d(y, sd[pfx + ".pointwise_conv1.weight"], sd[pfx + ".pointwise_conv1.bias"])
+    y = F.glu(y, dim=1)
+    y = F.conv1d(y, sd[pfx + ".depthwise_conv.weight"], sd[pfx + ".depthwise_conv.bias"],
+                 padding=0 if cfg.causal else (K - 1) // 2, groups=y.shape[1])
+    y = act(_ln(y.transpose(1, 2), sd, pfx + ".norm", 1e-5)).transpose(1, 2)
+    y = F.conv1d(y, sd[pfx + ".pointwise_conv2.weight"], sd[pfx + ".pointwise_conv2.bias"])
+    if mask_pad.size(2) > 0:
+        y = y.masked_fill(~mask_pad, 0.0)
+    return y.transpose(1, 2)
+
+
+def encoder_layer(sd, pfx: str, cfg: Config, x: Tensor, mask: Tensor, pos_emb: Tensor,
+                  training: bool = False) -> Tensor:
+    """modules/encoder_layer.py:64-112 (adapter branch is off in every config)."""
+    act = _act(cfg.activation_type)
+    pd = cfg.dropout_rate
+    h = cfg.attention_heads
+    ff_scale = 0.5 if cfg.macaron_style else 1.0
+    if cfg.macaron_style:
+        y = feed_forward(sd, pfx + ".feed_forward_macaron", _ln(x, sd, pfx + ".norm_ff_macaron", 1e-12),
+                         act, pd, training)
+        x = x + ff_scale * _drop(y, pd, training)
+    y = _ln(x, sd, pfx + ".norm_mha", 1e-12)
+    if cfg.use_cnn_module:
+        y = relpos_mha(sd, pfx + ".self_attn", h, y, mask, pos_emb, pd, training)
+    else:
+        y = mha(sd, pfx + ".self_attn", h, y, y, y, mask, pd, training)
+    x = x + _drop(y, pd, training)
+    if cfg.use_cnn_module:
+        y = conv_module(sd, pfx + ".conv_module", cfg, _ln(x, sd, pfx + ".norm_conv", 1e-12), mask, act)
+        x = x + _drop(y, pd, training)
+    y = feed_forward(sd, pfx + ".feed_forward", _ln(x, sd, pfx + ".norm_ff", 1e-12), act, pd, training)
+    x = x + ff_scale * _drop(y, pd, training)
+    if cfg.use_cnn_module:
+        x = _ln(x, sd, pfx + ".norm_final", 1e-12)
+    return x
+
+
+def encoder(sd, cfg: Config, feats: Tensor, masks: Tensor, training: bool = False):
+    """modules/encoder.py:208-229 (TransformerEncoder.forward)."""
+    x = feats
+    if cfg.has_cmvn:  # modules/cmvn.py:35-46
+        x = (x - sd["encoder.global_cmvn.mean"]) * sd["encoder.global_cmvn.istd"]
+    assert cfg.input_layer == "conv2d"
+    x, masks, pos = subsample4(sd, cfg, x, masks)
+    n_unique = cfg.encoder_num_blocks // cfg.encoder_num_blocks_share
+    for i in range(n_unique):
+        for _ in range(cfg.encoder_num_blocks_share):
+            x = encoder_layer(sd, f"encoder.encoders.{i}", cfg, x, masks, pos, training)
+    x = _ln(x, sd, "encoder.after_norm", 1e-5)
+    return x, masks, pos
+
+
+# --------------------------------------------------------------------------- #
+# losses
+# --------------------------------------------------------------------------- #
+def ctc_loss(sd, cfg: Config, hs: Tensor, hlens: Tensor, ys_pad: Tensor, ys_lens: Tensor) -> Tensor:
+    """modules/ctc.py:27-45.  aten::_ctc_loss is the arithmetic the reference
+    itself calls; ``oracle/ctc_np.py`` holds an independent alpha/beta
+    restatement that pins it in the tests."""
+    logp = _lin(hs, sd, "ctc.ctc_lo").transpose(0, 1).log_softmax(2)
+    red = "mean" if cfg.length_normalized_loss else "sum"
+    loss = F.ctc_loss(logp, ys_pad, hlens, ys_lens, blank=0, reduction=red, zero_infinity=True)
+    return loss / logp.size(1)
+
+
+def label_smoothing_loss(cfg: Config, x: Tensor, target: Tensor) -> Tensor:
+    """modules/label_smoothing_loss.py:58-91 (keeps the t*log t constant)."""
+    V = cfg.vocab_size
+    B = x.size(0)
+    x = x.reshape(-1, V)
+    target = target.reshape(-1)
+    ignore = target == cfg.ignore_id
+    tgt = target.masked_fill(ignore, 0)
+    true_dist = torch.full_like(x, cfg.lsm_weight / (V - 1))
+    true_dist.scatter_(1, tgt.unsqueeze(1), 1.0 - cfg.lsm_weight)
+    kl = F.kl_div(torch.log_softmax(x, dim=1), true_dist, reduction="none")
+    denom = (target.numel() - int(ignore.sum())) if cfg.length_normalized_loss else B
+    return kl.masked_fill(ignore.unsqueeze(1), 0).sum() / denom
+
+
+# --------------------------------------------------------------------------- #
+# decoder
+# --------------------------------------------------------------------------- #
+def decoder_layer(sd, pfx: str, cfg: Config, tgt: Tensor, tgt_mask: Tensor, memory: Tensor,
+                  memory_mask: Tensor, cache: Optional[Tensor] = None, training: bool = False) -> Tensor:
+    """modules/decoder_layer.py:47-111."""
+    h, pd = cfg.attention_heads, cfg.dropout_rate
+    residual = tgt
+    y = _ln(tgt, sd, pfx + ".norm1", 1e-12)
+    if cache is None:
+        q, q_mask = y, tgt_mask
+    else:
+        assert cache.shape == (y.shape[0], y.shape[1] - 1, y.shape[2])
+        q, residual, q_mask = y[:, -1:, :], residual[:, -1:, :], tgt_mask[:, -1:, :]
+    x = residual + _drop(mha(sd, pfx + ".self_attn", h, q, y, y, q_mask, pd, training), pd, training)
+    y = _ln(x, sd, pfx + ".norm2", 1e-12)
+    x = x + _drop(mha(sd, pfx + ".src_attn", h, y, memory, memory, memory_mask, pd, training), pd, training)
+    y = _ln(x, sd, pfx + ".norm3", 1e-12)
+    x = x + _drop(feed_forward(sd, pfx + ".feed_forward", y, F.relu, pd, training), pd, training)
+    if cache is not None:
+        x = torch.cat([cache, x], dim=1)
+    return x
+
+
+def _embed_tokens(sd, pfx: str, cfg: Config, tokens: Tensor) -> Tensor:
+    """modules/decoder.py:144-147,186: Embedding then abs positional encoding."""
+    e = F.embedding(tokens, sd[pfx + ".embed.0.weight"])
+    y, _ = position_encode("abs_pos", e)
+    return y
+
+
+def _n_dec_layers(cfg: Config, side: str) -> int:
+    n = cfg.decoder_num_blocks if side == "left_decoder" else cfg.r_decoder_num_blocks
+    return n // cfg.decoder_num_blocks_share
+
+
+def transformer_decoder(sd, cfg: Config, side: str, tokens: Tensor, tgt_mask: Tensor,
+                        memory: Tensor, memory_mask: Tensor, training: bool = False):
+    """modules/decoder.py:167-194 -> (logits, pre_logits)."""
+    pfx = f"decoder.{side}"
+    x = _embed_tokens(sd, pfx, cfg, tokens)
+    for i in range(_n_dec_layers(cfg, side)):
+        for _ in range(cfg.decoder_num_blocks_share):
+            x = decoder_layer(sd, f"{pfx}.decoders.{i}", cfg, x, tgt_mask, memory, memory_mask,
+                              training=training)
+    pre = _ln(x, sd, pfx + ".after_norm", 1e-12)
+    return _lin(pre, sd, pfx + ".output_layer"), pre
+
+
+def decoder_one_step(sd, cfg: Config, tokens: Tensor, tgt_mask: Tensor, memory: Tensor,
+                     memory_mask: Tensor, cache: Optional[List[Tensor]] = None):
+    """modules/decoder.py:196-232 (left decoder only, :311-335)."""
+    pfx = "decoder.left_decoder"
+    x = _embed_tokens(sd, pfx, cfg, tokens)
+    new_cache = []
+    share = cfg.decoder_num_blocks_share
+    for i in range(_n_dec_layers(cfg, "left_decoder")):
+        for j in range(share):
+            c = None if cache is None else cache[i * share + j]
+            x = decoder_layer(sd, f"{pfx}.decoders.{i}", cfg, x, tgt_mask, memory, memory_mask, cache=c)
+            new_cache.append(x)
+    pre = _ln(x[:, -1], sd, pfx + ".after_norm", 1e-12)
+    return _lin(pre, sd, pfx + ".output_layer"), new_cache, pre
+
+
+def bi_decoder(sd, cfg: Config, memory, memory_mask, ys_in, r_ys_in, tgt_mask, training=False):
+    """modules/decoder.py:278-309."""
+    l_x, pre = transformer_decoder(sd, cfg, "left_decoder", ys_in, tgt_mask, memory, memory_mask, training)
+    r_x = torch.tensor(0.0)
+    if cfg.r_decoder_num_blocks > 0:
+        r_x, _ = transformer_decoder(sd, cfg, "right_decoder", r_ys_in, tgt_mask, memory, memory_mask, training)
+    return l_x, r_x, pre
+
+
+# --------------------------------------------------------------------------- #
+# model level (models/asr_model.py)
+# --------------------------------------------------------------------------- #
+def attention_loss(sd, cfg: Config, enc_out, enc_mask, ys_pad, ys_lens, training=False):
+    """models/asr_model.py:159-203."""
+    ys_in, ys_out = with_sos_eos(ys_pad, cfg.sos, cfg.eos, cfg.ignore_id)
+    in_lens = ys_lens + 1
+    tgt_mask = (~pad_mask(in_lens, ys_in.size(1))).unsqueeze(1) & causal_mask(ys_in.size(1)).unsqueeze(0)
+    r_in = torch.tensor(0.0)
+    if cfg.reverse_weight > 0:
+        r_pad = reversed_targets(ys_pad, ys_lens, cfg.ignore_id)
+        r_in, r_out = with_sos_eos(r_pad, cfg.sos, cfg.eos, cfg.ignore_id)
+    l_x, r_x, _ = bi_decoder(sd, cfg, enc_out, enc_mask, ys_in, r_in, tgt_mask, training)
+    loss = label_smoothing_loss(cfg, l_x, ys_out)
+    r_loss = torch.tensor(0.0)
+    if cfg.reverse_weight > 0:
+        r_loss = label_smoothing_loss(cfg, r_x, r_out)
+    loss = loss * (1 - cfg.reverse_weight) + r_loss * cfg.reverse_weight
+    acc = token_accuracy(l_x.view(-1, cfg.vocab_size), ys_out, cfg.ignore_id)
+    return loss, acc
+
+
+def forward(sd, cfg: Config, feats, feat_lens, targets, target_lens, training=False):
+    """models/asr_model.py:126-157 -> (loss, acc)."""
+    assert target_lens.dim() == 1
+    assert feats.shape[0] == feat_lens.shape[0] == targets.shape[0] == target_lens.shape[0]
+    masks = (~pad_mask(feat_lens, feats.size(1))).unsqueeze(1)
+    enc, enc_mask, _ = encoder(sd, cfg, feats, masks, training)
+    enc_lens = enc_mask.squeeze(1).sum(1)
+    l_ctc = ctc_loss(sd, cfg, enc, enc_lens, targets, target_lens)
+    if cfg.ctc_weight < 1:
+        l_att, acc = attention_loss(sd, cfg, enc, enc_mask, targets, target_lens, training)
+        return cfg.ctc_weight * l_ctc + (1 - cfg.ctc_weight) * l_att, acc
+    return l_ctc, None
+
+
+def ctc_logits(sd, enc: Tensor) -> Tensor:
+    return _lin(enc, sd, "ctc.ctc_lo")
+
+
+def ctc_greedy_search(sd, cfg: Config, feats, feat_lens) -> List[List[int]]:
+    """models/asr_model.py:297-326: padded frames become eos before collapsing."""
+    masks = (~pad_mask(feat_lens, feats.size(1))).unsqueeze(1)
+    enc, enc_mask, _ = encoder(sd, cfg, feats, masks)
+    lens = enc_mask.squeeze(1).sum(1)
+    logp = F.log_softmax(ctc_logits(sd, enc), dim=-1)
+    best = logp.topk(1, dim=2)[1].view(enc.size(0), enc.size(1))
+    best = best.masked_fill(pad_mask(lens, enc.size(1)), cfg.eos)
+    return [collapse_ctc_path(row.tolist()) for row in best]
+
+
+def prefix_beam_from_logp(logp: Tensor, beam: int):
+    """models/asr_model.py:359-396 on a (T, V) log-prob matrix."""
+    NEG = -float("inf")
+    hyps = [(tuple(), (0.0, NEG))]
+    for t in range(logp.size(0)):
+        row = logp[t]
+        nxt: Dict[tuple, Tuple[float, float]] = {}
+        _, top = row.topk(beam)
+        for s in top.tolist():
+            ps = row[s].item()
+            for prefix, (pb, pnb) in hyps:
+                last = prefix[-1] if prefix else None
+                if s == 0:
+                    b0, n0 = nxt.get(prefix, (NEG, NEG))
+                    nxt[prefix] = (log_sum_exp([b0, pb + ps, pnb + ps]), n0)
+                elif s == last:
+                    b0, n0 = nxt.get(prefix, (NEG, NEG))
+                    nxt[prefix] = (b0, log_sum_exp([n0, pnb + ps]))
+                    ext = prefix + (s,)
+                    b1, n1 = nxt.get(ext, (NEG, NEG))
+                    nxt[ext] = (b1, log_sum_exp([n1, pb + ps]))
+                else:
+                    ext = prefix + (s,)
+                    b1, n1 = nxt.get(ext, (NEG, NEG))
+                    nxt[ext] = (b1, log_sum_exp([n1, pb + ps, pnb + ps]))
+        ranked = sorted(nxt.items(), key=lambda kv: log_sum_exp(list(kv[1])), reverse=True)
+        hyps = ranked[:beam]
+    return [(p, log_sum_exp([pb, pnb])) for p, (pb, pnb) in hyps]
+
+
+def ctc_prefix_beam_search(sd, cfg: Config, feats, feat_lens, beam: int):
+    """models/asr_model.py:328-396 (batch of one)."""
+    assert feats.shape[0] == 1
+    masks = (~pad_mask(feat_lens, feats.size(1))).unsqueeze(1)
+    enc, _, _ = encoder(sd, cfg, feats, masks)
+    logp = F.log_softmax(ctc_logits(sd, enc), dim=-1).squeeze(0)
+    return prefix_beam_from_logp(logp, beam), enc
+
+
+def attention_rescoring(sd, cfg: Config, feats, feat_lens, beam: int, ctc_weight: float = 0.0,
+                        reverse_weight: float = 0.0):
+    """models/asr_model.py:418-534 without the optional LM term."""
+    hyps, enc = ctc_prefix_beam_search(sd, cfg, feats, feat_lens, beam)
+    assert len(hyps) == beam
+    lens = torch.tensor([len(h[0]) for h in hyps], dtype=torch.long)
+    Lm = int(lens.max())
+    pad = torch.full((beam, Lm), cfg.ignore_id, dtype=torch.long)
+    for i, h in enumerate(hyps):
+        pad[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long)
+    ys_in, _ = with_sos_eos(pad, cfg.sos, cfg.eos, cfg.ignore_id)
+    in_lens = lens + 1
+    tgt_mask = (~pad_mask(in_lens, ys_in.size(1))).unsqueeze(1) & causal_mask(ys_in.size(1)).unsqueeze(0)
+    mem = enc.repeat(beam, 1, 1)
+    mem_mask = torch.ones(beam, 1, mem.size(1), dtype=torch.bool)
+    # NB the reference reverses with hyps_lens + 1 (asr_model.py:474); slices
+    # past the row end are clamped by python slicing, so pad (-1) entries may
+    # enter the reversed row - reproduced here via the same slicing.
+    r_rows = [torch.flip(pad[i, : int(in_lens[i])].int(), [0]) for i in range(beam)]
+    r_pad = torch.nn.utils.rnn.pad_sequence(r_rows, True, cfg.ignore_id)
+    r_in, _ = with_sos_eos(r_pad, cfg.sos, cfg.eos, cfg.ignore_id)
+    l_x, r_x, pre = bi_decoder(sd, cfg, mem, mem_mask, ys_in, r_in, tgt_mask)
+    l_lp = F.log_softmax(l_x, dim=-1)
+    r_lp = F.log_softmax(r_x, dim=-1) if cfg.r_decoder_num_blocks > 0 else None
+    best, best_i, scores = -float("inf"), 0, []
+    for i, (hyp, ctc_score) in enumerate(hyps):
+        s = sum(l_lp[i, j, w].item() for j, w in enumerate(hyp)) + l_lp[i, len(hyp), cfg.eos].item()
+        if reverse_weight > 0:
+            r = sum(r_lp[i, len(hyp) - j - 1, w].item() for j, w in enumerate(hyp))
+            r += r_lp[i, len(hyp), cfg.eos].item()
+            s = s * (1 - reverse_weight) + r * reverse_weight
+        s += ctc_score * ctc_weight
+        scores.append(s)
+        if s > best:
+            best, best_i = s, i
+    return hyps[best_i][0], scores, hyps
