@@ -1,0 +1,20 @@
+#!/bin/bash
+# Build libopeneat_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../lib
+mkdir -p "$OUT" obj
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -ffp-contract=fast"
+pids=()
+for f in *.hip; do
+  o=obj/${f%.hip}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ oe_common.h -nt "$o" ] || [ ../../include/openeat_hip.h -nt "$o" ]; then
+    echo "hipcc $f"
+    $HIPCC $FLAGS -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libopeneat_hip.so" obj/*.o
+echo "built $OUT/libopeneat_hip.so"

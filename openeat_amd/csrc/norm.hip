@@ -1,0 +1,187 @@
+// LayerNorm forward / backward (wave per row) and column sums.
+// HBM-bound: forward reads x once and writes y once (2*rows*d*4 bytes);
+// backward reads dy and x, writes dx (3*rows*d*4 bytes).
+#include "oe_common.h"
+#include "../../include/openeat_hip.h"
+
+#define LN_MAXV 8   // float4 per lane -> d <= 2048
+
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int rows, int d,
+                                                             const unsigned char* __restrict__ rowmask,
+                                                             float* __restrict__ y, float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = d >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+    float4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) { v[j] = xr[i]; s += v[j].x + v[j].y + v[j].z + v[j].w; }
+    }
+    const float mean = wave_sum(s) / d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+            float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+            q += a * a + b * b + c * c + e * e;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / d + eps);
+    if (stats && lane == 0) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    const bool dead = rowmask && !rowmask[row];
+    float4* yr = reinterpret_cast<float4*>(y + row * d);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!dead) {
+                const float4 g = g4[i], bb = b4[i];
+                o.x = (v[j].x - mean) * rstd * g.x + bb.x;
+                o.y = (v[j].y - mean) * rstd * g.y + bb.y;
+                o.z = (v[j].z - mean) * rstd * g.z + bb.z;
+                o.w = (v[j].w - mean) * rstd * g.w + bb.w;
+            }
+            yr[i] = o;
+        }
+    }
+}
+
+#define LNB_ROWS 32   // rows per block in backward (8 per wave)
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                             int rows, int d, const unsigned char* __restrict__ rowmask,
+                                                             float* __restrict__ dx, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][d]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nv = d >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    float4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = lane + 64 * j;
+        gam[j] = (i < nv) ? g4[i] : make_float4(0, 0, 0, 0);
+        dg[j] = make_float4(0, 0, 0, 0);
+        db[j] = make_float4(0, 0, 0, 0);
+    }
+    const long r0 = (long)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
+    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
+        const long row = r0 + rr;
+        if (row >= rows) break;
+        float4* dxr = reinterpret_cast<float4*>(dx + row * d);
+        if (rowmask && !rowmask[row]) {
+#pragma unroll
+            for (int j = 0; j < LN_MAXV; ++j) { const int i = lane + 64 * j; if (i < nv) dxr[i] = make_float4(0, 0, 0, 0); }
+            continue;
+        }
+        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+        const float4* dyr = reinterpret_cast<const float4*>(dy + row * d);
+        const float4* xr = reinterpret_cast<const float4*>(x + row * d);
+        float4 g[LN_MAXV], xh[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                const float4 dyv = dyr[i], xv = xr[i];
+                xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                g[j] = make_float4(dyv.x * gam[j].x, dyv.y * gam[j].y, dyv.z * gam[j].z, dyv.w * gam[j].w);
+                s1 += g[j].x + g[j].y + g[j].z + g[j].w;
+                s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
+                dg[j].x += dyv.x * xh[j].x; dg[j].y += dyv.y * xh[j].y; dg[j].z += dyv.z * xh[j].z; dg[j].w += dyv.w * xh[j].w;
+                db[j].x += dyv.x; db[j].y += dyv.y; db[j].z += dyv.z; db[j].w += dyv.w;
+            }
+        }
+        const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+        for (int j = 0; j < LN_MAXV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                float4 o;
+                o.x = rstd * (g[j].x - c1 - xh[j].x * c2);
+                o.y = rstd * (g[j].y - c1 - xh[j].y * c2);
+                o.z = rstd * (g[j].z - c1 - xh[j].z * c2);
+                o.w = rstd * (g[j].w - c1 - xh[j].w * c2);
+                dxr[i] = o;
+            }
+        }
+    }
+    // cross-wave reduction of the parameter gradients, then one atomic per column per block
+    float4* shg = reinterpret_cast<float4*>(sh) + wave * 2 * nv;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) { shg[i] = dg[j]; shg[nv + i] = db[j]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * d; c += 256) {
+        const float v = sh[c] + sh[2 * d + c] + sh[4 * d + c] + sh[6 * d + c];
+        if (c < d) atomicAdd(dgamma + c, v); else atomicAdd(dbeta + (c - d), v);
+    }
+}
+
+extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
+                                const unsigned char* rowmask, float* y, float* stats, void* stream) {
+    OE_REQUIRE(x && gamma && beta && y, "oe_layernorm_fwd: null pointer");
+    OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
+                       rows, d, rowmask, y, stats);
+    OE_LAUNCH_CHECK("layernorm_fwd");
+    return 0;
+}
+
+extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int d,
+                                const unsigned char* rowmask, float* dx, float* dgamma, float* dbeta, void* stream) {
+    OE_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta, "oe_layernorm_bwd: null pointer");
+    OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(oe_cdiv(rows, LNB_ROWS)), dim3(256), (size_t)8 * d * sizeof(float),
+                       (hipStream_t)stream, dy, x, gamma, stats, rows, d, rowmask, dx, dgamma, dbeta);
+    OE_LAUNCH_CHECK("layernorm_bwd");
+    return 0;
+}
+
+// ---- column sums (bias gradients) -------------------------------------------
+#define CS_ROWS 256
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, int m, int n, float alpha,
+                                                      const float* __restrict__ alpha_dev, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cx;
+    const long r0 = (long)blockIdx.y * CS_ROWS;
+    float s = 0.f;
+    if (col < n) {
+        const long r1 = min((long)m, r0 + CS_ROWS);
+        for (long r = r0 + ry; r < r1; r += 4) s += x[r * ldx + col];
+    }
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && col < n) {
+        float a = alpha;
+        if (alpha_dev) a *= *alpha_dev;
+        atomicAdd(out + col, (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) * a);
+    }
+}
+
+extern "C" int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const float* alpha_dev, float* out,
+                             int accumulate, void* stream) {
+    OE_REQUIRE(x && out && m > 0 && n > 0 && ldx >= n, "oe_colsum_f32: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st);
+        if (e != hipSuccess) { oe_set_error("oe_colsum_f32: memset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
+    hipLaunchKernelGGL(colsum_kernel, dim3(oe_cdiv(n, 64), oe_cdiv(m, CS_ROWS)), dim3(256), 0, st, x, ldx, m, n, alpha,
+                       alpha_dev, out);
+    OE_LAUNCH_CHECK("colsum");
+    return 0;
+}

@@ -1,0 +1,102 @@
+// Shared device/host helpers for the gfx950 kernels (internal; the public
+// C ABI is include/openeat_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <math.h>
+
+#define OE_WAVE 64
+
+// ---- error plumbing -------------------------------------------------------
+extern "C" void oe_set_error(const char* fmt, ...);
+
+#define OE_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            oe_set_error(__VA_ARGS__);                          \
+            return -1;                                          \
+        }                                                       \
+    } while (0)
+
+#define OE_LAUNCH_CHECK(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            oe_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));      \
+            return (int)e_;                                                          \
+        }                                                                            \
+    } while (0)
+
+static inline int oe_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave-level reductions (64 lanes) --------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// (max, sum-of-exp) pair merge for online log-sum-exp
+__device__ __forceinline__ void lse_merge(float& m, float& s, float m2, float s2) {
+    float mn = fmaxf(m, m2);
+    if (mn == -INFINITY) { s = 0.f; m = mn; return; }
+    s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+    m = mn;
+}
+__device__ __forceinline__ void wave_lse(float& m, float& s) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        float m2 = __shfl_xor(m, o, 64);
+        float s2 = __shfl_xor(s, o, 64);
+        lse_merge(m, s, m2, s2);
+    }
+}
+
+// ---- counter-based RNG for dropout (Philox-4x32-10) -------------------------
+// One call yields 4 uniform 32-bit words for (seed, counter); masks are
+// regenerated in backward from the same (seed, element index), never stored.
+__device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+// keep-mask scale for element `idx` (idx = flat element index of the tensor the
+// dropout is applied to): returns 0 or 1/(1-p).
+__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
+    uint4 r = philox4(seed, idx >> 2);
+    uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
+    // uniform in [0,1): keep iff u >= p
+    float u = (float)(w >> 8) * (1.0f / 16777216.0f);
+    return u >= p ? inv_keep : 0.f;
+}
+
+// ---- activations ------------------------------------------------------------
+enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2 };
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float act_fwd(int act, float x) {
+    if (act == OE_ACT_RELU) return fmaxf(x, 0.f);
+    if (act == OE_ACT_SWISH) return x * sigmoidf_(x);
+    return x;
+}
+__device__ __forceinline__ float act_bwd(int act, float x) {  // d act / dx at pre-activation x
+    if (act == OE_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+    if (act == OE_ACT_SWISH) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+    return 1.f;
+}

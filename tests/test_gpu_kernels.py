@@ -1,0 +1,271 @@
+"""GPU: each HIP kernel, called through the C ABI, against the CPU oracle /
+a plain fp32 torch restatement of the same op on the same seeded inputs.
+
+Tolerances (fp32 kernels; the MFMA GEMM is exact-fp32 products with a
+different summation order than aten): rtol 1e-4 / atol scaled to the data.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from openeat_amd import hip  # noqa: E402
+from oracle import ctc_np  # noqa: E402
+
+DEV = "cuda"
+
+
+def cu(t):
+    return t.to(DEV).contiguous()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ GEMM -----
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 70), (1000, 256, 1024), (77, 3246, 256), (4096, 1024, 256)])
+def test_gemm_nt_bias(M, N, K):
+    torch.manual_seed(0)
+    x, w, b = torch.randn(M, K), torch.randn(N, K), torch.randn(N)
+    ref = x.double() @ w.double().T + b.double()
+    xd, wd, bd = cu(x), cu(w), cu(b)
+    out = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(xd, wd, out, M, N, K, lda=K, ldb=K, ldc=N, bias=bd)
+    sync()
+    torch.testing.assert_close(out.cpu().double(), ref, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+
+
+def test_gemm_padded_ld_and_unaligned_k():
+    """ldc with padding columns (V=3246 stored with ld 3248) and K not a multiple of 4/16."""
+    torch.manual_seed(1)
+    M, N, K, ldc = 130, 3246, 50, 3248
+    x, w = torch.randn(M, K), torch.randn(N, K)
+    out = torch.zeros(M, ldc, device=DEV)
+    hip.gemm(cu(x), cu(w), out, M, N, K, lda=K, ldb=K, ldc=ldc)
+    sync()
+    torch.testing.assert_close(out[:, :N].cpu(), x @ w.T, rtol=1e-4, atol=1e-3)
+    assert torch.all(out[:, N:] == 0)
+    # dgrad through the padded tensor: dx[M,K] = dy[M,N(ld 3248)] @ w[N,K]
+    dy = torch.zeros(M, ldc)
+    dy[:, :N] = torch.randn(M, N)
+    dx = torch.empty(M, K, device=DEV)
+    hip.gemm(cu(dy), cu(w), dx, M, K, N, lda=ldc, ldb=K, ldc=K, b_kmajor=True)
+    sync()
+    torch.testing.assert_close(dx.cpu(), dy[:, :N] @ w, rtol=1e-4, atol=1e-2)
+
+
+def test_gemm_nn_and_tn_splitk():
+    torch.manual_seed(2)
+    M, N, K = 900, 256, 1024     # y = x W^T ; x (M,K), W (N,K)
+    x, w, dy = torch.randn(M, K), torch.randn(N, K), torch.randn(M, N)
+    dx = torch.empty(M, K, device=DEV)
+    hip.gemm(cu(dy), cu(w), dx, M, K, N, lda=N, ldb=K, ldc=K, b_kmajor=True)
+    dw = torch.zeros(N, K, device=DEV)
+    hip.gemm(cu(dy), cu(x), dw, N, K, M, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, split_k=5, atomic_out=True)
+    sync()
+    torch.testing.assert_close(dx.cpu(), dy @ w, rtol=1e-4, atol=2e-3)
+    torch.testing.assert_close(dw.cpu(), dy.T @ x, rtol=1e-4, atol=3e-3)
+    # accumulate into an existing gradient (beta=1 semantics used for shared blocks)
+    dw2 = torch.ones(N, K, device=DEV)
+    hip.gemm(cu(dy), cu(x), dw2, N, K, M, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, accumulate=True)
+    sync()
+    torch.testing.assert_close(dw2.cpu(), dy.T @ x + 1.0, rtol=1e-4, atol=3e-3)
+
+
+@pytest.mark.parametrize("act", ["relu", "swish"])
+def test_gemm_epilogue_activation_residual_rowmask(act):
+    torch.manual_seed(3)
+    M, N, K = 333, 192, 96
+    x, w, b, res = torch.randn(M, K), torch.randn(N, K) * 0.2, torch.randn(N), torch.randn(M, N)
+    rowmask = (torch.rand(M) > 0.3).to(torch.uint8)
+    pre_ref = x @ w.T + b
+    a_ref = F.relu(pre_ref) if act == "relu" else pre_ref * torch.sigmoid(pre_ref)
+    out = torch.empty(M, N, device=DEV)
+    pre = torch.empty(M, N, device=DEV)
+    hip.gemm(cu(x), cu(w), out, M, N, K, lda=K, ldb=K, ldc=N, bias=cu(b), act=hip.ACT[act], preact_out=pre, ld_aux=N,
+             rowmask=cu(rowmask), residual=cu(res), ldr=N, beta=0.5)
+    sync()
+    torch.testing.assert_close(pre.cpu(), pre_ref, rtol=1e-4, atol=1e-4)
+    ref = res + 0.5 * a_ref * rowmask[:, None].float()
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    # act-grad epilogue: dh = (dy @ W2) * act'(pre)
+    dy, w2 = torch.randn(M, K), torch.randn(K, N) * 0.2            # here N plays the hidden dim
+    prer = pre_ref.clone().requires_grad_()
+    (F.relu(prer) if act == "relu" else prer * torch.sigmoid(prer)).backward(dy @ w2)
+    dh = torch.empty(M, N, device=DEV)
+    hip.gemm(cu(dy), cu(w2), dh, M, N, K, lda=K, ldb=N, ldc=N, b_kmajor=True, act=hip.ACT[act], actgrad_in=pre, ld_aux=N)
+    sync()
+    torch.testing.assert_close(dh.cpu(), prer.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_dropout_epilogue_statistics_and_determinism():
+    M, N, K = 512, 256, 32
+    x, w = torch.ones(M, K), torch.ones(N, K) / K
+    a = torch.empty(M, N, device=DEV)
+    b = torch.empty(M, N, device=DEV)
+    hip.gemm(cu(x), cu(w), a, M, N, K, lda=K, ldb=K, ldc=N, drop_p=0.1, seed=1234)
+    hip.gemm(cu(x), cu(w), b, M, N, K, lda=K, ldb=K, ldc=N, drop_p=0.1, seed=1234)
+    c = torch.empty(M, N, device=DEV)
+    hip.gemm(cu(x), cu(w), c, M, N, K, lda=K, ldb=K, ldc=N, drop_p=0.1, seed=99)
+    sync()
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    keep = (a != 0).float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    torch.testing.assert_close(a[a != 0], torch.full_like(a[a != 0], 1 / 0.9), rtol=1e-5, atol=1e-5)
+
+
+def test_gemm_conv2_implicit_forward_and_wgrad():
+    """Conv2d(C,C,3,stride 2) over NHWC as an implicit GEMM (subsampling.py:79)."""
+    torch.manual_seed(4)
+    B, T1, F1, Cc = 3, 21, 11, 32
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    x = torch.randn(B, Cc, T1, F1)
+    w = torch.randn(Cc, Cc, 3, 3) * 0.1
+    bias = torch.randn(Cc)
+    ref = F.conv2d(x, w, bias, stride=2)                                   # (B,C,T2,F2)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()                            # (B,T1,F1,C)
+    w_g = w.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc).contiguous()           # [co][kh][kw][ci]
+    M = B * T2 * F2
+    out = torch.empty(M, Cc, device=DEV)
+    conv = (T1, F1, T2, F2, Cc)
+    hip.gemm(cu(x_nhwc), cu(w_g), out, M, Cc, 9 * Cc, lda=0, ldb=9 * Cc, ldc=Cc, bias=cu(bias), conv=conv,
+             conv_gather=hip.GATHER_A)
+    sync()
+    got = out.cpu().view(B, T2, F2, Cc).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    # wgrad: dW_g[co][k] = sum_m dy[m][co] * col[m][k]
+    dy = torch.randn(B, Cc, T2, F2)
+    xr = x.clone().requires_grad_()
+    wr = w.clone().requires_grad_()
+    F.conv2d(xr, wr, None, stride=2).backward(dy)
+    dy_m = dy.permute(0, 2, 3, 1).reshape(M, Cc).contiguous()
+    dwg = torch.zeros(Cc, 9 * Cc, device=DEV)
+    hip.gemm(cu(dy_m), cu(x_nhwc), dwg, Cc, 9 * Cc, M, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True,
+             split_k=3, atomic_out=True, conv=conv, conv_gather=hip.GATHER_B)
+    sync()
+    got_dw = dwg.cpu().view(Cc, 3, 3, Cc).permute(0, 3, 1, 2)
+    torch.testing.assert_close(got_dw, wr.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_colsum():
+    torch.manual_seed(5)
+    x = torch.randn(1000, 300)
+    out = torch.full((300,), 7.0, device=DEV)
+    hip.check(hip.lib().oe_colsum_f32(hip.ptr(cu(x)), 300, 1000, 300, 0.5, None, hip.ptr(out), 0, hip.stream()), "colsum")
+    sync()
+    torch.testing.assert_close(out.cpu(), 0.5 * x.sum(0), rtol=1e-4, atol=1e-3)
+
+
+# -------------------------------------------------------------- LayerNorm ----
+@pytest.mark.parametrize("rows,d,eps", [(1000, 256, 1e-12), (37, 32, 1e-5), (64, 512, 1e-5)])
+def test_layernorm_fwd_bwd(rows, d, eps):
+    torch.manual_seed(6)
+    x = (torch.randn(rows, d) * 2 + 0.3).requires_grad_()
+    g = (torch.randn(d) * 0.5 + 1).requires_grad_()
+    b = torch.randn(d).requires_grad_()
+    dy = torch.randn(rows, d)
+    mask = (torch.rand(rows) > 0.25).to(torch.uint8)
+    y_ref = F.layer_norm(x, (d,), g, b, eps) * mask[:, None].float()
+    y_ref.backward(dy)
+    xd, gd, bd, dyd, md = cu(x.detach()), cu(g.detach()), cu(b.detach()), cu(dy), cu(mask)
+    y = torch.empty(rows, d, device=DEV)
+    stats = torch.empty(rows, 2, device=DEV)
+    L = hip.lib()
+    hip.check(L.oe_layernorm_fwd(hip.ptr(xd), hip.ptr(gd), hip.ptr(bd), eps, rows, d, hip.ptr(md), hip.ptr(y),
+                                 hip.ptr(stats), hip.stream()), "ln_fwd")
+    dx = torch.empty(rows, d, device=DEV)
+    dg = torch.zeros(d, device=DEV)
+    db = torch.zeros(d, device=DEV)
+    hip.check(L.oe_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(gd), hip.ptr(stats), rows, d, hip.ptr(md),
+                                 hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.stream()), "ln_bwd")
+    sync()
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dg.cpu(), g.grad, rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-3)
+
+
+# -------------------------------------------------------------------- CTC ----
+def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False):
+    B, T, V = logits.shape
+    ldv = ldv or V
+    buf = torch.zeros(B, T, ldv, device=DEV)
+    buf[:, :, :V] = logits.to(DEV)
+    Lmax = ys.shape[1]
+    hl, yl, yd = cu(hlens.int()), cu(ylens.int()), cu(ys.int())
+    L = hip.lib()
+    ws = torch.empty(L.oe_ctc_workspace_floats(B, T, Lmax), device=DEV)
+    nll = torch.empty(B, device=DEV)
+    tot = torch.empty(1, device=DEV)
+    dl = buf if inplace else torch.full((B, T, ldv), float("nan"), device=DEV)
+    hip.check(L.oe_ctc_loss_fused(hip.ptr(buf), ldv, B, T, V, hip.ptr(hl), hip.ptr(yd), Lmax, hip.ptr(yl), scale,
+                                  hip.ptr(nll), hip.ptr(tot), hip.ptr(dl), hip.ptr(ws), hip.stream()), "ctc")
+    sync()
+    return nll.cpu(), tot.cpu(), dl[:, :, :V].cpu()
+
+
+def test_ctc_golden_f07():
+    """The reference's own numbers (fixture F7): infeasible utterance, empty target, repeats."""
+    from conftest import load_golden
+    g = load_golden("f07_ctc")
+    logits, hl, ys, yl = g["out"]["logits"], g["in"]["hlens"], g["in"]["ys"], g["in"]["ylens"]
+    B = logits.shape[0]
+    nll, tot, dl = run_ctc(logits, hl, ys, yl, ldv=20, scale=1.0 / B)
+    torch.testing.assert_close(nll, g["out"]["per_utt"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(tot[0] / B, g["out"]["loss"], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(dl, g["grad"]["logits"], rtol=1e-3, atol=1e-5)
+    assert torch.all(dl[2] == 0) and torch.all(dl[1, 9:] == 0)       # exact zeros, as the reference
+
+
+@pytest.mark.parametrize("B,T,V,Lmax,ldv", [(6, 50, 37, 9, 40), (4, 120, 3246, 40, 3248), (3, 90, 501, 70, 504),
+                                             (2, 300, 100, 140, 100)])
+def test_ctc_vs_oracle(B, T, V, Lmax, ldv):
+    torch.manual_seed(7)
+    logits = torch.randn(B, T, V) * 2
+    hl = torch.randint(T // 2, T + 1, (B,))
+    hl[0] = T
+    yl = torch.randint(1, Lmax + 1, (B,))
+    yl[-1] = Lmax
+    ys = torch.randint(1, V, (B, Lmax))
+    lg = logits.clone().requires_grad_()
+    logp = lg.transpose(0, 1).log_softmax(2)
+    per = F.ctc_loss(logp, ys, hl, yl, reduction="none", zero_infinity=True)
+    per.sum().backward()
+    nll, tot, dl = run_ctc(logits, hl, ys, yl, ldv=ldv, inplace=True)
+    torch.testing.assert_close(nll, per.detach(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(tot[0], per.sum().detach(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dl, lg.grad, rtol=2e-3, atol=2e-5)
+    if B * T * V < 50000:   # third opinion: float64 loop-level alpha/beta
+        n2, g2 = ctc_np.ctc_nll_and_grad(logits.numpy(), hl.numpy(), ys.numpy(), yl.numpy())
+        np.testing.assert_allclose(nll.numpy(), n2, rtol=1e-4, atol=1e-3)
+        np.testing.assert_allclose(dl.numpy(), g2, rtol=2e-3, atol=2e-5)
+
+
+def test_ctc_greedy_matches_topk_and_collapse():
+    from oracle import asr as O
+    torch.manual_seed(8)
+    B, T, V = 5, 61, 50
+    logits = torch.randn(B, T, V)
+    logits[0, 3, 7] = logits[0, 3, 9] = 50.0           # exact tie -> lowest index (topk semantics)
+    logits[:, ::3, 0] += 6.0                             # plenty of blanks
+    logits[:, 1::3, :] = logits[:, 0::3, :][:, :20].clone()   # repeats
+    hl = torch.tensor([61, 40, 61, 7, 1], dtype=torch.int32)
+    eos = V - 1
+    best = F.log_softmax(logits, -1).topk(1, dim=2)[1].view(B, T)
+    best = best.masked_fill(O.pad_mask(hl, T), eos)
+    want = [O.collapse_ctc_path(r.tolist()) for r in best]
+    fb = torch.empty(B, T, dtype=torch.int32, device=DEV)
+    ot = torch.empty(B, T, dtype=torch.int32, device=DEV)
+    ol = torch.empty(B, dtype=torch.int32, device=DEV)
+    hip.check(hip.lib().oe_ctc_greedy(hip.ptr(cu(logits)), V, B, T, V, hip.ptr(cu(hl)), eos, hip.ptr(fb), hip.ptr(ot),
+                                      hip.ptr(ol), hip.stream()), "greedy")
+    sync()
+    got = [ot[b, : int(ol[b])].tolist() for b in range(B)]
+    assert got == want
+    assert int(fb[0, 3]) == 7
