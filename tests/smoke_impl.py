@@ -18,8 +18,9 @@ def run():
     buf = logits.to(dev).contiguous()
     ws = torch.empty(L.oe_ctc_workspace_floats(B, T, Lmax), device=dev)
     nll = torch.empty(B, device=dev)
-    hip.check(L.oe_ctc_loss_fused(hip.ptr(buf), V, B, T, V, hip.ptr(hl.to(dev)), hip.ptr(ys.to(dev)), Lmax,
-                                  hip.ptr(yl.to(dev)), 1.0, hip.ptr(nll), None, None, hip.ptr(ws), hip.stream()), "ctc")
+    hl_d, ys_d, yl_d = hl.to(dev), ys.to(dev), yl.to(dev)
+    hip.check(L.oe_ctc_loss_fused(hip.ptr(buf), V, B, T, V, hip.ptr(hl_d), hip.ptr(ys_d), Lmax,
+                                  hip.ptr(yl_d), 1.0, hip.ptr(nll), None, None, hip.ptr(ws), hip.stream()), "ctc")
     torch.cuda.synchronize()
     torch.testing.assert_close(nll.cpu(), per, rtol=1e-4, atol=1e-3)
     print("smoke OK: ctc nll", nll.cpu().tolist())

@@ -157,7 +157,8 @@ def test_colsum():
     torch.manual_seed(5)
     x = torch.randn(1000, 300)
     out = torch.full((300,), 7.0, device=DEV)
-    hip.check(hip.lib().oe_colsum_f32(hip.ptr(cu(x)), 300, 1000, 300, 0.5, None, hip.ptr(out), 0, hip.stream()), "colsum")
+    xd = cu(x)
+    hip.check(hip.lib().oe_colsum_f32(hip.ptr(xd), 300, 1000, 300, 0.5, None, hip.ptr(out), 0, hip.stream()), "colsum")
     sync()
     torch.testing.assert_close(out.cpu(), 0.5 * x.sum(0), rtol=1e-4, atol=1e-3)
 
@@ -263,7 +264,8 @@ def test_ctc_greedy_matches_topk_and_collapse():
     fb = torch.empty(B, T, dtype=torch.int32, device=DEV)
     ot = torch.empty(B, T, dtype=torch.int32, device=DEV)
     ol = torch.empty(B, dtype=torch.int32, device=DEV)
-    hip.check(hip.lib().oe_ctc_greedy(hip.ptr(cu(logits)), V, B, T, V, hip.ptr(cu(hl)), eos, hip.ptr(fb), hip.ptr(ot),
+    lg_d, hl_d = cu(logits), cu(hl)     # keep the device copies alive until the launch is enqueued
+    hip.check(hip.lib().oe_ctc_greedy(hip.ptr(lg_d), V, B, T, V, hip.ptr(hl_d), eos, hip.ptr(fb), hip.ptr(ot),
                                       hip.ptr(ol), hip.stream()), "greedy")
     sync()
     got = [ot[b, : int(ol[b])].tolist() for b in range(B)]
