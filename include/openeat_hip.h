@@ -42,7 +42,9 @@ int oe_abi_version(void);
  *                      1 = operand stored [k][rows].
  *   epilogue order: v = alpha*acc (+bias[n]) ; preact_out <- v ;
  *     v = actgrad_in ? v*act'(actgrad_in[m,n]) : act(v) ; dropout(drop_p,seed,
- *     index m*n_cols+n) ; rowmask[m]==0 -> 0 ; v = residual[m,n] + beta*v ;
+ *     index m*n_cols+n) ; rowmask[m]==0 -> 0 ; v = beta*v (+ residual[m',n],
+ *     m' = m % res_row_mod when res_row_mod > 0: a (T,d) table broadcast over
+ *     the batch, i.e. x*sqrt(d)+pe of embedding.py:59) ;
  *     C = v | C += v (accumulate) | atomicAdd (atomic_out, required when
  *     split_k > 1; C must hold the running value, e.g. zeros).
  * ------------------------------------------------------------------------- */
@@ -60,7 +62,7 @@ typedef struct oe_gemm_args {
     float* preact_out; const float* actgrad_in; long ld_aux;
     float drop_p; unsigned long long seed;
     const unsigned char* rowmask;
-    const float* residual; long ldr; float beta;
+    const float* residual; long ldr; int res_row_mod; float beta;
     int accumulate; int atomic_out;
     int conv_gather; int conv_t1, conv_f1, conv_t2, conv_f2, conv_c;
 } oe_gemm_args;
@@ -81,10 +83,13 @@ int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const flo
  * ------------------------------------------------------------------------- */
 int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
                      const unsigned char* rowmask, float* y, float* stats, void* stream);
-/* dx written; dgamma/dbeta ACCUMULATED atomically (caller zeroes them).
- * rowmask as in forward (masked rows: dx = 0, no dgamma/dbeta contribution). */
+/* dx = LN'(dy) (+ add, optional: the residual branch's gradient of the
+ * pre-norm blocks, may alias dx); dgamma/dbeta ACCUMULATED atomically (caller
+ * zeroes them).  rowmask as in forward (masked rows: LN'(dy) = 0, no
+ * dgamma/dbeta contribution). */
 int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int d,
-                     const unsigned char* rowmask, float* dx, float* dgamma, float* dbeta, void* stream);
+                     const unsigned char* rowmask, const float* add, float* dx, float* dgamma, float* dbeta,
+                     void* stream);
 
 /* ------------------------------------------------------------------------- *
  * CTC head: log_softmax + CTCLoss(reduction='sum', zero_infinity=True) and
@@ -109,6 +114,125 @@ int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const 
  * padded with -1; out_lens (B). */
 int oe_ctc_greedy(const float* logits, long ldv, int B, int T, int V, const int* hlens, int eos,
                   int* frame_best, int* out_tokens, int* out_lens, void* stream);
+
+/* ------------------------------------------------------------------------- *
+ * Fused multi-head attention (scores -> mask -> softmax -> 0-fill -> dropout
+ * -> .V), forward and backward, for attention.py:65-97,112-117,189-209.
+ *   q (B,T1,H,D), k/v (B,T2,H,D), out (B,T1,H,D): element (b,t,h,d) at
+ *   base + b*bstride + t*rstride + h*D + d (so q/k/v may be slices of one
+ *   fused projection buffer).  D <= 64.
+ *   mask: bytes, (b,i,j) at mask + b*mask_bstride + i*mask_rstride + j;
+ *         mask_rstride = 0 for a (B,1,T2) key mask.  0 = masked out.  Rows
+ *         with no valid key produce zeros (the reference's 0-fill).
+ *   keybias (B,H,T2): added to the scaled score (relative-position term,
+ *         see oe_relpos_prepare); NULL for plain attention.
+ *   scores = scale * q.k + keybias;  lse (B,H,T1) natural-log normaliser.
+ *   dropout acts on the normalised weights, index ((b*H+h)*T1+i)*T2+j.
+ * backward: needs out, lse, d_out; writes dq, dk, dv (same strides as q,k,v),
+ *   dkeybias (B,H,T2) if keybias was given; delta (B,H,T1) is scratch.
+ * ------------------------------------------------------------------------- */
+typedef struct oe_attn_args {
+    const float* q; long q_bstride, q_rstride;
+    const float* k; long k_bstride, k_rstride;
+    const float* v; long v_bstride, v_rstride;
+    float* out; long o_bstride, o_rstride;
+    float* lse;
+    const unsigned char* mask; long mask_bstride, mask_rstride;
+    const float* keybias;
+    int B, H, T1, T2, D;
+    float scale;
+    float drop_p; unsigned long long seed;
+    /* backward only */
+    const float* d_out;
+    float* dq; float* dk; float* dv;
+    float* dkeybias;
+    float* delta;
+} oe_attn_args;
+
+int oe_attention_fwd(const oe_attn_args* args, void* stream);
+int oe_attention_bwd(const oe_attn_args* args, void* stream);
+
+/* Relative-position attention preparation (attention.py:185-200 without
+ * rel_shift):  kp[b,t,h,:] = k[b,t,h,:] + p[t,h,:]  (dense (B,T,H,D)),
+ * keybias[b,h,t] = scale*(u_h . k[b,t,h,:] + v_h . p[t,h,:]).
+ * k: element (b,t,h,d) at k + b*k_bstride + t*k_rstride + h*D + d; p = linear_pos(pos_emb), row stride p_rstride. */
+int oe_relpos_prepare(const float* k, long k_bstride, long k_rstride, const float* p, long p_rstride,
+                      const float* u, const float* v, int B, int T, int H, int D, float scale, float* kp,
+                      float* keybias, void* stream);
+/* backward of the above: dk (k's strides) written, dp (T,H,D; row stride
+ * dp_rstride) written, du/dv (H,D) accumulated atomically. */
+int oe_relpos_backward(const float* dkp, const float* dkeybias, const float* k, long k_bstride, long k_rstride,
+                       const float* p, long p_rstride, const float* u, const float* v, int B, int T, int H, int D,
+                       float scale, float* dk, float* dp, long dp_rstride, float* du, float* dv, void* stream);
+
+/* GLU over channels, a (rows, 2d) -> y (rows, d)  (convolution.py:104). */
+int oe_glu_fwd(const float* a, long rows, int d, float* y, void* stream);
+int oe_glu_bwd(const float* a, const float* dy, long rows, int d, float* da, void* stream);
+
+/* out[i] = alpha * x[i] * dropmask(seed, i)/(1-p); rows (of `cols`) with
+ * rowmask==0 -> 0.  Backward of the dropout/mask epilogues (torch.nn.Dropout in
+ * encoder_layer.py:83,89,95,106 and decoder_layer.py:92,97,106). */
+int oe_dropout_scale(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
+                     const unsigned char* rowmask, float* out, void* stream);
+
+/* Token embedding * sqrt(d) + positional table (decoder.py:144-147 +
+ * embedding.py:59): out[r,:] = table[tok[r],:]*xscale + pe[r % L,:]; backward
+ * accumulates into dtable atomically. tokens int64. */
+int oe_embed_fwd(const long long* tokens, const float* table, const float* pe, long rows, int L, int d, int V,
+                 float xscale, float* out, void* stream);
+int oe_embed_bwd(const long long* tokens, const float* dout, long rows, int d, int V, float xscale, float* dtable,
+                 void* stream);
+
+/* in [A][B][C] -> out [A][C][B] (optionally accumulated): weight layout change
+ * between the checkpoint layout (subsampling.py:79 OIHW, :113 channel-major
+ * flatten) and the NHWC kernels. */
+int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out, int accumulate, void* stream);
+
+/* out = a*x + b*y (y may be NULL). */
+int oe_axpby(const float* x, const float* y, long n, float a, float b, float* out, void* stream);
+
+/* GlobalCMVN (modules/cmvn.py:43-45): y = (x - mean[f]) * istd[f]. */
+int oe_global_cmvn(const float* x, const float* mean, const float* istd, long n, int F, float* y, void* stream);
+
+/* Conv2d(1,C,3,stride 2)+ReLU of the subsampling front (subsampling.py:77-78):
+ * x (B,T,F) -> y (B,T1,F1,C) NHWC, w (C,1,3,3).  wgrad: dy must already be
+ * masked by y>0; dw/db accumulated atomically. */
+int oe_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y, void* stream);
+int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int F, int C, float* dw, float* db, void* stream);
+
+/* Input gradient of Conv2d(C,C,3,stride 2) in gather form, fused with the
+ * ReLU mask of the layer below (autograd of subsampling.py:78-79):
+ * dcol (B*T2*F2, 9C) = dy @ W[co][kh][kw][ci]  ->  dx (B,T1,F1,C) * (y1 > 0). */
+int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, int C, float* dx, void* stream);
+
+/* GLU + depthwise Conv1d(K, groups=d) of the Conformer conv module
+ * (convolution.py:104-107): a (B,T,2d) -> y (B,T,d); w (d,1,K); causal => left
+ * padding K-1 (convolution.py:40-47,92-93).  backward: da (B,T,2d) written,
+ * dw/db accumulated atomically. */
+int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, int B, int T, int d, int K, int causal,
+                      float* y, void* stream);
+int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, int B, int T, int d, int K, int causal,
+                      float* da, float* dw, float* db, void* stream);
+
+/* Label-smoothed KL loss + accuracy + gradient, fused
+ * (label_smoothing_loss.py:58-91, common.py:135-157).  logits (rows, ldv) are
+ * OVERWRITTEN by grad_scale/denom * (softmax - true_dist) when write_grad;
+ * rows with target == ignore_id give 0.  denom = batch_size, or the number of
+ * non-ignored rows when normalize_length.  out3 = {loss, #correct, #valid}.
+ * target int64.  workspace: oe_lsm_workspace_bytes(rows). */
+size_t oe_lsm_workspace_bytes(long rows);
+int oe_lsm_loss_fused(float* logits, long ldv, long rows, int V, const long long* target, int ignore_id, float smoothing,
+                      int normalize_length, float batch_size, float grad_scale, int write_grad, float* out3,
+                      void* workspace, void* stream);
+
+/* Global L2 norm of the flat gradient arena (clip_grad_norm_, executor.py:58). */
+size_t oe_grad_norm_workspace_floats(void);
+int oe_grad_norm(const float* g, long n, float* workspace, float* norm_out, void* stream);
+/* clip + Adam over the flat arenas (torch.optim.Adam defaults; executor.py:59-61:
+ * the step is skipped when the norm is not finite).  state: float[2] device,
+ * state[0] = step count, state[1] = 0.  lr_dev (device scalar) overrides lr. */
+int oe_adam_step(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float lr, float beta1,
+                 float beta2, float eps, float max_norm, const float* total_norm, float* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,370 @@
+// Fused multi-head attention for the encoder (relative-position form) and the
+// decoder (plain form): scores -> mask -> softmax -> dropout -> .V without ever
+// materialising the (B,H,T1,T2) score tensor, forward and backward.
+//
+// Replaces /root/reference/openeat/modules/attention.py:65-97 (forward_attention),
+// :112-117 and :189-209 (score computation) and their autograd.
+//
+// Relative-position scores without rel_shift (attention.py:202-204) factor as
+//     ((q+u) K^T + (q+v) P^T)/sqrt(dk) = q (K+P)^T / sqrt(dk) + (u.K_j + v.P_j)/sqrt(dk)
+// i.e. ordinary attention on keys K' = K+P plus a per-key bias; the host side
+// prepares K' and the bias (oe_relpos_prepare), so one kernel serves both forms.
+//
+// Matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32).  Layout trick: the forward
+// and dQ kernels compute the TRANSPOSED score tile S^T = K Q^T, so the query
+// sits on the lane (softmax statistics are per-lane scalars) and the key on
+// the accumulator rows, which is exactly the B-operand layout of the following
+// product over keys (O^T = V^T P^T, dQ^T = K^T dS^T): P never leaves registers.
+// The dK/dV kernel uses the untransposed tile for the products over queries.
+//
+// Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); algorithmic flops
+// fwd = 4*B*H*T1*T2*D, bwd = 14*B*H*T1*T2*D (S recomputed in both kernels).
+#include "oe_common.h"
+#include "../../include/openeat_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define NEG_INF (-INFINITY)
+#define ATT_WAVES 2
+#define ATT_THREADS (64 * ATT_WAVES)
+
+struct AttnParams {
+    const float* q; long q_bs, q_rs;     // batch stride, row (time) stride; head h at +h*D
+    const float* k; long k_bs, k_rs;
+    const float* v; long v_bs, v_rs;
+    float* o; long o_bs, o_rs;
+    const float* d_o;                    // same strides as o
+    const float* o_in;
+    float* dq; float* dk; float* dv;     // same strides as q / k / v
+    float* lse;                          // (B,H,T1)
+    float* delta;                        // (B,H,T1)
+    const unsigned char* mask; long m_bs, m_rs;   // (B, 1|T1, T2) bytes; m_rs = 0 for a key-only mask
+    const float* keybias;                // (B,H,T2) or null (already divided by sqrt(dk))
+    float* dkeybias;                     // (B,H,T2) or null
+    int B, H, T1, T2, D;
+    float scale;
+    float drop_p; unsigned long long seed;
+};
+
+__device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+
+// Stage a [32][DPAD] tile (rows r0.., `nrows` valid, D valid columns) into LDS with row stride LD.
+template <int DPAD, int LD>
+__device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs, int r0, int nrows_total, int D,
+                                           float mul) {
+    const bool vec = (rs % 4 == 0) && ((((uintptr_t)src) & 15) == 0) && (D % 4 == 0);
+    for (int e = threadIdx.x; e < 32 * (DPAD / 4); e += ATT_THREADS) {
+        const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
+        float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int gr = r0 + row;
+        if (gr < nrows_total && c4 < D) {
+            const float* p = src + (long)gr * rs + c4;
+            if (vec) val = *reinterpret_cast<const float4*>(p);
+            else { val.x = p[0]; if (c4 + 1 < D) val.y = p[1]; if (c4 + 2 < D) val.z = p[2]; if (c4 + 3 < D) val.w = p[3]; }
+        }
+        float* d = dst + row * LD + c4;
+        d[0] = val.x * mul; d[1] = val.y * mul; d[2] = val.z * mul; d[3] = val.w * mul;
+    }
+}
+
+// ------------------------------------------------------------------ forward --
+// MODE 0: forward (writes O, LSE).  MODE 1: dQ (reads dO, LSE, delta; writes dQ).
+template <int DPAD, int MODE>
+__global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
+    constexpr int LD = DPAD + 1;
+    constexpr int DT = DPAD / 32;
+    __shared__ float Ks[32 * LD];
+    __shared__ float Vs[32 * LD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lq = lane & 31, lk = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = (blockIdx.x * ATT_WAVES + wave) * 32;
+    const int qi = q0 + lq;                       // this lane's query
+    const bool q_ok = qi < p.T1;
+    const float* qb = p.q + (long)b * p.q_bs + h * p.D;
+    const float* kb = p.k + (long)b * p.k_bs + h * p.D;
+    const float* vb = p.v + (long)b * p.v_bs + h * p.D;
+    const long bh = (long)b * p.H + h;
+
+    // Q^T fragments (B operand of S^T = K Q^T), pre-scaled; for dQ also dO^T fragments
+    float qf[DPAD / 2];
+    float dof[MODE == 1 ? DPAD / 2 : 1];
+#pragma unroll
+    for (int s = 0; s < DPAD / 2; ++s) {
+        const int d = 2 * s + lk;
+        qf[s] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
+        if (MODE == 1) dof[s] = (q_ok && d < p.D) ? p.d_o[(long)b * p.o_bs + (long)qi * p.o_rs + h * p.D + d] : 0.f;
+    }
+    float m_run = NEG_INF, l_run = 0.f;
+    float lse_i = 0.f, delta_i = 0.f;
+    if (MODE == 1 && q_ok) { lse_i = p.lse[bh * p.T1 + qi]; delta_i = p.delta[bh * p.T1 + qi]; }
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
+    const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const unsigned char* mrow = p.mask ? p.mask + (long)b * p.m_bs + (long)(q_ok ? qi : 0) * p.m_rs : nullptr;
+
+    for (int j0 = 0; j0 < p.T2; j0 += 32) {
+        __syncthreads();
+        stage_tile<DPAD, LD>(Ks, kb, p.k_rs, j0, p.T2, p.D, 1.f);
+        stage_tile<DPAD, LD>(Vs, vb, p.v_rs, j0, p.T2, p.D, 1.f);
+        __syncthreads();
+        // S^T[key, query]
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < DPAD / 2; ++s)
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LD + 2 * s + lk], qf[s], sacc, 0, 0, 0);
+        float pr[16];
+        float tmax = NEG_INF;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kj = j0 + acc_row(r, lk);
+            bool ok = kj < p.T2;
+            if (ok && mrow) ok = mrow[kj] != 0;
+            float sv = sacc[r];
+            if (ok && p.keybias) sv += p.keybias[bh * p.T2 + kj];
+            sv = ok ? sv : NEG_INF;
+            pr[r] = sv;
+            tmax = fmaxf(tmax, sv);
+        }
+        if (MODE == 0) {
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float m_new = fmaxf(m_run, tmax);
+            const float corr = (m_new == NEG_INF) ? 1.f : __expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = (pr[r] == NEG_INF) ? 0.f : __expf(pr[r] - m_new);
+                psum += e;
+                pr[r] = e;
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            l_run = l_run * corr + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(r, lk));
+                    pr[r] *= dropout_scale(p.seed, idx, p.drop_p, inv_keep);
+                }
+            }
+            // O^T[dv, query] += V^T[dv, key] P^T[key, query]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = acc_row(r, lk);
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[krow * LD + t * 32 + lq], pr[r], oacc[t], 0, 0, 0);
+            }
+        } else {
+            // P^T = exp(S^T - lse); dP^T[key, query] = V[key,:] . dO[query,:]
+            f32x16 dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < DPAD / 2; ++s)
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[lq * LD + 2 * s + lk], dof[s], dpacc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = (pr[r] == NEG_INF) ? 0.f : __expf(pr[r] - lse_i);
+                float dpv = dpacc[r];
+                if (p.drop_p > 0.f) {
+                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(r, lk));
+                    dpv *= dropout_scale(p.seed, idx, p.drop_p, inv_keep);
+                }
+                pr[r] = pv * (dpv - delta_i);     // dS^T
+            }
+            // dQ^T[d, query] += K^T[d, key] dS^T[key, query]
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int krow = acc_row(r, lk);
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LD + t * 32 + lq], pr[r], oacc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- write back: lane = query, accumulator rows = feature index
+    if (!q_ok) return;
+    float mul;
+    float* dst;
+    if (MODE == 0) {
+        mul = (l_run > 0.f) ? 1.f / l_run : 0.f;
+        dst = p.o + (long)b * p.o_bs + (long)qi * p.o_rs + h * p.D;
+        if (lk == 0) p.lse[bh * p.T1 + qi] = (l_run > 0.f) ? m_run + __logf(l_run) : NEG_INF;
+    } else {
+        mul = p.scale;
+        dst = p.dq + (long)b * p.q_bs + (long)qi * p.q_rs + h * p.D;
+    }
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = t * 32 + acc_row(r, lk);
+            if (d < p.D) dst[d] = oacc[t][r] * mul;
+        }
+}
+
+// ------------------------------------------------------------- dK / dV -------
+template <int DPAD>
+__global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams p) {
+    constexpr int LD = DPAD + 1;
+    constexpr int DT = DPAD / 32;
+    __shared__ float Qs[32 * LD];
+    __shared__ float Os[32 * LD];      // dO tile
+    __shared__ float lse_s[32], delta_s[32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lj = lane & 31, lk = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int k0 = (blockIdx.x * ATT_WAVES + wave) * 32;
+    const int kj = k0 + lj;                      // this lane's key
+    const bool k_ok = kj < p.T2;
+    const float* qb = p.q + (long)b * p.q_bs + h * p.D;
+    const float* dob = p.d_o + (long)b * p.o_bs + h * p.D;
+    const long bh = (long)b * p.H + h;
+    float kf[DPAD / 2], vf[DPAD / 2];
+#pragma unroll
+    for (int s = 0; s < DPAD / 2; ++s) {
+        const int d = 2 * s + lk;
+        const bool ok = k_ok && d < p.D;
+        kf[s] = ok ? p.k[(long)b * p.k_bs + (long)kj * p.k_rs + h * p.D + d] * p.scale : 0.f;
+        vf[s] = ok ? p.v[(long)b * p.v_bs + (long)kj * p.v_rs + h * p.D + d] : 0.f;
+    }
+    const float kbias = (p.keybias && k_ok) ? p.keybias[bh * p.T2 + kj] : 0.f;
+    f32x16 dkacc[DT], dvacc[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
+    float dbias = 0.f;
+    const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+
+    for (int i0 = 0; i0 < p.T1; i0 += 32) {
+        __syncthreads();
+        stage_tile<DPAD, LD>(Qs, qb, p.q_rs, i0, p.T1, p.D, 1.f);
+        stage_tile<DPAD, LD>(Os, dob, p.o_rs, i0, p.T1, p.D, 1.f);
+        if (threadIdx.x < 32) {
+            const int qi = i0 + threadIdx.x;
+            lse_s[threadIdx.x] = qi < p.T1 ? p.lse[bh * p.T1 + qi] : 0.f;
+            delta_s[threadIdx.x] = qi < p.T1 ? p.delta[bh * p.T1 + qi] : 0.f;
+        }
+        __syncthreads();
+        f32x16 sacc, dpacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < DPAD / 2; ++s) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[lj * LD + 2 * s + lk], kf[s], sacc, 0, 0, 0);
+            dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[lj * LD + 2 * s + lk], vf[s], dpacc, 0, 0, 0);
+        }
+        float pd[16], ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = acc_row(r, lk);
+            const int qi = i0 + qr;
+            bool ok = k_ok && qi < p.T1;
+            if (ok && p.mask) ok = p.mask[(long)b * p.m_bs + (long)qi * p.m_rs + kj] != 0;
+            const float pv = ok ? __expf(sacc[r] + kbias - lse_s[qr]) : 0.f;
+            float dscale = 1.f;
+            if (p.drop_p > 0.f) dscale = dropout_scale(p.seed, ((unsigned long long)(bh * p.T1 + min(qi, p.T1 - 1))) * p.T2 + min(kj, p.T2 - 1), p.drop_p, inv_keep);
+            pd[r] = pv * dscale;                                   // dropped attention weights
+            ds[r] = pv * (dpacc[r] * dscale - delta_s[qr]);        // dS
+            dbias += ds[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = acc_row(r, lk);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                dvacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[qr * LD + t * 32 + lj], pd[r], dvacc[t], 0, 0, 0);
+                dkacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qr * LD + t * 32 + lj], ds[r], dkacc[t], 0, 0, 0);
+            }
+        }
+    }
+    dbias += __shfl_xor(dbias, 32, 64);
+    if (!k_ok) return;
+    if (p.dkeybias && lk == 0) p.dkeybias[bh * p.T2 + kj] = dbias;
+    float* dkd = p.dk + (long)b * p.k_bs + (long)kj * p.k_rs + h * p.D;
+    float* dvd = p.dv + (long)b * p.v_bs + (long)kj * p.v_rs + h * p.D;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = t * 32 + acc_row(r, lk);
+            if (d < p.D) { dkd[d] = dkacc[t][r] * p.scale; dvd[d] = dvacc[t][r]; }
+        }
+}
+
+// delta[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d]
+__global__ void attn_delta_kernel(AttnParams p) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.B * p.H * p.T1;
+    if (idx >= total) return;
+    const int i = (int)(idx % p.T1);
+    const long bh = idx / p.T1;
+    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const float* a = p.d_o + (long)b * p.o_bs + (long)i * p.o_rs + h * p.D;
+    const float* o = p.o_in + (long)b * p.o_bs + (long)i * p.o_rs + h * p.D;
+    float s = 0.f;
+    for (int d = 0; d < p.D; ++d) s += a[d] * o[d];
+    p.delta[idx] = s;
+}
+
+static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {
+    if (!(a && a->q && a->k && a->v)) { oe_set_error("%s: null q/k/v", who); return -1; }
+    if (!(a->B > 0 && a->H > 0 && a->T1 > 0 && a->T2 > 0 && a->D > 0 && a->D <= 64)) {
+        oe_set_error("%s: bad shape B=%d H=%d T1=%d T2=%d D=%d (D must be <= 64)", who, a->B, a->H, a->T1, a->T2, a->D);
+        return -1;
+    }
+    if (!(a->drop_p >= 0.f && a->drop_p < 1.f)) { oe_set_error("%s: drop_p out of range", who); return -1; }
+    p.q = a->q; p.q_bs = a->q_bstride; p.q_rs = a->q_rstride;
+    p.k = a->k; p.k_bs = a->k_bstride; p.k_rs = a->k_rstride;
+    p.v = a->v; p.v_bs = a->v_bstride; p.v_rs = a->v_rstride;
+    p.o = a->out; p.o_in = a->out; p.o_bs = a->o_bstride; p.o_rs = a->o_rstride;
+    p.d_o = a->d_out; p.dq = a->dq; p.dk = a->dk; p.dv = a->dv;
+    p.lse = a->lse; p.delta = a->delta;
+    p.mask = a->mask; p.m_bs = a->mask_bstride; p.m_rs = a->mask_rstride;
+    p.keybias = a->keybias; p.dkeybias = a->dkeybias;
+    p.B = a->B; p.H = a->H; p.T1 = a->T1; p.T2 = a->T2; p.D = a->D;
+    p.scale = a->scale; p.drop_p = a->drop_p; p.seed = a->seed;
+    return 0;
+}
+
+extern "C" int oe_attention_fwd(const oe_attn_args* a, void* stream) {
+    AttnParams p{};
+    if (int rc = fill_params(p, a, "oe_attention_fwd")) return rc;
+    OE_REQUIRE(a->out && a->lse, "oe_attention_fwd: null out/lse");
+    dim3 grid(oe_cdiv(p.T1, 32 * ATT_WAVES), p.H, p.B);
+    hipStream_t st = (hipStream_t)stream;
+    if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0>), grid, dim3(ATT_THREADS), 0, st, p);
+    else hipLaunchKernelGGL((attn_qtile_kernel<64, 0>), grid, dim3(ATT_THREADS), 0, st, p);
+    OE_LAUNCH_CHECK("oe_attention_fwd");
+    return 0;
+}
+
+extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
+    AttnParams p{};
+    if (int rc = fill_params(p, a, "oe_attention_bwd")) return rc;
+    OE_REQUIRE(a->out && a->lse && a->d_out && a->dq && a->dk && a->dv && a->delta, "oe_attention_bwd: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const long rows = (long)p.B * p.H * p.T1;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(oe_cdiv(rows, 256)), dim3(256), 0, st, p);
+    OE_LAUNCH_CHECK("attn_delta");
+    dim3 gq(oe_cdiv(p.T1, 32 * ATT_WAVES), p.H, p.B), gk(oe_cdiv(p.T2, 32 * ATT_WAVES), p.H, p.B);
+    if (p.D <= 32) {
+        hipLaunchKernelGGL((attn_qtile_kernel<32, 1>), gq, dim3(ATT_THREADS), 0, st, p);
+        hipLaunchKernelGGL((attn_ktile_bwd_kernel<32>), gk, dim3(ATT_THREADS), 0, st, p);
+    } else {
+        hipLaunchKernelGGL((attn_qtile_kernel<64, 1>), gq, dim3(ATT_THREADS), 0, st, p);
+        hipLaunchKernelGGL((attn_ktile_bwd_kernel<64>), gk, dim3(ATT_THREADS), 0, st, p);
+    }
+    OE_LAUNCH_CHECK("oe_attention_bwd");
+    return 0;
+}

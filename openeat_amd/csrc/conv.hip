@@ -1,0 +1,305 @@
+// Convolution kernels of the path that are not GEMM-shaped:
+//   conv1   Conv2d(1, C, 3, stride 2) + ReLU        (subsampling.py:77-78), NHWC output
+//   col2im  gather form of the Conv2d(C,C,3,2) input gradient + ReLU mask
+//   dwconv  GLU + depthwise Conv1d(K) of the Conformer conv module (convolution.py:104-107)
+// All HBM-bound (a handful of MACs per byte); windows are staged in LDS.
+#include "oe_common.h"
+#include "../../include/openeat_hip.h"
+
+// ------------------------------------------------------------------ conv1 ----
+// y[b,t,f,c] = relu(bias[c] + sum_{kh,kw} w[c][kh][kw] * x[b, 2t+kh, 2f+kw])
+// thread = 4 consecutive channels of one output position; weights live in registers.
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int B, int T, int F, int T1, int F1,
+                                                         int C, int pos_per_block, float* __restrict__ y) {
+    const int cpt = C >> 2;                        // threads per position
+    const int grp = threadIdx.x / cpt;             // position slot inside the block
+    const int c4 = (threadIdx.x % cpt) * 4;
+    const int ngrp = blockDim.x / cpt;
+    float wr[4][9], br[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        br[e] = bias[c4 + e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wr[e][k] = w[(c4 + e) * 9 + k];
+    }
+    const long npos = (long)B * T1 * F1;
+    const long p0 = (long)blockIdx.x * pos_per_block;
+    for (long pos = p0 + grp; pos < min(npos, p0 + pos_per_block); pos += ngrp) {
+        const int f = (int)(pos % F1);
+        const int t = (int)((pos / F1) % T1);
+        const long b = pos / ((long)F1 * T1);
+        const float* xp = x + (b * T + 2 * t) * F + 2 * f;
+        float xv[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xp[kh * F + kw];
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float s = br[e];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s += wr[e][k] * xv[k];
+            o[e] = fmaxf(s, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + pos * C + c4) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dw[c][k] += sum_pos dy[pos,c] * x[.., 2t+kh, 2f+kw] ; db[c] += sum_pos dy[pos,c]
+// (dy is the gradient w.r.t. the pre-ReLU output, i.e. already masked by y>0.)
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int T,
+                                                           int F, int T1, int F1, int C, int pos_per_block,
+                                                           float* __restrict__ dw, float* __restrict__ db) {
+    const int cpt = C >> 2;
+    const int grp = threadIdx.x / cpt;
+    const int c4 = (threadIdx.x % cpt) * 4;
+    const int ngrp = blockDim.x / cpt;
+    float acc[4][10];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) acc[e][k] = 0.f;
+    const long npos = (long)B * T1 * F1;
+    const long p0 = (long)blockIdx.x * pos_per_block;
+    for (long pos = p0 + grp; pos < min(npos, p0 + pos_per_block); pos += ngrp) {
+        const int f = (int)(pos % F1);
+        const int t = (int)((pos / F1) % T1);
+        const long b = pos / ((long)F1 * T1);
+        const float* xp = x + (b * T + 2 * t) * F + 2 * f;
+        float xv[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xp[kh * F + kw];
+        const float4 g4 = *reinterpret_cast<const float4*>(dy + pos * C + c4);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[e][k] += g[e] * xv[k];
+            acc[e][9] += g[e];
+        }
+    }
+    // reduce the position slots of this block through LDS, then one atomic per output per block
+    extern __shared__ float sh[];                  // [ngrp][C][10]
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < 10; ++k) sh[(grp * C + c4 + e) * 10 + k] = acc[e][k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
+        float s = 0.f;
+        for (int gq = 0; gq < ngrp; ++gq) s += sh[gq * C * 10 + i];
+        const int c = i / 10, k = i % 10;
+        if (k < 9) atomicAdd(dw + c * 9 + k, s); else atomicAdd(db + c, s);
+    }
+}
+
+static int conv1_block(int C) {
+    const int cpt = C / 4;
+    return cpt * (256 / cpt > 0 ? 256 / cpt : 1);
+}
+
+extern "C" int oe_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
+                            void* stream) {
+    OE_REQUIRE(x && w && bias && y, "oe_conv1_fwd: null pointer");
+    OE_REQUIRE(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 4 == 0 && C <= 1024, "oe_conv1_fwd: bad shape (C %% 4 == 0, C <= 1024)");
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const long npos = (long)B * T1 * F1;
+    const int ppb = 64;
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(oe_cdiv(npos, ppb)), dim3(conv1_block(C)), 0, (hipStream_t)stream, x, w, bias, B, T,
+                       F, T1, F1, C, ppb, y);
+    OE_LAUNCH_CHECK("conv1_fwd");
+    return 0;
+}
+
+extern "C" int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int F, int C, float* dw, float* db, void* stream) {
+    OE_REQUIRE(x && dy && dw && db, "oe_conv1_wgrad: null pointer");
+    OE_REQUIRE(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 4 == 0 && C <= 1024, "oe_conv1_wgrad: bad shape");
+    const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
+    const long npos = (long)B * T1 * F1;
+    const int ppb = 512;
+    const int threads = conv1_block(C);
+    const int ngrp = threads / (C / 4);
+    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(oe_cdiv(npos, ppb)), dim3(threads), (size_t)ngrp * C * 10 * sizeof(float),
+                       (hipStream_t)stream, x, dy, B, T, F, T1, F1, C, ppb, dw, db);
+    OE_LAUNCH_CHECK("conv1_wgrad");
+    return 0;
+}
+
+// ----------------------------------------------------------------- col2im ----
+// dx[b,t1,f1,c] = (y1[b,t1,f1,c] > 0) * sum_{kh,kw : t=(t1-kh)/2, f=(f1-kw)/2 integral, in range}
+//                 dcol[(b,t,f)][(kh*3+kw)*C + c]
+__global__ __launch_bounds__(256) void col2im_relu_kernel(const float* __restrict__ dcol, const float* __restrict__ y1, int B,
+                                                           int T1, int F1, int T2, int F2, int C, float* __restrict__ dx) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
+    const int cv = C >> 2;
+    const long total = (long)B * T1 * F1 * cv;
+    if (idx >= total) return;
+    const int c = (int)(idx % cv) * 4;
+    const long pos = idx / cv;
+    const int f1 = (int)(pos % F1);
+    const int t1 = (int)((pos / F1) % T1);
+    const long b = pos / ((long)F1 * T1);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int tt = t1 - kh;
+        if (tt < 0 || (tt & 1) || (tt >> 1) >= T2) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int ff = f1 - kw;
+            if (ff < 0 || (ff & 1) || (ff >> 1) >= F2) continue;
+            const long m = (b * T2 + (tt >> 1)) * F2 + (ff >> 1);
+            const float4 v = *reinterpret_cast<const float4*>(dcol + m * (9L * C) + (kh * 3 + kw) * C + c);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    const float4 y = *reinterpret_cast<const float4*>(y1 + pos * C + c);
+    s.x = y.x > 0.f ? s.x : 0.f; s.y = y.y > 0.f ? s.y : 0.f; s.z = y.z > 0.f ? s.z : 0.f; s.w = y.w > 0.f ? s.w : 0.f;
+    *reinterpret_cast<float4*>(dx + pos * C + c) = s;
+}
+
+extern "C" int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, int C, float* dx, void* stream) {
+    OE_REQUIRE(dcol && y1 && dx && B > 0 && T1 >= 3 && F1 >= 3 && C > 0 && C % 4 == 0, "oe_col2im_relu: bad arguments");
+    const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+    const long total = (long)B * T1 * F1 * (C / 4);
+    hipLaunchKernelGGL(col2im_relu_kernel, dim3(oe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, y1, B, T1, F1, T2,
+                       F2, C, dx);
+    OE_LAUNCH_CHECK("col2im_relu");
+    return 0;
+}
+
+// -------------------------------------------------------- GLU + depthwise ----
+#define DW_TT 16
+#define DW_MAXK 31
+// y[b,t,c] = bias[c] + sum_k w[c][k] * g[b, t - pad_left + k, c],  g = a[:, :d] * sigmoid(a[:, d:])
+__global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, int T, int d, int K, int pad_left,
+                                                              float* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) float win[];       // [(DW_TT + K - 1)][d]
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * DW_TT;
+    const int rows = DW_TT + K - 1;
+    const int dv = d >> 2;
+    for (int e = threadIdx.x; e < rows * dv; e += 256) {
+        const int r = e / dv, c = (e % dv) * 4;
+        const int t = t0 - pad_left + r;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < T) {
+            const float* ap = a + ((long)b * T + t) * 2 * d;
+            const float4 xv = *reinterpret_cast<const float4*>(ap + c);
+            const float4 gv = *reinterpret_cast<const float4*>(ap + d + c);
+            g = make_float4(xv.x * sigmoidf_(gv.x), xv.y * sigmoidf_(gv.y), xv.z * sigmoidf_(gv.z), xv.w * sigmoidf_(gv.w));
+        }
+        *reinterpret_cast<float4*>(win + r * d + c) = g;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float wk[DW_MAXK];
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; ++k) wk[k] = k < K ? w[c * K + k] : 0.f;
+        const float bc = bias[c];
+        for (int tt = 0; tt < DW_TT; ++tt) {
+            const int t = t0 + tt;
+            if (t >= T) break;
+            float s = bc;
+#pragma unroll
+            for (int k = 0; k < DW_MAXK; ++k) if (k < K) s += wk[k] * win[(tt + k) * d + c];
+            y[((long)b * T + t) * d + c] = s;
+        }
+    }
+}
+
+// da (B*T, 2d) = GLU'(a, dg),  dg[t,c] = sum_k w[c][k] * dy[t + pad_left - k, c]
+// dw[c][k] += sum_t dy[t,c] * g[t - pad_left + k, c] ; db[c] += sum_t dy[t,c]
+__global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
+                                                              const float* __restrict__ w, int T, int d, int K, int pad_left,
+                                                              float* __restrict__ da, float* __restrict__ dw,
+                                                              float* __restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];
+    const int rows = DW_TT + K - 1;
+    float* gwin = sh;                   // g rows  t0 - pad_left ..            (for dw)
+    float* dwin = sh + rows * d;        // dy rows t0 + pad_left - (K-1) ..    (for dg)
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.x * DW_TT;
+    const int dv = d >> 2;
+    for (int e = threadIdx.x; e < rows * dv; e += 256) {
+        const int r = e / dv, c = (e % dv) * 4;
+        const int tg = t0 - pad_left + r;
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tg >= 0 && tg < T) {
+            const float* ap = a + ((long)b * T + tg) * 2 * d;
+            const float4 xv = *reinterpret_cast<const float4*>(ap + c);
+            const float4 gv = *reinterpret_cast<const float4*>(ap + d + c);
+            g = make_float4(xv.x * sigmoidf_(gv.x), xv.y * sigmoidf_(gv.y), xv.z * sigmoidf_(gv.z), xv.w * sigmoidf_(gv.w));
+        }
+        *reinterpret_cast<float4*>(gwin + r * d + c) = g;
+        const int td = t0 + pad_left - (K - 1) + r;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (td >= 0 && td < T) q = *reinterpret_cast<const float4*>(dy + ((long)b * T + td) * d + c);
+        *reinterpret_cast<float4*>(dwin + r * d + c) = q;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+        float wk[DW_MAXK], dwk[DW_MAXK];
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; ++k) { wk[k] = k < K ? w[c * K + k] : 0.f; dwk[k] = 0.f; }
+        float dbs = 0.f;
+        for (int tt = 0; tt < DW_TT; ++tt) {
+            const int t = t0 + tt;
+            if (t >= T) break;
+            // dy[t] sits at window row tt + (K-1) - pad_left ... relative to dwin start t0 + pad_left - (K-1):
+            //   row(td) = td - (t0 + pad_left - (K-1));  td = t + pad_left - k  ->  row = tt + (K-1) - k
+            float dg = 0.f;
+#pragma unroll
+            for (int k = 0; k < DW_MAXK; ++k) if (k < K) dg += wk[k] * dwin[(tt + (K - 1) - k) * d + c];
+            // GLU backward at (t, c)
+            const float* ap = a + ((long)b * T + t) * 2 * d;
+            const float xv = ap[c], gv = ap[d + c];
+            const float sg = sigmoidf_(gv);
+            float* dap = da + ((long)b * T + t) * 2 * d;
+            dap[c] = dg * sg;
+            dap[d + c] = dg * xv * sg * (1.f - sg);
+            // parameter gradients: dy[t] is dwin row tt + (K-1) - pad_left ; g[t - pad_left + k] is gwin row tt + k
+            const float dyt = dwin[(tt + (K - 1) - pad_left) * d + c];
+            dbs += dyt;
+#pragma unroll
+            for (int k = 0; k < DW_MAXK; ++k) if (k < K) dwk[k] += dyt * gwin[(tt + k) * d + c];
+        }
+#pragma unroll
+        for (int k = 0; k < DW_MAXK; ++k) if (k < K) atomicAdd(dw + c * K + k, dwk[k]);
+        atomicAdd(db + c, dbs);
+    }
+}
+
+extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, int B, int T, int d, int K, int causal,
+                                 float* y, void* stream) {
+    OE_REQUIRE(a && w && bias && y, "oe_dwconv_glu_fwd: null pointer");
+    OE_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0 && K >= 1 && K <= DW_MAXK, "oe_dwconv_glu_fwd: bad shape (d %% 4, K <= %d)", DW_MAXK);
+    OE_REQUIRE(causal || (K % 2 == 1), "oe_dwconv_glu_fwd: kernel size must be odd for the symmetric convolution");
+    const int pad_left = causal ? K - 1 : (K - 1) / 2;
+    const size_t lds = (size_t)(DW_TT + K - 1) * d * sizeof(float);
+    OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_fwd: window does not fit LDS (d=%d)", d);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dwconv_glu_fwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, T, d, K,
+                       pad_left, y);
+    OE_LAUNCH_CHECK("dwconv_glu_fwd");
+    return 0;
+}
+
+extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, int B, int T, int d, int K, int causal,
+                                 float* da, float* dw, float* db, void* stream) {
+    OE_REQUIRE(a && dy && w && da && dw && db, "oe_dwconv_glu_bwd: null pointer");
+    OE_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0 && K >= 1 && K <= DW_MAXK, "oe_dwconv_glu_bwd: bad shape");
+    const int pad_left = causal ? K - 1 : (K - 1) / 2;
+    const size_t lds = (size_t)2 * (DW_TT + K - 1) * d * sizeof(float);
+    OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_bwd: window does not fit LDS (d=%d)", d);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(dwconv_glu_bwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, T, d, K,
+                       pad_left, da, dw, db);
+    OE_LAUNCH_CHECK("dwconv_glu_bwd");
+    return 0;
+}

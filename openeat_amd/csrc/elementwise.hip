@@ -1,0 +1,221 @@
+// Small memory-bound kernels of the path: relative-position key preparation,
+// GLU, dropout scaling, token embedding, weight layout swaps, axpby.
+// All HBM-bound: bytes moved = inputs read once + outputs written once.
+#include "oe_common.h"
+#include "../../include/openeat_hip.h"
+
+// ---------------------------------------------------------------- rel-pos ----
+// kp[b,t,h,:] = k[b,t,h,:] + p[t,h,:] ; keybias[b,h,t] = scale*(u_h.k + v_h.p)
+__global__ void relpos_prepare_kernel(const float* __restrict__ k, long k_bs, long k_rs, const float* __restrict__ p, long p_rs,
+                                      const float* __restrict__ u, const float* __restrict__ v, int B, int T, int H, int D,
+                                      float scale, float* __restrict__ kp, float* __restrict__ keybias) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * T * H) return;
+    const int h = (int)(idx % H);
+    const int t = (int)((idx / H) % T);
+    const int b = (int)(idx / ((long)H * T));
+    const float* kr = k + (long)b * k_bs + (long)t * k_rs + h * D;
+    const float* pr = p + (long)t * p_rs + h * D;
+    float* out = kp + ((long)b * T + t) * H * D + h * D;
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) {
+        const float kv = kr[d], pv = pr[d];
+        out[d] = kv + pv;
+        s += u[h * D + d] * kv + v[h * D + d] * pv;
+    }
+    keybias[((long)b * H + h) * T + t] = s * scale;
+}
+
+// dk[b,t,h,:] = dkp + scale*dkb*u_h (written with k's strides);
+// dp[t,h,:]   = sum_b (dkp + scale*dkb*v_h) ; du_h += sum scale*dkb*k ; dv_h += sum scale*dkb*p
+__global__ void relpos_backward_kernel(const float* __restrict__ dkp, const float* __restrict__ dkeybias,
+                                       const float* __restrict__ k, long k_bs, long k_rs, const float* __restrict__ p, long p_rs,
+                                       const float* __restrict__ u, const float* __restrict__ v, int B, int T, int H, int D,
+                                       float scale, float* __restrict__ dk, float* __restrict__ dp, long dp_rs,
+                                       float* __restrict__ du, float* __restrict__ dv) {
+    // one thread per (t, h, d): loops over the batch -> deterministic dp
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)T * H * D) return;
+    const int d = (int)(idx % D);
+    const int h = (int)((idx / D) % H);
+    const int t = (int)(idx / ((long)D * H));
+    const float uu = u[h * D + d], vv = v[h * D + d], pv = p[(long)t * p_rs + h * D + d];
+    float dps = 0.f, dus = 0.f, dvs = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float g = dkp[((long)b * T + t) * H * D + h * D + d];
+        const float gb = dkeybias[((long)b * H + h) * T + t] * scale;
+        const long ko = (long)b * k_bs + (long)t * k_rs + h * D + d;
+        dus += gb * k[ko];
+        dk[ko] = g + gb * uu;
+        dps += g + gb * vv;
+        dvs += gb * pv;
+    }
+    dp[(long)t * dp_rs + h * D + d] = dps;
+    atomicAdd(du + h * D + d, dus);
+    atomicAdd(dv + h * D + d, dvs);
+}
+
+extern "C" int oe_relpos_prepare(const float* k, long k_bstride, long k_rstride, const float* p, long p_rstride,
+                                 const float* u, const float* v, int B, int T, int H, int D, float scale, float* kp,
+                                 float* keybias, void* stream) {
+    OE_REQUIRE(k && p && u && v && kp && keybias && B > 0 && T > 0 && H > 0 && D > 0, "oe_relpos_prepare: bad arguments");
+    const long n = (long)B * T * H;
+    hipLaunchKernelGGL(relpos_prepare_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k, k_bstride, k_rstride,
+                       p, p_rstride, u, v, B, T, H, D, scale, kp, keybias);
+    OE_LAUNCH_CHECK("relpos_prepare");
+    return 0;
+}
+
+extern "C" int oe_relpos_backward(const float* dkp, const float* dkeybias, const float* k, long k_bstride, long k_rstride,
+                                  const float* p, long p_rstride, const float* u, const float* v, int B, int T, int H, int D,
+                                  float scale, float* dk, float* dp, long dp_rstride, float* du, float* dv, void* stream) {
+    OE_REQUIRE(dkp && dkeybias && k && p && u && v && dk && dp && du && dv, "oe_relpos_backward: null pointer");
+    const long n = (long)T * H * D;
+    hipLaunchKernelGGL(relpos_backward_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dkp, dkeybias, k,
+                       k_bstride, k_rstride, p, p_rstride, u, v, B, T, H, D, scale, dk, dp, dp_rstride, du, dv);
+    OE_LAUNCH_CHECK("relpos_backward");
+    return 0;
+}
+
+// -------------------------------------------------------------------- GLU ----
+// y[m,c] = a[m,c] * sigmoid(a[m,c+d])   (torch.nn.functional.glu over channels)
+__global__ void glu_fwd_kernel(const float* __restrict__ a, long rows, int d, float* __restrict__ y) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // one float4 of y
+    const int dv = d >> 2;
+    if (idx >= rows * dv) return;
+    const long r = idx / dv;
+    const int c = (int)(idx % dv) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(a + r * 2 * d + c);
+    const float4 g = *reinterpret_cast<const float4*>(a + r * 2 * d + d + c);
+    float4 o = make_float4(x.x * sigmoidf_(g.x), x.y * sigmoidf_(g.y), x.z * sigmoidf_(g.z), x.w * sigmoidf_(g.w));
+    *reinterpret_cast<float4*>(y + r * d + c) = o;
+}
+__global__ void glu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy, long rows, int d, float* __restrict__ da) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int dv = d >> 2;
+    if (idx >= rows * dv) return;
+    const long r = idx / dv;
+    const int c = (int)(idx % dv) * 4;
+    const float4 x = *reinterpret_cast<const float4*>(a + r * 2 * d + c);
+    const float4 g = *reinterpret_cast<const float4*>(a + r * 2 * d + d + c);
+    const float4 gy = *reinterpret_cast<const float4*>(dy + r * d + c);
+    const float sx = sigmoidf_(g.x), sy = sigmoidf_(g.y), sz = sigmoidf_(g.z), sw = sigmoidf_(g.w);
+    *reinterpret_cast<float4*>(da + r * 2 * d + c) = make_float4(gy.x * sx, gy.y * sy, gy.z * sz, gy.w * sw);
+    *reinterpret_cast<float4*>(da + r * 2 * d + d + c) =
+        make_float4(gy.x * x.x * sx * (1.f - sx), gy.y * x.y * sy * (1.f - sy), gy.z * x.z * sz * (1.f - sz), gy.w * x.w * sw * (1.f - sw));
+}
+extern "C" int oe_glu_fwd(const float* a, long rows, int d, float* y, void* stream) {
+    OE_REQUIRE(a && y && rows > 0 && d > 0 && d % 4 == 0, "oe_glu_fwd: bad arguments (d %% 4 == 0 required)");
+    hipLaunchKernelGGL(glu_fwd_kernel, dim3(oe_cdiv(rows * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, rows, d, y);
+    OE_LAUNCH_CHECK("glu_fwd");
+    return 0;
+}
+extern "C" int oe_glu_bwd(const float* a, const float* dy, long rows, int d, float* da, void* stream) {
+    OE_REQUIRE(a && dy && da && rows > 0 && d > 0 && d % 4 == 0, "oe_glu_bwd: bad arguments (d %% 4 == 0 required)");
+    hipLaunchKernelGGL(glu_bwd_kernel, dim3(oe_cdiv(rows * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, a, dy, rows, d, da);
+    OE_LAUNCH_CHECK("glu_bwd");
+    return 0;
+}
+
+// ---------------------------------------------------------------- dropout ----
+// out[i] = alpha * x[i] * keep(seed, i)/(1-p) ; rowmask (optional, per row of `cols`) zeroes rows.
+__global__ void dropout_scale_kernel(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
+                                     const unsigned char* __restrict__ rowmask, float* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = x[i] * alpha;
+    if (p > 0.f) v *= dropout_scale(seed, (unsigned long long)i, p, 1.f / (1.f - p));
+    if (rowmask && !rowmask[i / cols]) v = 0.f;
+    out[i] = v;
+}
+extern "C" int oe_dropout_scale(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
+                                const unsigned char* rowmask, float* out, void* stream) {
+    OE_REQUIRE(x && out && n > 0 && cols > 0 && p >= 0.f && p < 1.f, "oe_dropout_scale: bad arguments");
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, cols, alpha, p, seed,
+                       rowmask, out);
+    OE_LAUNCH_CHECK("dropout_scale");
+    return 0;
+}
+
+// -------------------------------------------------------------- embedding ----
+// out[r,:] = table[tok[r],:]*xscale + pe[r % L,:]   (decoder.py:144-147,186 ; embedding.py:59)
+__global__ void embed_fwd_kernel(const long long* __restrict__ tok, const float* __restrict__ table, const float* __restrict__ pe,
+                                 long rows, int L, int d, int V, float xscale, float* __restrict__ out) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * d) return;
+    const long r = idx / d;
+    const int c = (int)(idx % d);
+    long long t = tok[r];
+    if (t < 0 || t >= V) t = 0;
+    out[idx] = table[t * d + c] * xscale + pe[(r % L) * d + c];
+}
+__global__ void embed_bwd_kernel(const long long* __restrict__ tok, const float* __restrict__ dout, long rows, int d, int V,
+                                 float xscale, float* __restrict__ dtable) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * d) return;
+    const long r = idx / d;
+    const int c = (int)(idx % d);
+    const long long t = tok[r];
+    if (t < 0 || t >= V) return;
+    atomicAdd(dtable + t * d + c, dout[idx] * xscale);
+}
+extern "C" int oe_embed_fwd(const long long* tokens, const float* table, const float* pe, long rows, int L, int d, int V,
+                            float xscale, float* out, void* stream) {
+    OE_REQUIRE(tokens && table && pe && out && rows > 0 && L > 0 && d > 0 && V > 0, "oe_embed_fwd: bad arguments");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(oe_cdiv(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, tokens, table, pe, rows,
+                       L, d, V, xscale, out);
+    OE_LAUNCH_CHECK("embed_fwd");
+    return 0;
+}
+extern "C" int oe_embed_bwd(const long long* tokens, const float* dout, long rows, int d, int V, float xscale, float* dtable,
+                            void* stream) {
+    OE_REQUIRE(tokens && dout && dtable && rows > 0 && d > 0 && V > 0, "oe_embed_bwd: bad arguments");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(oe_cdiv(rows * d, 256)), dim3(256), 0, (hipStream_t)stream, tokens, dout, rows, d, V,
+                       xscale, dtable);
+    OE_LAUNCH_CHECK("embed_bwd");
+    return 0;
+}
+
+// ------------------------------------------------------------ layout swap ----
+// in [A][B][C] -> out [A][C][B]  (conv2 weight OIHW <-> O(HW)I, Linear(19d->d) column order)
+__global__ void swap_last2_kernel(const float* __restrict__ in, long A, int Bd, int Cd, float* __restrict__ out, int accumulate) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;     // index into out
+    if (idx >= A * Bd * Cd) return;
+    const int b = (int)(idx % Bd);
+    const int c = (int)((idx / Bd) % Cd);
+    const long a = idx / ((long)Bd * Cd);
+    const float v = in[(a * Bd + b) * Cd + c];
+    out[idx] = accumulate ? out[idx] + v : v;
+}
+extern "C" int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out, int accumulate, void* stream) {
+    OE_REQUIRE(in && out && A > 0 && Bd > 0 && Cd > 0, "oe_swap_last2: bad arguments");
+    hipLaunchKernelGGL(swap_last2_kernel, dim3(oe_cdiv(A * Bd * Cd, 256)), dim3(256), 0, (hipStream_t)stream, in, A, Bd, Cd, out,
+                       accumulate);
+    OE_LAUNCH_CHECK("swap_last2");
+    return 0;
+}
+
+// ------------------------------------------------------------------ axpby ----
+__global__ void axpby_kernel(const float* x, const float* y, long n, float a, float b, float* out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+extern "C" int oe_axpby(const float* x, const float* y, long n, float a, float b, float* out, void* stream) {
+    OE_REQUIRE(x && out && n > 0, "oe_axpby: bad arguments");
+    hipLaunchKernelGGL(axpby_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b, out);
+    OE_LAUNCH_CHECK("axpby");
+    return 0;
+}
+
+// global CMVN (modules/cmvn.py:43-45): y = (x - mean[f]) * istd[f]
+__global__ void cmvn_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ istd, long n, int F,
+                            float* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int f = (int)(i % F); y[i] = (x[i] - mean[f]) * istd[f]; }
+}
+extern "C" int oe_global_cmvn(const float* x, const float* mean, const float* istd, long n, int F, float* y, void* stream) {
+    OE_REQUIRE(x && mean && istd && y && n > 0 && F > 0, "oe_global_cmvn: bad arguments");
+    hipLaunchKernelGGL(cmvn_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, istd, n, F, y);
+    OE_LAUNCH_CHECK("global_cmvn");
+    return 0;
+}

@@ -74,6 +74,7 @@ struct EpiParams {
     const unsigned char* rowmask;
     const float* residual;
     long ldr;
+    int res_row_mod;
     float beta;
     int accumulate;
     int atomic;
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
                     else for (int e = 0; e < ncol; ++e) aux[e] = ap[e];
                 }
                 if (ep.residual) {
-                    const float* rp = ep.residual + row * ep.ldr + col;
+                    const float* rp = ep.residual + (ep.res_row_mod > 0 ? row % ep.res_row_mod : row) * ep.ldr + col;
                     if (full && res_vec) { float4 r4 = *reinterpret_cast<const float4*>(rp); res[0] = r4.x; res[1] = r4.y; res[2] = r4.z; res[3] = r4.w; }
                     else for (int e = 0; e < ncol; ++e) res[e] = rp[e];
                 }
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
                     else x = act_fwd(ep.act, x);
                     if (ep.drop_p > 0.f) x *= dropout_scale(ep.seed, (unsigned long long)(row * N + col + e), ep.drop_p, inv_keep);
                     if (row_dead) x = 0.f;
-                    if (ep.residual) x = res[e] + ep.beta * x;
+                    x = res[e] + ep.beta * x;
                     v[e] = x;
                 }
                 if (ep.preact_out) {
@@ -311,7 +312,7 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     OE_REQUIRE(g->m > 0 && g->n > 0 && g->k >= 0, "oe_gemm_f32: bad shape m=%d n=%d k=%d", g->m, g->n, g->k);
     OE_REQUIRE(g->split_k >= 1, "oe_gemm_f32: split_k must be >= 1");
     OE_REQUIRE(!(g->split_k > 1 && !g->atomic_out), "oe_gemm_f32: split_k > 1 needs atomic_out");
-    OE_REQUIRE(!(g->atomic_out && (g->act || g->residual || g->preact_out || g->actgrad_in || g->drop_p > 0.f)),
+    OE_REQUIRE(!(g->atomic_out && (g->act || g->residual || g->preact_out || g->actgrad_in || g->drop_p > 0.f || g->beta != 1.f)),
                "oe_gemm_f32: atomic_out supports only alpha/bias epilogues");
     OE_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "oe_gemm_f32: drop_p out of range");
     hipStream_t st = (hipStream_t)stream;
@@ -332,7 +333,7 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     ep.alpha = g->alpha; ep.alpha_dev = g->alpha_dev; ep.bias = g->bias; ep.act = g->act;
     ep.preact_out = g->preact_out; ep.actgrad_in = g->actgrad_in; ep.ld_aux = g->ld_aux ? g->ld_aux : g->ldc;
     ep.drop_p = g->drop_p; ep.seed = g->seed; ep.rowmask = g->rowmask;
-    ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta;
+    ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
     ep.accumulate = g->accumulate; ep.atomic = g->atomic_out;
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
     const long blocks128 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;

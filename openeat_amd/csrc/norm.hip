@@ -60,8 +60,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ stats,
                                                              int rows, int d, const unsigned char* __restrict__ rowmask,
-                                                             float* __restrict__ dx, float* __restrict__ dgamma,
-                                                             float* __restrict__ dbeta) {
+                                                             const float* add, float* dx,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -79,9 +79,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const long row = r0 + rr;
         if (row >= rows) break;
         float4* dxr = reinterpret_cast<float4*>(dx + row * d);
+        const float4* addr = add ? reinterpret_cast<const float4*>(add + row * d) : nullptr;
         if (rowmask && !rowmask[row]) {
 #pragma unroll
-            for (int j = 0; j < LN_MAXV; ++j) { const int i = lane + 64 * j; if (i < nv) dxr[i] = make_float4(0, 0, 0, 0); }
+            for (int j = 0; j < LN_MAXV; ++j) {
+                const int i = lane + 64 * j;
+                if (i < nv) dxr[i] = addr ? addr[i] : make_float4(0, 0, 0, 0);
+            }
             continue;
         }
         const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                 o.y = rstd * (g[j].y - c1 - xh[j].y * c2);
                 o.z = rstd * (g[j].z - c1 - xh[j].z * c2);
                 o.w = rstd * (g[j].w - c1 - xh[j].w * c2);
+                if (addr) { const float4 a4 = addr[i]; o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w; }
                 dxr[i] = o;
             }
         }
@@ -141,11 +146,12 @@ extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float*
 }
 
 extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int d,
-                                const unsigned char* rowmask, float* dx, float* dgamma, float* dbeta, void* stream) {
+                                const unsigned char* rowmask, const float* add, float* dx, float* dgamma, float* dbeta,
+                                void* stream) {
     OE_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta, "oe_layernorm_bwd: null pointer");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(oe_cdiv(rows, LNB_ROWS)), dim3(256), (size_t)8 * d * sizeof(float),
-                       (hipStream_t)stream, dy, x, gamma, stats, rows, d, rowmask, dx, dgamma, dbeta);
+                       (hipStream_t)stream, dy, x, gamma, stats, rows, d, rowmask, add, dx, dgamma, dbeta);
     OE_LAUNCH_CHECK("layernorm_bwd");
     return 0;
 }

@@ -35,10 +35,26 @@ class GemmArgs(C.Structure):
         ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
         ("drop_p", C.c_float), ("seed", C.c_ulonglong),
         ("rowmask", c_fp),
-        ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
+        ("residual", c_fp), ("ldr", C.c_long), ("res_row_mod", C.c_int), ("beta", C.c_float),
         ("accumulate", C.c_int), ("atomic_out", C.c_int),
         ("conv_gather", C.c_int), ("conv_t1", C.c_int), ("conv_f1", C.c_int), ("conv_t2", C.c_int),
         ("conv_f2", C.c_int), ("conv_c", C.c_int),
+    ]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [
+        ("q", c_fp), ("q_bstride", C.c_long), ("q_rstride", C.c_long),
+        ("k", c_fp), ("k_bstride", C.c_long), ("k_rstride", C.c_long),
+        ("v", c_fp), ("v_bstride", C.c_long), ("v_rstride", C.c_long),
+        ("out", c_fp), ("o_bstride", C.c_long), ("o_rstride", C.c_long),
+        ("lse", c_fp),
+        ("mask", c_fp), ("mask_bstride", C.c_long), ("mask_rstride", C.c_long),
+        ("keybias", c_fp),
+        ("B", C.c_int), ("H", C.c_int), ("T1", C.c_int), ("T2", C.c_int), ("D", C.c_int),
+        ("scale", C.c_float),
+        ("drop_p", C.c_float), ("seed", C.c_ulonglong),
+        ("d_out", c_fp), ("dq", c_fp), ("dk", c_fp), ("dv", c_fp), ("dkeybias", c_fp), ("delta", c_fp),
     ]
 
 
@@ -71,10 +87,32 @@ _SIGNATURES = {
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, P, P, P]),
-    "oe_layernorm_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P]),
+    "oe_layernorm_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
+    "oe_attention_fwd": (I, [C.POINTER(AttnArgs), P]),
+    "oe_attention_bwd": (I, [C.POINTER(AttnArgs), P]),
+    "oe_relpos_prepare": (I, [P, L, L, P, L, P, P, I, I, I, I, F, P, P, P]),
+    "oe_relpos_backward": (I, [P, P, P, L, L, P, L, P, P, I, I, I, I, F, P, P, L, P, P, P]),
+    "oe_glu_fwd": (I, [P, L, I, P, P]),
+    "oe_glu_bwd": (I, [P, P, L, I, P, P]),
+    "oe_dropout_scale": (I, [P, L, I, F, F, U64, P, P, P]),
+    "oe_embed_fwd": (I, [P, P, P, L, I, I, I, F, P, P]),
+    "oe_embed_bwd": (I, [P, P, L, I, I, F, P, P]),
+    "oe_swap_last2": (I, [P, L, I, I, P, I, P]),
+    "oe_axpby": (I, [P, P, L, F, F, P, P]),
+    "oe_global_cmvn": (I, [P, P, P, L, I, P, P]),
+    "oe_conv1_fwd": (I, [P, P, P, I, I, I, I, P, P]),
+    "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
+    "oe_col2im_relu": (I, [P, P, I, I, I, I, P, P]),
+    "oe_dwconv_glu_fwd": (I, [P, P, P, I, I, I, I, I, P, P]),
+    "oe_dwconv_glu_bwd": (I, [P, P, P, I, I, I, I, I, P, P, P, P]),
+    "oe_lsm_workspace_bytes": (SZ, [L]),
+    "oe_lsm_loss_fused": (I, [P, L, L, I, P, I, F, I, F, F, I, P, P, P]),
+    "oe_grad_norm_workspace_floats": (SZ, []),
+    "oe_grad_norm": (I, [P, L, P, P, P]),
+    "oe_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, P, P, P]),
 }
 
 
@@ -109,7 +147,7 @@ def _dev_f32(t: torch.Tensor, name: str):
 # --------------------------------------------------------------------------- #
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
          bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, rowmask=None,
-         residual=None, ldr=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE):
+         residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE):
     g = GemmArgs()
     g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
     g.b, g.ldb, g.b_kmajor = b.data_ptr(), ldb, int(b_kmajor)
@@ -125,9 +163,46 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.drop_p, g.seed = drop_p, seed
     g.rowmask = None if rowmask is None else rowmask.data_ptr()
     g.residual = None if residual is None else residual.data_ptr()
-    g.ldr, g.beta = ldr, beta
+    g.ldr, g.beta, g.res_row_mod = ldr, beta, res_row_mod
     g.accumulate, g.atomic_out = int(accumulate), int(atomic_out)
     g.conv_gather = conv_gather
     if conv is not None:
         g.conv_t1, g.conv_f1, g.conv_t2, g.conv_f2, g.conv_c = conv
     check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
+
+
+def call(name, *args):
+    """Invoke a C-ABI entry point with (tensor | None | scalar) arguments on the current stream."""
+    conv = []
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            conv.append(C.c_void_p(a.data_ptr()))
+        else:
+            conv.append(a)
+    check(getattr(lib(), name)(*conv, stream()), name)
+
+
+def attn_args(q, k, v, out, lse, B, H, T1, T2, D, scale, *, q_strides, k_strides, v_strides, o_strides, mask=None,
+              mask_strides=(0, 0), keybias=None, drop_p=0.0, seed=0, d_out=None, dq=None, dk=None, dv=None,
+              dkeybias=None, delta=None):
+    a = AttnArgs()
+    dp = lambda t: None if t is None else t.data_ptr()
+    a.q, (a.q_bstride, a.q_rstride) = dp(q), q_strides
+    a.k, (a.k_bstride, a.k_rstride) = dp(k), k_strides
+    a.v, (a.v_bstride, a.v_rstride) = dp(v), v_strides
+    a.out, (a.o_bstride, a.o_rstride) = dp(out), o_strides
+    a.lse = dp(lse)
+    a.mask, (a.mask_bstride, a.mask_rstride) = dp(mask), mask_strides
+    a.keybias = dp(keybias)
+    a.B, a.H, a.T1, a.T2, a.D = B, H, T1, T2, D
+    a.scale, a.drop_p, a.seed = scale, drop_p, seed
+    a.d_out, a.dq, a.dk, a.dv, a.dkeybias, a.delta = dp(d_out), dp(dq), dp(dk), dp(dv), dp(dkeybias), dp(delta)
+    return a
+
+
+def attention_fwd(a: AttnArgs):
+    check(lib().oe_attention_fwd(C.byref(a), stream()), "oe_attention_fwd")
+
+
+def attention_bwd(a: AttnArgs):
+    check(lib().oe_attention_bwd(C.byref(a), stream()), "oe_attention_bwd")

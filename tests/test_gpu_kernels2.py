@@ -1,0 +1,368 @@
+"""GPU: attention, conv, loss and optimiser kernels through the C ABI against
+fp32 CPU restatements (oracle / plain torch) on the same seeded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from openeat_amd import hip  # noqa: E402
+from oracle import asr as O  # noqa: E402
+
+DEV = "cuda"
+TOL = dict(rtol=2e-4, atol=2e-5)
+
+
+def cu(t):
+    return t.to(DEV).contiguous()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------- attention -----
+def ref_attention(q, k, v, mask, keybias, scale):
+    """q (B,T1,H,D) ... -> out (B,T1,H,D); mask (B,1|T1,T2) bool; keybias (B,H,T2)."""
+    s = torch.einsum("bihd,bjhd->bhij", q, k) * scale
+    if keybias is not None:
+        s = s + keybias[:, :, None, :]
+    if mask is not None:
+        m = mask.unsqueeze(1).eq(0)
+        s = s.masked_fill(m, -float("inf"))
+        a = torch.softmax(s, dim=-1).masked_fill(m, 0.0)
+    else:
+        a = torch.softmax(s, dim=-1)
+    return torch.einsum("bhij,bjhd->bihd", a, v)
+
+
+@pytest.mark.parametrize("B,H,T1,T2,D,mask_kind,bias", [
+    (2, 4, 50, 50, 64, "key", True),
+    (3, 4, 13, 13, 8, "key", True),
+    (2, 2, 31, 70, 32, "key", False),
+    (3, 4, 9, 9, 16, "full", False),
+    (1, 4, 130, 130, 64, "none", False),
+    (2, 4, 40, 40, 36, "key", True),
+])
+def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias):
+    torch.manual_seed(11)
+    q = torch.randn(B, T1, H, D, requires_grad=True)
+    k = torch.randn(B, T2, H, D, requires_grad=True)
+    v = torch.randn(B, T2, H, D, requires_grad=True)
+    kb = (torch.randn(B, H, T2) * 0.5).requires_grad_() if bias else None
+    scale = 1.0 / math.sqrt(D)
+    mask = None
+    if mask_kind == "key":
+        lens = torch.randint(1, T2 + 1, (B,))
+        lens[0] = T2
+        mask = (~O.pad_mask(lens, T2)).unsqueeze(1)
+    elif mask_kind == "full":
+        lens = torch.randint(1, T2 + 1, (B,))
+        mask = (~O.pad_mask(lens, T2)).unsqueeze(1) & O.causal_mask(T1).unsqueeze(0)
+    out_ref = ref_attention(q, k, v, mask, kb, scale)
+    w = torch.randn_like(out_ref)
+    (out_ref * w).sum().backward()
+
+    # device: q/k/v as slices of one fused (B,T,3*H*D) buffer when T1 == T2, to exercise strides
+    d = H * D
+    if T1 == T2:
+        qkv = torch.cat([q.detach().reshape(B, T1, d), k.detach().reshape(B, T1, d), v.detach().reshape(B, T1, d)], -1).to(DEV)
+        qd, kd, vd = qkv[:, :, :d], qkv[:, :, d:2 * d], qkv[:, :, 2 * d:]
+        qs = ks = vs = (T1 * 3 * d, 3 * d)
+        dqkv = torch.full_like(qkv, float("nan"))
+        dqd, dkd, dvd = dqkv[:, :, :d], dqkv[:, :, d:2 * d], dqkv[:, :, 2 * d:]
+    else:
+        qd, kd, vd = cu(q.detach()), cu(k.detach()), cu(v.detach())
+        qs, ks, vs = (T1 * d, d), (T2 * d, d), (T2 * d, d)
+        dqd, dkd, dvd = torch.empty_like(qd), torch.empty_like(kd), torch.empty_like(vd)
+    out = torch.full((B, T1, H, D), float("nan"), device=DEV)
+    lse = torch.empty(B, H, T1, device=DEV)
+    md = None if mask is None else cu(mask.to(torch.uint8))
+    mstr = (0, 0) if mask is None else (mask.shape[1] * T2, 0 if mask.shape[1] == 1 else T2)
+    kbd = None if kb is None else cu(kb.detach())
+    a = hip.attn_args(qd, kd, vd, out, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=ks, v_strides=vs,
+                      o_strides=(T1 * d, d), mask=md, mask_strides=mstr, keybias=kbd)
+    hip.attention_fwd(a)
+    sync()
+    torch.testing.assert_close(out.cpu(), out_ref.detach(), **TOL)
+
+    wd = cu(w)
+    dkb = torch.empty(B, H, T2, device=DEV) if bias else None
+    delta = torch.empty(B, H, T1, device=DEV)
+    a2 = hip.attn_args(qd, kd, vd, out, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=ks, v_strides=vs,
+                       o_strides=(T1 * d, d), mask=md, mask_strides=mstr, keybias=kbd, d_out=wd, dq=dqd, dk=dkd, dv=dvd,
+                       dkeybias=dkb, delta=delta)
+    hip.attention_bwd(a2)
+    sync()
+    g = dict(rtol=5e-4, atol=5e-5)
+    torch.testing.assert_close(dqd.cpu().reshape(B, T1, H, D), q.grad, **g)
+    torch.testing.assert_close(dkd.cpu().reshape(B, T2, H, D), k.grad, **g)
+    torch.testing.assert_close(dvd.cpu().reshape(B, T2, H, D), v.grad, **g)
+    if bias:
+        torch.testing.assert_close(dkb.cpu(), kb.grad, **g)
+
+
+def test_attention_fully_masked_rows_give_zeros():
+    torch.manual_seed(12)
+    B, H, T, D = 2, 2, 10, 16
+    q, k, v = (torch.randn(B, T, H, D) for _ in range(3))
+    mask = torch.ones(B, 1, T, dtype=torch.uint8)
+    mask[1] = 0                               # utterance 1: every key masked (length 0)
+    out = torch.full((B, T, H, D), float("nan"), device=DEV)
+    lse = torch.empty(B, H, T, device=DEV)
+    d = H * D
+    qd, kd, vd, md = cu(q), cu(k), cu(v), cu(mask)
+    a = hip.attn_args(qd, kd, vd, out, lse, B, H, T, T, D, 0.25, q_strides=(T * d, d), k_strides=(T * d, d),
+                      v_strides=(T * d, d), o_strides=(T * d, d), mask=md, mask_strides=(T, 0))
+    hip.attention_fwd(a)
+    sync()
+    assert torch.all(out[1] == 0) and torch.isfinite(out[0]).all()
+
+
+def test_attention_dropout_consistency():
+    """Dropout in the attention weights: forward == sum of (mask/keep * softmax) V with the kernel's own mask,
+    recovered from a V = identity probe; backward consistent with that mask."""
+    torch.manual_seed(13)
+    B, H, T, D = 1, 1, 32, 32
+    q, k = torch.randn(B, T, H, D), torch.randn(B, T, H, D)
+    v = torch.eye(T).view(B, T, H, D)         # out row i = dropped attention weights of query i
+    d = H * D
+    qd, kd, vd = cu(q), cu(k), cu(v)
+    out = torch.empty(B, T, H, D, device=DEV)
+    lse = torch.empty(B, H, T, device=DEV)
+    mk = lambda **kw: hip.attn_args(qd, kd, vd, out, lse, B, H, T, T, D, 0.2, q_strides=(T * d, d), k_strides=(T * d, d),
+                                    v_strides=(T * d, d), o_strides=(T * d, d), drop_p=0.25, seed=77, **kw)
+    hip.attention_fwd(mk())
+    sync()
+    attn = torch.softmax(torch.einsum("bihd,bjhd->bhij", q, k) * 0.2, -1)[0, 0]
+    got = out.cpu()[0, :, 0, :]
+    keep = got != 0
+    assert abs(keep.float().mean().item() - 0.75) < 0.05
+    torch.testing.assert_close(got[keep], (attn / 0.75)[keep], rtol=1e-4, atol=1e-6)
+    # backward with the same seed: dV = (dropped attn)^T dO
+    w = torch.randn(B, T, H, D)
+    wd = cu(w)
+    dq, dk, dv = (torch.empty(B, T, H, D, device=DEV) for _ in range(3))
+    delta = torch.empty(B, H, T, device=DEV)
+    hip.attention_bwd(mk(d_out=wd, dq=dq, dk=dk, dv=dv, delta=delta))
+    sync()
+    torch.testing.assert_close(dv.cpu()[0, :, 0, :], got.T @ w[0, :, 0, :], rtol=1e-4, atol=1e-5)
+
+
+def test_relpos_prepare_and_backward():
+    torch.manual_seed(14)
+    B, T, H, D = 3, 17, 4, 8
+    d = H * D
+    qkv = torch.randn(B, T, 3 * d)
+    k = qkv[:, :, d:2 * d].reshape(B, T, H, D).clone().requires_grad_()
+    p = torch.randn(T, H, D, requires_grad=True)
+    u = torch.randn(H, D, requires_grad=True)
+    v = torch.randn(H, D, requires_grad=True)
+    scale = 1 / math.sqrt(D)
+    kp_ref = k + p[None]
+    kb_ref = scale * (torch.einsum("hd,bthd->bht", u, k) + torch.einsum("hd,thd->ht", v, p)[None])
+    gk, gb = torch.randn_like(kp_ref), torch.randn_like(kb_ref)
+    ((kp_ref * gk).sum() + (kb_ref * gb).sum()).backward()
+    qkvd, pd, ud, vd = cu(qkv), cu(p.detach().reshape(T, d)), cu(u.detach()), cu(v.detach())
+    kd = qkvd[:, :, d:2 * d]
+    kp = torch.empty(B, T, H, D, device=DEV)
+    kb = torch.empty(B, H, T, device=DEV)
+    hip.call("oe_relpos_prepare", kd, T * 3 * d, 3 * d, pd, d, ud, vd, B, T, H, D, scale, kp, kb)
+    sync()
+    torch.testing.assert_close(kp.cpu(), kp_ref.detach(), **TOL)
+    torch.testing.assert_close(kb.cpu(), kb_ref.detach(), **TOL)
+    dqkv = torch.zeros(B, T, 3 * d, device=DEV)
+    dp = torch.empty(T, d, device=DEV)
+    du, dv = torch.zeros(H, D, device=DEV), torch.zeros(H, D, device=DEV)
+    gkd, gbd = cu(gk), cu(gb)
+    hip.call("oe_relpos_backward", gkd, gbd, kd, T * 3 * d, 3 * d, pd, d, ud, vd, B, T, H, D, scale,
+             dqkv[:, :, d:2 * d], dp, d, du, dv)
+    sync()
+    torch.testing.assert_close(dqkv[:, :, d:2 * d].cpu().reshape(B, T, H, D), k.grad, **TOL)
+    torch.testing.assert_close(dp.cpu().view(T, H, D), p.grad, rtol=2e-4, atol=1e-4)
+    torch.testing.assert_close(du.cpu(), u.grad, rtol=2e-4, atol=1e-4)
+    torch.testing.assert_close(dv.cpu(), v.grad, rtol=2e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------ elementwise ----
+def test_glu_dropout_embed_swap_axpby_cmvn():
+    torch.manual_seed(15)
+    rows, d = 77, 32
+    a = torch.randn(rows, 2 * d, requires_grad=True)
+    y_ref = F.glu(a, dim=1)
+    gy = torch.randn(rows, d)
+    y_ref.backward(gy)
+    ad, gyd = cu(a.detach()), cu(gy)
+    y, da = torch.empty(rows, d, device=DEV), torch.empty(rows, 2 * d, device=DEV)
+    hip.call("oe_glu_fwd", ad, rows, d, y)
+    hip.call("oe_glu_bwd", ad, gyd, rows, d, da)
+    sync()
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), **TOL)
+    torch.testing.assert_close(da.cpu(), a.grad, **TOL)
+    # dropout_scale reproduces the GEMM epilogue mask (same seed / index)
+    M, N, K = 64, 128, 16
+    x, w = torch.randn(M, K), torch.randn(N, K)
+    xd, wd = cu(x), cu(w)
+    g1 = torch.empty(M, N, device=DEV)
+    hip.gemm(xd, wd, g1, M, N, K, lda=K, ldb=K, ldc=N, drop_p=0.3, seed=5)
+    g0 = torch.empty(M, N, device=DEV)
+    hip.gemm(xd, wd, g0, M, N, K, lda=K, ldb=K, ldc=N)
+    g2 = torch.empty(M, N, device=DEV)
+    rm = cu((torch.rand(M) > 0.5).to(torch.uint8))
+    hip.call("oe_dropout_scale", g0, M * N, N, 2.0, 0.3, 5, rm, g2)
+    sync()
+    torch.testing.assert_close(g2, 2.0 * g1 * rm[:, None].float(), rtol=1e-6, atol=1e-6)
+    # embedding
+    V, L, B = 30, 7, 3
+    table = torch.randn(V, d, requires_grad=True)
+    tok = torch.randint(0, V, (B, L))
+    pe = O.sinusoid_table(d)[0, :L]
+    ref = F.embedding(tok, table) * math.sqrt(d) + pe
+    go = torch.randn(B, L, d)
+    ref.backward(go)
+    td, tokd, ped, god = cu(table.detach()), cu(tok), cu(pe), cu(go)
+    out = torch.empty(B, L, d, device=DEV)
+    dt = torch.zeros(V, d, device=DEV)
+    hip.call("oe_embed_fwd", tokd, td, ped, B * L, L, d, V, math.sqrt(d), out)
+    hip.call("oe_embed_bwd", tokd, god, B * L, d, V, math.sqrt(d), dt)
+    sync()
+    torch.testing.assert_close(out.cpu(), ref.detach(), **TOL)
+    torch.testing.assert_close(dt.cpu(), table.grad, rtol=2e-4, atol=1e-4)
+    # swap / axpby / cmvn
+    t = torch.randn(5, 6, 9)
+    td2 = cu(t)
+    o = torch.empty(5, 9, 6, device=DEV)
+    hip.call("oe_swap_last2", td2, 5, 6, 9, o, 0)
+    z = torch.empty(5 * 6 * 9, device=DEV)
+    hip.call("oe_axpby", td2, td2, 5 * 6 * 9, 2.0, 0.5, z)
+    mean, istd = torch.randn(9), torch.rand(9) + 0.5
+    md, isd = cu(mean), cu(istd)
+    c = torch.empty(5, 6, 9, device=DEV)
+    hip.call("oe_global_cmvn", td2, md, isd, 5 * 6 * 9, 9, c)
+    sync()
+    assert torch.equal(o.cpu(), t.transpose(1, 2).contiguous())
+    torch.testing.assert_close(z.cpu(), 2.5 * t.flatten())
+    torch.testing.assert_close(c.cpu(), (t - mean) * istd, **TOL)
+
+
+# -------------------------------------------------------------------- conv ----
+def test_conv1_fwd_wgrad_and_conv2_dgrad():
+    torch.manual_seed(16)
+    B, T, Fd, C = 3, 37, 20, 32
+    x = torch.randn(B, T, Fd)
+    w1 = (torch.randn(C, 1, 3, 3) * 0.5).requires_grad_()
+    b1 = torch.randn(C, requires_grad=True)
+    w2 = (torch.randn(C, C, 3, 3) * 0.1).requires_grad_()
+    y1_ref = F.relu(F.conv2d(x.unsqueeze(1), w1, b1, stride=2))            # (B,C,T1,F1)
+    y2_ref = F.conv2d(y1_ref, w2, None, stride=2)
+    g2 = torch.randn_like(y2_ref)
+    y2_ref.backward(g2)
+    T1, F1 = y1_ref.shape[2:]
+    T2, F2 = y2_ref.shape[2:]
+    xd, w1d, b1d = cu(x), cu(w1.detach()), cu(b1.detach())
+    y1 = torch.empty(B, T1, F1, C, device=DEV)
+    hip.call("oe_conv1_fwd", xd, w1d, b1d, B, T, Fd, C, y1)
+    sync()
+    torch.testing.assert_close(y1.cpu().permute(0, 3, 1, 2), y1_ref.detach(), **TOL)
+    # conv2 input gradient: dcol = dy @ W2g (k-major B), then gather + relu mask
+    M = B * T2 * F2
+    w2g = cu(w2.detach().permute(0, 2, 3, 1).reshape(C, 9 * C))
+    dy2 = cu(g2.permute(0, 2, 3, 1).reshape(M, C))
+    dcol = torch.empty(M, 9 * C, device=DEV)
+    hip.gemm(dy2, w2g, dcol, M, 9 * C, C, lda=C, ldb=9 * C, ldc=9 * C, b_kmajor=True)
+    dy1 = torch.empty(B, T1, F1, C, device=DEV)
+    hip.call("oe_col2im_relu", dcol, y1, B, T1, F1, C, dy1)
+    dw1 = torch.zeros(C, 9, device=DEV)
+    db1 = torch.zeros(C, device=DEV)
+    hip.call("oe_conv1_wgrad", xd, dy1, B, T, Fd, C, dw1, db1)
+    sync()
+    torch.testing.assert_close(dw1.cpu().view(C, 1, 3, 3), w1.grad, rtol=5e-4, atol=5e-4)
+    torch.testing.assert_close(db1.cpu(), b1.grad, rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("causal,K,d,T", [(False, 15, 32, 21), (True, 15, 32, 21), (False, 7, 256, 50), (False, 31, 64, 40)])
+def test_dwconv_glu_fwd_bwd(causal, K, d, T):
+    torch.manual_seed(17)
+    B = 3
+    a = torch.randn(B, T, 2 * d, requires_grad=True)
+    w = (torch.randn(d, 1, K) * 0.3).requires_grad_()
+    b = torch.randn(d, requires_grad=True)
+    g = F.glu(a.transpose(1, 2), dim=1)
+    if causal:
+        g = F.pad(g, (K - 1, 0))
+    y_ref = F.conv1d(g, w, b, padding=0 if causal else (K - 1) // 2, groups=d).transpose(1, 2)
+    gy = torch.randn(B, T, d)
+    y_ref.backward(gy)
+    ad, wd, bd, gyd = cu(a.detach()), cu(w.detach()), cu(b.detach()), cu(gy)
+    y = torch.empty(B, T, d, device=DEV)
+    hip.call("oe_dwconv_glu_fwd", ad, wd, bd, B, T, d, K, int(causal), y)
+    da = torch.empty(B, T, 2 * d, device=DEV)
+    dw, db = torch.zeros(d, K, device=DEV), torch.zeros(d, device=DEV)
+    hip.call("oe_dwconv_glu_bwd", ad, gyd, wd, B, T, d, K, int(causal), da, dw, db)
+    sync()
+    torch.testing.assert_close(y.cpu(), y_ref.detach(), **TOL)
+    torch.testing.assert_close(da.cpu(), a.grad, rtol=5e-4, atol=5e-5)
+    torch.testing.assert_close(dw.cpu().view(d, 1, K), w.grad, rtol=5e-4, atol=2e-4)
+    torch.testing.assert_close(db.cpu(), b.grad, rtol=5e-4, atol=2e-4)
+
+
+# -------------------------------------------------------------------- loss ----
+@pytest.mark.parametrize("V,ldv,smooth,nl", [(23, 24, 0.1, False), (3246, 3248, 0.1, False), (50, 52, 0.0, False), (23, 23, 0.1, True)])
+def test_label_smoothing_fused(V, ldv, smooth, nl):
+    torch.manual_seed(18)
+    B, L = 4, 6
+    x = (torch.randn(B, L, V) * 2).requires_grad_()
+    tgt = torch.randint(0, V, (B, L))
+    tgt[1, 4:] = -1
+    tgt[3, 2:] = -1
+    cfg = O.Config(vocab_size=V, lsm_weight=smooth, length_normalized_loss=nl)
+    loss = O.label_smoothing_loss(cfg, x, tgt)
+    loss.backward()
+    acc = O.token_accuracy(x.detach().view(-1, V), tgt, -1)
+    buf = torch.zeros(B * L, ldv, device=DEV)
+    buf[:, :V] = x.detach().reshape(B * L, V).to(DEV)
+    tg = cu(tgt.reshape(-1))
+    out3 = torch.empty(3, device=DEV)
+    ws = torch.empty(hip.lib().oe_lsm_workspace_bytes(B * L), dtype=torch.uint8, device=DEV)
+    hip.call("oe_lsm_loss_fused", buf, ldv, B * L, V, tg, -1, smooth, int(nl), float(B), 1.0, 1, out3, ws)
+    sync()
+    o = out3.cpu()
+    torch.testing.assert_close(o[0], loss.detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(o[1] / o[2], acc, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(buf[:, :V].cpu().view(B, L, V), x.grad, rtol=1e-3, atol=1e-6)
+
+
+# --------------------------------------------------------------- optimiser ----
+def test_grad_norm_and_adam_match_torch():
+    torch.manual_seed(19)
+    n = 100003
+    p0, g0 = torch.randn(n), torch.randn(n) * 3
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    p = torch.zeros(n + 1, device=DEV)[:n]          # 16-byte aligned arena
+    p.copy_(p0)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    state = torch.zeros(2, device=DEV)
+    ws = torch.empty(hip.lib().oe_grad_norm_workspace_floats(), device=DEV)
+    norm = torch.empty(1, device=DEV)
+    lr_dev = torch.tensor([1e-3], device=DEV)
+    for it in range(3):
+        g = g0 * (it + 1)
+        ref.grad = g.clone()
+        tn = torch.nn.utils.clip_grad_norm_([ref], 5.0)
+        opt.step()
+        gd = cu(g)
+        hip.call("oe_grad_norm", gd, n, ws, norm)
+        hip.call("oe_adam_step", p, gd, m, v, n, lr_dev, 0.0, 0.9, 0.999, 1e-8, 5.0, norm, state)
+        sync()
+        torch.testing.assert_close(norm.cpu()[0], tn, rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(p.cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    # a non-finite gradient norm skips the step entirely (executor.py:59-60)
+    before, step_before = p.clone(), state.clone()
+    bad = cu(torch.full((n,), float("inf")))
+    hip.call("oe_grad_norm", bad, n, ws, norm)
+    hip.call("oe_adam_step", p, bad, m, v, n, lr_dev, 0.0, 0.9, 0.999, 1e-8, 5.0, norm, state)
+    sync()
+    assert torch.equal(p, before) and torch.equal(state, step_before)
