@@ -47,6 +47,10 @@ int oe_abi_version(void);
  *     the batch, i.e. x*sqrt(d)+pe of embedding.py:59) ;
  *     C = v | C += v (accumulate) | atomicAdd (atomic_out, required when
  *     split_k > 1; C must hold the running value, e.g. zeros).
+ *   beta must be set (1.0 = plain).  Dropout masks are a pure function of
+ *   (seed + *seed_dev * golden, element index): the same arguments regenerate
+ *   the mask in backward; seed_dev (optional device counter) lets a captured
+ *   HIP graph draw fresh masks on every replay.
  * ------------------------------------------------------------------------- */
 enum { OE_GATHER_NONE = 0, OE_GATHER_A = 1, OE_GATHER_B = 2 };
 
@@ -60,7 +64,7 @@ typedef struct oe_gemm_args {
     const float* bias;
     int act;
     float* preact_out; const float* actgrad_in; long ld_aux;
-    float drop_p; unsigned long long seed;
+    float drop_p; unsigned long long seed; const unsigned long long* seed_dev;
     const unsigned char* rowmask;
     const float* residual; long ldr; int res_row_mod; float beta;
     int accumulate; int atomic_out;
@@ -80,16 +84,18 @@ int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const flo
  * rowmask (optional, [rows] bytes): rows with 0 produce an all-zero output
  * row - the masked_fill_ of convolution.py:88-89 fused into norm_conv.
  * stats (optional out): [rows][2] = (mean, rstd) kept for backward.
+ * act: activation applied to the normalised output (convolution.py:110:
+ * activation(norm(x))); backward then needs beta to rebuild the pre-activation.
  * ------------------------------------------------------------------------- */
 int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
-                     const unsigned char* rowmask, float* y, float* stats, void* stream);
+                     const unsigned char* rowmask, int act, float* y, float* stats, void* stream);
 /* dx = LN'(dy) (+ add, optional: the residual branch's gradient of the
  * pre-norm blocks, may alias dx); dgamma/dbeta ACCUMULATED atomically (caller
  * zeroes them).  rowmask as in forward (masked rows: LN'(dy) = 0, no
  * dgamma/dbeta contribution). */
-int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int d,
-                     const unsigned char* rowmask, const float* add, float* dx, float* dgamma, float* dbeta,
-                     void* stream);
+int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                     const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
+                     float* dx, float* dgamma, float* dbeta, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * CTC head: log_softmax + CTCLoss(reduction='sum', zero_infinity=True) and
@@ -141,7 +147,7 @@ typedef struct oe_attn_args {
     const float* keybias;
     int B, H, T1, T2, D;
     float scale;
-    float drop_p; unsigned long long seed;
+    float drop_p; unsigned long long seed; const unsigned long long* seed_dev;
     /* backward only */
     const float* d_out;
     float* dq; float* dk; float* dv;
@@ -173,7 +179,7 @@ int oe_glu_bwd(const float* a, const float* dy, long rows, int d, float* da, voi
  * rowmask==0 -> 0.  Backward of the dropout/mask epilogues (torch.nn.Dropout in
  * encoder_layer.py:83,89,95,106 and decoder_layer.py:92,97,106). */
 int oe_dropout_scale(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
-                     const unsigned char* rowmask, float* out, void* stream);
+                     const unsigned long long* seed_dev, const unsigned char* rowmask, float* out, void* stream);
 
 /* Token embedding * sqrt(d) + positional table (decoder.py:144-147 +
  * embedding.py:59): out[r,:] = table[tok[r],:]*xscale + pe[r % L,:]; backward
@@ -188,8 +194,15 @@ int oe_embed_bwd(const long long* tokens, const float* dout, long rows, int d, i
  * flatten) and the NHWC kernels. */
 int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out, int accumulate, void* stream);
 
-/* out = a*x + b*y (y may be NULL). */
-int oe_axpby(const float* x, const float* y, long n, float a, float b, float* out, void* stream);
+/* out = a*(*a_dev)*x + b*y (y, a_dev may be NULL). */
+int oe_axpby(const float* x, const float* y, long n, float a, float b, const float* a_dev, float* out, void* stream);
+
+/* y = act(x) (swish.py:15-17) and out = dy * act'(pre). */
+int oe_act_fwd(const float* x, long n, int act, float* y, void* stream);
+int oe_act_grad(const float* dy, const float* pre, long n, int act, float* out, void* stream);
+
+/* log_softmax over the last dim (ctc.py:56-64; asr_model.py:484-488). */
+int oe_log_softmax(const float* x, long rows, int V, float* out, void* stream);
 
 /* GlobalCMVN (modules/cmvn.py:43-45): y = (x - mean[f]) * istd[f]. */
 int oe_global_cmvn(const float* x, const float* mean, const float* istd, long n, int F, float* y, void* stream);

@@ -42,8 +42,11 @@ struct AttnParams {
     float* dkeybias;                     // (B,H,T2) or null
     int B, H, T1, T2, D;
     float scale;
-    float drop_p; unsigned long long seed;
+    float drop_p; unsigned long long seed; const unsigned long long* seed_dev;
 };
+__device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, const unsigned long long* dev) {
+    return seed + (dev ? *dev * 0x9E3779B97F4A7C15ull : 0ull);
+}
 
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
@@ -103,6 +106,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
     const unsigned char* mrow = p.mask ? p.mask + (long)b * p.m_bs + (long)(q_ok ? qi : 0) * p.m_rs : nullptr;
 
     for (int j0 = 0; j0 < p.T2; j0 += 32) {
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(r, lk));
-                    pr[r] *= dropout_scale(p.seed, idx, p.drop_p, inv_keep);
+                    pr[r] *= dropout_scale(seed_eff, idx, p.drop_p, inv_keep);
                 }
             }
             // O^T[dv, query] += V^T[dv, key] P^T[key, query]
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
                 float dpv = dpacc[r];
                 if (p.drop_p > 0.f) {
                     const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(r, lk));
-                    dpv *= dropout_scale(p.seed, idx, p.drop_p, inv_keep);
+                    dpv *= dropout_scale(seed_eff, idx, p.drop_p, inv_keep);
                 }
                 pr[r] = pv * (dpv - delta_i);     // dS^T
             }
@@ -245,6 +249,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
         for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
     float dbias = 0.f;
     const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
 
     for (int i0 = 0; i0 < p.T1; i0 += 32) {
         __syncthreads();
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
             if (ok && p.mask) ok = p.mask[(long)b * p.m_bs + (long)qi * p.m_rs + kj] != 0;
             const float pv = ok ? __expf(sacc[r] + kbias - lse_s[qr]) : 0.f;
             float dscale = 1.f;
-            if (p.drop_p > 0.f) dscale = dropout_scale(p.seed, ((unsigned long long)(bh * p.T1 + min(qi, p.T1 - 1))) * p.T2 + min(kj, p.T2 - 1), p.drop_p, inv_keep);
+            if (p.drop_p > 0.f) dscale = dropout_scale(seed_eff, ((unsigned long long)(bh * p.T1 + min(qi, p.T1 - 1))) * p.T2 + min(kj, p.T2 - 1), p.drop_p, inv_keep);
             pd[r] = pv * dscale;                                   // dropped attention weights
             ds[r] = pv * (dpacc[r] * dscale - delta_s[qr]);        // dS
             dbias += ds[r];
@@ -333,7 +338,7 @@ static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {
     p.mask = a->mask; p.m_bs = a->mask_bstride; p.m_rs = a->mask_rstride;
     p.keybias = a->keybias; p.dkeybias = a->dkeybias;
     p.B = a->B; p.H = a->H; p.T1 = a->T1; p.T2 = a->T2; p.D = a->D;
-    p.scale = a->scale; p.drop_p = a->drop_p; p.seed = a->seed;
+    p.scale = a->scale; p.drop_p = a->drop_p; p.seed = a->seed; p.seed_dev = a->seed_dev;
     return 0;
 }
 

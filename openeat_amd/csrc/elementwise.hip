@@ -120,19 +120,21 @@ extern "C" int oe_glu_bwd(const float* a, const float* dy, long rows, int d, flo
 // ---------------------------------------------------------------- dropout ----
 // out[i] = alpha * x[i] * keep(seed, i)/(1-p) ; rowmask (optional, per row of `cols`) zeroes rows.
 __global__ void dropout_scale_kernel(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
+                                     const unsigned long long* __restrict__ seed_dev,
                                      const unsigned char* __restrict__ rowmask, float* out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
     float v = x[i] * alpha;
     if (p > 0.f) v *= dropout_scale(seed, (unsigned long long)i, p, 1.f / (1.f - p));
     if (rowmask && !rowmask[i / cols]) v = 0.f;
     out[i] = v;
 }
 extern "C" int oe_dropout_scale(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
-                                const unsigned char* rowmask, float* out, void* stream) {
+                                const unsigned long long* seed_dev, const unsigned char* rowmask, float* out, void* stream) {
     OE_REQUIRE(x && out && n > 0 && cols > 0 && p >= 0.f && p < 1.f, "oe_dropout_scale: bad arguments");
     hipLaunchKernelGGL(dropout_scale_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, cols, alpha, p, seed,
-                       rowmask, out);
+                       seed_dev, rowmask, out);
     OE_LAUNCH_CHECK("dropout_scale");
     return 0;
 }
@@ -196,13 +198,14 @@ extern "C" int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out
 }
 
 // ------------------------------------------------------------------ axpby ----
-__global__ void axpby_kernel(const float* x, const float* y, long n, float a, float b, float* out) {
+__global__ void axpby_kernel(const float* x, const float* y, long n, float a, float b, const float* a_dev, float* out) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a_dev) a *= *a_dev;
     if (i < n) out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
-extern "C" int oe_axpby(const float* x, const float* y, long n, float a, float b, float* out, void* stream) {
+extern "C" int oe_axpby(const float* x, const float* y, long n, float a, float b, const float* a_dev, float* out, void* stream) {
     OE_REQUIRE(x && out && n > 0, "oe_axpby: bad arguments");
-    hipLaunchKernelGGL(axpby_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b, out);
+    hipLaunchKernelGGL(axpby_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, a, b, a_dev, out);
     OE_LAUNCH_CHECK("axpby");
     return 0;
 }
@@ -217,5 +220,54 @@ extern "C" int oe_global_cmvn(const float* x, const float* mean, const float* is
     OE_REQUIRE(x && mean && istd && y && n > 0 && F > 0, "oe_global_cmvn: bad arguments");
     hipLaunchKernelGGL(cmvn_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, mean, istd, n, F, y);
     OE_LAUNCH_CHECK("global_cmvn");
+    return 0;
+}
+
+// out = dy * act'(pre)  (stand-alone Linear+activation backward)
+__global__ void act_grad_kernel(const float* __restrict__ dy, const float* __restrict__ pre, long n, int act, float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = dy[i] * act_bwd(act, pre[i]);
+}
+extern "C" int oe_act_grad(const float* dy, const float* pre, long n, int act, float* out, void* stream) {
+    OE_REQUIRE(dy && pre && out && n > 0, "oe_act_grad: bad arguments");
+    hipLaunchKernelGGL(act_grad_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dy, pre, n, act, out);
+    OE_LAUNCH_CHECK("act_grad");
+    return 0;
+}
+
+// log_softmax over rows (ctc.py:56-64; asr_model.py:484-488), one wave per row
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ x, long rows, int V, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + row * V;
+    float m = -INFINITY, s = 0.f;
+    for (int i = lane; i < V; i += 64) {
+        const float v = p[i];
+        const float mn = fmaxf(m, v);
+        s = s * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    }
+    if (m == -INFINITY) s = 0.f;
+    wave_lse(m, s);
+    const float lse = m + __logf(s);
+    for (int i = lane; i < V; i += 64) out[row * V + i] = p[i] - lse;
+}
+extern "C" int oe_log_softmax(const float* x, long rows, int V, float* out, void* stream) {
+    OE_REQUIRE(x && out && rows > 0 && V > 0, "oe_log_softmax: bad arguments");
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, V, out);
+    OE_LAUNCH_CHECK("log_softmax");
+    return 0;
+}
+
+// y = act(x) (stand-alone activation module, swish.py:15-17)
+__global__ void act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = act_fwd(act, x[i]);
+}
+extern "C" int oe_act_fwd(const float* x, long n, int act, float* y, void* stream) {
+    OE_REQUIRE(x && y && n > 0, "oe_act_fwd: bad arguments");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, n, act, y);
+    OE_LAUNCH_CHECK("act_fwd");
     return 0;
 }

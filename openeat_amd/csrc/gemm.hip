@@ -71,6 +71,7 @@ struct EpiParams {
     long ld_aux;
     float drop_p;
     unsigned long long seed;
+    const unsigned long long* seed_dev;
     const unsigned char* rowmask;
     const float* residual;
     long ldr;
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
     float alpha = ep.alpha;
     if (ep.alpha_dev) alpha *= *ep.alpha_dev;
     const float inv_keep = ep.drop_p > 0.f ? 1.f / (1.f - ep.drop_p) : 1.f;
+    const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const bool first_split = (blockIdx.z == 0);
     constexpr int EP_LD = 36;
     float* patch = lds + wave * (32 * EP_LD);
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
                     pre[e] = x;
                     if (ep.actgrad_in) x *= act_bwd(ep.act, aux[e]);
                     else x = act_fwd(ep.act, x);
-                    if (ep.drop_p > 0.f) x *= dropout_scale(ep.seed, (unsigned long long)(row * N + col + e), ep.drop_p, inv_keep);
+                    if (ep.drop_p > 0.f) x *= dropout_scale(seed, (unsigned long long)(row * N + col + e), ep.drop_p, inv_keep);
                     if (row_dead) x = 0.f;
                     x = res[e] + ep.beta * x;
                     v[e] = x;
@@ -332,7 +334,7 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     EpiParams ep{};
     ep.alpha = g->alpha; ep.alpha_dev = g->alpha_dev; ep.bias = g->bias; ep.act = g->act;
     ep.preact_out = g->preact_out; ep.actgrad_in = g->actgrad_in; ep.ld_aux = g->ld_aux ? g->ld_aux : g->ldc;
-    ep.drop_p = g->drop_p; ep.seed = g->seed; ep.rowmask = g->rowmask;
+    ep.drop_p = g->drop_p; ep.seed = g->seed; ep.seed_dev = g->seed_dev; ep.rowmask = g->rowmask;
     ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
     ep.accumulate = g->accumulate; ep.atomic = g->atomic_out;
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;

@@ -8,7 +8,7 @@
 
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int rows, int d,
-                                                             const unsigned char* __restrict__ rowmask,
+                                                             const unsigned char* __restrict__ rowmask, int act,
                                                              float* __restrict__ y, float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -45,10 +45,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!dead) {
                 const float4 g = g4[i], bb = b4[i];
-                o.x = (v[j].x - mean) * rstd * g.x + bb.x;
-                o.y = (v[j].y - mean) * rstd * g.y + bb.y;
-                o.z = (v[j].z - mean) * rstd * g.z + bb.z;
-                o.w = (v[j].w - mean) * rstd * g.w + bb.w;
+                o.x = act_fwd(act, (v[j].x - mean) * rstd * g.x + bb.x);
+                o.y = act_fwd(act, (v[j].y - mean) * rstd * g.y + bb.y);
+                o.z = act_fwd(act, (v[j].z - mean) * rstd * g.z + bb.z);
+                o.w = act_fwd(act, (v[j].w - mean) * rstd * g.w + bb.w);
             }
             yr[i] = o;
         }
@@ -58,7 +58,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 #define LNB_ROWS 32   // rows per block in backward (8 per wave)
 
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                             const float* __restrict__ gamma, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int act,
+                                                             const float* __restrict__ stats,
                                                              int rows, int d, const unsigned char* __restrict__ rowmask,
                                                              const float* add, float* dx,
                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -66,11 +67,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    float4 gam[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+    float4 gam[LN_MAXV], bet[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
         const int i = lane + 64 * j;
         gam[j] = (i < nv) ? g4[i] : make_float4(0, 0, 0, 0);
+        bet[j] = (i < nv && act) ? b4[i] : make_float4(0, 0, 0, 0);
         dg[j] = make_float4(0, 0, 0, 0);
         db[j] = make_float4(0, 0, 0, 0);
     }
@@ -97,8 +100,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int j = 0; j < LN_MAXV; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
-                const float4 dyv = dyr[i], xv = xr[i];
+                float4 dyv = dyr[i];
+                const float4 xv = xr[i];
                 xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                if (act) {   // y = act(ln): chain through the activation at the recomputed pre-activation
+                    dyv.x *= act_bwd(act, xh[j].x * gam[j].x + bet[j].x); dyv.y *= act_bwd(act, xh[j].y * gam[j].y + bet[j].y);
+                    dyv.z *= act_bwd(act, xh[j].z * gam[j].z + bet[j].z); dyv.w *= act_bwd(act, xh[j].w * gam[j].w + bet[j].w);
+                }
                 g[j] = make_float4(dyv.x * gam[j].x, dyv.y * gam[j].y, dyv.z * gam[j].z, dyv.w * gam[j].w);
                 s1 += g[j].x + g[j].y + g[j].z + g[j].w;
                 s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
@@ -136,22 +144,22 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
-                                const unsigned char* rowmask, float* y, float* stats, void* stream) {
+                                const unsigned char* rowmask, int act, float* y, float* stats, void* stream) {
     OE_REQUIRE(x && gamma && beta && y, "oe_layernorm_fwd: null pointer");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
-                       rows, d, rowmask, y, stats);
+                       rows, d, rowmask, act, y, stats);
     OE_LAUNCH_CHECK("layernorm_fwd");
     return 0;
 }
 
-extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, int rows, int d,
-                                const unsigned char* rowmask, const float* add, float* dx, float* dgamma, float* dbeta,
-                                void* stream) {
-    OE_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta, "oe_layernorm_bwd: null pointer");
+extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                                const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
+                                float* dx, float* dgamma, float* dbeta, void* stream) {
+    OE_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta && (beta || !act), "oe_layernorm_bwd: null pointer");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(oe_cdiv(rows, LNB_ROWS)), dim3(256), (size_t)8 * d * sizeof(float),
-                       (hipStream_t)stream, dy, x, gamma, stats, rows, d, rowmask, add, dx, dgamma, dbeta);
+                       (hipStream_t)stream, dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dgamma, dbeta);
     OE_LAUNCH_CHECK("layernorm_bwd");
     return 0;
 }

@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
         ("bias", c_fp),
         ("act", C.c_int),
         ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
-        ("drop_p", C.c_float), ("seed", C.c_ulonglong),
+        ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("seed_dev", c_fp),
         ("rowmask", c_fp),
         ("residual", c_fp), ("ldr", C.c_long), ("res_row_mod", C.c_int), ("beta", C.c_float),
         ("accumulate", C.c_int), ("atomic_out", C.c_int),
@@ -53,7 +53,7 @@ class AttnArgs(C.Structure):
         ("keybias", c_fp),
         ("B", C.c_int), ("H", C.c_int), ("T1", C.c_int), ("T2", C.c_int), ("D", C.c_int),
         ("scale", C.c_float),
-        ("drop_p", C.c_float), ("seed", C.c_ulonglong),
+        ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("seed_dev", c_fp),
         ("d_out", c_fp), ("dq", c_fp), ("dk", c_fp), ("dv", c_fp), ("dkeybias", c_fp), ("delta", c_fp),
     ]
 
@@ -86,8 +86,8 @@ _SIGNATURES = {
     "oe_abi_version": (I, []),
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
-    "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, P, P, P]),
-    "oe_layernorm_bwd": (I, [P, P, P, P, I, I, P, P, P, P, P, P]),
+    "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
+    "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
@@ -97,11 +97,14 @@ _SIGNATURES = {
     "oe_relpos_backward": (I, [P, P, P, L, L, P, L, P, P, I, I, I, I, F, P, P, L, P, P, P]),
     "oe_glu_fwd": (I, [P, L, I, P, P]),
     "oe_glu_bwd": (I, [P, P, L, I, P, P]),
-    "oe_dropout_scale": (I, [P, L, I, F, F, U64, P, P, P]),
+    "oe_dropout_scale": (I, [P, L, I, F, F, U64, P, P, P, P]),
     "oe_embed_fwd": (I, [P, P, P, L, I, I, I, F, P, P]),
     "oe_embed_bwd": (I, [P, P, L, I, I, F, P, P]),
     "oe_swap_last2": (I, [P, L, I, I, P, I, P]),
-    "oe_axpby": (I, [P, P, L, F, F, P, P]),
+    "oe_axpby": (I, [P, P, L, F, F, P, P, P]),
+    "oe_act_fwd": (I, [P, L, I, P, P]),
+    "oe_act_grad": (I, [P, P, L, I, P, P]),
+    "oe_log_softmax": (I, [P, L, I, P, P]),
     "oe_global_cmvn": (I, [P, P, P, L, I, P, P]),
     "oe_conv1_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
@@ -146,7 +149,7 @@ def _dev_f32(t: torch.Tensor, name: str):
 # thin typed wrappers
 # --------------------------------------------------------------------------- #
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
-         bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, rowmask=None,
+         bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, seed_dev=None, rowmask=None,
          residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE):
     g = GemmArgs()
     g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
@@ -161,6 +164,7 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.actgrad_in = None if actgrad_in is None else actgrad_in.data_ptr()
     g.ld_aux = ld_aux
     g.drop_p, g.seed = drop_p, seed
+    g.seed_dev = None if seed_dev is None else seed_dev.data_ptr()
     g.rowmask = None if rowmask is None else rowmask.data_ptr()
     g.residual = None if residual is None else residual.data_ptr()
     g.ldr, g.beta, g.res_row_mod = ldr, beta, res_row_mod
@@ -183,7 +187,7 @@ def call(name, *args):
 
 
 def attn_args(q, k, v, out, lse, B, H, T1, T2, D, scale, *, q_strides, k_strides, v_strides, o_strides, mask=None,
-              mask_strides=(0, 0), keybias=None, drop_p=0.0, seed=0, d_out=None, dq=None, dk=None, dv=None,
+              mask_strides=(0, 0), keybias=None, drop_p=0.0, seed=0, seed_dev=None, d_out=None, dq=None, dk=None, dv=None,
               dkeybias=None, delta=None):
     a = AttnArgs()
     dp = lambda t: None if t is None else t.data_ptr()
@@ -196,6 +200,7 @@ def attn_args(q, k, v, out, lse, B, H, T1, T2, D, scale, *, q_strides, k_strides
     a.keybias = dp(keybias)
     a.B, a.H, a.T1, a.T2, a.D = B, H, T1, T2, D
     a.scale, a.drop_p, a.seed = scale, drop_p, seed
+    a.seed_dev = dp(seed_dev)
     a.d_out, a.dq, a.dk, a.dv, a.dkeybias, a.delta = dp(d_out), dp(dq), dp(dk), dp(dv), dp(dkeybias), dp(delta)
     return a
 

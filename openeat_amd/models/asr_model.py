@@ -1,0 +1,219 @@
+"""CTC / attention hybrid ASR model with the reference's public surface
+(/root/reference/openeat/models/asr_model.py): constructor kwargs = YAML
+``model_conf`` keys, ``forward(features, features_length, targets,
+targets_length) -> (loss, acc)``, the four decoding entry points, and the same
+flat state-dict keys.  All tensor arithmetic runs in the gfx950 kernels."""
+from collections import defaultdict
+from typing import List, Optional, Tuple
+
+import torch
+
+from openeat_amd import ops
+from openeat_amd.modules.cmvn import GlobalCMVN
+from openeat_amd.modules.ctc import CTC
+from openeat_amd.modules.decoder import BiTransformerDecoder
+from openeat_amd.modules.encoder import TransformerEncoder
+from openeat_amd.modules.label_smoothing_loss import LabelSmoothingLoss
+from openeat_amd.utils.cmvn import load_cmvn
+from openeat_amd.utils.common import (IGNORE_ID, add_sos_eos, log_add, remove_duplicates_and_blank, reverse_pad_list)
+from openeat_amd.utils.mask import make_pad_mask, mask_finished_preds, mask_finished_scores, subsequent_mask
+
+
+class ASRModel(torch.nn.Module):
+    def __init__(self, input_size: int, vocab_size: int, is_json_cmvn: bool = True, cmvn_file: str = None,
+                 cn_cmvn_file: str = None, en_cmvn_file: str = None, encoder_num_blocks: int = 12,
+                 encoder_num_blocks_share: int = 1, decoder_num_blocks: int = 6, r_decoder_num_blocks: int = 0,
+                 decoder_num_blocks_share: int = 1, input_layer: str = "conv2d", pos_enc_layer_type: str = "rel_pos",
+                 d_model: int = 256, attention_heads: int = 4, linear_units: int = 1024, dropout_rate: float = 0.1,
+                 activation_type: str = "swish", macaron_style: bool = True, use_cnn_module: bool = True,
+                 cnn_module_kernel: int = 15, causal: bool = False, encoder_use_adapter: bool = False,
+                 decoder_use_adapter: bool = False, down_size: int = 64, scalar: float = 0.1, ctc_weight: float = 0.3,
+                 lsm_weight: float = 0.1, reverse_weight: float = 0.0, length_normalized_loss: bool = False,
+                 ignore_id=IGNORE_ID):
+        super().__init__()
+        self.input_size = input_size
+        self.vocab_size = vocab_size
+        self.sos = vocab_size - 1
+        self.eos = vocab_size - 1
+        self.ignore_id = ignore_id
+        self.ctc_weight = ctc_weight
+        self.reverse_weight = reverse_weight
+        global_cmvn = None
+        if cmvn_file is not None:
+            mean, istd = load_cmvn(cmvn_file, is_json_cmvn)
+            global_cmvn = GlobalCMVN(torch.from_numpy(mean).float(), torch.from_numpy(istd).float())
+        self.encoder = TransformerEncoder(
+            input_size, input_layer, pos_enc_layer_type, d_model, dropout_rate, attention_heads, linear_units,
+            activation_type, macaron_style, use_cnn_module, cnn_module_kernel, causal, encoder_use_adapter, down_size,
+            scalar, num_blocks=encoder_num_blocks, num_blocks_share=encoder_num_blocks_share, global_cmvn=global_cmvn)
+        self.ctc = CTC(vocab_size, d_model, length_normalized_loss)
+        self.decoder = BiTransformerDecoder(
+            vocab_size, d_model, dropout_rate, attention_heads, linear_units, decoder_use_adapter, down_size, scalar,
+            num_blocks=decoder_num_blocks, r_num_blocks=r_decoder_num_blocks, num_blocks_share=decoder_num_blocks_share)
+        self.criterion_att = LabelSmoothingLoss(size=vocab_size, padding_idx=ignore_id, smoothing=lsm_weight,
+                                                normalize_length=length_normalized_loss)
+
+    # ------------------------------------------------------------------ train --
+    def _encode(self, features, features_length):
+        masks = ~make_pad_mask(features_length, features.size(1)).unsqueeze(1)      # (B,1,T)
+        return self.encoder(features, masks)
+
+    def forward(self, features: torch.Tensor, features_length: torch.Tensor, targets: torch.Tensor,
+                targets_length: torch.Tensor) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """asr_model.py:126-157."""
+        assert targets_length.dim() == 1, targets_length.shape
+        assert (features.shape[0] == features_length.shape[0] == targets.shape[0] == targets_length.shape[0]), \
+            (features.shape, features_length.shape, targets.shape, targets_length.shape)
+        encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        encoder_out_lens = encoder_mask.squeeze(1).sum(1)
+        loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
+        if self.ctc_weight < 1:
+            loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length)
+            return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att, acc
+        return loss_ctc, None
+
+    def _calc_att_loss(self, encoder_out, encoder_mask, ys_pad, ys_pad_lens):
+        """asr_model.py:159-203; the output layers are fused with the loss."""
+        ys_in_pad, ys_out_pad = add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
+        ys_in_lens = ys_pad_lens + 1
+        L = ys_in_pad.size(1)
+        tgt_mask = (~make_pad_mask(ys_in_lens, L)).unsqueeze(1) & subsequent_mask(L, device=ys_in_pad.device).unsqueeze(0)
+        dec = self.decoder
+        l_hid = dec.left_decoder.hidden(ys_in_pad, tgt_mask, encoder_out, encoder_mask)
+        lo = dec.left_decoder.output_layer
+        loss_att, n_ok, n_valid = self.criterion_att.fused_head(l_hid, lo.weight, lo.bias, ys_out_pad)
+        if self.reverse_weight > 0:
+            r_ys_pad = reverse_pad_list(ys_pad, ys_pad_lens, float(self.ignore_id))
+            r_ys_in_pad, r_ys_out_pad = add_sos_eos(r_ys_pad, self.sos, self.eos, self.ignore_id)
+            r_hid = dec.right_decoder.hidden(r_ys_in_pad, tgt_mask, encoder_out, encoder_mask)
+            ro = dec.right_decoder.output_layer
+            r_loss, _, _ = self.criterion_att.fused_head(r_hid, ro.weight, ro.bias, r_ys_out_pad)
+            loss_att = loss_att * (1 - self.reverse_weight) + r_loss * self.reverse_weight
+        return loss_att, torch.true_divide(n_ok, n_valid)
+
+    # ----------------------------------------------------------------- decode --
+    def ctc_greedy_search(self, features: torch.Tensor, features_length: torch.Tensor) -> List[List[int]]:
+        """asr_model.py:297-326: argmax / eos-fill / collapse all on device; one D2H copy of the result."""
+        assert features.shape[0] == features_length.shape[0]
+        encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        lens = encoder_mask.squeeze(1).sum(1)
+        logits = self.ctc.logits(encoder_out)
+        B, T, V = logits.shape
+        toks, n = ops.ctc_greedy(logits, V, B, T, V, lens, self.eos)
+        toks, n = toks.cpu(), n.cpu()
+        return [toks[b, : int(n[b])].tolist() for b in range(B)]
+
+    def _ctc_prefix_beam_search(self, features, features_length, beam_size: int):
+        """asr_model.py:328-396 (batch of one): log-probs computed on device, the prefix recursion on host."""
+        assert features.shape[0] == features_length.shape[0]
+        assert features.shape[0] == 1
+        encoder_out, _, _ = self._encode(features, features_length)
+        ctc_probs = self.ctc.log_softmax(encoder_out).squeeze(0)
+        top_p, top_i = ctc_probs.topk(beam_size, dim=1)
+        top_p, top_i = top_p.cpu().tolist(), top_i.cpu().tolist()
+        NEG = -float("inf")
+        cur = [(tuple(), (0.0, NEG))]
+        for t in range(len(top_i)):
+            nxt = defaultdict(lambda: (NEG, NEG))
+            for s, ps in zip(top_i[t], top_p[t]):
+                for prefix, (pb, pnb) in cur:
+                    last = prefix[-1] if prefix else None
+                    if s == 0:
+                        b0, n0 = nxt[prefix]
+                        nxt[prefix] = (log_add([b0, pb + ps, pnb + ps]), n0)
+                    elif s == last:
+                        b0, n0 = nxt[prefix]
+                        nxt[prefix] = (b0, log_add([n0, pnb + ps]))
+                        ext = prefix + (s,)
+                        b1, n1 = nxt[ext]
+                        nxt[ext] = (b1, log_add([n1, pb + ps]))
+                    else:
+                        ext = prefix + (s,)
+                        b1, n1 = nxt[ext]
+                        nxt[ext] = (b1, log_add([n1, pb + ps, pnb + ps]))
+            cur = sorted(nxt.items(), key=lambda kv: log_add(list(kv[1])), reverse=True)[:beam_size]
+        return [(p, log_add([pb, pnb])) for p, (pb, pnb) in cur], encoder_out
+
+    def ctc_prefix_beam_search(self, features, features_length, beam_size: int) -> List[int]:
+        hyps, _ = self._ctc_prefix_beam_search(features, features_length, beam_size)
+        return hyps[0][0]
+
+    def attention_rescoring(self, features, features_length, beam_size: int, ctc_weight: float = 0.0,
+                            reverse_weight: float = 0.0, lm: Optional[torch.nn.Module] = None, lm_weight: float = 0,
+                            autoregressive: bool = True, token2char: dict = {}):
+        """asr_model.py:418-534."""
+        assert features.shape[0] == features_length.shape[0] == 1
+        device = features.device
+        hyps, encoder_out = self._ctc_prefix_beam_search(features, features_length, beam_size)
+        assert len(hyps) == beam_size
+        lens = torch.tensor([len(h[0]) for h in hyps], device=device, dtype=torch.long)
+        Lm = int(lens.max())
+        ori = torch.full((beam_size, Lm), self.ignore_id, dtype=torch.long, device=device)
+        for i, h in enumerate(hyps):
+            ori[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long, device=device)
+        hyps_pad, _ = add_sos_eos(ori, self.sos, self.eos, self.ignore_id)
+        in_lens = lens + 1
+        L = hyps_pad.size(1)
+        hyps_mask = (~make_pad_mask(in_lens, L)).unsqueeze(1) & subsequent_mask(L, device=device).unsqueeze(0)
+        enc = encoder_out.repeat(beam_size, 1, 1)
+        enc_mask = torch.ones(beam_size, 1, enc.size(1), dtype=torch.bool, device=device)
+        r_pad = reverse_pad_list(ori, lens, self.ignore_id)
+        r_hyps_pad, _ = add_sos_eos(r_pad, self.sos, self.eos, self.ignore_id)
+        if reverse_weight > 0 and self.decoder.r_num_blocks == 0:
+            raise IndexError("reverse_weight > 0 needs r_decoder_num_blocks > 0 (as in the reference)")
+        decoder_out, r_decoder_out, pre = self.decoder(enc, enc_mask, hyps_pad, r_hyps_pad, hyps_mask)
+        l_lp = ops.log_softmax_rows(decoder_out).cpu().numpy()
+        r_lp = ops.log_softmax_rows(r_decoder_out).cpu().numpy() if self.decoder.r_num_blocks > 0 else None
+        use_nn_lm = lm_weight > 0 and isinstance(lm, torch.nn.Module)
+        if use_nn_lm:
+            raise NotImplementedError("the reference LanguageModel cannot be constructed (language_model.py:53); "
+                                      "neural LM fusion is specified in DESIGN.md as a next step")
+        best, best_i = -float("inf"), 0
+        for i, (hyp, ctc_score) in enumerate(hyps):
+            score = sum(l_lp[i][j][w] for j, w in enumerate(hyp)) + l_lp[i][len(hyp)][self.eos]
+            lm_score = 0.0
+            if lm_weight > 0 and lm is not None:
+                lm_score = lm.score(" ".join(token2char[w] for w in hyp), bos=True, eos=True)
+            if reverse_weight > 0:
+                r = sum(r_lp[i][len(hyp) - j - 1][w] for j, w in enumerate(hyp)) + r_lp[i][len(hyp)][self.eos]
+                score = score * (1 - reverse_weight) + r * reverse_weight
+            score += ctc_score * ctc_weight + lm_score * lm_weight
+            if score > best:
+                best, best_i = score, i
+        return hyps[best_i][0], enc, pre
+
+    def recognize(self, features: torch.Tensor, features_length: torch.Tensor, beam_size: int = 10) -> torch.Tensor:
+        """asr_model.py:205-295: batched attention beam search (incl. the reference's un-reordered cache)."""
+        assert features.shape[0] == features_length.shape[0]
+        device = features.device
+        B = features.shape[0]
+        encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        maxlen, d = encoder_out.size(1), encoder_out.size(2)
+        R = B * beam_size
+        encoder_out = encoder_out.unsqueeze(1).repeat(1, beam_size, 1, 1).view(R, maxlen, d)
+        encoder_mask = encoder_mask.unsqueeze(1).repeat(1, beam_size, 1, 1).view(R, 1, maxlen)
+        hyps = torch.full((R, 1), self.sos, dtype=torch.long, device=device)
+        scores = torch.tensor([0.0] + [-float("inf")] * (beam_size - 1), device=device).repeat(B).unsqueeze(1)
+        end_flag = torch.zeros_like(scores, dtype=torch.bool)
+        cache = None
+        for i in range(1, maxlen + 1):
+            if end_flag.sum() == R:
+                break
+            hyps_mask = subsequent_mask(i, device=device).unsqueeze(0).repeat(R, 1, 1)
+            p, cache, _ = self.decoder.forward_one_step(hyps, hyps_mask, encoder_out, encoder_mask, cache=cache)
+            logp = ops.log_softmax_rows(p)
+            top_k_logp, top_k_index = logp.topk(beam_size)
+            top_k_logp = mask_finished_scores(top_k_logp, end_flag)
+            top_k_index = mask_finished_preds(top_k_index, end_flag, self.eos)
+            scores = (scores + top_k_logp).view(B, beam_size * beam_size)
+            scores, offset_k_index = scores.topk(k=beam_size)
+            scores = scores.view(-1, 1)
+            base = torch.arange(B, device=device).view(-1, 1).repeat(1, beam_size) * beam_size * beam_size
+            best_k_index = base.view(-1) + offset_k_index.view(-1)
+            best_k_pred = torch.index_select(top_k_index.view(-1), dim=-1, index=best_k_index)
+            best_hyps_index = best_k_index // beam_size
+            hyps = torch.cat((torch.index_select(hyps, 0, best_hyps_index), best_k_pred.view(-1, 1)), dim=1)
+            end_flag = torch.eq(hyps[:, -1], self.eos).view(-1, 1)
+        scores = scores.view(B, beam_size)
+        best_index = torch.argmax(scores, dim=-1).long() + torch.arange(B, dtype=torch.long, device=device) * beam_size
+        return torch.index_select(hyps, 0, best_index)[:, 1:]

@@ -1,0 +1,94 @@
+"""Encoder stack (/root/reference/openeat/modules/encoder.py:113-229):
+[GlobalCMVN] -> Conv2dSubsampling4 (+pos. encoding) -> N x EncoderLayer -> LayerNorm(1e-5)."""
+import torch
+
+from openeat_amd import ops
+from openeat_amd.modules.attention import MultiHeadedAttention, RelPositionMultiHeadedAttention
+from openeat_amd.modules.convolution import ConvolutionModule
+from openeat_amd.modules.embedding import PositionalEncoding, RelPositionalEncoding
+from openeat_amd.modules.encoder_layer import EncoderLayer
+from openeat_amd.modules.positionwise_feed_forward import PositionwiseFeedForward
+from openeat_amd.modules.subsampling import (Conv2dSubsampling4, Conv2dSubsampling6, Conv2dSubsampling8,
+                                             LinearNoSubsampling)
+from openeat_amd.utils.common import get_activation
+
+
+def _layers(d_model, dropout_rate, attention_heads, linear_units, activation_type, macaron_style, use_cnn_module,
+            cnn_module_kernel, causal, use_adapter, n_unique):
+    if use_adapter:
+        raise NotImplementedError("adapters are outside the accelerated path")
+    attn_cls = RelPositionMultiHeadedAttention if use_cnn_module else MultiHeadedAttention
+
+    def ff():
+        return PositionwiseFeedForward(d_model, linear_units, dropout_rate, get_activation(activation_type))
+
+    return torch.nn.ModuleList([
+        EncoderLayer(d_model, ff() if macaron_style else None, attn_cls(attention_heads, d_model, dropout_rate),
+                     ConvolutionModule(d_model, cnn_module_kernel, get_activation(activation_type), causal)
+                     if use_cnn_module else None, ff(), None, dropout_rate)
+        for _ in range(n_unique)])
+
+
+class Encoder(torch.nn.Module):
+    """encoder.py:25-110: the embedding-free stack (used by the LM in the reference)."""
+
+    def __init__(self, d_model: int = 256, dropout_rate: float = 0.1, attention_heads: int = 4, linear_units: int = 2048,
+                 activation_type: str = "swish", macaron_style: bool = True, use_cnn_module: bool = True,
+                 cnn_module_kernel: int = 15, causal: bool = False, use_adapter: bool = False, down_size: int = 64,
+                 scalar: float = 0.1, num_blocks: int = 6, num_blocks_share: int = 1):
+        super().__init__()
+        self._output_size = d_model
+        self.num_blocks_share = num_blocks_share
+        self.encoders = _layers(d_model, dropout_rate, attention_heads, linear_units, activation_type, macaron_style,
+                                use_cnn_module, cnn_module_kernel, causal, use_adapter, num_blocks // num_blocks_share)
+        self.after_norm = torch.nn.LayerNorm(d_model, eps=1e-5)
+
+    def output_size(self) -> int:
+        return self._output_size
+
+    def forward(self, xs: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor):
+        m8 = masks.to(torch.uint8) if masks.dtype != torch.uint8 else masks
+        for layer in self.encoders:
+            for _ in range(self.num_blocks_share):
+                xs, _ = layer(xs, m8, pos_emb)
+        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+        return xs, masks, pos_emb
+
+
+class TransformerEncoder(torch.nn.Module):
+    def __init__(self, input_size: int, input_layer: str = "conv2d", pos_enc_layer_type: str = "abs_pos",
+                 d_model: int = 256, dropout_rate: float = 0.1, attention_heads: int = 4, linear_units: int = 2048,
+                 activation_type: str = "swish", macaron_style: bool = True, use_cnn_module: bool = True,
+                 cnn_module_kernel: int = 15, causal: bool = False, use_adapter: bool = False, down_size: int = 64,
+                 scalar: float = 0.1, num_blocks: int = 6, num_blocks_share: int = 1,
+                 global_cmvn: torch.nn.Module = None):
+        super().__init__()
+        self._output_size = d_model
+        self.num_blocks_share = num_blocks_share
+        sub = {"linear": LinearNoSubsampling, "conv2d": Conv2dSubsampling4, "conv2d6": Conv2dSubsampling6,
+               "conv2d8": Conv2dSubsampling8}
+        if input_layer not in sub:
+            raise ValueError("unknown input_layer: " + input_layer)
+        pos = {"abs_pos": PositionalEncoding, "rel_pos": RelPositionalEncoding}
+        if pos_enc_layer_type not in pos:
+            raise ValueError("unknown pos_enc_layer: " + pos_enc_layer_type)
+        self.global_cmvn = global_cmvn
+        self.embed = sub[input_layer](input_size, d_model, pos[pos_enc_layer_type](d_model))
+        self.encoders = _layers(d_model, dropout_rate, attention_heads, linear_units, activation_type, macaron_style,
+                                use_cnn_module, cnn_module_kernel, causal, use_adapter, num_blocks // num_blocks_share)
+        self.after_norm = torch.nn.LayerNorm(d_model, eps=1e-5)
+
+    def output_size(self) -> int:
+        return self._output_size
+
+    def forward(self, xs: torch.Tensor, masks: torch.Tensor):
+        """xs (B,T,F) features, masks (B,1,T) bool -> (encoded (B,T',d), masks (B,1,T'), pos_emb (1,T',d))."""
+        if self.global_cmvn is not None:
+            xs = self.global_cmvn(xs)
+        xs, masks, pos_emb = self.embed(xs, masks)
+        m8 = masks.to(torch.uint8).contiguous()
+        for layer in self.encoders:
+            for _ in range(self.num_blocks_share):
+                xs, _ = layer(xs, m8, pos_emb)
+        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+        return xs, masks, pos_emb

@@ -1,0 +1,57 @@
+"""Conformer / Transformer encoder block (/root/reference/openeat/modules/encoder_layer.py:64-112):
+[x + 1/2 FFN(LN x)] -> x + MHA(LN x) -> [x + Conv(LN x)] -> x + s FFN(LN x) -> [LN].  Every
+``residual + scale * dropout(.)`` is fused into the last GEMM of its branch."""
+from typing import Optional
+
+import torch
+from torch import nn
+
+from openeat_amd import ops
+
+
+class EncoderLayer(nn.Module):
+    def __init__(self, size: int, feed_forward_macaron: Optional[nn.Module], self_attn: nn.Module,
+                 conv_module: Optional[nn.Module], feed_forward: nn.Module, adapter: Optional[nn.Module],
+                 dropout_rate: float = 0.1):
+        super().__init__()
+        if adapter is not None:
+            raise NotImplementedError("adapters are off in every shipped config and outside the accelerated path")
+        self.size = size
+        self.feed_forward_macaron = feed_forward_macaron
+        self.self_attn = self_attn
+        self.conv_module = conv_module
+        self.feed_forward = feed_forward
+        self.adapter = None
+        self.ff_scale = 1
+        if feed_forward_macaron is not None:
+            self.ff_scale = 0.5
+            self.norm_ff_macaron = nn.LayerNorm(size, eps=1e-12)
+        self.norm_mha = nn.LayerNorm(size, eps=1e-12)
+        if conv_module is not None:
+            self.norm_conv = nn.LayerNorm(size, eps=1e-12)
+        self.norm_ff = nn.LayerNorm(size, eps=1e-12)
+        self.dropout = nn.Dropout(dropout_rate)
+        if conv_module is not None:
+            self.norm_final = nn.LayerNorm(size, eps=1e-12)
+
+    @staticmethod
+    def _ln(norm: nn.LayerNorm, x, rowmask=None):
+        return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, rowmask)
+
+    def forward(self, x: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor):
+        p = self.dropout.p
+        if self.feed_forward_macaron is not None:
+            x = self.feed_forward_macaron(self._ln(self.norm_ff_macaron, x), residual=x, out_scale=self.ff_scale, out_dropout=p)
+        y = self._ln(self.norm_mha, x)
+        x = self.self_attn(y, y, y, masks, pos_emb, residual=x, out_dropout=p)
+        if self.conv_module is not None:
+            m8 = masks if masks.dtype == torch.uint8 else masks.to(torch.uint8)
+            rowmask = m8.contiguous().view(-1)
+            # the reference zeroes padded frames of norm_conv's output in place (convolution.py:88-89):
+            # fused into the LayerNorm kernel, so the module skips its own input-mask pass.
+            y = self._ln(self.norm_conv, x, rowmask)
+            x = self.conv_module(y, m8, residual=x, out_dropout=p, input_masked=True)
+        x = self.feed_forward(self._ln(self.norm_ff, x), residual=x, out_scale=self.ff_scale, out_dropout=p)
+        if self.conv_module is not None:
+            x = self._ln(self.norm_final, x)
+        return x, masks

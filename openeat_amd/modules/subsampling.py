@@ -1,0 +1,53 @@
+"""Conv2d subsampling front end (/root/reference/openeat/modules/subsampling.py).
+Only the 1/4 variant used by every shipped config has a HIP path so far."""
+from typing import Tuple
+
+import torch
+
+from openeat_amd import ops
+
+
+class BaseSubsampling(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.right_context = 0
+        self.subsampling_rate = 1
+
+
+class Conv2dSubsampling4(BaseSubsampling):
+    """subsampling.py:65-116.  Parameters keep the reference's names/shapes:
+    conv.0 (d,1,3,3), conv.2 (d,d,3,3), out.0 (d, d*((idim-1)//2-1)//2)."""
+
+    def __init__(self, idim: int, odim: int, pos_enc_class: torch.nn.Module):
+        super().__init__()
+        self.conv = torch.nn.Sequential(
+            torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(), torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU())
+        self.out = torch.nn.Sequential(torch.nn.Linear(odim * (((idim - 1) // 2 - 1) // 2), odim))
+        self.pos_enc = pos_enc_class
+        self.subsampling_rate = 4
+        self.right_context = 6
+
+    def forward(self, x: torch.Tensor, x_mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        t_out = ((x.size(1) - 1) // 2 - 1) // 2
+        pos = self.pos_enc.table(x.device, t_out)
+        pe = pos if self.pos_enc.kind == "abs_pos" else None
+        c0, c2, lin = self.conv[0], self.conv[2], self.out[0]
+        y = ops.subsampling4(x, c0.weight, c0.bias, c2.weight, c2.bias, lin.weight, lin.bias, pe, self.pos_enc.xscale)
+        return y, x_mask[:, :, :-2:2][:, :, :-2:2], pos
+
+
+class _NoKernelYet(BaseSubsampling):
+    def __init__(self, *a, **k):
+        raise NotImplementedError(f"{type(self).__name__}: no gfx950 kernel yet; use input_layer='conv2d'")
+
+
+class Conv2dSubsampling6(_NoKernelYet):
+    pass
+
+
+class Conv2dSubsampling8(_NoKernelYet):
+    pass
+
+
+class LinearNoSubsampling(_NoKernelYet):
+    pass

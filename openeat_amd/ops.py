@@ -1,0 +1,686 @@
+"""Autograd-level composition of the HIP kernels.
+
+Each ``torch.autograd.Function`` below is one block of the reference's hot path
+(feed-forward, attention, conv module, subsampling, CTC head, label-smoothing
+head ...) whose forward AND backward are sequences of C-ABI calls
+(``openeat_amd.hip``).  PyTorch only owns the buffers and the tape.  No op
+here has a CPU path: tensors must be float32 CUDA tensors.
+"""
+from __future__ import annotations
+
+import itertools
+import math
+from typing import Optional
+
+import torch
+
+from . import hip
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+ACT_IDS = {"relu": ACT_RELU, "swish": ACT_SWISH, "none": ACT_NONE}
+
+
+# --------------------------------------------------------------------------- #
+# dropout seeds: a host counter gives every dropout site a distinct stream; an
+# optional device step counter (set by the training engine) is mixed in inside
+# the kernels so that a captured HIP graph still draws fresh masks per replay.
+# --------------------------------------------------------------------------- #
+_seed_counter = itertools.count(0x5EED0001)
+_seed_dev: Optional[torch.Tensor] = None
+
+
+def next_seed() -> int:
+    return next(_seed_counter) * 0x9E3779B1 & 0xFFFFFFFFFFFF
+
+
+def set_seed_device_counter(t: Optional[torch.Tensor]):
+    global _seed_dev
+    _seed_dev = t
+
+
+def manual_seed(seed: int):
+    global _seed_counter
+    _seed_counter = itertools.count(0x5EED0001 + (seed & 0xFFFFFFF) * 7919)
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise TypeError(f"{name}: openeat_amd ops need float32 CUDA tensors (got {t.dtype} on {t.device}); "
+                        "there is no CPU fallback")
+    return t.contiguous()
+
+
+def _new(*shape, like: torch.Tensor, zero=False):
+    return (torch.zeros if zero else torch.empty)(shape, device=like.device, dtype=torch.float32)
+
+
+# --------------------------------------------------------------------------- #
+# GEMM helpers
+# --------------------------------------------------------------------------- #
+def _split_k(out_rows: int, out_cols: int, k: int) -> int:
+    tiles = -(-out_rows // 64) * -(-out_cols // 64)
+    want = max(1, 768 // max(tiles, 1))
+    return int(max(1, min(want, k // 256 if k >= 512 else 1)))
+
+
+def gemm_nt(x, w, bias=None, out=None, **epi):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = _new(M, N, like=x)
+    hip.gemm(x, w, out, M, N, K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, **epi)
+    return out
+
+
+def gemm_nn(dy, w, out=None, **epi):
+    """dx[M,K] = dy[M,N] @ w[N,K]."""
+    M, N = dy.shape
+    K = w.shape[1]
+    if out is None:
+        out = _new(M, K, like=dy)
+    hip.gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, **epi)
+    return out
+
+
+def gemm_tn(dy, x, out=None, alpha=1.0, alpha_dev=None):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]  (split-K, atomic accumulation into `out`)."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if out is None:
+        out = _new(N, K, like=dy, zero=True)
+    hip.gemm(dy, x, out, N, K, M, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kmajor=True, b_kmajor=True,
+             split_k=_split_k(N, K, M), atomic_out=True, alpha=alpha, alpha_dev=alpha_dev)
+    return out
+
+
+def colsum(x, alpha=1.0, alpha_dev=None, n=None):
+    M = x.shape[0]
+    n = x.shape[1] if n is None else n
+    out = _new(n, like=x)
+    hip.call("oe_colsum_f32", x, x.stride(0), M, n, alpha, alpha_dev, out, 0)
+    return out
+
+
+def dropout_scale(x, alpha=1.0, p=0.0, seed=0, rowmask=None, cols=None):
+    out = torch.empty_like(x)
+    cols = x.shape[-1] if cols is None else cols
+    hip.call("oe_dropout_scale", x, x.numel(), cols, alpha, p, seed, _seed_dev, rowmask, out)
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# LayerNorm
+# --------------------------------------------------------------------------- #
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, rowmask, act):
+        x = _chk(x, "layer_norm")
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        stats = _new(rows, 2, like=x)
+        hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, act, y, stats)
+        ctx.save_for_backward(x, gamma, beta, stats, rowmask)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, stats, rowmask = ctx.saved_tensors
+        dy = dy.contiguous()
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+        hip.call("oe_layernorm_bwd", dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db)
+        return dx, dg, db, None, None, None
+
+
+def layer_norm(x, gamma, beta, eps, rowmask=None, act=ACT_NONE):
+    return LayerNormFn.apply(x, gamma, beta, eps, rowmask, act)
+
+
+# --------------------------------------------------------------------------- #
+# Linear (single GEMM with bias / activation)
+# --------------------------------------------------------------------------- #
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act):
+        x = _chk(x, "linear")
+        x2 = x.reshape(-1, x.shape[-1])
+        pre = _new(x2.shape[0], w.shape[0], like=x) if act != ACT_NONE else None
+        y = gemm_nt(x2, w, b, act=act, preact_out=pre, ld_aux=w.shape[0])
+        ctx.save_for_backward(x2, w, pre)
+        ctx.act, ctx.has_bias, ctx.in_shape = act, b is not None, x.shape
+        return y.view(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, pre = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, w.shape[0])
+        if ctx.act != ACT_NONE:
+            dy2 = _act_grad(dy2, pre, ctx.act)
+        dx = gemm_nn(dy2, w).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
+        dw = gemm_tn(dy2, x2)
+        db = colsum(dy2) if ctx.has_bias else None
+        return dx, dw, db, None
+
+
+def _act_grad(dy2, pre, act):
+    """dy * act'(pre)."""
+    out = torch.empty_like(dy2)
+    hip.call("oe_act_grad", dy2, pre, dy2.numel(), act, out)
+    return out
+
+
+def linear(x, w, b=None, act=ACT_NONE):
+    return LinearFn.apply(x, w, b, act)
+
+
+class ActivationFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        x = _chk(x, "activation")
+        y = torch.empty_like(x)
+        hip.call("oe_act_fwd", x, x.numel(), act, y)
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return _act_grad(dy.contiguous(), x, ctx.act), None
+
+
+def activation(x, act):
+    return ActivationFn.apply(x, act)
+
+
+class CmvnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mean, istd):
+        x = _chk(x, "cmvn")
+        y = torch.empty_like(x)
+        hip.call("oe_global_cmvn", x, mean, istd, x.numel(), x.shape[-1], y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raise NotImplementedError("GlobalCMVN is applied to input features, which carry no gradient")
+
+
+def global_cmvn(x, mean, istd):
+    return CmvnFn.apply(x, mean, istd)
+
+
+# --------------------------------------------------------------------------- #
+# Position-wise feed forward (+ optional fused residual / outer dropout)
+# --------------------------------------------------------------------------- #
+class FeedForwardFn(torch.autograd.Function):
+    """y = [residual + out_scale * drop_out(] w_2(drop_in(act(w_1 x + b_1))) + b_2 [)]
+    positionwise_feed_forward.py:36-43 and encoder_layer.py:81-83,104-106 / decoder_layer.py:104-106."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, act, p_in, residual, out_scale, p_out):
+        x = _chk(x, "feed_forward")
+        d = x.shape[-1]
+        x2 = x.reshape(-1, d)
+        M, ff = x2.shape[0], w1.shape[0]
+        s_in, s_out = (next_seed() if p_in > 0 else 0), (next_seed() if p_out > 0 else 0)
+        pre = _new(M, ff, like=x)
+        a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+        res2 = None if residual is None else _chk(residual, "residual").reshape(-1, w2.shape[0])
+        y = gemm_nt(a, w2, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, residual=res2,
+                    ldr=0 if res2 is None else res2.stride(0), beta=out_scale)
+        ctx.save_for_backward(x2, w1, w2, pre, a)
+        ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w1, w2, pre, a = ctx.saved_tensors
+        act, p_in, s_in, out_scale, p_out, s_out, has_res, in_shape = ctx.cfg
+        dy = dy.contiguous()
+        dy2 = dy.view(-1, w2.shape[0])
+        g2 = dy2 if (p_out == 0 and out_scale == 1.0) else dropout_scale(dy2, out_scale, p_out, s_out)
+        dw2 = gemm_tn(g2, a)
+        db2 = colsum(g2)
+        dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+        dw1 = gemm_tn(dh, x2)
+        db1 = colsum(dh)
+        dx = gemm_nn(dh, w1).view(in_shape)
+        return dx, dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
+
+
+def feed_forward(x, w1, b1, w2, b2, act, p_in=0.0, residual=None, out_scale=1.0, p_out=0.0):
+    return FeedForwardFn.apply(x, w1, b1, w2, b2, act, p_in, residual, out_scale, p_out)
+
+
+# --------------------------------------------------------------------------- #
+# Multi-head attention (plain and relative-position)
+# --------------------------------------------------------------------------- #
+def _mask_u8(mask: Optional[torch.Tensor]):
+    if mask is None:
+        return None, (0, 0)
+    m = mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
+    m = m.contiguous()
+    assert m.dim() == 3, "mask must be (B, 1|T1, T2)"
+    return m, (m.shape[1] * m.shape[2], 0 if m.shape[1] == 1 else m.shape[2])
+
+
+class AttentionFn(torch.autograd.Function):
+    """attention.py:99-117 (MultiHeadedAttention.forward) and :166-209
+    (RelPositionMultiHeadedAttention.forward) incl. linear_q/k/v/out, with an
+    optional fused `residual + dropout(.)` of the caller (encoder_layer.py:89)."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out):
+        xq = _chk(xq, "attention query")
+        self_attn = xkv is None
+        B, T1, d = xq.shape
+        D = d // H
+        scale = 1.0 / math.sqrt(D)
+        xq2 = xq.view(-1, d)
+        if self_attn:
+            T2 = T1
+            wqkv = torch.cat([wq, wk, wv], 0)
+            bqkv = torch.cat([bq, bk, bv], 0)
+            qkv = gemm_nt(xq2, wqkv, bqkv)                       # (B*T, 3d)
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            qs = ks = vs = (T1 * 3 * d, 3 * d)
+            xkv2 = xq2
+        else:
+            xkv = _chk(xkv, "attention key/value")
+            T2 = xkv.shape[1]
+            xkv2 = xkv.view(-1, d)
+            q = gemm_nt(xq2, wq, bq)
+            wkv = torch.cat([wk, wv], 0)
+            bkv = torch.cat([bk, bv], 0)
+            kv = gemm_nt(xkv2, wkv, bkv)                         # (B*T2, 2d)
+            k, v = kv[:, :d], kv[:, d:]
+            qs, ks, vs = (T1 * d, d), (T2 * 2 * d, 2 * d), (T2 * 2 * d, 2 * d)
+            qkv = None
+        rel = pos_emb is not None
+        kp = keybias = pp = None
+        k_att, k_att_s = k, ks
+        if rel:
+            assert self_attn and pos_emb.shape[-2] == T2
+            pe2 = _chk(pos_emb, "pos_emb").reshape(-1, d)
+            pp = gemm_nt(pe2, wpos)                              # (T, d): linear_pos has no bias
+            kp = _new(B, T2, d, like=xq)
+            keybias = _new(B, H, T2, like=xq)
+            hip.call("oe_relpos_prepare", k, ks[0], ks[1], pp, d, pu, pv, B, T2, H, D, scale, kp, keybias)
+            k_att, k_att_s = kp, (T2 * d, d)
+        m8, mstr = _mask_u8(mask)
+        s_att, s_out = (next_seed() if p_attn > 0 else 0), (next_seed() if p_out > 0 else 0)
+        att = _new(B, T1, d, like=xq)
+        lse = _new(B, H, T1, like=xq)
+        a = hip.attn_args(q, k_att, v, att, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=k_att_s, v_strides=vs,
+                          o_strides=(T1 * d, d), mask=m8, mask_strides=mstr, keybias=keybias, drop_p=p_attn, seed=s_att,
+                          seed_dev=_seed_dev)
+        hip.attention_fwd(a)
+        res2 = None if residual is None else _chk(residual, "residual").view(-1, d)
+        y = gemm_nt(att.view(-1, d), wo, bo, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, residual=res2,
+                    ldr=0 if res2 is None else d)
+        ctx.save_for_backward(xq2, xkv2 if not self_attn else None, wq, wk, wv, wo, qkv, None if self_attn else q,
+                              None if self_attn else kv, kp, keybias, pp, None if not rel else pe2, wpos, pu, pv, m8, att, lse)
+        ctx.cfg = (self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, residual is not None, mstr)
+        return y.view(B, T1, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xq2, xkv2, wq, wk, wv, wo, qkv, q_x, kv_x, kp, keybias, pp, pe2, wpos, pu, pv, m8, att, lse) = ctx.saved_tensors
+        self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, has_res, mstr = ctx.cfg
+        dy = dy.contiguous()
+        dy2 = dy.view(-1, d)
+        g = dy2 if p_out == 0 else dropout_scale(dy2, 1.0, p_out, s_out)
+        att2 = att.view(-1, d)
+        dwo = gemm_tn(g, att2)
+        dbo = colsum(g)
+        datt = gemm_nn(g, wo)
+        delta = _new(B, H, T1, like=dy)
+        if self_attn:
+            dqkv = _new(B * T1, 3 * d, like=dy)
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            dq, dk, dv = dqkv[:, :d], dqkv[:, d:2 * d], dqkv[:, 2 * d:]
+            qs = ks = vs = (T1 * 3 * d, 3 * d)
+        else:
+            q, k, v = q_x, kv_x[:, :d], kv_x[:, d:]
+            dq = _new(B * T1, d, like=dy)
+            dkv = _new(B * T2, 2 * d, like=dy)
+            dk, dv = dkv[:, :d], dkv[:, d:]
+            qs, ks, vs = (T1 * d, d), (T2 * 2 * d, 2 * d), (T2 * 2 * d, 2 * d)
+        k_att, k_att_s, dk_att, dkb = k, ks, dk, None
+        if rel:
+            dkp = _new(B, T2, d, like=dy)
+            dkb = _new(B, H, T2, like=dy)
+            k_att, k_att_s, dk_att = kp, (T2 * d, d), dkp
+        a = hip.attn_args(q, k_att, v, att, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=k_att_s, v_strides=vs,
+                          o_strides=(T1 * d, d), mask=m8, mask_strides=mstr, keybias=keybias, drop_p=p_attn, seed=s_att,
+                          seed_dev=_seed_dev, d_out=datt, dq=dq, dk=dk_att, dv=dv, dkeybias=dkb, delta=delta)
+        hip.attention_bwd(a)
+        dwpos = dpu = dpv = None
+        if rel:
+            dpp = _new(T2, d, like=dy)
+            dpu, dpv = torch.zeros_like(pu), torch.zeros_like(pv)
+            hip.call("oe_relpos_backward", dkp, dkb, k, ks[0], ks[1], pp, d, pu, pv, B, T2, H, D, scale, dk, dpp, d, dpu, dpv)
+            dwpos = gemm_tn(dpp, pe2)
+        if self_attn:
+            wqkv = torch.cat([wq, wk, wv], 0)
+            dx = gemm_nn(dqkv, wqkv).view(B, T1, d)
+            dwqkv = gemm_tn(dqkv, xq2)
+            dbqkv = colsum(dqkv)
+            dwq, dwk, dwv = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
+            dbq, dbk, dbv = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
+            dxkv = None
+        else:
+            dx = gemm_nn(dq, wq).view(B, T1, d)
+            dwq, dbq = gemm_tn(dq, xq2), colsum(dq)
+            wkv = torch.cat([wk, wv], 0)
+            dxkv = gemm_nn(dkv, wkv).view(B, T2, d)
+            dwkv, dbkv = gemm_tn(dkv, xkv2), colsum(dkv)
+            dwk, dwv, dbk, dbv = dwkv[:d], dwkv[d:], dbkv[:d], dbkv[d:]
+        return (dx, dxkv, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, dwpos, dpu, dpv, None, None,
+                (dy if has_res else None), None)
+
+
+def attention(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_attn=0.0, pos_emb=None, wpos=None, pu=None, pv=None,
+              residual=None, p_out=0.0):
+    return AttentionFn.apply(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out)
+
+
+# --------------------------------------------------------------------------- #
+# Conformer convolution module
+# --------------------------------------------------------------------------- #
+class ConvModuleFn(torch.autograd.Function):
+    """convolution.py:72-120: mask -> pw1 -> GLU -> depthwise -> LayerNorm -> act -> pw2 -> mask
+    (+ optional fused `residual + dropout(.)`, encoder_layer.py:95)."""
+
+    @staticmethod
+    def forward(ctx, x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residual, p_out, input_masked):
+        x = _chk(x, "conv_module")
+        B, T, d = x.shape
+        x2 = x.view(-1, d)
+        xm = x2 if (rowmask is None or input_masked) else dropout_scale(x2, 1.0, 0.0, 0, rowmask)
+        w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
+        a = gemm_nt(xm, w1m, b1)                                  # (B*T, 2d)
+        yc = _new(B * T, d, like=x)
+        hip.call("oe_dwconv_glu_fwd", a, wd, bd, B, T, d, K, int(causal), yc)
+        z = torch.empty_like(yc)
+        stats = _new(B * T, 2, like=x)
+        hip.call("oe_layernorm_fwd", yc, g, b, 1e-5, B * T, d, None, act, z, stats)
+        s_out = next_seed() if p_out > 0 else 0
+        res2 = None if residual is None else _chk(residual, "residual").view(-1, d)
+        y = gemm_nt(z, w2m, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, rowmask=rowmask, residual=res2,
+                    ldr=0 if res2 is None else d)
+        ctx.save_for_backward(xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z)
+        ctx.cfg = (B, T, d, K, causal, act, p_out, s_out, residual is not None)
+        return y.view(B, T, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z = ctx.saved_tensors
+        B, T, d, K, causal, act, p_out, s_out, has_res = ctx.cfg
+        dy = dy.contiguous()
+        dy2 = dy.view(-1, d)
+        w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
+        gq = dy2 if (p_out == 0 and rowmask is None) else dropout_scale(dy2, 1.0, p_out, s_out, rowmask)
+        dw2 = gemm_tn(gq, z).view_as(w2)
+        db2 = colsum(gq)
+        dz = gemm_nn(gq, w2m)
+        dyc = torch.empty_like(yc)
+        dg, dbeta = torch.zeros_like(g), torch.zeros_like(b)
+        hip.call("oe_layernorm_bwd", dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta)
+        da = torch.empty_like(a)
+        dwd, dbd = torch.zeros_like(wd), torch.zeros(d, device=dy.device)
+        hip.call("oe_dwconv_glu_bwd", a, dyc, wd, B, T, d, K, int(causal), da, dwd, dbd)
+        dw1 = gemm_tn(da, xm).view_as(w1)
+        db1 = colsum(da)
+        dx = gemm_nn(da, w1m, rowmask=rowmask).view(B, T, d)
+        return dx, None, dw1, db1, dwd, dbd, dg, dbeta, dw2, db2, None, None, None, (dy if has_res else None), None, None
+
+
+def conv_module(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residual=None, p_out=0.0, input_masked=False):
+    return ConvModuleFn.apply(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residual, p_out, input_masked)
+
+
+# --------------------------------------------------------------------------- #
+# Conv2d subsampling (1/4) + output Linear + positional scaling
+# --------------------------------------------------------------------------- #
+class Subsampling4Fn(torch.autograd.Function):
+    """subsampling.py:110-116 + embedding.py:44-60/75-88.  Activations are kept
+    NHWC so the second conv is an implicit GEMM and the flatten before the
+    Linear is free; the checkpoint's OIHW / channel-major weights are
+    re-laid-out on the fly (tiny)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, wl, bl, pe, xscale):
+        x = _chk(x, "subsampling input")
+        B, T, Fd = x.shape
+        C = w1.shape[0]
+        T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        d = wl.shape[0]
+        assert wl.shape[1] == C * F2, "Linear input size does not match the conv output"
+        y1 = _new(B, T1, F1, C, like=x)
+        hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y1)
+        w2g = _new(C, 9 * C, like=x)                               # [co][kh][kw][ci]
+        hip.call("oe_swap_last2", w2, C, C, 9, w2g, 0)
+        M2 = B * T2 * F2
+        y2 = _new(M2, C, like=x)
+        conv = (T1, F1, T2, F2, C)
+        hip.gemm(y1, w2g, y2, M2, C, 9 * C, lda=0, ldb=9 * C, ldc=C, bias=b2, act=ACT_RELU, conv=conv,
+                 conv_gather=hip.GATHER_A)
+        wlg = _new(d, F2 * C, like=x)                              # columns reordered to (f, c)
+        hip.call("oe_swap_last2", wl, d, C, F2, wlg, 0)
+        y2v = y2.view(B * T2, F2 * C)
+        pe2 = None if pe is None else _chk(pe, "pe").reshape(-1, d)[:T2]
+        out = gemm_nt(y2v, wlg, bl, beta=xscale, residual=pe2, ldr=0 if pe2 is None else d, res_row_mod=0 if pe2 is None else T2)
+        ctx.save_for_backward(x, y1, w2g, y2, wlg)
+        ctx.cfg = (B, T, Fd, C, T1, F1, T2, F2, d, xscale)
+        return out.view(B, T2, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, w2g, y2, wlg = ctx.saved_tensors
+        B, T, Fd, C, T1, F1, T2, F2, d, xscale = ctx.cfg
+        do2 = dout.contiguous().view(B * T2, d)
+        y2v = y2.view(B * T2, F2 * C)
+        dwlg = gemm_tn(do2, y2v, alpha=xscale)
+        dwl = _new(d, C * F2, like=do2)
+        hip.call("oe_swap_last2", dwlg, d, F2, C, dwl, 0)
+        dbl = colsum(do2, alpha=xscale)
+        dy2 = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=y2v, ld_aux=F2 * C).view(B * T2 * F2, C)
+        M2 = B * T2 * F2
+        conv = (T1, F1, T2, F2, C)
+        dw2g = _new(C, 9 * C, like=do2, zero=True)
+        hip.gemm(dy2, y1, dw2g, C, 9 * C, M2, lda=C, ldb=0, ldc=9 * C, a_kmajor=True, b_kmajor=True,
+                 split_k=_split_k(C, 9 * C, M2), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B)
+        dw2 = _new(C, C, 3, 3, like=do2)
+        hip.call("oe_swap_last2", dw2g, C, 9, C, dw2, 0)
+        db2 = colsum(dy2)
+        dcol = gemm_nn(dy2, w2g)                                   # (M2, 9C)
+        dy1 = torch.empty_like(y1)
+        hip.call("oe_col2im_relu", dcol, y1, B, T1, F1, C, dy1)
+        del dcol
+        dw1 = _new(C, 1, 3, 3, like=do2, zero=True)
+        db1 = _new(C, like=do2, zero=True)
+        hip.call("oe_conv1_wgrad", x, dy1, B, T, Fd, C, dw1, db1)
+        return None, dw1, db1, dw2, db2, dwl, dbl, None, None
+
+
+def subsampling4(x, w1, b1, w2, b2, wl, bl, pe, xscale):
+    return Subsampling4Fn.apply(x, w1, b1, w2, b2, wl, bl, pe, xscale)
+
+
+# --------------------------------------------------------------------------- #
+# heads
+# --------------------------------------------------------------------------- #
+def _vpad(V: int) -> int:
+    return (V + 3) // 4 * 4
+
+
+class CTCHeadFn(torch.autograd.Function):
+    """ctc.py:38-45: ctc_lo -> log_softmax -> CTCLoss(sum, zero_infinity) / B, fused with its
+    gradient; the logits buffer is overwritten by d loss/d logits (never read again)."""
+
+    @staticmethod
+    def forward(ctx, hs, w, b, hlens, ys, ylens):
+        hs = _chk(hs, "ctc input")
+        B, T, d = hs.shape
+        V = w.shape[0]
+        Vp = _vpad(V)
+        hs2 = hs.view(-1, d)
+        logits = _new(B * T, Vp, like=hs)
+        hip.gemm(hs2, w, logits, B * T, V, d, lda=d, ldb=d, ldc=Vp, bias=b)
+        if Vp != V:
+            logits[:, V:].zero_()
+        Lmax = max(int(ys.shape[1]), 1)
+        ys32 = ys.to(torch.int32).contiguous()
+        if ys32.shape[1] == 0:
+            ys32 = torch.zeros(B, 1, dtype=torch.int32, device=hs.device)
+        hl32, yl32 = hlens.to(torch.int32).contiguous(), ylens.to(torch.int32).contiguous()
+        ws = _new(hip.lib().oe_ctc_workspace_floats(B, T, Lmax), like=hs)
+        nll = _new(B, like=hs)
+        tot = _new(1, like=hs)
+        hip.call("oe_ctc_loss_fused", logits, Vp, B, T, V, hl32, ys32, Lmax, yl32, 1.0 / B, nll, tot, logits, ws)
+        ctx.save_for_backward(hs2, w, logits)
+        ctx.shape = (B, T, d, V)
+        return tot[0] / B
+
+    @staticmethod
+    def backward(ctx, g):
+        hs2, w, dlogits = ctx.saved_tensors
+        B, T, d, V = ctx.shape
+        g = g.contiguous().view(1)
+        dl = dlogits[:, :V]
+        dhs = gemm_nn(dl, w, alpha_dev=g).view(B, T, d)
+        dw = gemm_tn(dl, hs2, alpha_dev=g)
+        db = colsum(dlogits, alpha_dev=g, n=V)
+        return dhs, dw, db, None, None, None
+
+
+def ctc_head(hs, w, b, hlens, ys, ylens):
+    return CTCHeadFn.apply(hs, w, b, hlens, ys, ylens)
+
+
+class LSMHeadFn(torch.autograd.Function):
+    """decoder.py:192 (output_layer) + label_smoothing_loss.py:58-91 + common.py:135-157, fused.
+    Returns (loss, n_correct, n_valid)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, target, smoothing, normalize_length, ignore_id):
+        x = _chk(x, "decoder output")
+        B = x.shape[0]
+        d = x.shape[-1]
+        V = w.shape[0]
+        Vp = _vpad(V)
+        x2 = x.reshape(-1, d)
+        rows = x2.shape[0]
+        logits = _new(rows, Vp, like=x)
+        hip.gemm(x2, w, logits, rows, V, d, lda=d, ldb=d, ldc=Vp, bias=b)
+        tgt = target.reshape(-1).to(torch.int64).contiguous()
+        ws = torch.empty(hip.lib().oe_lsm_workspace_bytes(rows), dtype=torch.uint8, device=x.device)
+        out3 = _new(3, like=x)
+        hip.call("oe_lsm_loss_fused", logits, Vp, rows, V, tgt, ignore_id, smoothing, int(normalize_length), float(B), 1.0,
+                 1, out3, ws)
+        ctx.save_for_backward(x2, w, logits)
+        ctx.shape = (x.shape, V)
+        ctx.mark_non_differentiable(out3[1], out3[2])
+        return out3[0], out3[1], out3[2]
+
+    @staticmethod
+    def backward(ctx, g, _g1, _g2):
+        x2, w, dlogits = ctx.saved_tensors
+        shape, V = ctx.shape
+        g = g.contiguous().view(1)
+        dl = dlogits[:, :V]
+        dx = gemm_nn(dl, w, alpha_dev=g).view(shape)
+        dw = gemm_tn(dl, x2, alpha_dev=g)
+        db = colsum(dlogits, alpha_dev=g, n=V)
+        return dx, dw, db, None, None, None, None
+
+
+def lsm_head(x, w, b, target, smoothing, normalize_length=False, ignore_id=-1):
+    return LSMHeadFn.apply(x, w, b, target, smoothing, normalize_length, ignore_id)
+
+
+class LSMLossFn(torch.autograd.Function):
+    """label_smoothing_loss.py:58-91 on materialised logits (module API)."""
+
+    @staticmethod
+    def forward(ctx, x, target, smoothing, normalize_length, ignore_id):
+        x = _chk(x, "logits")
+        B, V = x.shape[0], x.shape[-1]
+        Vp = _vpad(V)
+        rows = x.numel() // V
+        buf = _new(rows, Vp, like=x, zero=(Vp != V))
+        buf[:, :V].copy_(x.reshape(rows, V))
+        tgt = target.reshape(-1).to(torch.int64).contiguous()
+        ws = torch.empty(hip.lib().oe_lsm_workspace_bytes(rows), dtype=torch.uint8, device=x.device)
+        out3 = _new(3, like=x)
+        hip.call("oe_lsm_loss_fused", buf, Vp, rows, V, tgt, ignore_id, smoothing, int(normalize_length), float(B), 1.0, 1,
+                 out3, ws)
+        ctx.save_for_backward(buf)
+        ctx.shape = (x.shape, V)
+        return out3[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (buf,) = ctx.saved_tensors
+        shape, V = ctx.shape
+        src = buf[:, :V].contiguous()
+        out = torch.empty_like(src)
+        hip.call("oe_axpby", src, None, out.numel(), 1.0, 0.0, g.contiguous().view(1), out)
+        return out.view(shape), None, None, None, None
+
+
+class EmbedFn(torch.autograd.Function):
+    """decoder.py:144-147,186: Embedding -> x*sqrt(d) + pe."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, pe, xscale):
+        B, L = tokens.shape
+        V, d = table.shape
+        tok = tokens.to(torch.int64).contiguous()
+        out = _new(B, L, d, like=table)
+        hip.call("oe_embed_fwd", tok, table, pe, B * L, L, d, V, xscale, out)
+        ctx.save_for_backward(tok)
+        ctx.cfg = (V, d, xscale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok,) = ctx.saved_tensors
+        V, d, xscale = ctx.cfg
+        dout = dout.contiguous()
+        dt = torch.zeros(V, d, device=dout.device)
+        hip.call("oe_embed_bwd", tok, dout, tok.numel(), d, V, xscale, dt)
+        return None, dt, None, None
+
+
+def embed(tokens, table, pe, xscale):
+    return EmbedFn.apply(tokens, table, pe, xscale)
+
+
+# --------------------------------------------------------------------------- #
+# inference helpers
+# --------------------------------------------------------------------------- #
+def ctc_greedy(logits, ldv, B, T, V, hlens, eos):
+    fb = torch.empty(B, T, dtype=torch.int32, device=logits.device)
+    ot = torch.empty(B, T, dtype=torch.int32, device=logits.device)
+    ol = torch.empty(B, dtype=torch.int32, device=logits.device)
+    hl = hlens.to(torch.int32).contiguous()
+    hip.call("oe_ctc_greedy", logits, ldv, B, T, V, hl, eos, fb, ot, ol)
+    return ot, ol
+
+
+def log_softmax_rows(x):
+    """log_softmax over the last dim (ctc.py:56-64, asr_model.py:484-488) on device."""
+    x = _chk(x, "log_softmax")
+    out = torch.empty_like(x)
+    V = x.shape[-1]
+    hip.call("oe_log_softmax", x, x.numel() // V, V, out)
+    return out

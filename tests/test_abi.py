@@ -35,5 +35,5 @@ def test_python_binding_covers_the_header():
 def test_invalid_arguments_are_reported_not_launched():
     from openeat_amd import hip
     lib = hip.lib()
-    rc = lib.oe_layernorm_fwd(None, None, None, 1e-5, 4, 32, None, None, None, None)
+    rc = lib.oe_layernorm_fwd(None, None, None, 1e-5, 4, 32, None, 0, None, None, None)
     assert rc != 0 and b"null" in lib.oe_last_error()

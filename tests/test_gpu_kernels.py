@@ -178,14 +178,14 @@ def test_layernorm_fwd_bwd(rows, d, eps):
     y = torch.empty(rows, d, device=DEV)
     stats = torch.empty(rows, 2, device=DEV)
     L = hip.lib()
-    hip.check(L.oe_layernorm_fwd(hip.ptr(xd), hip.ptr(gd), hip.ptr(bd), eps, rows, d, hip.ptr(md), hip.ptr(y),
+    hip.check(L.oe_layernorm_fwd(hip.ptr(xd), hip.ptr(gd), hip.ptr(bd), eps, rows, d, hip.ptr(md), 0, hip.ptr(y),
                                  hip.ptr(stats), hip.stream()), "ln_fwd")
     dx = torch.empty(rows, d, device=DEV)
     dg = torch.zeros(d, device=DEV)
     db = torch.zeros(d, device=DEV)
     add = torch.randn(rows, d)
     addd = cu(add)
-    hip.check(L.oe_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(gd), hip.ptr(stats), rows, d, hip.ptr(md),
+    hip.check(L.oe_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(gd), hip.ptr(bd), 0, hip.ptr(stats), rows, d, hip.ptr(md),
                                  hip.ptr(addd), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.stream()), "ln_bwd")
     sync()
     dx = dx - addd

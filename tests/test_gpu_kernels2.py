@@ -211,7 +211,7 @@ def test_glu_dropout_embed_swap_axpby_cmvn():
     hip.gemm(xd, wd, g0, M, N, K, lda=K, ldb=K, ldc=N)
     g2 = torch.empty(M, N, device=DEV)
     rm = cu((torch.rand(M) > 0.5).to(torch.uint8))
-    hip.call("oe_dropout_scale", g0, M * N, N, 2.0, 0.3, 5, rm, g2)
+    hip.call("oe_dropout_scale", g0, M * N, N, 2.0, 0.3, 5, None, rm, g2)
     sync()
     torch.testing.assert_close(g2, 2.0 * g1 * rm[:, None].float(), rtol=1e-6, atol=1e-6)
     # embedding
@@ -236,7 +236,7 @@ def test_glu_dropout_embed_swap_axpby_cmvn():
     o = torch.empty(5, 9, 6, device=DEV)
     hip.call("oe_swap_last2", td2, 5, 6, 9, o, 0)
     z = torch.empty(5 * 6 * 9, device=DEV)
-    hip.call("oe_axpby", td2, td2, 5 * 6 * 9, 2.0, 0.5, z)
+    hip.call("oe_axpby", td2, td2, 5 * 6 * 9, 2.0, 0.5, None, z)
     mean, istd = torch.randn(9), torch.rand(9) + 0.5
     md, isd = cu(mean), cu(istd)
     c = torch.empty(5, 6, 9, device=DEV)

@@ -1,0 +1,219 @@
+"""GPU: the module mirror (openeat_amd.modules / models) against the golden vectors
+produced by the REFERENCE (tests/golden/*.npz) - same parameters, same inputs.
+
+fp32 kernels; tolerances: module outputs rtol 1e-4 / atol 5e-5 (x the data
+scale), parameter gradients rtol 1e-3 with an absolute floor tied to the gradient
+magnitude (different summation order + atomic accumulation), end-to-end loss
+rtol 2e-4.  CTC greedy / prefix-beam token ids are compared bit-exactly.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, load_golden_json, redraw_state_dict  # noqa: E402
+from openeat_amd.models.asr_model import ASRModel  # noqa: E402
+from openeat_amd.modules.attention import MultiHeadedAttention, RelPositionMultiHeadedAttention  # noqa: E402
+from openeat_amd.modules.convolution import ConvolutionModule  # noqa: E402
+from openeat_amd.modules.ctc import CTC  # noqa: E402
+from openeat_amd.modules.decoder import BiTransformerDecoder  # noqa: E402
+from openeat_amd.modules.embedding import PositionalEncoding, RelPositionalEncoding  # noqa: E402
+from openeat_amd.modules.encoder import TransformerEncoder  # noqa: E402
+from openeat_amd.modules.cmvn import GlobalCMVN  # noqa: E402
+from openeat_amd.modules.label_smoothing_loss import LabelSmoothingLoss  # noqa: E402
+from openeat_amd.modules.subsampling import Conv2dSubsampling4  # noqa: E402
+from openeat_amd.modules.swish import Swish  # noqa: E402
+
+DEV = "cuda"
+
+
+def load_into(module, sd, prefix):
+    own = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    module.load_state_dict(own, strict=True)
+    return module.to(DEV)
+
+
+def close(a, b, rtol=1e-4, atol=5e-5, msg=""):
+    torch.testing.assert_close(a.detach().cpu(), b, rtol=rtol, atol=atol, msg=lambda m: f"{msg}: {m}")
+
+
+def check_param_grads(module, ref, prefix, rtol=1e-3, rel_floor=2e-4):
+    for k, p in module.named_parameters():
+        key = prefix + k
+        if key in ref:
+            assert p.grad is not None, key
+            g = ref[key]
+            close(p.grad, g, rtol=rtol, atol=rel_floor * max(1.0, float(g.abs().max())), msg=key)
+
+
+def test_f01_subsampling4():
+    g = load_golden("f01_subsampling4")
+    m = load_into(Conv2dSubsampling4(80, 32, RelPositionalEncoding(32)), g["sd"], "encoder.embed.")
+    y, mask, pos = m(g["in"]["x"].to(DEV), g["in"]["mask"].to(DEV))
+    close(y, g["out"]["y"], msg="y")
+    assert torch.equal(mask.cpu(), g["out"]["mask"])
+    close(pos, g["out"]["pos"], msg="pos")
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    check_param_grads(m, g["grad"], "encoder.embed.")
+    m2 = load_into(Conv2dSubsampling4(80, 32, PositionalEncoding(32)), g["sd"], "encoder.embed.")
+    y2, _, _ = m2(g["in"]["x"].to(DEV), g["in"]["mask"].to(DEV))
+    close(y2, g["out"]["y_abs"], msg="y_abs")
+
+
+def test_f02_relpos_mha():
+    g = load_golden("f02_relpos_mha")
+    m = load_into(RelPositionMultiHeadedAttention(4, 32, 0.0), g["sd"], "attn.")
+    x = g["in"]["x"].to(DEV).requires_grad_()
+    y = m(x, x, x, g["in"]["mask"].to(DEV), g["in"]["pos"].to(DEV))
+    close(y, g["out"]["y"], msg="y")
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4, msg="dx")
+    check_param_grads(m, g["grad"], "attn.")
+
+
+def test_f03_mha_key_mask_and_full_mask():
+    g = load_golden("f03_mha")
+    m = load_into(MultiHeadedAttention(4, 32, 0.0), g["sd"], "attn.")
+    q = g["in"]["q"].to(DEV).requires_grad_()
+    kv = g["in"]["kv"].to(DEV).requires_grad_()
+    y1 = m(q, kv, kv, g["in"]["mask_k"].to(DEV))
+    close(y1, g["out"]["y1"], msg="y1")
+    (y1 * g["in"]["w1"].to(DEV)).sum().backward()
+    close(q.grad, g["grad1"]["q"], rtol=1e-3, atol=2e-4, msg="dq")
+    close(kv.grad, g["grad1"]["kv"], rtol=1e-3, atol=2e-4, msg="dkv")
+    check_param_grads(m, g["grad1"], "attn.")
+    m.zero_grad()
+    s = g["in"]["s"].to(DEV).requires_grad_()
+    y2 = m(s, s, s, g["in"]["mask_full"].to(DEV))
+    close(y2, g["out"]["y2"], msg="y2")
+    (y2 * g["in"]["w2"].to(DEV)).sum().backward()
+    close(s.grad, g["grad2"]["s"], rtol=1e-3, atol=2e-4, msg="ds")
+    check_param_grads(m, g["grad2"], "attn.")
+
+
+@pytest.mark.parametrize("name,causal", [("f04_conv_module", False), ("f04_conv_module_causal", True)])
+def test_f04_conv_module(name, causal):
+    g = load_golden(name)
+    m = load_into(ConvolutionModule(32, 15, Swish(), causal), g["sd"], "conv.")
+    x = g["in"]["x"].to(DEV).requires_grad_()
+    y = m(x, g["in"]["mask"].to(DEV))
+    close(y, g["out"]["y"], msg="y")
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4, msg="dx")
+    check_param_grads(m, g["grad"], "conv.")
+
+
+def build_encoder(name, sd):
+    conformer = "conformer" in name
+    gc = None
+    if "cmvn" in name:
+        gc = GlobalCMVN(sd["encoder.global_cmvn.mean"].clone(), sd["encoder.global_cmvn.istd"].clone())
+    if conformer:
+        enc = TransformerEncoder(80, "conv2d", "rel_pos", 32, 0.0, 4, 64, "swish", True, True, 15, False, False, 64, 0.1,
+                                 num_blocks=2, global_cmvn=gc)
+    else:
+        enc = TransformerEncoder(80, "conv2d", "abs_pos", 32, 0.0, 4, 64, "relu", False, False, 15, False, False, 64, 0.1,
+                                 num_blocks=2, global_cmvn=gc)
+    return load_into(enc, sd, "encoder.")
+
+
+@pytest.mark.parametrize("name", ["f06_encoder_conformer", "f06_encoder_conformer_cmvn", "f06_encoder_transformer"])
+def test_f05_f06_encoder(name):
+    g = load_golden(name)
+    enc = build_encoder(name, g["sd"])
+    y, mask, pos = enc(g["in"]["x"].to(DEV), g["in"]["mask"].to(DEV))
+    close(y, g["out"]["y"], rtol=5e-4, atol=2e-4, msg="y")
+    assert torch.equal(mask.cpu(), g["out"]["mask"])
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    check_param_grads(enc, g["grad"], "encoder.", rtol=3e-3, rel_floor=1e-3)
+    # one layer on its own (F5)
+    enc.zero_grad()
+    xl = g["in"]["xl"].to(DEV).requires_grad_()
+    yl, _ = enc.encoders[0](xl, g["out"]["mask"].to(DEV), g["out"]["pos"].to(DEV))
+    close(yl, g["out"]["yl"], msg="yl")
+    (yl * g["in"]["wl"].to(DEV)).sum().backward()
+    close(xl.grad, g["grad_layer"]["xl"], rtol=1e-3, atol=2e-4, msg="dxl")
+    check_param_grads(enc.encoders[0], g["grad_layer"], "encoder.encoders.0.")
+
+
+def test_f07_ctc_module():
+    g = load_golden("f07_ctc")
+    m = load_into(CTC(20, 16), g["sd"], "ctc.")
+    hs = g["in"]["hs"].to(DEV).requires_grad_()
+    loss = m(hs, g["in"]["hlens"].to(DEV), g["in"]["ys"].to(DEV), g["in"]["ylens"].to(DEV))
+    close(loss, g["out"]["loss"], msg="loss")
+    loss.backward()
+    close(hs.grad, g["grad"]["hs"], rtol=1e-3, atol=1e-5, msg="dhs")
+    check_param_grads(m, g["grad"], "ctc.")
+    close(m.logits(g["in"]["hs"].to(DEV)), g["out"]["logits"], msg="logits")
+
+
+def test_f08_label_smoothing_module():
+    g = load_golden("f08_lsm")
+    for nl, sm, tag in ((False, 0.1, "b"), (True, 0.1, "l"), (False, 0.0, "ce")):
+        crit = LabelSmoothingLoss(23, -1, sm, nl)
+        x = g["in"]["x"].to(DEV).requires_grad_()
+        loss = crit(x, g["in"]["tgt"].to(DEV))
+        close(loss, g["out"]["loss_" + tag], msg="loss_" + tag)
+        loss.backward()
+        close(x.grad, g["grad"]["x_" + tag], rtol=1e-3, atol=1e-6, msg="dx_" + tag)
+
+
+def test_f09_bidecoder_and_incremental_decoding():
+    g = load_golden("f09_decoder")
+    i = g["in"]
+    dec = load_into(BiTransformerDecoder(30, 32, 0.0, 4, 64, False, 64, 0.1, num_blocks=2, r_num_blocks=1), g["sd"], "decoder.")
+    mem = i["mem"].to(DEV).requires_grad_()
+    l_x, r_x, pre = dec(mem, i["mem_mask"].to(DEV), i["ys_in"].to(DEV), i["r_in"].to(DEV), i["tgt_mask"].to(DEV))
+    close(l_x, g["out"]["l_x"], rtol=2e-4, atol=1e-4, msg="l_x")
+    close(r_x, g["out"]["r_x"], rtol=2e-4, atol=1e-4, msg="r_x")
+    close(pre, g["out"]["pre"], rtol=2e-4, atol=1e-4, msg="pre")
+    ((l_x * i["wl"].to(DEV)).sum() + (r_x * i["wr"].to(DEV)).sum()).backward()
+    close(mem.grad, g["grad"]["mem"], rtol=2e-3, atol=5e-4, msg="dmem")
+    check_param_grads(dec, g["grad"], "decoder.", rtol=3e-3, rel_floor=1e-3)
+    dec.eval()
+    cache = None
+    from openeat_amd.utils.mask import subsequent_mask
+    with torch.no_grad():
+        for step in range(1, 5):
+            hm = subsequent_mask(step, device=DEV).unsqueeze(0).repeat(3, 1, 1)
+            p, cache, _ = dec.forward_one_step(i["ys_in"][:, :step].to(DEV), hm, i["mem"].to(DEV), i["mem_mask"].to(DEV), cache)
+            close(p, g["out"]["steps"][step - 1], rtol=2e-4, atol=1e-4, msg=f"step{step}")
+
+
+E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False}
+
+
+@pytest.mark.parametrize("name", list(E2E))
+def test_f11_f12_end_to_end_against_reference(name):
+    """BASELINE.json configs[0] (F11) and a tiny Conformer with the bi-decoder (F12):
+    loss, accuracy, every parameter-gradient norm, greedy ids, prefix-beam n-best, rescoring."""
+    g = load_golden(name)
+    meta = load_golden_json(name)
+    sd = redraw_state_dict(meta) if E2E[name] else g["sd"]
+    model = ASRModel(80, meta["V"], **meta["kwargs"])
+    model.load_state_dict(sd)
+    model = model.to(DEV).eval()
+    i = {k: v.to(DEV) for k, v in g["in"].items()}
+    loss, acc = model(i["feats"], i["flen"], i["tgt"], i["tlen"])
+    close(loss, g["out"]["loss"], rtol=2e-4, atol=2e-4, msg="loss")
+    close(acc, g["out"]["acc"], rtol=1e-6, atol=1e-6, msg="acc")
+    loss.backward()
+    grads = dict(model.named_parameters())
+    for k, n in meta["grad_norm"].items():
+        got = float(grads[k].grad.norm())
+        assert abs(got - n) <= 3e-3 * max(1.0, abs(n)), (k, got, n)
+    check_param_grads(model, g["grad"], "", rtol=3e-3, rel_floor=1e-3)
+    with torch.no_grad():
+        assert model.ctc_greedy_search(i["feats"], i["flen"]) == meta["greedy"]            # bit-exact token ids
+        n0 = int(i["flen"][0])
+        nbest, _ = model._ctc_prefix_beam_search(i["feats"][:1, :n0].contiguous(), i["flen"][:1], meta["beam"])
+        assert [list(p) for p, _ in nbest] == [p for p, _ in meta["nbest"]]
+        for (_, s), (_, r) in zip(nbest, meta["nbest"]):
+            assert abs(s - r) < 1e-3 * max(1.0, abs(r))
+        tok2chr = {t: str(t) for t in range(meta["V"])}
+        best, _, _ = model.attention_rescoring(i["feats"][:1, :n0].contiguous(), i["flen"][:1], meta["beam"], ctc_weight=0.5,
+                                               reverse_weight=meta["kwargs"].get("reverse_weight", 0.0), token2char=tok2chr)
+        assert list(best) == meta["rescored"]
+        rec = model.recognize(i["feats"][:2].contiguous(), i["flen"][:2], beam_size=3)
+        assert rec.tolist() == meta["recognize"]

@@ -1,0 +1,129 @@
+"""CPU: host-side logic of the product (no kernels launched): helper tables against the
+reference's golden vectors, checkpoint layout, scheduler, and the no-CPU-fallback rule."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, load_golden, load_golden_json
+from openeat_amd.models.asr_model import ASRModel
+from openeat_amd.utils import common as C
+from openeat_amd.utils import mask as M
+from openeat_amd.utils.checkpoint import load_checkpoint, load_trained_modules, save_checkpoint
+from openeat_amd.utils.cmvn import load_cmvn
+from openeat_amd.utils.scheduler import WarmupLR
+
+
+def test_helper_tables_match_reference_f10():
+    j = load_golden_json("f10_helpers")
+    ys = torch.tensor(j["ys"], dtype=torch.int32)
+    ys_in, ys_out = C.add_sos_eos(ys, 10, 11, -1)
+    assert ys_in.tolist() == j["ys_in"] and ys_out.tolist() == j["ys_out"]
+    assert ys_in.dtype == torch.long and ys_out.dtype == torch.long
+    assert C.reverse_pad_list(ys, torch.tensor(j["lens"]), -1.0).tolist() == j["rev"]
+    assert M.make_pad_mask(torch.tensor([5, 3, 2])).int().tolist() == j["pad_mask"]
+    assert M.make_pad_mask(torch.tensor([5, 3, 2]), 8).int().tolist() == j["pad_mask8"]
+    assert M.subsequent_mask(5).int().tolist() == j["subsequent"]
+    assert [C.remove_duplicates_and_blank(p) for p in j["paths"]] == j["collapsed"]
+    la = [C.log_add([-1.0, -2.5, -float("inf")]), C.log_add([-float("inf")] * 2), C.log_add([0.3])]
+    for a, b in zip(la, j["log_add"]):
+        b = -float("inf") if b == "-inf" else b
+        assert a == b or abs(a - b) < 1e-12
+
+
+def test_add_sos_eos_static_shapes_and_interior_padding():
+    ys = torch.tensor([[3, 4, 5], [6, -1, -1]], dtype=torch.int32)
+    C.STATIC_SHAPES = True
+    try:
+        a, b = C.add_sos_eos(ys, 9, 9, -1)
+        r = C.reverse_pad_list(ys, torch.tensor([3, 1]), -1)
+    finally:
+        C.STATIC_SHAPES = False
+    assert a.tolist() == [[9, 3, 4, 5], [9, 6, 9, 9]] and b.tolist() == [[3, 4, 5, 9], [6, 9, -1, -1]]
+    assert r.tolist() == [[5, 4, 3], [6, -1, -1]]
+    # the reference drops ignore_id wherever it sits (common.py:126)
+    a, b = C.add_sos_eos(torch.tensor([[-1, 7, 8]]), 9, 9, -1)
+    assert a.tolist() == [[9, 7, 8]] and b.tolist() == [[7, 8, 9]]
+
+
+def test_finished_beam_masks():
+    score = torch.zeros(4, 3)
+    flag = torch.tensor([[True], [False], [True], [False]])
+    out = M.mask_finished_scores(score.clone() + 1.5, flag)
+    assert out[0].tolist() == [0.0, -float("inf"), -float("inf")] and out[1].tolist() == [1.5] * 3
+    pred = M.mask_finished_preds(torch.arange(12).view(4, 3), flag, 99)
+    assert pred[0].tolist() == [99] * 3 and pred[1].tolist() == [3, 4, 5]
+
+
+def test_state_dict_layout_matches_reference_checkpoint():
+    meta = load_golden_json("f12_tiny_conformer")
+    g = load_golden("f12_tiny_conformer")
+    model = ASRModel(80, meta["V"], **meta["kwargs"])
+    own = model.state_dict()
+    assert list(own.keys()) == list(g["sd"].keys())            # same keys, same order as the reference
+    for k, v in g["sd"].items():
+        assert tuple(own[k].shape) == tuple(v.shape), k
+    model.load_state_dict(g["sd"])                              # a reference checkpoint loads strictly
+    meta11 = load_golden_json("f11_config1_transformer")
+    m11 = ASRModel(80, meta11["V"], **meta11["kwargs"])
+    assert [[k, list(p.shape)] for k, p in m11.named_parameters()] == meta11["param_order"]
+
+
+def test_unknown_config_key_raises_like_the_reference():
+    with pytest.raises(TypeError):
+        ASRModel(80, 50, not_a_key=1)
+
+
+def test_checkpoint_roundtrip(tmp_path):
+    m = ASRModel(80, 30, encoder_num_blocks=1, decoder_num_blocks=1, d_model=16, attention_heads=4, linear_units=32)
+    path = str(tmp_path / "3.pt")
+    save_checkpoint(m, path, {"epoch": 3, "lr": 0.001, "step": 77})
+    assert os.path.exists(str(tmp_path / "3.yaml"))
+    sd = torch.load(path)
+    assert list(sd.keys()) == list(m.state_dict().keys())       # flat state_dict, no wrapper key
+    m2 = ASRModel(80, 30, encoder_num_blocks=1, decoder_num_blocks=1, d_model=16, attention_heads=4, linear_units=32)
+    info = load_checkpoint(m2, path)
+    assert info == {"epoch": 3, "lr": 0.001, "step": 77}
+    for a, b in zip(m.state_dict().values(), m2.state_dict().values()):
+        assert torch.equal(a, b)
+    m3 = ASRModel(80, 30, encoder_num_blocks=1, decoder_num_blocks=1, d_model=16, attention_heads=4, linear_units=32)
+    before = m3.decoder.left_decoder.output_layer.weight.clone()
+    load_trained_modules(m3, path, ["encoder.", "ctc."])
+    assert torch.equal(m3.ctc.ctc_lo.weight, m.ctc.ctc_lo.weight)
+    assert torch.equal(m3.decoder.left_decoder.output_layer.weight, before)
+
+
+def test_warmup_lr_and_cmvn_match_reference_f13():
+    g = load_golden("f13_misc")
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=1e-3)
+    sch = WarmupLR(opt, warmup_steps=25)
+    lrs = []
+    for _ in range(60):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    np.testing.assert_allclose(np.array(lrs), g["out"]["lrs"].numpy(), rtol=1e-12)
+    mean, istd = load_cmvn(os.path.join(GOLDEN, "f13_cmvn_stats.json"), True)
+    np.testing.assert_allclose(mean, g["out"]["cmvn_mean"].numpy(), rtol=1e-12)
+    np.testing.assert_allclose(istd, g["out"]["cmvn_istd"].numpy(), rtol=1e-12)
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing on the host."""
+    from openeat_amd import ops
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        ops.layer_norm(torch.randn(4, 32), torch.ones(32), torch.zeros(32), 1e-5)
+    m = ASRModel(80, 30, encoder_num_blocks=1, decoder_num_blocks=1, d_model=16, attention_heads=4, linear_units=32)
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        m(torch.randn(2, 40, 80), torch.tensor([40, 30]), torch.randint(1, 29, (2, 4), dtype=torch.int32),
+          torch.tensor([4, 3], dtype=torch.int32))
+
+
+def test_product_never_imports_the_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import openeat_amd.models.asr_model, openeat_amd.ops; "
+            "bad=[m for m in sys.modules if m=='oracle' or m.startswith('oracle.')]; assert not bad, bad")
+    subprocess.check_call([sys.executable, "-c", code], cwd=os.path.dirname(GOLDEN) + "/..")
