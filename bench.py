@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training throughput of the 12-layer Conformer (BASELINE.json
+configs[1]) on synthetic 16 kHz audio, hot path end to end on the GPU:
+
+    wav (B x 10 s) -> fbank + per-utterance norm -> Conv2dSubsampling4 -> 12 x Conformer ->
+    CTC head + bi-directional attention decoder -> joint loss -> backward -> gradient
+    all-reduce (N > 1) -> clip + Adam.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Prints ONE JSON line on rank 0.  A "step" is one optimizer step on one batch of
+B utterances per GPU; `value` = audio frames (10 ms) processed per second by the
+whole job, inputs resident in HBM when the timed region starts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "audio-frames/sec/GPU (train) + RTF (attention-rescoring decode), 12L Conformer"
+V = 3246
+MODEL_CONF = dict(encoder_num_blocks=12, decoder_num_blocks=3, r_decoder_num_blocks=3, d_model=256, attention_heads=4,
+                  linear_units=1024, dropout_rate=0.1, input_layer="conv2d", pos_enc_layer_type="rel_pos",
+                  activation_type="swish", macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, causal=False,
+                  ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3, length_normalized_loss=False)
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def synth_batch(B, seconds, L, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    wav = (torch.rand(B, int(16000 * seconds), generator=g) - 0.5)
+    tgt = torch.randint(2, V - 1, (B, L), generator=g, dtype=torch.int32)
+    tlen = torch.full((B,), L, dtype=torch.int32)
+    return wav.to(device), tgt.to(device), tlen.to(device)
+
+
+def cpu_baseline(B, seconds, L, steps):
+    """The oracle (CPU restatement of the reference, oracle/) timed on this box's host cores on a
+    bounded sample of the same workload: same model, B utterances of `seconds` s, fwd+bwd+clip+Adam."""
+    from oracle import asr as O
+    from oracle import fbank as FB
+    from openeat_amd.models.asr_model import ASRModel
+    torch.manual_seed(777)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = ASRModel(80, V, **MODEL_CONF)                       # only used as a parameter container / initialiser
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
+    cfg = O.Config(input_size=80, vocab_size=V, **MODEL_CONF)
+    params = [v for v in sd.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    wav, tgt, tlen = synth_batch(B, seconds, L, 0, "cpu")
+    frames = 0
+    times = []
+    for it in range(steps + 1):
+        t0 = time.perf_counter()
+        feats = torch.stack([FB.utt_normalize(FB.fbank(w)) for w in wav])
+        flen = torch.full((B,), feats.shape[1], dtype=torch.int32)
+        loss, _ = O.forward(sd, cfg, feats, flen, tgt, tlen, training=True)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, 5.0)
+        opt.step()
+        dt = time.perf_counter() - t0
+        if it > 0:                                              # first iteration = warm-up
+            times.append(dt)
+            frames += B * feats.shape[1]
+    return {"value": frames / sum(times), "unit": "audio-frames/s", "cores": cores, "kind": "port",
+            "sample": f"B={B} x {seconds:g} s utterances, {steps} timed fwd+bwd+clip+Adam steps after 1 warm-up, dropout 0.1"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--target-len", type=int, default=30)
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step as a HIP graph (N=1 only uses it)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    from openeat_amd import ddp, hip
+    rank, local, world = ddp.init_from_env()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (openeat_amd has no CPU path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    hip.lib()
+
+    from openeat_amd.engine import TrainEngine
+    from openeat_amd.frontend import Fbank, utt_normalize_
+    from openeat_amd.models.asr_model import ASRModel
+
+    torch.manual_seed(777)
+    model = ASRModel(80, V, **MODEL_CONF).to(dev).train()
+    engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    fb = Fbank(80, device=dev)
+    wav, tgt, tlen = synth_batch(args.batch, args.seconds, args.target_len, seed=rank, device=dev)
+    T = fb.num_frames(wav.shape[1])
+    feats = torch.empty(args.batch, T, 80, device=dev)
+    flen = torch.full((args.batch,), T, dtype=torch.int32, device=dev)
+
+    class WithFrontend(torch.nn.Module):
+        """fbank + per-utterance normalisation in front of the model: the whole hot path is one step."""
+        def __init__(self, m):
+            super().__init__()
+            self.m = m
+
+        def forward(self, wav, targets, targets_length):
+            fb(wav, out=feats)
+            utt_normalize_(feats, flen)
+            return self.m(feats, flen, targets, targets_length)
+
+    engine.model = WithFrontend(model)
+    batch = {"wav": wav, "targets": tgt, "targets_length": tlen}
+    use_graph = (world == 1) and not args.no_graph
+    if use_graph:
+        engine.capture(batch, warmup=max(1, args.warmup))
+        run = lambda: engine.replay()
+    else:
+        run = lambda: engine.step(batch)
+        for _ in range(args.warmup):
+            run()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    loss = float(out[0])
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.batch * T / (elapsed / args.steps)
+
+    # ---- roofline of the dominant kernel (fp32 MFMA GEMM), measured live with HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        hip.PROFILE = []
+        for _ in range(2):
+            engine.step(batch)                                  # eager steps: every GEMM launch bracketed by events
+        torch.cuda.synchronize()
+        recs, hip.PROFILE = hip.PROFILE, None
+        recs = recs[len(recs) // 2:]                            # second step only
+        flops = sum(r[2] for r in recs)
+        secs = sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+        ach = flops / secs / 1e12
+        roof = {"kernel": "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)", "bound": "mfma", "achieved": ach,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "launches_per_step": len(recs), "avg_launch_us": secs / max(len(recs), 1) * 1e6,
+                "gemm_ms_per_step": secs * 1e3, "algorithmic_gflop_per_step": flops / 1e9}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.cpu_batch, args.seconds, args.target_len, args.cpu_steps)
+
+    if rank == 0:
+        line = {"metric": METRIC, "value": value, "unit": "audio-frames/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[1]: 12L Conformer d=256 (12+3+3, h=4, ff=1024, K=15, V=3246), "
+                                       f"B={args.batch}/GPU x {args.seconds:g} s 16 kHz wav (T={T} frames), L={args.target_len}, "
+                                       "CTC+attention joint loss, fbank+fwd+bwd+clip+Adam, dropout 0.1",
+                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph},
+                "loss": loss, "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -220,12 +220,14 @@ int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, in
 
 /* GLU + depthwise Conv1d(K, groups=d) of the Conformer conv module
  * (convolution.py:104-107): a (B,T,2d) -> y (B,T,d); w (d,1,K); causal => left
- * padding K-1 (convolution.py:40-47,92-93).  backward: da (B,T,2d) written,
- * dw/db accumulated atomically. */
-int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, int B, int T, int d, int K, int causal,
-                      float* y, void* stream);
-int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, int B, int T, int d, int K, int causal,
-                      float* da, float* dw, float* db, void* stream);
+ * padding K-1 (convolution.py:40-47,92-93).  gpad (optional, [d]): value of the
+ * GLU output on the virtual frames t < 0 - the reference pads BEFORE the
+ * pointwise conv, so they carry GLU(pointwise bias); dgpad accumulates its
+ * gradient.  backward: da (B,T,2d) written, dw/db accumulated atomically. */
+int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
+                      int K, int causal, float* y, void* stream);
+int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, const float* gpad, int B, int T, int d, int K,
+                      int causal, float* da, float* dw, float* db, float* dgpad, void* stream);
 
 /* Label-smoothed KL loss + accuracy + gradient, fused
  * (label_smoothing_loss.py:58-91, common.py:135-157).  logits (rows, ldv) are
@@ -246,6 +248,23 @@ int oe_grad_norm(const float* g, long n, float* workspace, float* norm_out, void
  * state[0] = step count, state[1] = 0.  lr_dev (device scalar) overrides lr. */
 int oe_adam_step(float* p, const float* g, float* m, float* v, long n, const float* lr_dev, float lr, float beta1,
                  float beta2, float eps, float max_norm, const float* total_norm, float* state, void* stream);
+
+/* Kaldi log-mel filterbank on device, replacing the torchaudio.compliance.kaldi.fbank
+ * call of dataset.py:93-100 (frame_length 25 ms, frame_shift 10 ms, snip_edges,
+ * remove_dc_offset, preemphasis 0.97, povey window, power spectrum, 20 Hz..Nyquist
+ * mel triangles, log with FLT_EPSILON floor) incl. the x 2^15 of dataset.py:75.
+ *   wav (B, wav_stride) float; nsamples (B) valid samples per row or NULL (= wav_stride)
+ *   out (B, Tmax, n_mel); frames beyond 1+(n-win)/hop are written as 0.
+ *   window [win]; twiddle [256][2] = (cos, -sin)(2 pi k/512); mel filter m covers FFT bins
+ *   mel_start[m] .. with weights mel_w[mel_off[m] .. mel_off[m+1]).
+ *   cmvn_mean/istd (optional, [n_mel]): GlobalCMVN (modules/cmvn.py:43-45) fused in. */
+int oe_fbank(const float* wav, const int* nsamples, int B, long wav_stride, int Tmax, int win, int hop, int n_mel,
+             float scale, float preemph, const float* window, const float* twiddle, const int* mel_start,
+             const int* mel_off, const float* mel_w, float floor_eps, const float* cmvn_mean,
+             const float* cmvn_istd, float* out, void* stream);
+/* Per-utterance (x - mean_t)/std_t over each utterance's own nframes[b] frames, in place
+ * (feature_processor.py:5-8: population std, no epsilon). */
+int oe_utt_normalize(float* x, const int* nframes, int B, int Tmax, int F, void* stream);
 
 #ifdef __cplusplus
 }

@@ -176,9 +176,11 @@ extern "C" int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1,
 #define DW_TT 16
 #define DW_MAXK 31
 // y[b,t,c] = bias[c] + sum_k w[c][k] * g[b, t - pad_left + k, c],  g = a[:, :d] * sigmoid(a[:, d:])
+// gpad (optional, [d]): value of g on the virtual frames t < 0.  The causal variant of the reference pads
+// its input BEFORE the pointwise conv (convolution.py:92-93), so those frames carry GLU(pointwise bias).
 __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, int T, int d, int K, int pad_left,
-                                                              float* __restrict__ y) {
+                                                              const float* __restrict__ bias, const float* __restrict__ gpad,
+                                                              int T, int d, int K, int pad_left, float* __restrict__ y) {
     extern __shared__ __attribute__((aligned(16))) float win[];       // [(DW_TT + K - 1)][d]
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * DW_TT;
@@ -193,6 +195,8 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
             const float4 xv = *reinterpret_cast<const float4*>(ap + c);
             const float4 gv = *reinterpret_cast<const float4*>(ap + d + c);
             g = make_float4(xv.x * sigmoidf_(gv.x), xv.y * sigmoidf_(gv.y), xv.z * sigmoidf_(gv.z), xv.w * sigmoidf_(gv.w));
+        } else if (t < 0 && gpad) {
+            g = *reinterpret_cast<const float4*>(gpad + c);
         }
         *reinterpret_cast<float4*>(win + r * d + c) = g;
     }
@@ -216,9 +220,10 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
 // da (B*T, 2d) = GLU'(a, dg),  dg[t,c] = sum_k w[c][k] * dy[t + pad_left - k, c]
 // dw[c][k] += sum_t dy[t,c] * g[t - pad_left + k, c] ; db[c] += sum_t dy[t,c]
 __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
-                                                              const float* __restrict__ w, int T, int d, int K, int pad_left,
+                                                              const float* __restrict__ w, const float* __restrict__ gpad,
+                                                              int T, int d, int K, int pad_left,
                                                               float* __restrict__ da, float* __restrict__ dw,
-                                                              float* __restrict__ db) {
+                                                              float* __restrict__ db, float* __restrict__ dgpad) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int rows = DW_TT + K - 1;
     float* gwin = sh;                   // g rows  t0 - pad_left ..            (for dw)
@@ -235,6 +240,8 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             const float4 xv = *reinterpret_cast<const float4*>(ap + c);
             const float4 gv = *reinterpret_cast<const float4*>(ap + d + c);
             g = make_float4(xv.x * sigmoidf_(gv.x), xv.y * sigmoidf_(gv.y), xv.z * sigmoidf_(gv.z), xv.w * sigmoidf_(gv.w));
+        } else if (tg < 0 && gpad) {
+            g = *reinterpret_cast<const float4*>(gpad + c);
         }
         *reinterpret_cast<float4*>(gwin + r * d + c) = g;
         const int td = t0 + pad_left - (K - 1) + r;
@@ -272,11 +279,24 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
 #pragma unroll
         for (int k = 0; k < DW_MAXK; ++k) if (k < K) atomicAdd(dw + c * K + k, dwk[k]);
         atomicAdd(db + c, dbs);
+        // gradient of the pad value: virtual frames tau in [-pad_left, -1] (first time tile only; its dy
+        // window starts at frame pad_left-(K-1) <= 0):  dg[tau] = sum_k w[k] dy[tau + pad_left - k]
+        if (dgpad && blockIdx.x == 0) {
+            float acc = 0.f;
+            const int td0 = pad_left - (K - 1);
+            for (int tau = -pad_left; tau < 0; ++tau)
+#pragma unroll
+                for (int k = 0; k < DW_MAXK; ++k) {
+                    const int td = tau + pad_left - k;
+                    if (k < K && td >= 0 && td - td0 < rows) acc += wk[k] * dwin[(td - td0) * d + c];
+                }
+            atomicAdd(dgpad + c, acc);
+        }
     }
 }
 
-extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, int B, int T, int d, int K, int causal,
-                                 float* y, void* stream) {
+extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
+                                 int K, int causal, float* y, void* stream) {
     OE_REQUIRE(a && w && bias && y, "oe_dwconv_glu_fwd: null pointer");
     OE_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0 && K >= 1 && K <= DW_MAXK, "oe_dwconv_glu_fwd: bad shape (d %% 4, K <= %d)", DW_MAXK);
     OE_REQUIRE(causal || (K % 2 == 1), "oe_dwconv_glu_fwd: kernel size must be odd for the symmetric convolution");
@@ -284,22 +304,23 @@ extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bi
     const size_t lds = (size_t)(DW_TT + K - 1) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_fwd: window does not fit LDS (d=%d)", d);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dwconv_glu_fwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, T, d, K,
+    hipLaunchKernelGGL(dwconv_glu_fwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, gpad, T, d, K,
                        pad_left, y);
     OE_LAUNCH_CHECK("dwconv_glu_fwd");
     return 0;
 }
 
-extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, int B, int T, int d, int K, int causal,
-                                 float* da, float* dw, float* db, void* stream) {
+extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, const float* gpad, int B, int T, int d, int K,
+                                 int causal, float* da, float* dw, float* db, float* dgpad, void* stream) {
     OE_REQUIRE(a && dy && w && da && dw && db, "oe_dwconv_glu_bwd: null pointer");
+    OE_REQUIRE(!dgpad || (K - 1 <= DW_TT + K - 1), "oe_dwconv_glu_bwd: pad window");
     OE_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0 && K >= 1 && K <= DW_MAXK, "oe_dwconv_glu_bwd: bad shape");
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
     const size_t lds = (size_t)2 * (DW_TT + K - 1) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_bwd: window does not fit LDS (d=%d)", d);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dwconv_glu_bwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, T, d, K,
-                       pad_left, da, dw, db);
+    hipLaunchKernelGGL(dwconv_glu_bwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, K,
+                       pad_left, da, dw, db, dgpad);
     OE_LAUNCH_CHECK("dwconv_glu_bwd");
     return 0;
 }

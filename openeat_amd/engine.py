@@ -1,0 +1,92 @@
+"""Training step engine: forward + backward + gradient exchange + clip + Adam,
+optionally replayed as one HIP graph (the step of the reference's
+Executor.train, /root/reference/openeat/utils/executor.py:36-63)."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from openeat_amd import ops
+from openeat_amd.arena import ParamArena
+from openeat_amd.ddp import GradAllReduce
+from openeat_amd.optim import FusedAdam
+from openeat_amd.utils import common
+
+
+class TrainEngine:
+    def __init__(self, model: torch.nn.Module, lr: float = 1e-3, grad_clip: float = 5.0, accum_grad: int = 1,
+                 n_allreduce_chunks: int = 4, static_shapes: bool = False):
+        self.model = model
+        self.arena = ParamArena(model).activate()
+        self.optimizer = FusedAdam(self.arena, lr=lr, max_grad_norm=grad_clip)
+        self.reducer = GradAllReduce(self.arena.grad, n_allreduce_chunks)
+        self.reducer.broadcast_parameters(self.arena.flat)
+        self.accum_grad = accum_grad
+        self.static_shapes = static_shapes
+        dev = self.arena.flat.device
+        self.seed_counter = torch.zeros(1, dtype=torch.int64, device=dev)      # advanced once per step on device
+        ops.set_seed_device_counter(self.seed_counter)
+        self._graph: Optional[torch.cuda.CUDAGraph] = None
+        self._static: Dict[str, torch.Tensor] = {}
+        self._out = None
+
+    # one micro-step: loss (already divided by accum_grad) and its backward
+    def _fwd_bwd(self, batch):
+        loss, acc = self.model(**batch)
+        loss = loss / self.accum_grad if self.accum_grad != 1 else loss
+        loss.backward()
+        return loss.detach(), None if acc is None else acc.detach()
+
+    def _finish(self):
+        self.reducer()
+        self.optimizer.step(lr_from_device=self._graph is not None or self._capturing)
+        self.seed_counter.add_(1)
+
+    _capturing = False
+
+    def step(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):
+        """Eager step (any shapes)."""
+        common.STATIC_SHAPES = self.static_shapes
+        if lr is not None:
+            self.optimizer.set_lr(lr)
+        self.arena.zero_grad()
+        out = self._fwd_bwd(batch)
+        self._finish()
+        return out
+
+    # ---- HIP-graph path: fixed shapes, no host sync inside the step -----------------------------
+    def capture(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
+        assert self.reducer.world == 1, "graph capture of the collective is not enabled; use step() for N > 1"
+        common.STATIC_SHAPES = True
+        self.static_shapes = True
+        self._static = {k: v.clone() for k, v in example_batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.arena.zero_grad()
+                self._fwd_bwd(self._static)
+                self._finish()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g):
+                self.arena.grad.zero_()
+                self._out = self._fwd_bwd(self._static)
+                self._finish()
+        finally:
+            self._capturing = False
+        self._graph = g
+
+    def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
+        assert self._graph is not None
+        if batch is not None:
+            for k, v in batch.items():
+                self._static[k].copy_(v)
+        if lr is not None:
+            self.optimizer.set_lr(lr)
+            self.optimizer.lr_dev.fill_(lr)
+        self._graph.replay()
+        return self._out

@@ -13,6 +13,10 @@ from typing import Optional
 
 import torch
 
+# When set to a list, every oe_gemm_f32 launch is bracketed by events on the launch stream and
+# (start, end, algorithmic flops) is appended: bench.py's live roofline measurement.
+PROFILE = None
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libopeneat_hip.so")
 _lib = None
 
@@ -109,10 +113,12 @@ _SIGNATURES = {
     "oe_conv1_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
     "oe_col2im_relu": (I, [P, P, I, I, I, I, P, P]),
-    "oe_dwconv_glu_fwd": (I, [P, P, P, I, I, I, I, I, P, P]),
-    "oe_dwconv_glu_bwd": (I, [P, P, P, I, I, I, I, I, P, P, P, P]),
+    "oe_dwconv_glu_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P]),
+    "oe_dwconv_glu_bwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P]),
     "oe_lsm_workspace_bytes": (SZ, [L]),
     "oe_lsm_loss_fused": (I, [P, L, L, I, P, I, F, I, F, F, I, P, P, P]),
+    "oe_fbank": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, P, P]),
+    "oe_utt_normalize": (I, [P, P, I, I, I, P]),
     "oe_grad_norm_workspace_floats": (SZ, []),
     "oe_grad_norm": (I, [P, L, P, P, P]),
     "oe_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, P, P, P]),
@@ -172,6 +178,13 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.conv_gather = conv_gather
     if conv is not None:
         g.conv_t1, g.conv_f1, g.conv_t2, g.conv_f2, g.conv_c = conv
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * m * n * k))
+        return
     check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
 
 

@@ -15,6 +15,7 @@ from typing import Optional
 import torch
 
 from . import hip
+from . import arena as _arena
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 ACT_IDS = {"relu": ACT_RELU, "swish": ACT_SWISH, "none": ACT_NONE}
@@ -94,12 +95,64 @@ def gemm_tn(dy, x, out=None, alpha=1.0, alpha_dev=None):
     return out
 
 
-def colsum(x, alpha=1.0, alpha_dev=None, n=None):
+def colsum(x, alpha=1.0, alpha_dev=None, n=None, out=None):
     M = x.shape[0]
     n = x.shape[1] if n is None else n
-    out = _new(n, like=x)
-    hip.call("oe_colsum_f32", x, x.stride(0), M, n, alpha, alpha_dev, out, 0)
+    acc = out is not None
+    if out is None:
+        out = _new(n, like=x)
+    hip.call("oe_colsum_f32", x, x.stride(0), M, n, alpha, alpha_dev, out, int(acc))
     return out
+
+
+# ---- parameter-gradient sinks ------------------------------------------------
+# With a ParamArena active the kernels accumulate into the flat gradient buffer and
+# autograd is told "no gradient" (None); otherwise a fresh tensor is returned.
+def wgrad(param, dy, x, alpha=1.0, alpha_dev=None):
+    tgt = _arena.grad_target(param)
+    if tgt is None:
+        return gemm_tn(dy, x, alpha=alpha, alpha_dev=alpha_dev).view(param.shape)
+    gemm_tn(dy, x, out=tgt.view(dy.shape[1], x.shape[1]), alpha=alpha, alpha_dev=alpha_dev)
+    return None
+
+
+def _sink_swapped(param, src, A, Bd, Cd):
+    """param-grad = swap_last2(src viewed [A][Bd][Cd]) accumulated into the arena or returned."""
+    tgt = _arena.grad_target(param)
+    if tgt is None:
+        out = torch.empty_like(param)
+        hip.call("oe_swap_last2", src, A, Bd, Cd, out, 0)
+        return out
+    hip.call("oe_swap_last2", src, A, Bd, Cd, tgt, 1)
+    return None
+
+
+def bgrad(param, dy, alpha=1.0, alpha_dev=None, n=None):
+    if param is None:
+        return None
+    tgt = _arena.grad_target(param)
+    if tgt is None:
+        return colsum(dy, alpha, alpha_dev, n)
+    colsum(dy, alpha, alpha_dev, n, out=tgt)
+    return None
+
+
+def grad_sink(param):
+    """(buffer the kernel accumulates into, value to hand back to autograd)."""
+    tgt = _arena.grad_target(param)
+    if tgt is None:
+        z = torch.zeros_like(param)
+        return z, z
+    return tgt.view(param.shape), None
+
+
+def _fused_rows(parts, cat_dim0=True):
+    """Weights that sit back to back in the arena are used in place; otherwise concatenated."""
+    a = _arena.active()
+    if a is not None and a.enabled and a.adjacent(*parts):
+        rows = sum(p.shape[0] for p in parts)
+        return torch.as_strided(parts[0], (rows,) + tuple(parts[0].shape[1:]), parts[0].stride()), True
+    return torch.cat(list(parts), 0), False
 
 
 def dropout_scale(x, alpha=1.0, p=0.0, seed=0, rowmask=None, cols=None):
@@ -132,9 +185,9 @@ class LayerNormFn(torch.autograd.Function):
         d = x.shape[-1]
         rows = x.numel() // d
         dx = torch.empty_like(x)
-        dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+        (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
         hip.call("oe_layernorm_bwd", dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db)
-        return dx, dg, db, None, None, None
+        return dx, rg, rb, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps, rowmask=None, act=ACT_NONE):
@@ -153,6 +206,7 @@ class LinearFn(torch.autograd.Function):
         y = gemm_nt(x2, w, b, act=act, preact_out=pre, ld_aux=w.shape[0])
         ctx.save_for_backward(x2, w, pre)
         ctx.act, ctx.has_bias, ctx.in_shape = act, b is not None, x.shape
+        ctx.bias_ref = b
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
@@ -162,8 +216,8 @@ class LinearFn(torch.autograd.Function):
         if ctx.act != ACT_NONE:
             dy2 = _act_grad(dy2, pre, ctx.act)
         dx = gemm_nn(dy2, w).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
-        dw = gemm_tn(dy2, x2)
-        db = colsum(dy2) if ctx.has_bias else None
+        dw = wgrad(w, dy2, x2)
+        db = bgrad(ctx.bias_ref, dy2) if ctx.has_bias else None
         return dx, dw, db, None
 
 
@@ -235,6 +289,7 @@ class FeedForwardFn(torch.autograd.Function):
         y = gemm_nt(a, w2, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, residual=res2,
                     ldr=0 if res2 is None else res2.stride(0), beta=out_scale)
         ctx.save_for_backward(x2, w1, w2, pre, a)
+        ctx.biases = (b1, b2)
         ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
         return y.view(*x.shape[:-1], w2.shape[0])
 
@@ -245,11 +300,12 @@ class FeedForwardFn(torch.autograd.Function):
         dy = dy.contiguous()
         dy2 = dy.view(-1, w2.shape[0])
         g2 = dy2 if (p_out == 0 and out_scale == 1.0) else dropout_scale(dy2, out_scale, p_out, s_out)
-        dw2 = gemm_tn(g2, a)
-        db2 = colsum(g2)
+        b1, b2 = ctx.biases
+        dw2 = wgrad(w2, g2, a)
+        db2 = bgrad(b2, g2)
         dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
-        dw1 = gemm_tn(dh, x2)
-        db1 = colsum(dh)
+        dw1 = wgrad(w1, dh, x2)
+        db1 = bgrad(b1, dh)
         dx = gemm_nn(dh, w1).view(in_shape)
         return dx, dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
 
@@ -285,8 +341,8 @@ class AttentionFn(torch.autograd.Function):
         xq2 = xq.view(-1, d)
         if self_attn:
             T2 = T1
-            wqkv = torch.cat([wq, wk, wv], 0)
-            bqkv = torch.cat([bq, bk, bv], 0)
+            wqkv, _ = _fused_rows((wq, wk, wv))
+            bqkv, _ = _fused_rows((bq, bk, bv))
             qkv = gemm_nt(xq2, wqkv, bqkv)                       # (B*T, 3d)
             q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
             qs = ks = vs = (T1 * 3 * d, 3 * d)
@@ -296,8 +352,8 @@ class AttentionFn(torch.autograd.Function):
             T2 = xkv.shape[1]
             xkv2 = xkv.view(-1, d)
             q = gemm_nt(xq2, wq, bq)
-            wkv = torch.cat([wk, wv], 0)
-            bkv = torch.cat([bk, bv], 0)
+            wkv, _ = _fused_rows((wk, wv))
+            bkv, _ = _fused_rows((bk, bv))
             kv = gemm_nt(xkv2, wkv, bkv)                         # (B*T2, 2d)
             k, v = kv[:, :d], kv[:, d:]
             qs, ks, vs = (T1 * d, d), (T2 * 2 * d, 2 * d), (T2 * 2 * d, 2 * d)
@@ -327,6 +383,7 @@ class AttentionFn(torch.autograd.Function):
         ctx.save_for_backward(xq2, xkv2 if not self_attn else None, wq, wk, wv, wo, qkv, None if self_attn else q,
                               None if self_attn else kv, kp, keybias, pp, None if not rel else pe2, wpos, pu, pv, m8, att, lse)
         ctx.cfg = (self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, residual is not None, mstr)
+        ctx.biases = (bq, bk, bv, bo)
         return y.view(B, T1, d)
 
     @staticmethod
@@ -337,8 +394,9 @@ class AttentionFn(torch.autograd.Function):
         dy2 = dy.view(-1, d)
         g = dy2 if p_out == 0 else dropout_scale(dy2, 1.0, p_out, s_out)
         att2 = att.view(-1, d)
-        dwo = gemm_tn(g, att2)
-        dbo = colsum(g)
+        bq, bk, bv, bo = ctx.biases
+        dwo = wgrad(wo, g, att2)
+        dbo = bgrad(bo, g)
         datt = gemm_nn(g, wo)
         delta = _new(B, H, T1, like=dy)
         if self_attn:
@@ -361,28 +419,47 @@ class AttentionFn(torch.autograd.Function):
                           o_strides=(T1 * d, d), mask=m8, mask_strides=mstr, keybias=keybias, drop_p=p_attn, seed=s_att,
                           seed_dev=_seed_dev, d_out=datt, dq=dq, dk=dk_att, dv=dv, dkeybias=dkb, delta=delta)
         hip.attention_bwd(a)
-        dwpos = dpu = dpv = None
+        dwpos = rpu = rpv = None
         if rel:
             dpp = _new(T2, d, like=dy)
-            dpu, dpv = torch.zeros_like(pu), torch.zeros_like(pv)
+            (dpu, rpu), (dpv, rpv) = grad_sink(pu), grad_sink(pv)
             hip.call("oe_relpos_backward", dkp, dkb, k, ks[0], ks[1], pp, d, pu, pv, B, T2, H, D, scale, dk, dpp, d, dpu, dpv)
-            dwpos = gemm_tn(dpp, pe2)
+            dwpos = wgrad(wpos, dpp, pe2)
+
+        def split_or_sink(parts_w, parts_b, dy_fused, x_in):
+            """Weight/bias gradients of a fused projection: one GEMM / one column sum."""
+            fw, in_place = _fused_rows(parts_w)
+            dx_in = gemm_nn(dy_fused, fw)
+            if in_place and _arena.grad_target(parts_w[0]) is not None:
+                n = dy_fused.shape[1]
+                gw = _arena.grad_target(parts_w[0])
+                gw_all = torch.as_strided(gw, (n, x_in.shape[1]), (x_in.shape[1], 1))
+                gemm_tn(dy_fused, x_in, out=gw_all)
+                gb = _arena.grad_target(parts_b[0])
+                colsum(dy_fused, out=torch.as_strided(gb, (n,), (1,)))
+                return dx_in, [None] * len(parts_w), [None] * len(parts_b)
+            dwf, dbf = gemm_tn(dy_fused, x_in), colsum(dy_fused)
+            ws, bs, o = [], [], 0
+            for pw, pb in zip(parts_w, parts_b):
+                r = pw.shape[0]
+                tw, tb = _arena.grad_target(pw), _arena.grad_target(pb)
+                if tw is not None:
+                    tw.add_(dwf[o:o + r]); tb.add_(dbf[o:o + r]); ws.append(None); bs.append(None)
+                else:
+                    ws.append(dwf[o:o + r]); bs.append(dbf[o:o + r])
+                o += r
+            return dx_in, ws, bs
+
         if self_attn:
-            wqkv = torch.cat([wq, wk, wv], 0)
-            dx = gemm_nn(dqkv, wqkv).view(B, T1, d)
-            dwqkv = gemm_tn(dqkv, xq2)
-            dbqkv = colsum(dqkv)
-            dwq, dwk, dwv = dwqkv[:d], dwqkv[d:2 * d], dwqkv[2 * d:]
-            dbq, dbk, dbv = dbqkv[:d], dbqkv[d:2 * d], dbqkv[2 * d:]
+            dx, (dwq, dwk, dwv), (dbq, dbk, dbv) = split_or_sink((wq, wk, wv), (bq, bk, bv), dqkv, xq2)
+            dx = dx.view(B, T1, d)
             dxkv = None
         else:
             dx = gemm_nn(dq, wq).view(B, T1, d)
-            dwq, dbq = gemm_tn(dq, xq2), colsum(dq)
-            wkv = torch.cat([wk, wv], 0)
-            dxkv = gemm_nn(dkv, wkv).view(B, T2, d)
-            dwkv, dbkv = gemm_tn(dkv, xkv2), colsum(dkv)
-            dwk, dwv, dbk, dbv = dwkv[:d], dwkv[d:], dbkv[:d], dbkv[d:]
-        return (dx, dxkv, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, dwpos, dpu, dpv, None, None,
+            dwq, dbq = wgrad(wq, dq, xq2), bgrad(bq, dq)
+            dxkv, (dwk, dwv), (dbk, dbv) = split_or_sink((wk, wv), (bk, bv), dkv, xkv2)
+            dxkv = dxkv.view(B, T2, d)
+        return (dx, dxkv, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, dwpos, rpu, rpv, None, None,
                 (dy if has_res else None), None)
 
 
@@ -407,7 +484,11 @@ class ConvModuleFn(torch.autograd.Function):
         w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
         a = gemm_nt(xm, w1m, b1)                                  # (B*T, 2d)
         yc = _new(B * T, d, like=x)
-        hip.call("oe_dwconv_glu_fwd", a, wd, bd, B, T, d, K, int(causal), yc)
+        gpad = None
+        if causal:   # the reference pads before pointwise_conv1: padded frames hold GLU(bias)
+            gpad = _new(d, like=x)
+            hip.call("oe_glu_fwd", b1, 1, d, gpad)
+        hip.call("oe_dwconv_glu_fwd", a, wd, bd, gpad, B, T, d, K, int(causal), yc)
         z = torch.empty_like(yc)
         stats = _new(B * T, 2, like=x)
         hip.call("oe_layernorm_fwd", yc, g, b, 1e-5, B * T, d, None, act, z, stats)
@@ -415,31 +496,39 @@ class ConvModuleFn(torch.autograd.Function):
         res2 = None if residual is None else _chk(residual, "residual").view(-1, d)
         y = gemm_nt(z, w2m, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, rowmask=rowmask, residual=res2,
                     ldr=0 if res2 is None else d)
-        ctx.save_for_backward(xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z)
+        ctx.save_for_backward(xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z, gpad)
+        ctx.biases = (b1, bd, b2)
         ctx.cfg = (B, T, d, K, causal, act, p_out, s_out, residual is not None)
         return y.view(B, T, d)
 
     @staticmethod
     def backward(ctx, dy):
-        xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z = ctx.saved_tensors
+        xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z, gpad = ctx.saved_tensors
+        b1, bd, b2 = ctx.biases
         B, T, d, K, causal, act, p_out, s_out, has_res = ctx.cfg
         dy = dy.contiguous()
         dy2 = dy.view(-1, d)
         w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
         gq = dy2 if (p_out == 0 and rowmask is None) else dropout_scale(dy2, 1.0, p_out, s_out, rowmask)
-        dw2 = gemm_tn(gq, z).view_as(w2)
-        db2 = colsum(gq)
+        dw2 = wgrad(w2, gq, z)
+        db2 = bgrad(b2, gq)
         dz = gemm_nn(gq, w2m)
         dyc = torch.empty_like(yc)
-        dg, dbeta = torch.zeros_like(g), torch.zeros_like(b)
+        (dg, rg), (dbeta, rbeta) = grad_sink(g), grad_sink(b)
         hip.call("oe_layernorm_bwd", dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta)
         da = torch.empty_like(a)
-        dwd, dbd = torch.zeros_like(wd), torch.zeros(d, device=dy.device)
-        hip.call("oe_dwconv_glu_bwd", a, dyc, wd, B, T, d, K, int(causal), da, dwd, dbd)
-        dw1 = gemm_tn(da, xm).view_as(w1)
-        db1 = colsum(da)
+        (dwd, rwd), (dbd, rbd) = grad_sink(wd), grad_sink(bd)
+        dgpad = torch.zeros(d, device=dy.device) if causal else None
+        hip.call("oe_dwconv_glu_bwd", a, dyc, wd, gpad, B, T, d, K, int(causal), da, dwd, dbd, dgpad)
+        dw1 = wgrad(w1, da, xm)
+        (db1, rb1) = grad_sink(b1)
+        colsum(da, out=db1)
+        if causal:
+            db1_pad = torch.empty_like(db1)
+            hip.call("oe_glu_bwd", b1, dgpad, 1, d, db1_pad)
+            hip.call("oe_axpby", db1_pad, db1, 2 * d, 1.0, 1.0, None, db1)
         dx = gemm_nn(da, w1m, rowmask=rowmask).view(B, T, d)
-        return dx, None, dw1, db1, dwd, dbd, dg, dbeta, dw2, db2, None, None, None, (dy if has_res else None), None, None
+        return dx, None, dw1, rb1, rwd, rbd, rg, rbeta, dw2, db2, None, None, None, (dy if has_res else None), None, None
 
 
 def conv_module(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residual=None, p_out=0.0, input_masked=False):
@@ -479,36 +568,35 @@ class Subsampling4Fn(torch.autograd.Function):
         pe2 = None if pe is None else _chk(pe, "pe").reshape(-1, d)[:T2]
         out = gemm_nt(y2v, wlg, bl, beta=xscale, residual=pe2, ldr=0 if pe2 is None else d, res_row_mod=0 if pe2 is None else T2)
         ctx.save_for_backward(x, y1, w2g, y2, wlg)
+        ctx.params = (w1, b1, w2, b2, wl, bl)
         ctx.cfg = (B, T, Fd, C, T1, F1, T2, F2, d, xscale)
         return out.view(B, T2, d)
 
     @staticmethod
     def backward(ctx, dout):
         x, y1, w2g, y2, wlg = ctx.saved_tensors
+        w1, b1, w2, b2, wl, bl = ctx.params
         B, T, Fd, C, T1, F1, T2, F2, d, xscale = ctx.cfg
         do2 = dout.contiguous().view(B * T2, d)
         y2v = y2.view(B * T2, F2 * C)
         dwlg = gemm_tn(do2, y2v, alpha=xscale)
-        dwl = _new(d, C * F2, like=do2)
-        hip.call("oe_swap_last2", dwlg, d, F2, C, dwl, 0)
-        dbl = colsum(do2, alpha=xscale)
+        dwl = _sink_swapped(wl, dwlg, d, F2, C)
+        dbl = bgrad(bl, do2, alpha=xscale)
         dy2 = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=y2v, ld_aux=F2 * C).view(B * T2 * F2, C)
         M2 = B * T2 * F2
         conv = (T1, F1, T2, F2, C)
         dw2g = _new(C, 9 * C, like=do2, zero=True)
         hip.gemm(dy2, y1, dw2g, C, 9 * C, M2, lda=C, ldb=0, ldc=9 * C, a_kmajor=True, b_kmajor=True,
                  split_k=_split_k(C, 9 * C, M2), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B)
-        dw2 = _new(C, C, 3, 3, like=do2)
-        hip.call("oe_swap_last2", dw2g, C, 9, C, dw2, 0)
-        db2 = colsum(dy2)
+        dw2 = _sink_swapped(w2, dw2g, C, 9, C)
+        db2 = bgrad(b2, dy2)
         dcol = gemm_nn(dy2, w2g)                                   # (M2, 9C)
         dy1 = torch.empty_like(y1)
         hip.call("oe_col2im_relu", dcol, y1, B, T1, F1, C, dy1)
         del dcol
-        dw1 = _new(C, 1, 3, 3, like=do2, zero=True)
-        db1 = _new(C, like=do2, zero=True)
+        (dw1, rw1), (db1, rb1) = grad_sink(w1), grad_sink(b1)
         hip.call("oe_conv1_wgrad", x, dy1, B, T, Fd, C, dw1, db1)
-        return None, dw1, db1, dw2, db2, dwl, dbl, None, None
+        return None, rw1, rb1, dw2, db2, dwl, dbl, None, None
 
 
 def subsampling4(x, w1, b1, w2, b2, wl, bl, pe, xscale):
@@ -548,6 +636,7 @@ class CTCHeadFn(torch.autograd.Function):
         hip.call("oe_ctc_loss_fused", logits, Vp, B, T, V, hl32, ys32, Lmax, yl32, 1.0 / B, nll, tot, logits, ws)
         ctx.save_for_backward(hs2, w, logits)
         ctx.shape = (B, T, d, V)
+        ctx.bias_ref = b
         return tot[0] / B
 
     @staticmethod
@@ -557,8 +646,8 @@ class CTCHeadFn(torch.autograd.Function):
         g = g.contiguous().view(1)
         dl = dlogits[:, :V]
         dhs = gemm_nn(dl, w, alpha_dev=g).view(B, T, d)
-        dw = gemm_tn(dl, hs2, alpha_dev=g)
-        db = colsum(dlogits, alpha_dev=g, n=V)
+        dw = wgrad(w, dl, hs2, alpha_dev=g)
+        db = bgrad(ctx.bias_ref, dlogits, alpha_dev=g, n=V)
         return dhs, dw, db, None, None, None
 
 
@@ -588,6 +677,7 @@ class LSMHeadFn(torch.autograd.Function):
                  1, out3, ws)
         ctx.save_for_backward(x2, w, logits)
         ctx.shape = (x.shape, V)
+        ctx.bias_ref = b
         ctx.mark_non_differentiable(out3[1], out3[2])
         return out3[0], out3[1], out3[2]
 
@@ -598,8 +688,8 @@ class LSMHeadFn(torch.autograd.Function):
         g = g.contiguous().view(1)
         dl = dlogits[:, :V]
         dx = gemm_nn(dl, w, alpha_dev=g).view(shape)
-        dw = gemm_tn(dl, x2, alpha_dev=g)
-        db = colsum(dlogits, alpha_dev=g, n=V)
+        dw = wgrad(w, dl, x2, alpha_dev=g)
+        db = bgrad(ctx.bias_ref, dlogits, alpha_dev=g, n=V)
         return dx, dw, db, None, None, None, None
 
 
@@ -648,6 +738,7 @@ class EmbedFn(torch.autograd.Function):
         out = _new(B, L, d, like=table)
         hip.call("oe_embed_fwd", tok, table, pe, B * L, L, d, V, xscale, out)
         ctx.save_for_backward(tok)
+        ctx.table_ref = table
         ctx.cfg = (V, d, xscale)
         return out
 
@@ -656,9 +747,9 @@ class EmbedFn(torch.autograd.Function):
         (tok,) = ctx.saved_tensors
         V, d, xscale = ctx.cfg
         dout = dout.contiguous()
-        dt = torch.zeros(V, d, device=dout.device)
+        dt, rt = grad_sink(ctx.table_ref)
         hip.call("oe_embed_bwd", tok, dout, tok.numel(), d, V, xscale, dt)
-        return None, dt, None, None
+        return None, rt, None, None
 
 
 def embed(tokens, table, pe, xscale):

@@ -1,0 +1,155 @@
+"""GPU: front end, parameter arena, fused optimiser, training engine (eager and HIP-graph replay)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden, load_golden_json  # noqa: E402
+from openeat_amd import arena as A  # noqa: E402
+from openeat_amd import ops  # noqa: E402
+from openeat_amd.engine import TrainEngine  # noqa: E402
+from openeat_amd.frontend import Fbank, utt_normalize_  # noqa: E402
+from openeat_amd.models.asr_model import ASRModel  # noqa: E402
+from oracle import asr as O  # noqa: E402
+from oracle import fbank as FB  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_fbank_and_utt_norm_match_oracle():
+    """fp32; tolerance rtol 2e-4 / atol 2e-3 on log-mel (FFT summation order differs from pocketfft;
+    quiet bins amplify it through the log).  The oracle itself is UNPINNED against torchaudio."""
+    torch.manual_seed(3)
+    lens = [16000, 12345, 4000, 399]
+    wav = torch.zeros(4, 16000)
+    for b, n in enumerate(lens):
+        wav[b, :n] = (torch.rand(n) - 0.5) * (0.9 if b != 2 else 0.01)
+    fb = Fbank(80, device=DEV)
+    feats, nfr = fb(wav.to(DEV), torch.tensor(lens, device=DEV))
+    torch.cuda.synchronize()
+    assert nfr.tolist() == [98, 75, 23, 0]
+    for b, n in enumerate(lens):
+        ref = FB.fbank(wav[b, :n])
+        got = feats[b, : ref.shape[0]].cpu()
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-4, atol=2e-3)
+        assert torch.all(feats[b, ref.shape[0]:] == 0)              # padded frames are zero
+    f2 = feats.clone()
+    utt_normalize_(f2, nfr)
+    torch.cuda.synchronize()
+    for b in range(3):
+        n = int(nfr[b])
+        np.testing.assert_allclose(f2[b, :n].cpu().numpy(), FB.utt_normalize(feats[b, :n].cpu()).numpy(), rtol=1e-4, atol=1e-4)
+    # fused global CMVN
+    mean, istd = torch.randn(80), torch.rand(80) + 0.5
+    f3, _ = fb(wav.to(DEV), torch.tensor(lens, device=DEV), cmvn=(mean.to(DEV), istd.to(DEV)))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(f3[0].cpu().numpy(), ((feats[0].cpu() - mean) * istd).numpy(), rtol=1e-4, atol=1e-4)
+
+
+def tiny(seed=0, dropout=0.0):
+    torch.manual_seed(seed)
+    return ASRModel(80, 40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32,
+                    attention_heads=4, linear_units=64, dropout_rate=dropout, ctc_weight=0.3, lsm_weight=0.1,
+                    reverse_weight=0.3)
+
+
+def batch_of(B=3, T=95, L=7, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.randn(B, T, 80, generator=g)
+    flen = torch.full((B,), T, dtype=torch.int32)
+    tgt = torch.randint(2, 39, (B, L), generator=g, dtype=torch.int32)
+    tlen = torch.full((B,), L, dtype=torch.int32)
+    return {k: v.to(DEV) for k, v in dict(features=feats, features_length=flen, targets=tgt, targets_length=tlen).items()}
+
+
+def test_arena_gradients_equal_autograd_gradients():
+    """The same model with and without the flat arena: identical loss, identical gradients."""
+    m1, m2 = tiny().to(DEV), tiny().to(DEV)
+    b = batch_of()
+    l1, _ = m1(**b)
+    l1.backward()
+    ar = A.ParamArena(m2).activate()
+    try:
+        ar.zero_grad()
+        l2, _ = m2(**b)
+        l2.backward()
+        torch.cuda.synchronize()
+        assert torch.equal(l1, l2)
+        assert list(m2.state_dict().keys()) == list(m1.state_dict().keys())      # layout untouched
+        for (k, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert p2.grad is not None and p2.grad.data_ptr() == ar.by_ptr[p2.data_ptr()].data_ptr(), k
+            torch.testing.assert_close(p2.grad, p1.grad, rtol=1e-4, atol=1e-5 * max(1.0, float(p1.grad.abs().max())),
+                                       msg=lambda s, k=k: f"{k}: {s}")
+        att = m2.encoder.encoders[0].self_attn
+        assert ar.adjacent(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight)
+    finally:
+        ar.deactivate()
+
+
+def test_engine_step_matches_reference_training_step():
+    """One engine step == the reference Executor's step (clip_grad_norm_ 5.0 + torch Adam) run by the
+    CPU oracle on the same parameters and batch."""
+    model = tiny(seed=5).to(DEV).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    b = batch_of(seed=2)
+    eng = TrainEngine(model, lr=1e-3, grad_clip=5.0)
+    try:
+        loss, acc = eng.step(b)
+        loss2, _ = eng.step(b)
+        torch.cuda.synchronize()
+    finally:
+        eng.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    cfg = O.Config(input_size=80, vocab_size=40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1,
+                   d_model=32, attention_heads=4, linear_units=64, dropout_rate=0.0, ctc_weight=0.3, lsm_weight=0.1,
+                   reverse_weight=0.3)
+    sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    cb = {k: v.cpu() for k, v in b.items()}
+    ref_losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        l, _ = O.forward(sd, cfg, cb["features"], cb["features_length"], cb["targets"], cb["targets_length"])
+        l.backward()
+        torch.nn.utils.clip_grad_norm_(list(sd.values()), 5.0)
+        opt.step()
+        ref_losses.append(float(l))
+    assert abs(float(loss) - ref_losses[0]) < 2e-4 * abs(ref_losses[0])
+    assert abs(float(loss2) - ref_losses[1]) < 5e-4 * abs(ref_losses[1])
+    for k, v in model.state_dict().items():
+        torch.testing.assert_close(v.cpu(), sd[k].detach(), rtol=1e-3, atol=2e-5, msg=lambda s, k=k: f"{k}: {s}")
+
+
+def test_graph_replay_equals_eager_steps():
+    m1, m2 = tiny(seed=7).to(DEV).train(), tiny(seed=7).to(DEV).train()
+    b = batch_of(seed=3)
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    for _ in range(5):
+        l_eager, _ = e1.step(b)
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    try:
+        e2.capture(b, warmup=2)                 # 2 warm-up steps happen inside capture()
+        for _ in range(3):
+            l_graph, _ = e2.replay()
+        torch.cuda.synchronize()
+    finally:
+        e2.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    torch.testing.assert_close(l_graph, l_eager, rtol=1e-4, atol=1e-5)
+    for (k, a), (_, c) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        torch.testing.assert_close(c, a, rtol=1e-3, atol=2e-5, msg=lambda s, k=k: f"{k}: {s}")
+
+
+def test_dropout_training_step_runs_and_is_seed_dependent():
+    m = tiny(seed=9, dropout=0.1).to(DEV).train()
+    b = batch_of(seed=4)
+    l1, _ = m(**b)
+    l2, _ = m(**b)
+    m.eval()
+    l3, _ = m(**b)
+    l4, _ = m(**b)
+    torch.cuda.synchronize()
+    assert torch.isfinite(l1) and l1 != l2 and torch.equal(l3, l4)

@@ -282,7 +282,7 @@ def test_conv1_fwd_wgrad_and_conv2_dgrad():
     torch.testing.assert_close(db1.cpu(), b1.grad, rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize("causal,K,d,T", [(False, 15, 32, 21), (True, 15, 32, 21), (False, 7, 256, 50), (False, 31, 64, 40)])
+@pytest.mark.parametrize("causal,K,d,T", [(False, 15, 32, 21), (True, 15, 32, 21), (False, 7, 256, 50), (False, 31, 64, 40), (True, 7, 32, 5)])
 def test_dwconv_glu_fwd_bwd(causal, K, d, T):
     torch.manual_seed(17)
     B = 3
@@ -290,18 +290,23 @@ def test_dwconv_glu_fwd_bwd(causal, K, d, T):
     w = (torch.randn(d, 1, K) * 0.3).requires_grad_()
     b = torch.randn(d, requires_grad=True)
     g = F.glu(a.transpose(1, 2), dim=1)
+    gp = torch.randn(d, requires_grad=True)          # value on the virtual left frames (causal only)
     if causal:
-        g = F.pad(g, (K - 1, 0))
+        g = torch.cat([gp[None, :, None].expand(B, d, K - 1), g], dim=2)
     y_ref = F.conv1d(g, w, b, padding=0 if causal else (K - 1) // 2, groups=d).transpose(1, 2)
     gy = torch.randn(B, T, d)
     y_ref.backward(gy)
     ad, wd, bd, gyd = cu(a.detach()), cu(w.detach()), cu(b.detach()), cu(gy)
+    gpd = cu(gp.detach()) if causal else None
     y = torch.empty(B, T, d, device=DEV)
-    hip.call("oe_dwconv_glu_fwd", ad, wd, bd, B, T, d, K, int(causal), y)
+    hip.call("oe_dwconv_glu_fwd", ad, wd, bd, gpd, B, T, d, K, int(causal), y)
     da = torch.empty(B, T, 2 * d, device=DEV)
     dw, db = torch.zeros(d, K, device=DEV), torch.zeros(d, device=DEV)
-    hip.call("oe_dwconv_glu_bwd", ad, gyd, wd, B, T, d, K, int(causal), da, dw, db)
+    dgp = torch.zeros(d, device=DEV) if causal else None
+    hip.call("oe_dwconv_glu_bwd", ad, gyd, wd, gpd, B, T, d, K, int(causal), da, dw, db, dgp)
     sync()
+    if causal:
+        torch.testing.assert_close(dgp.cpu(), gp.grad, rtol=5e-4, atol=2e-4)
     torch.testing.assert_close(y.cpu(), y_ref.detach(), **TOL)
     torch.testing.assert_close(da.cpu(), a.grad, rtol=5e-4, atol=5e-5)
     torch.testing.assert_close(dw.cpu().view(d, 1, K), w.grad, rtol=5e-4, atol=2e-4)
