@@ -48,7 +48,11 @@ def cpu_baseline(B, seconds, L, steps):
     from oracle import fbank as FB
     from openeat_amd.models.asr_model import ASRModel
     torch.manual_seed(777)
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OE_CPU_BASELINE_THREADS", "16"))))   # the GPU box grants a 16-CPU share
     torch.set_num_threads(cores)
     model = ASRModel(80, V, **MODEL_CONF)                       # only used as a parameter container / initialiser
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in model.state_dict().items()}
@@ -68,11 +72,17 @@ def cpu_baseline(B, seconds, L, steps):
         torch.nn.utils.clip_grad_norm_(params, 5.0)
         opt.step()
         dt = time.perf_counter() - t0
+        log(f"  cpu step {it}: {dt:.1f} s")
         if it > 0:                                              # first iteration = warm-up
             times.append(dt)
             frames += B * feats.shape[1]
     return {"value": frames / sum(times), "unit": "audio-frames/s", "cores": cores, "kind": "port",
             "sample": f"B={B} x {seconds:g} s utterances, {steps} timed fwd+bwd+clip+Adam steps after 1 warm-up, dropout 0.1"}
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -86,7 +96,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step as a HIP graph (N=1 only uses it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=1)
     args = ap.parse_args()
 
     from openeat_amd import ddp, hip
@@ -101,6 +111,7 @@ def main():
     from openeat_amd.frontend import Fbank, utt_normalize_
     from openeat_amd.models.asr_model import ASRModel
 
+    log(f"world={world} device={torch.cuda.get_device_name(dev)}")
     torch.manual_seed(777)
     model = ASRModel(80, V, **MODEL_CONF).to(dev).train()
     engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True)
@@ -124,9 +135,14 @@ def main():
     engine.model = WithFrontend(model)
     batch = {"wav": wav, "targets": tgt, "targets_length": tlen}
     use_graph = (world == 1) and not args.no_graph
+    log("first eager step ...")
+    l0 = engine.step(batch)[0]
+    torch.cuda.synchronize()
+    log(f"first eager step done, loss={float(l0):.4f}")
     if use_graph:
         engine.capture(batch, warmup=max(1, args.warmup))
         run = lambda: engine.replay()
+        log("HIP graph captured")
     else:
         run = lambda: engine.step(batch)
         for _ in range(args.warmup):
@@ -148,6 +164,7 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     loss = float(out[0])
+    log(f"timed region done: {elapsed / args.steps * 1e3:.2f} ms/step")
     ms_per_step = elapsed / args.steps * 1e3
     value = world * args.batch * T / (elapsed / args.steps)
 
@@ -170,7 +187,9 @@ def main():
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        log("cpu baseline (oracle on host cores) ...")
         cpu = cpu_baseline(args.cpu_batch, args.seconds, args.target_len, args.cpu_steps)
+        log(f"cpu baseline done: {cpu['value']:.0f} frames/s on {cpu['cores']} threads")
 
     if rank == 0:
         line = {"metric": METRIC, "value": value, "unit": "audio-frames/s", "n_gpus": world, "steps": args.steps,

@@ -53,14 +53,15 @@ def add_sos_eos(ys_pad: torch.Tensor, sos: int, eos: int, ignore_id: int) -> Tup
     keep, lens, slot = _compact(ys_pad, ignore_id)
     width = (L if STATIC_SHAPES else (int(lens.max().item()) if B > 0 else 0)) + 1
     ys = ys_pad.to(torch.long)
-    ys_in = ys.new_full((B, width), eos)
-    ys_out = ys.new_full((B, width), ignore_id)
-    ys_in[:, 0] = sos
-    rows = torch.arange(B, device=ys.device).unsqueeze(1).expand(B, L)
-    ys_in[rows[keep], slot[keep] + 1] = ys[keep]
-    ys_out[rows[keep], slot[keep]] = ys[keep]
-    ys_out[torch.arange(B, device=ys.device), lens] = eos
-    return ys_in, ys_out
+    # sync-free compaction: dropped entries are scattered into a spare last column that is sliced off
+    spare = width
+    buf_in = ys.new_full((B, width + 1), eos)
+    buf_in[:, 0] = sos
+    buf_in.scatter_(1, torch.where(keep, slot + 1, torch.full_like(slot, spare)), ys)
+    buf_out = ys.new_full((B, width + 1), ignore_id)
+    buf_out.scatter_(1, torch.where(keep, slot, torch.full_like(slot, spare)), ys)
+    buf_out.scatter_(1, lens.unsqueeze(1), torch.full((B, 1), eos, dtype=torch.long, device=ys.device))
+    return buf_in[:, :width].contiguous(), buf_out[:, :width].contiguous()
 
 
 def reverse_pad_list(ys_pad: torch.Tensor, ys_lens: torch.Tensor, pad_value: float = -1.0) -> torch.Tensor:
