@@ -13,73 +13,12 @@
 // before the MFMA block of the current one (register staging).
 //
 // Roofline: MFMA-bound.  fp32-input MFMA peak on gfx950 = 157.3 TFLOP/s.
-#include "oe_common.h"
+#include "gemm_common.h"
 #include "../../include/openeat_hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define BK 16
 #define LDS_PAD 4
-
-struct OperandDesc {
-    const float* p;
-    long ld;
-    int vec_ok;     // 16-byte vector loads are legal (pointer/ld alignment)
-    // conv2 im2col gather (NHWC input (B,T1,F1,C), 3x3 stride 2, output (B,T2,F2)):
-    int T1, F1, T2, F2, C;
-};
-
-template <bool GATHER>
-__device__ __forceinline__ long addr_row(const OperandDesc& d, long r) {
-    if (!GATHER) return r * d.ld;
-    int f = (int)(r % d.F2);
-    long q = r / d.F2;
-    int t = (int)(q % d.T2);
-    long b = q / d.T2;
-    return ((b * d.T1 + 2 * t) * (long)d.F1 + 2 * f) * d.C;
-}
-template <bool GATHER>
-__device__ __forceinline__ long addr_col(const OperandDesc& d, long c) {
-    if (!GATHER) return c;
-    int seg = 3 * d.C;
-    int kh = (int)(c / seg);
-    return (long)kh * d.F1 * d.C + (c - (long)kh * seg);
-}
-
-// Load 4 consecutive logical elements (along the contiguous direction) with
-// bounds: n_valid in [0,4] elements are in range.
-__device__ __forceinline__ float4 load4(const float* p, int n_valid, bool vec_ok) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (n_valid >= 4 && vec_ok) {
-        v = *reinterpret_cast<const float4*>(p);
-    } else {
-        if (n_valid > 0) v.x = p[0];
-        if (n_valid > 1) v.y = p[1];
-        if (n_valid > 2) v.z = p[2];
-        if (n_valid > 3) v.w = p[3];
-    }
-    return v;
-}
-
-struct EpiParams {
-    float alpha;
-    const float* alpha_dev;
-    const float* bias;
-    int act;
-    float* preact_out;
-    const float* actgrad_in;
-    long ld_aux;
-    float drop_p;
-    unsigned long long seed;
-    const unsigned long long* seed_dev;
-    const unsigned char* rowmask;
-    const float* residual;
-    long ldr;
-    int res_row_mod;
-    float beta;
-    int accumulate;
-    int atomic;
-};
 
 template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
@@ -215,82 +154,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
         __syncthreads();
     }
 
-    // ---- epilogue --------------------------------------------------------------
-    // Each wave parks one 32x32 accumulator tile at a time in its own LDS patch
-    // and re-reads it row-major, so that every global access of the epilogue
-    // (C, residual, pre-activation, act-grad input) is a coalesced float4 row.
-    float alpha = ep.alpha;
-    if (ep.alpha_dev) alpha *= *ep.alpha_dev;
-    const float inv_keep = ep.drop_p > 0.f ? 1.f / (1.f - ep.drop_p) : 1.f;
-    const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
-    const bool first_split = (blockIdx.z == 0);
-    constexpr int EP_LD = 36;
-    float* patch = lds + wave * (32 * EP_LD);
-    const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && !ep.atomic;
-    const bool aux_vec = (ep.ld_aux % 4 == 0) && (((uintptr_t)ep.preact_out & 15) == 0) && (((uintptr_t)ep.actgrad_in & 15) == 0);
-    const bool res_vec = (ep.ldr % 4 == 0) && (((uintptr_t)ep.residual & 15) == 0);
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * EP_LD + lrow] = acc[i][j][r];
-            __syncthreads();
-            const long row_base = m0 + wm * (32 * TM) + i * 32;
-            const long col = n0 + wn * (32 * TN) + j * 32 + (lane & 7) * 4;
-            const int ncol = (int)max(0L, min(4L, (long)N - col));
-            float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-            if (ep.bias && first_split) for (int e = 0; e < ncol; ++e) bias4[e] = ep.bias[col + e];
-            for (int pass = 0; pass < 4; ++pass) {
-                const int lr = pass * 8 + (lane >> 3);
-                const long row = row_base + lr;
-                if (row >= M || ncol == 0) continue;
-                const float4 t4 = *reinterpret_cast<const float4*>(patch + lr * EP_LD + (lane & 7) * 4);
-                float v[4] = {t4.x, t4.y, t4.z, t4.w};
-                const bool full = (ncol == 4);
-                float aux[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
-                if (ep.actgrad_in) {
-                    const float* ap = ep.actgrad_in + row * ep.ld_aux + col;
-                    if (full && aux_vec) { float4 a4 = *reinterpret_cast<const float4*>(ap); aux[0] = a4.x; aux[1] = a4.y; aux[2] = a4.z; aux[3] = a4.w; }
-                    else for (int e = 0; e < ncol; ++e) aux[e] = ap[e];
-                }
-                if (ep.residual) {
-                    const float* rp = ep.residual + (ep.res_row_mod > 0 ? row % ep.res_row_mod : row) * ep.ldr + col;
-                    if (full && res_vec) { float4 r4 = *reinterpret_cast<const float4*>(rp); res[0] = r4.x; res[1] = r4.y; res[2] = r4.z; res[3] = r4.w; }
-                    else for (int e = 0; e < ncol; ++e) res[e] = rp[e];
-                }
-                const bool row_dead = ep.rowmask && !ep.rowmask[row];
-                float pre[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e] * alpha + bias4[e];
-                    pre[e] = x;
-                    if (ep.actgrad_in) x *= act_bwd(ep.act, aux[e]);
-                    else x = act_fwd(ep.act, x);
-                    if (ep.drop_p > 0.f) x *= dropout_scale(seed, (unsigned long long)(row * N + col + e), ep.drop_p, inv_keep);
-                    if (row_dead) x = 0.f;
-                    x = res[e] + ep.beta * x;
-                    v[e] = x;
-                }
-                if (ep.preact_out) {
-                    float* pp = ep.preact_out + row * ep.ld_aux + col;
-                    if (full && aux_vec) *reinterpret_cast<float4*>(pp) = make_float4(pre[0], pre[1], pre[2], pre[3]);
-                    else for (int e = 0; e < ncol; ++e) pp[e] = pre[e];
-                }
-                float* dst = C + row * ldc + col;
-                if (ep.atomic) {
-                    for (int e = 0; e < ncol; ++e) atomicAdd(dst + e, v[e]);
-                } else if (full && c_vec) {
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    if (ep.accumulate) { const float4 c4 = *reinterpret_cast<const float4*>(dst); o.x += c4.x; o.y += c4.y; o.z += c4.z; o.w += c4.w; }
-                    *reinterpret_cast<float4*>(dst) = o;
-                } else {
-                    for (int e = 0; e < ncol; ++e) dst[e] = ep.accumulate ? dst[e] + v[e] : v[e];
-                }
-            }
-        }
-    }
+    gemm_epilogue<TM, TN>(acc, lds, C, ldc, M, N, m0, n0, ep);
 }
 
 template <int TM, int TN, bool AK, bool BKM, bool GA, bool GB>
@@ -338,6 +202,8 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
     ep.accumulate = g->accumulate; ep.atomic = g->atomic_out;
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
+    OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3, "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");
+    if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);
     const long blocks128 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
     const bool big = blocks128 >= 320 && M >= 128 && N >= 128;
 #define OE_DISPATCH(AK, BKM, GA, GB)                                                                   \

@@ -1,0 +1,227 @@
+// bf16-input / fp32-accumulate GEMM on the CDNA4 matrix cores
+// (v_mfma_f32_32x32x16_bf16, dense peak ~2.5 PFLOP/s = 16x the fp32-input rate).
+// Operands stay fp32 in HBM and are converted while they are staged into LDS, so
+// every other kernel of the path is unchanged.  Two precisions:
+//   terms = 1 : a*b ~ hi(a)*hi(b)                       (bf16 products, ~3e-3 relative)
+//   terms = 3 : a*b ~ hi*hi + hi*lo + lo*hi, lo = bf16(x - hi(x))
+//               (error ~2^-17 per product: fp32-grade results at 3/16 of the fp32-MFMA cost)
+// Same operand addressing (plain / conv2 im2col gather) and epilogue as gemm.hip.
+//
+// Tiling: 256 threads = 2x2 waves, each wave TM x TN tiles of 32x32; K-tile 32.
+// LDS tiles are [row][k] bf16 with an 80-byte row pitch: the MFMA fragment read is one
+// ds_read_b128 per lane and is bank-conflict free (rows r..r+15 start on 16 distinct
+// 4-bank slots: 20*r mod 64).  k-major operands are transposed in registers on the way in
+// (4x4 micro-blocks, lane -> (k-block, row-block) = (l&7, l>>3) so that both the 128-byte
+// global segments and the ds_write_b64 pattern are conflict free).
+#include "gemm_common.h"
+#include "../../include/openeat_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define BK2 32
+#define PITCH 40   // bf16 elements per LDS row (32 data + 8 pad) = 80 bytes
+
+__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// One operand's staging state: ROWS x 32 tile.
+//   row-major (k contiguous): slot -> (row = idx/8, kq = idx%8), one float4 along k
+//   k-major (rows contiguous): micro-block idx -> kb = idx%8, mb = (idx/8)%8 + 8*(idx/64); four float4 along rows
+template <int ROWS, bool KMAJOR, bool GATHER>
+struct Stage {
+    static constexpr int NIDX = KMAJOR ? ROWS * 2 : ROWS * 8;           // work items per tile
+    static constexpr int NS = (NIDX + 255) / 256;                      // per thread
+    float4 reg[NS][KMAJOR ? 4 : 1];
+    long fix[NS];
+
+    __device__ __forceinline__ void init(const OperandDesc& d, long i0, long limit) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            if (!KMAJOR) {
+                const long r = i0 + idx / 8;
+                fix[s] = (idx < NIDX && r < limit) ? addr_row<GATHER>(d, r) : -1;
+            } else {
+                const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
+                fix[s] = (idx < NIDX) ? addr_col<GATHER>(d, i0 + 4 * mb) : -1;
+            }
+        }
+    }
+    __device__ __forceinline__ void load(const OperandDesc& d, long i0, long limit, int k0, int k_end) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            if (!KMAJOR) {
+                const int k = k0 + (idx & 7) * 4;
+                const int nv = (fix[s] < 0) ? 0 : max(0, min(4, k_end - k));
+                reg[s][0] = nv ? load4(d.p + fix[s] + addr_col<GATHER>(d, k), nv, d.vec_ok) : make_float4(0, 0, 0, 0);
+            } else {
+                const int kb = idx & 7;
+                const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
+                const long c = i0 + 4 * mb;
+                const int nvr = (fix[s] < 0) ? 0 : (int)max(0L, min(4L, limit - c));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = k0 + 4 * kb + i;
+                    reg[s][i] = (nvr && k < k_end) ? load4(d.p + addr_row<GATHER>(d, k) + fix[s], nvr, d.vec_ok)
+                                                   : make_float4(0, 0, 0, 0);
+                }
+            }
+        }
+    }
+    template <int TERMS>
+    __device__ __forceinline__ void store(__bf16* hi_tile, __bf16* lo_tile) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            if (idx < NIDX) {
+            if (!KMAJOR) {
+                const int row = idx >> 3, kq = (idx & 7) * 4;
+                bf16x4 h, l;
+                split4(reg[s][0], h, l);
+                *reinterpret_cast<bf16x4*>(hi_tile + row * PITCH + kq) = h;
+                if (TERMS == 3) *reinterpret_cast<bf16x4*>(lo_tile + row * PITCH + kq) = l;
+            } else {
+                const int kb = idx & 7;
+                const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
+                const float4 r0 = reg[s][0], r1 = reg[s][1], r2 = reg[s][2], r3 = reg[s][3];
+                const float4 t0 = make_float4(r0.x, r1.x, r2.x, r3.x), t1 = make_float4(r0.y, r1.y, r2.y, r3.y);
+                const float4 t2 = make_float4(r0.z, r1.z, r2.z, r3.z), t3 = make_float4(r0.w, r1.w, r2.w, r3.w);
+                bf16x4 h, l;
+                __bf16* hp = hi_tile + (4 * mb) * PITCH + 4 * kb;
+                __bf16* lp = lo_tile + (4 * mb) * PITCH + 4 * kb;
+                split4(t0, h, l); *reinterpret_cast<bf16x4*>(hp) = h;             if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp) = l;
+                split4(t1, h, l); *reinterpret_cast<bf16x4*>(hp + PITCH) = h;     if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp + PITCH) = l;
+                split4(t2, h, l); *reinterpret_cast<bf16x4*>(hp + 2 * PITCH) = h; if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp + 2 * PITCH) = l;
+                split4(t3, h, l); *reinterpret_cast<bf16x4*>(hp + 3 * PITCH) = h; if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp + 3 * PITCH) = l;
+            }
+            }
+        }
+    }
+};
+
+template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B, int TERMS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
+                                                         int M, int N, int K, int k_chunk, EpiParams ep) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int A_TILE = BM * PITCH, B_TILE = BN * PITCH;            // bf16 elements
+    constexpr int NT = (TERMS == 3) ? 2 : 1;                            // hi (+ lo) copies
+    constexpr int STAGE_ELEMS = NT * (A_TILE + B_TILE);
+    constexpr int LDS_BYTES = (2 * STAGE_ELEMS * 2 > 4 * 32 * 36 * 4) ? 2 * STAGE_ELEMS * 2 : 4 * 32 * 36 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+    __bf16* lds16 = reinterpret_cast<__bf16*>(lds_raw);
+    auto a_hi = [&](int buf) { return lds16 + buf * STAGE_ELEMS; };
+    auto a_lo = [&](int buf) { return lds16 + buf * STAGE_ELEMS + A_TILE; };
+    auto b_hi = [&](int buf) { return lds16 + buf * STAGE_ELEMS + NT * A_TILE; };
+    auto b_lo = [&](int buf) { return lds16 + buf * STAGE_ELEMS + NT * A_TILE + B_TILE; };
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
+    const int k_begin = blockIdx.z * k_chunk;
+    const int k_end = min(K, k_begin + k_chunk);
+    const int nk = (k_end - k_begin + BK2 - 1) / BK2;
+
+    Stage<BM, A_KMAJOR, GATHER_A> sa;
+    Stage<BN, B_KMAJOR, GATHER_B> sb;
+    sa.init(A, m0, M);
+    sb.init(B, n0, N);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (nk > 0) {
+        sa.load(A, m0, M, k_begin, k_end);
+        sb.load(B, n0, N, k_begin, k_end);
+        sa.template store<TERMS>(a_hi(0), a_lo(0));
+        sb.template store<TERMS>(b_hi(0), b_lo(0));
+    }
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) {
+            sa.load(A, m0, M, k_begin + (kt + 1) * BK2, k_end);
+            sb.load(B, n0, N, k_begin + (kt + 1) * BK2, k_end);
+        }
+        const __bf16* ah = a_hi(buf) + (wm * 32 * TM + frow) * PITCH + fk;
+        const __bf16* al = a_lo(buf) + (wm * 32 * TM + frow) * PITCH + fk;
+        const __bf16* bh = b_hi(buf) + (wn * 32 * TN + frow) * PITCH + fk;
+        const __bf16* bl = b_lo(buf) + (wn * 32 * TN + frow) * PITCH + fk;
+#pragma unroll
+        for (int ks = 0; ks < BK2 / 16; ++ks) {
+            bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                fah[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * PITCH + ks * 16);
+                if (TERMS == 3) fal[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * PITCH + ks * 16);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                fbh[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * PITCH + ks * 16);
+                if (TERMS == 3) fbl[j] = *reinterpret_cast<const bf16x8*>(bl + j * 32 * PITCH + ks * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (TERMS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) {
+            sa.template store<TERMS>(a_hi(buf ^ 1), a_lo(buf ^ 1));
+            sb.template store<TERMS>(b_hi(buf ^ 1), b_lo(buf ^ 1));
+        }
+        __syncthreads();
+    }
+    gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds_raw), C, ldc, M, N, m0, n0, ep);
+}
+
+template <int TM, int TN, bool AK, bool BKM, bool GA, bool GB, int TERMS>
+static int launch_bf16(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int splitk,
+                       const EpiParams& ep, hipStream_t st) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    int kc = oe_cdiv(oe_cdiv(K, splitk), BK2) * BK2;
+    if (kc <= 0) kc = BK2;
+    int nz = oe_cdiv(K, kc);
+    if (nz < 1) nz = 1;
+    dim3 grid(oe_cdiv(N, BN), oe_cdiv(M, BM), nz);
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, GA, GB, TERMS>), grid, dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, ep);
+    OE_LAUNCH_CHECK("oe_gemm (bf16 mfma)");
+    return 0;
+}
+
+// called from oe_gemm_f32 (gemm.hip) when args->precision is 1 or 3
+int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk,
+                          const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, int terms, hipStream_t st) {
+    const long blocks128 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
+    const bool big = blocks128 >= 200 && M >= 128 && N >= 128;
+#define OE_DISP(AK, BKM, GA, GB)                                                                                 \
+    do {                                                                                                         \
+        if (terms == 3)                                                                                          \
+            return big ? launch_bf16<2, 2, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st)                \
+                       : launch_bf16<1, 1, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);               \
+        return big ? launch_bf16<2, 2, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st)                    \
+                   : launch_bf16<1, 1, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st);                   \
+    } while (0)
+    if (!a_kmajor && !b_kmajor) { if (ga) OE_DISP(false, false, true, false); else OE_DISP(false, false, false, false); }
+    if (!a_kmajor && b_kmajor) OE_DISP(false, true, false, false);
+    if (a_kmajor && b_kmajor) { if (gb) OE_DISP(true, true, false, true); else OE_DISP(true, true, false, false); }
+#undef OE_DISP
+    oe_set_error("oe_gemm: layout a_kmajor=1,b_kmajor=0 is not supported");
+    return -1;
+}
