@@ -274,3 +274,65 @@ def test_ctc_greedy_matches_topk_and_collapse():
     got = [ot[b, : int(ol[b])].tolist() for b in range(B)]
     assert got == want
     assert int(fb[0, 3]) == 7
+
+
+# ------------------------------------------------------ bf16-MFMA GEMM modes -----
+@pytest.mark.parametrize("prec,rel", [(3, 2e-5), (1, 6e-3)])
+def test_gemm_bf16_precisions_all_layouts(prec, rel):
+    """precision 3 (hi*hi + hi*lo + lo*hi) is fp32-grade; precision 1 is plain bf16 products.
+    Error measured against float64, relative to sqrt(K) * |a| * |b| (the natural scale of the sum)."""
+    torch.manual_seed(20)
+    M, N, K = 700, 300, 520
+    x, w, dy = torch.randn(M, K), torch.randn(N, K), torch.randn(M, N)
+    b = torch.randn(N)
+    xd, wd, dyd, bd = cu(x), cu(w), cu(dy), cu(b)
+
+    def err(got, ref, k):
+        return float((got.cpu().double() - ref).abs().max()) / math.sqrt(k)
+
+    y = torch.empty(M, N, device=DEV)
+    hip.gemm(xd, wd, y, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, precision=prec)
+    dx = torch.empty(M, K, device=DEV)
+    hip.gemm(dyd, wd, dx, M, K, N, lda=N, ldb=K, ldc=K, b_kmajor=True, precision=prec)
+    dw = torch.zeros(N, K, device=DEV)
+    hip.gemm(dyd, xd, dw, N, K, M, lda=N, ldb=K, ldc=K, a_kmajor=True, b_kmajor=True, split_k=3, atomic_out=True, precision=prec)
+    sync()
+    assert err(y, x.double() @ w.double().T + b.double(), K) < rel * 3
+    assert err(dx, dy.double() @ w.double(), N) < rel * 3
+    assert err(dw, dy.double().T @ x.double(), M) < rel * 3
+    # big-tile path + ragged edges
+    M2, N2, K2 = 1100, 1030, 200
+    a2, b2 = torch.randn(M2, K2), torch.randn(N2, K2)
+    a2d, b2d = cu(a2), cu(b2)
+    c2 = torch.empty(M2, N2, device=DEV)
+    hip.gemm(a2d, b2d, c2, M2, N2, K2, lda=K2, ldb=K2, ldc=N2, precision=prec)
+    dw2 = torch.zeros(N2, K2, device=DEV)
+    g2 = torch.randn(M2, N2)
+    g2d = cu(g2)
+    hip.gemm(g2d, a2d, dw2, N2, K2, M2, lda=N2, ldb=K2, ldc=K2, a_kmajor=True, b_kmajor=True, split_k=1, atomic_out=True, precision=prec)
+    sync()
+    assert err(c2, a2.double() @ b2.double().T, K2) < rel * 3
+    assert err(dw2, g2.double().T @ a2.double(), M2) < rel * 3
+    # conv2 implicit GEMM (gather A forward, gather B wgrad)
+    B_, T1, F1, Cc = 2, 21, 11, 32
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    xc = torch.randn(B_, Cc, T1, F1)
+    wc = torch.randn(Cc, Cc, 3, 3) * 0.1
+    ref = F.conv2d(xc.double(), wc.double(), None, stride=2)
+    x_nhwc = cu(xc.permute(0, 2, 3, 1))
+    w_g = cu(wc.permute(0, 2, 3, 1).reshape(Cc, 9 * Cc))
+    Mc = B_ * T2 * F2
+    out = torch.empty(Mc, Cc, device=DEV)
+    conv = (T1, F1, T2, F2, Cc)
+    hip.gemm(x_nhwc, w_g, out, Mc, Cc, 9 * Cc, lda=0, ldb=9 * Cc, ldc=Cc, conv=conv, conv_gather=hip.GATHER_A, precision=prec)
+    dyc = torch.randn(Mc, Cc)
+    dycd = cu(dyc)
+    dwg = torch.zeros(Cc, 9 * Cc, device=DEV)
+    hip.gemm(dycd, x_nhwc, dwg, Cc, 9 * Cc, Mc, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True, split_k=2,
+             atomic_out=True, conv=conv, conv_gather=hip.GATHER_B, precision=prec)
+    sync()
+    got = out.cpu().view(B_, T2, F2, Cc).permute(0, 3, 1, 2)
+    assert float((got.double() - ref).abs().max()) / math.sqrt(9 * Cc) < rel * 3 * 0.2
+    col = F.unfold(xc.double(), 3, stride=2).transpose(1, 2).reshape(Mc, Cc, 9)      # (m, ci, kh*3+kw)
+    ref_dw = torch.einsum("mo,mck->okc", dyc.double(), col).reshape(Cc, 9 * Cc)
+    assert float((dwg.cpu().double() - ref_dw).abs().max()) / math.sqrt(Mc) < rel * 3

@@ -217,3 +217,32 @@ def test_f11_f12_end_to_end_against_reference(name):
         assert list(best) == meta["rescored"]
         rec = model.recognize(i["feats"][:2].contiguous(), i["flen"][:2], beam_size=3)
         assert rec.tolist() == meta["recognize"]
+
+
+@pytest.mark.parametrize("prec,loss_rtol,gn_rtol", [(3, 2e-4, 3e-3), (1, 1e-2, 5e-2)])
+def test_f12_end_to_end_bf16_mfma_modes(prec, loss_rtol, gn_rtol):
+    """The tiny Conformer against the reference's numbers with the GEMMs on the bf16 matrix cores.
+    precision 3 (3-term split) must meet the fp32 tolerances; precision 1 (plain bf16 products) the
+    north star's bf16 tolerance: loss within 1e-2 relative; greedy ids still exact on this fixture."""
+    from openeat_amd import hip
+    g = load_golden("f12_tiny_conformer")
+    meta = load_golden_json("f12_tiny_conformer")
+    model = ASRModel(80, meta["V"], **meta["kwargs"])
+    model.load_state_dict(g["sd"])
+    model = model.to(DEV).eval()
+    i = {k: v.to(DEV) for k, v in g["in"].items()}
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = prec
+    try:
+        loss, acc = model(i["feats"], i["flen"], i["tgt"], i["tlen"])
+        loss.backward()
+        with torch.no_grad():
+            greedy = model.ctc_greedy_search(i["feats"], i["flen"])
+    finally:
+        hip.GEMM_PRECISION = old
+    close(loss, g["out"]["loss"], rtol=loss_rtol, atol=loss_rtol, msg="loss")
+    grads = dict(model.named_parameters())
+    for k, n in meta["grad_norm"].items():
+        got = float(grads[k].grad.norm())
+        assert abs(got - n) <= gn_rtol * max(1.0, abs(n)), (k, got, n)
+    assert greedy == meta["greedy"]
