@@ -22,7 +22,18 @@
 
 template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
-                                                        int M, int N, int K, int k_chunk, EpiParams ep) {
+                                                        int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
+    // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (private L2s); give each
+    // XCD one contiguous range of tiles (x fastest) so blocks sharing an operand strip hit the same L2.
+    int tile_x, tile_y, tile_z;
+    {
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, j = id >> 3;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_x = swz % gx;
+        tile_y = (swz / gx) % gy;
+        tile_z = swz / (gx * gy);
+    }
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int LDA = BM + LDS_PAD, LDB = BN + LDS_PAD;
     constexpr int LDS_FLOATS = (2 * BK * (LDA + LDB) > 4 * 32 * 36) ? 2 * BK * (LDA + LDB) : 4 * 32 * 36;
@@ -33,8 +44,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
-    const int k_begin = blockIdx.z * k_chunk;
+    const long m0 = (long)tile_y * BM, n0 = (long)tile_x * BN;
+    const int k_begin = tile_z * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
@@ -154,7 +165,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(OperandDesc A, OperandDes
         __syncthreads();
     }
 
-    gemm_epilogue<TM, TN>(acc, lds, C, ldc, M, N, m0, n0, ep);
+    gemm_epilogue<TM, TN>(acc, lds, C, ldc, M, N, m0, n0, ep, tile_z);
 }
 
 template <int TM, int TN, bool AK, bool BKM, bool GA, bool GB>
@@ -165,8 +176,8 @@ static int launch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc
     if (kc <= 0) kc = BK;
     int nz = oe_cdiv(K, kc);
     if (nz < 1) nz = 1;
-    dim3 grid(oe_cdiv(N, BN), oe_cdiv(M, BM), nz);
-    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, AK, BKM, GA, GB>), grid, dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, ep);
+    const int gx = oe_cdiv(N, BN), gy = oe_cdiv(M, BM);
+    hipLaunchKernelGGL((gemm_f32_kernel<TM, TN, AK, BKM, GA, GB>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm_f32");
     return 0;
 }
@@ -204,11 +215,14 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
     OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3, "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);
-    const long blocks128 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
-    const bool big = blocks128 >= 320 && M >= 128 && N >= 128;
-#define OE_DISPATCH(AK, BKM, GA, GB)                                                                   \
-    return big ? launch<2, 2, AK, BKM, GA, GB>(A, B, g->c, g->ldc, M, N, K, sk, ep, st)                \
-               : launch<1, 1, AK, BKM, GA, GB>(A, B, g->c, g->ldc, M, N, K, sk, ep, st)
+    const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
+    const int tile = (b22 >= 200 && M >= 128 && N >= 128) ? 22 : (b12 >= 160 && N >= 128) ? 12 : 11;
+#define OE_DISPATCH(AK, BKM, GA, GB)                                                                       \
+    do {                                                                                                   \
+        if (tile == 22) return launch<2, 2, AK, BKM, GA, GB>(A, B, g->c, g->ldc, M, N, K, sk, ep, st);     \
+        if (tile == 12) return launch<1, 2, AK, BKM, GA, GB>(A, B, g->c, g->ldc, M, N, K, sk, ep, st);     \
+        return launch<1, 1, AK, BKM, GA, GB>(A, B, g->c, g->ldc, M, N, K, sk, ep, st);                     \
+    } while (0)
     if (!g->a_kmajor && !g->b_kmajor) { if (ga) { OE_DISPATCH(false, false, true, false); } else { OE_DISPATCH(false, false, false, false); } }
     if (!g->a_kmajor && g->b_kmajor) { OE_DISPATCH(false, true, false, false); }
     if (g->a_kmajor && g->b_kmajor) { if (gb) { OE_DISPATCH(true, true, false, true); } else { OE_DISPATCH(true, true, false, false); } }

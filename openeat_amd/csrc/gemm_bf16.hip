@@ -106,7 +106,18 @@ struct Stage {
 
 template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B, int TERMS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
-                                                         int M, int N, int K, int k_chunk, EpiParams ep) {
+                                                         int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
+    // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (private L2s); give each
+    // XCD one contiguous range of tiles (x fastest) so blocks sharing an operand strip hit the same L2.
+    int tile_x, tile_y, tile_z;
+    {
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, j = id >> 3;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_x = swz % gx;
+        tile_y = (swz / gx) % gy;
+        tile_z = swz / (gx * gy);
+    }
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_TILE = BM * PITCH, B_TILE = BN * PITCH;            // bf16 elements
     constexpr int NT = (TERMS == 3) ? 2 : 1;                            // hi (+ lo) copies
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const long m0 = (long)blockIdx.y * BM, n0 = (long)blockIdx.x * BN;
-    const int k_begin = blockIdx.z * k_chunk;
+    const long m0 = (long)tile_y * BM, n0 = (long)tile_x * BN;
+    const int k_begin = tile_z * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
     const int nk = (k_end - k_begin + BK2 - 1) / BK2;
 
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
         }
         __syncthreads();
     }
-    gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds_raw), C, ldc, M, N, m0, n0, ep);
+    gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds_raw), C, ldc, M, N, m0, n0, ep, tile_z);
 }
 
 template <int TM, int TN, bool AK, bool BKM, bool GA, bool GB, int TERMS>
@@ -199,8 +210,8 @@ static int launch_bf16(const OperandDesc& A, const OperandDesc& B, float* C, lon
     if (kc <= 0) kc = BK2;
     int nz = oe_cdiv(K, kc);
     if (nz < 1) nz = 1;
-    dim3 grid(oe_cdiv(N, BN), oe_cdiv(M, BM), nz);
-    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, GA, GB, TERMS>), grid, dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, ep);
+    const int gx = oe_cdiv(N, BN), gy = oe_cdiv(M, BM);
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, GA, GB, TERMS>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm (bf16 mfma)");
     return 0;
 }
@@ -208,15 +219,19 @@ static int launch_bf16(const OperandDesc& A, const OperandDesc& B, float* C, lon
 // called from oe_gemm_f32 (gemm.hip) when args->precision is 1 or 3
 int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk,
                           const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, int terms, hipStream_t st) {
-    const long blocks128 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
-    const bool big = blocks128 >= 200 && M >= 128 && N >= 128;
+    // largest tile that still gives the 256 CUs ~one block each
+    const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
+    const int tile = (b22 >= 200 && M >= 128 && N >= 128) ? 22 : (b12 >= 160 && N >= 128) ? 12 : 11;
 #define OE_DISP(AK, BKM, GA, GB)                                                                                 \
     do {                                                                                                         \
-        if (terms == 3)                                                                                          \
-            return big ? launch_bf16<2, 2, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st)                \
-                       : launch_bf16<1, 1, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);               \
-        return big ? launch_bf16<2, 2, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st)                    \
-                   : launch_bf16<1, 1, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st);                   \
+        if (terms == 3) {                                                                                        \
+            if (tile == 22) return launch_bf16<2, 2, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);     \
+            if (tile == 12) return launch_bf16<1, 2, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);     \
+            return launch_bf16<1, 1, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);                     \
+        }                                                                                                        \
+        if (tile == 22) return launch_bf16<2, 2, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st);         \
+        if (tile == 12) return launch_bf16<1, 2, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st);         \
+        return launch_bf16<1, 1, AK, BKM, GA, GB, 1>(A, B, C, ldc, M, N, K, sk, ep, st);                         \
     } while (0)
     if (!a_kmajor && !b_kmajor) { if (ga) OE_DISP(false, false, true, false); else OE_DISP(false, false, false, false); }
     if (!a_kmajor && b_kmajor) OE_DISP(false, true, false, false);

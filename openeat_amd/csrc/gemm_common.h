@@ -75,7 +75,7 @@ int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, 
 // waves of the block must call this together (it synchronises).
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, float* __restrict__ C, long ldc, int M, int N,
-                                              long m0, long n0, const EpiParams& ep) {
+                                              long m0, long n0, const EpiParams& ep, int tile_z) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lk = lane >> 5;
@@ -86,7 +86,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     if (ep.alpha_dev) alpha *= *ep.alpha_dev;
     const float inv_keep = ep.drop_p > 0.f ? 1.f / (1.f - ep.drop_p) : 1.f;
     const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
-    const bool first_split = (blockIdx.z == 0);
+    const bool first_split = (tile_z == 0);
     constexpr int EP_LD = 36;
     float* patch = lds + wave * (32 * EP_LD);
     const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && !ep.atomic;

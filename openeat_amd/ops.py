@@ -59,9 +59,11 @@ def _new(*shape, like: torch.Tensor, zero=False):
 # GEMM helpers
 # --------------------------------------------------------------------------- #
 def _split_k(out_rows: int, out_cols: int, k: int) -> int:
-    tiles = -(-out_rows // 64) * -(-out_cols // 64)
-    want = max(1, 768 // max(tiles, 1))
-    return int(max(1, min(want, k // 256 if k >= 512 else 1)))
+    """Split of the reduction dimension of a weight-gradient GEMM: enough 128x128 output tiles x splits
+    to give each of the 256 CUs a block, with K-chunks of at least 256."""
+    tiles = -(-out_rows // 128) * -(-out_cols // 128)
+    want = -(-256 // max(tiles, 1))
+    return int(max(1, min(want, 64, k // 256 if k >= 512 else 1)))
 
 
 def gemm_nt(x, w, bias=None, out=None, **epi):
