@@ -93,11 +93,13 @@ int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, floa
                      const unsigned char* rowmask, int act, float* y, float* stats, void* stream);
 /* dx = LN'(dy) (+ add, optional: the residual branch's gradient of the
  * pre-norm blocks, may alias dx); dgamma/dbeta ACCUMULATED atomically (caller
- * zeroes them).  rowmask as in forward (masked rows: LN'(dy) = 0, no
+ * zeroes them; block partials in `workspace` are summed in a fixed order:
+ * deterministic).  rowmask as in forward (masked rows: LN'(dy) = 0, no
  * dgamma/dbeta contribution). */
+size_t oe_layernorm_bwd_workspace_floats(int rows, int d);
 int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, int act,
                      const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
-                     float* dx, float* dgamma, float* dbeta, void* stream);
+                     float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * CTC head: log_softmax + CTCLoss(reduction='sum', zero_infinity=True) and
@@ -228,8 +230,9 @@ int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, in
  * gradient.  backward: da (B,T,2d) written, dw/db accumulated atomically. */
 int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
                       int K, int causal, float* y, void* stream);
+size_t oe_dwconv_glu_bwd_workspace_floats(int B, int T, int d, int K);
 int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, const float* gpad, int B, int T, int d, int K,
-                      int causal, float* da, float* dw, float* db, float* dgpad, void* stream);
+                      int causal, float* da, float* dw, float* db, float* dgpad, float* workspace, void* stream);
 
 /* Label-smoothed KL loss + accuracy + gradient, fused
  * (label_smoothing_loss.py:58-91, common.py:135-157).  logits (rows, ldv) are

@@ -222,8 +222,8 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
                                                               const float* __restrict__ w, const float* __restrict__ gpad,
                                                               int T, int d, int K, int pad_left,
-                                                              float* __restrict__ da, float* __restrict__ dw,
-                                                              float* __restrict__ db, float* __restrict__ dgpad) {
+                                                              float* __restrict__ da, float* __restrict__ partial,
+                                                              float* __restrict__ dgpad) {
     extern __shared__ __attribute__((aligned(16))) float sh[];
     const int rows = DW_TT + K - 1;
     float* gwin = sh;                   // g rows  t0 - pad_left ..            (for dw)
@@ -276,9 +276,11 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
 #pragma unroll
             for (int k = 0; k < DW_MAXK; ++k) if (k < K) dwk[k] += dyt * gwin[(tt + k) * d + c];
         }
+        // per-block partials [blk][K+1][d] (coalesced over c); reduced in fixed order afterwards
+        float* pp = partial + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (K + 1)) * d + c;
 #pragma unroll
-        for (int k = 0; k < DW_MAXK; ++k) if (k < K) atomicAdd(dw + c * K + k, dwk[k]);
-        atomicAdd(db + c, dbs);
+        for (int k = 0; k < DW_MAXK; ++k) if (k < K) pp[(long)k * d] = dwk[k];
+        pp[(long)K * d] = dbs;
         // gradient of the pad value: virtual frames tau in [-pad_left, -1] (first time tile only; its dy
         // window starts at frame pad_left-(K-1) <= 0):  dg[tau] = sum_k w[k] dy[tau + pad_left - k]
         if (dgpad && blockIdx.x == 0) {
@@ -293,6 +295,20 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             atomicAdd(dgpad + c, acc);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void dwconv_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int d, int K,
+                                                                   float* __restrict__ dw, float* __restrict__ db) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;           // (k, c), c fastest
+    if (idx >= (K + 1) * d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * (K + 1) * d + idx];
+    const int k = idx / d, c = idx % d;
+    if (k < K) dw[c * K + k] += s; else db[c] += s;
+}
+
+extern "C" size_t oe_dwconv_glu_bwd_workspace_floats(int B, int T, int d, int K) {
+    return (size_t)B * oe_cdiv(T, DW_TT) * (K + 1) * d;
 }
 
 extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
@@ -311,8 +327,8 @@ extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bi
 }
 
 extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, const float* gpad, int B, int T, int d, int K,
-                                 int causal, float* da, float* dw, float* db, float* dgpad, void* stream) {
-    OE_REQUIRE(a && dy && w && da && dw && db, "oe_dwconv_glu_bwd: null pointer");
+                                 int causal, float* da, float* dw, float* db, float* dgpad, float* workspace, void* stream) {
+    OE_REQUIRE(a && dy && w && da && dw && db && workspace, "oe_dwconv_glu_bwd: null pointer");
     OE_REQUIRE(!dgpad || (K - 1 <= DW_TT + K - 1), "oe_dwconv_glu_bwd: pad window");
     OE_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0 && K >= 1 && K <= DW_MAXK, "oe_dwconv_glu_bwd: bad shape");
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
@@ -320,7 +336,10 @@ extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_bwd: window does not fit LDS (d=%d)", d);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(dwconv_glu_bwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, K,
-                       pad_left, da, dw, db, dgpad);
+                       pad_left, da, workspace, dgpad);
     OE_LAUNCH_CHECK("dwconv_glu_bwd");
+    hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+                       B * oe_cdiv(T, DW_TT), d, K, dw, db);
+    OE_LAUNCH_CHECK("dwconv_param_reduce");
     return 0;
 }

@@ -37,6 +37,7 @@ struct Stage {
     static constexpr int NS = (NIDX + 255) / 256;                      // per thread
     float4 reg[NS][KMAJOR ? 4 : 1];
     long fix[NS];
+    const float* ptr[NS];     // fast path: address of this slot's data for the current K-tile
 
     __device__ __forceinline__ void init(const OperandDesc& d, long i0, long limit) {
 #pragma unroll
@@ -48,6 +49,32 @@ struct Stage {
             } else {
                 const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
                 fix[s] = (idx < NIDX) ? addr_col<GATHER>(d, i0 + 4 * mb) : -1;
+            }
+        }
+    }
+    // Fast path (tile fully inside the matrix, vector loads legal, no gather): plain pointers that
+    // advance by a wave-uniform stride per K-tile - no bounds checks, no 64-bit index math in the loop.
+    __device__ __forceinline__ void init_fast(const OperandDesc& d, long i0, int k0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            if (!KMAJOR) ptr[s] = d.p + (i0 + (idx >> 3)) * d.ld + k0 + (idx & 7) * 4;
+            else ptr[s] = d.p + (long)(k0 + 4 * (idx & 7)) * d.ld + i0 + 4 * (((idx >> 3) & 7) + 8 * (idx >> 6));
+        }
+    }
+    __device__ __forceinline__ void load_fast(long ld) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            if (idx < NIDX) {
+                if (!KMAJOR) {
+                    reg[s][0] = *reinterpret_cast<const float4*>(ptr[s]);
+                    ptr[s] += BK2;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) reg[s][i] = *reinterpret_cast<const float4*>(ptr[s] + i * ld);
+                    ptr[s] += BK2 * ld;
+                }
             }
         }
     }
@@ -139,8 +166,16 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
 
     Stage<BM, A_KMAJOR, GATHER_A> sa;
     Stage<BN, B_KMAJOR, GATHER_B> sb;
-    sa.init(A, m0, M);
-    sb.init(B, n0, N);
+    // block-uniform: whole tile interior, K-range a multiple of the K-tile, vector loads legal
+    const bool fast = !GATHER_A && !GATHER_B && A.vec_ok && B.vec_ok && (m0 + BM <= M) && (n0 + BN <= N) &&
+                      ((k_end - k_begin) % BK2 == 0);
+    if (fast) {
+        sa.init_fast(A, m0, k_begin);
+        sb.init_fast(B, n0, k_begin);
+    } else {
+        sa.init(A, m0, M);
+        sb.init(B, n0, N);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -151,8 +186,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (nk > 0) {
-        sa.load(A, m0, M, k_begin, k_end);
-        sb.load(B, n0, N, k_begin, k_end);
+        if (fast) { sa.load_fast(A.ld); sb.load_fast(B.ld); }
+        else { sa.load(A, m0, M, k_begin, k_end); sb.load(B, n0, N, k_begin, k_end); }
         sa.template store<TERMS>(a_hi(0), a_lo(0));
         sb.template store<TERMS>(b_hi(0), b_lo(0));
     }
@@ -162,8 +197,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
-            sa.load(A, m0, M, k_begin + (kt + 1) * BK2, k_end);
-            sb.load(B, n0, N, k_begin + (kt + 1) * BK2, k_end);
+            if (fast) { sa.load_fast(A.ld); sb.load_fast(B.ld); }
+            else { sa.load(A, m0, M, k_begin + (kt + 1) * BK2, k_end); sb.load(B, n0, N, k_begin + (kt + 1) * BK2, k_end); }
         }
         const __bf16* ah = a_hi(buf) + (wm * 32 * TM + frow) * PITCH + fk;
         const __bf16* al = a_lo(buf) + (wm * 32 * TM + frow) * PITCH + fk;

@@ -89,6 +89,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     const bool first_split = (tile_z == 0);
     constexpr int EP_LD = 36;
     float* patch = lds + wave * (32 * EP_LD);
+    __syncthreads();   // every wave is done with the operand tiles that the patches overlay
     const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && !ep.atomic;
     const bool aux_vec = (ep.ld_aux % 4 == 0) && (((uintptr_t)ep.preact_out & 15) == 0) && (((uintptr_t)ep.actgrad_in & 15) == 0);
     const bool res_vec = (ep.ldr % 4 == 0) && (((uintptr_t)ep.residual & 15) == 0);
@@ -96,10 +97,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            __syncthreads();
+            // the patch is private to this wave: LDS operations of one wave complete in order, so a
+            // wave-level fence (wait for our own LDS traffic, then a compiler barrier) is enough
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * EP_LD + lrow] = acc[i][j][r];
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
             const long row_base = m0 + wm * (32 * TM) + i * 32;
             const long col = n0 + wn * (32 * TN) + j * 32 + (lane & 7) * 4;
             const int ncol = (int)max(0L, min(4L, (long)N - col));

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              const float* __restrict__ stats,
                                                              int rows, int d, const unsigned char* __restrict__ rowmask,
                                                              const float* add, float* dx,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                             float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][d]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
@@ -137,10 +137,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         if (i < nv) { shg[i] = dg[j]; shg[nv + i] = db[j]; }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < 2 * d; c += 256) {
-        const float v = sh[c] + sh[2 * d + c] + sh[4 * d + c] + sh[6 * d + c];
-        if (c < d) atomicAdd(dgamma + c, v); else atomicAdd(dbeta + (c - d), v);
-    }
+    // one partial row [dgamma | dbeta] per block; summed in fixed order by ln_param_reduce_kernel
+    for (int c = threadIdx.x; c < 2 * d; c += 256)
+        partial[(long)blockIdx.x * 2 * d + c] = sh[c] + sh[2 * d + c] + sh[4 * d + c] + sh[6 * d + c];
+}
+
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int d,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= 2 * d) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * 2 * d + c];
+    if (c < d) dgamma[c] += s; else dbeta[c - d] += s;
 }
 
 extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
@@ -153,36 +161,62 @@ extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float*
     return 0;
 }
 
+extern "C" size_t oe_layernorm_bwd_workspace_floats(int rows, int d) { return (size_t)oe_cdiv(rows, LNB_ROWS) * 2 * d; }
+
 extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, int act,
                                 const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
-                                float* dx, float* dgamma, float* dbeta, void* stream) {
+                                float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
     OE_REQUIRE(dy && x && gamma && stats && dx && dgamma && dbeta && (beta || !act), "oe_layernorm_bwd: null pointer");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(oe_cdiv(rows, LNB_ROWS)), dim3(256), (size_t)8 * d * sizeof(float),
-                       (hipStream_t)stream, dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dgamma, dbeta);
+    OE_REQUIRE(workspace, "oe_layernorm_bwd: null workspace");
+    const int nb = oe_cdiv(rows, LNB_ROWS);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * d * sizeof(float),
+                       (hipStream_t)stream, dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace);
     OE_LAUNCH_CHECK("layernorm_bwd");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 256)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,
+                       dgamma, dbeta);
+    OE_LAUNCH_CHECK("ln_param_reduce");
     return 0;
 }
 
 // ---- column sums (bias gradients) -------------------------------------------
-#define CS_ROWS 256
+// block = 64 float4 column groups x 4 row groups over CS_ROWS rows; LDS reduce over the row groups,
+// then one atomic per column per block (few hundred adders per address: cheap next to the read).
+#define CS_ROWS 32
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ldx, int m, int n, float alpha,
-                                                      const float* __restrict__ alpha_dev, float* __restrict__ out) {
-    __shared__ float sh[4][64];
+                                                      const float* __restrict__ alpha_dev, float* __restrict__ out, int vec) {
+    __shared__ float4 sh[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + cx;
+    const int col = (blockIdx.x * 64 + cx) * 4;
     const long r0 = (long)blockIdx.y * CS_ROWS;
-    float s = 0.f;
+    const long r1 = min((long)m, r0 + CS_ROWS);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (col < n) {
-        const long r1 = min((long)m, r0 + CS_ROWS);
-        for (long r = r0 + ry; r < r1; r += 4) s += x[r * ldx + col];
+        if (vec && col + 3 < n) {
+            for (long r = r0 + ry; r < r1; r += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(x + r * ldx + col);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        } else {
+            for (long r = r0 + ry; r < r1; r += 4) {
+                const float* p = x + r * ldx + col;
+                s.x += p[0];
+                if (col + 1 < n) s.y += p[1];
+                if (col + 2 < n) s.z += p[2];
+                if (col + 3 < n) s.w += p[3];
+            }
+        }
     }
     sh[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && col < n) {
         float a = alpha;
         if (alpha_dev) a *= *alpha_dev;
-        atomicAdd(out + col, (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) * a);
+        const float4 t0 = sh[0][cx], t1 = sh[1][cx], t2 = sh[2][cx], t3 = sh[3][cx];
+        atomicAdd(out + col, (t0.x + t1.x + t2.x + t3.x) * a);
+        if (col + 1 < n) atomicAdd(out + col + 1, (t0.y + t1.y + t2.y + t3.y) * a);
+        if (col + 2 < n) atomicAdd(out + col + 2, (t0.z + t1.z + t2.z + t3.z) * a);
+        if (col + 3 < n) atomicAdd(out + col + 3, (t0.w + t1.w + t2.w + t3.w) * a);
     }
 }
 
@@ -194,8 +228,9 @@ extern "C" int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha
         hipError_t e = hipMemsetAsync(out, 0, (size_t)n * sizeof(float), st);
         if (e != hipSuccess) { oe_set_error("oe_colsum_f32: memset failed: %s", hipGetErrorString(e)); return (int)e; }
     }
-    hipLaunchKernelGGL(colsum_kernel, dim3(oe_cdiv(n, 64), oe_cdiv(m, CS_ROWS)), dim3(256), 0, st, x, ldx, m, n, alpha,
-                       alpha_dev, out);
+    const int vec = (ldx % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    hipLaunchKernelGGL(colsum_kernel, dim3(oe_cdiv(n, 256), oe_cdiv(m, CS_ROWS)), dim3(256), 0, st, x, ldx, m, n, alpha,
+                       alpha_dev, out, vec);
     OE_LAUNCH_CHECK("colsum");
     return 0;
 }

@@ -95,7 +95,8 @@ _SIGNATURES = {
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
-    "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P]),
+    "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
+    "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
@@ -118,7 +119,8 @@ _SIGNATURES = {
     "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
     "oe_col2im_relu": (I, [P, P, I, I, I, I, P, P]),
     "oe_dwconv_glu_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P]),
-    "oe_dwconv_glu_bwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P]),
+    "oe_dwconv_glu_bwd_workspace_floats": (SZ, [I, I, I, I]),
+    "oe_dwconv_glu_bwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "oe_lsm_workspace_bytes": (SZ, [L]),
     "oe_lsm_loss_fused": (I, [P, L, L, I, P, I, F, I, F, F, I, P, P, P]),
     "oe_fbank": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, P, P]),

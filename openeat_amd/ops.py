@@ -167,6 +167,10 @@ def dropout_scale(x, alpha=1.0, p=0.0, seed=0, rowmask=None, cols=None):
 # --------------------------------------------------------------------------- #
 # LayerNorm
 # --------------------------------------------------------------------------- #
+def _ln_ws(like, rows, d):
+    return _new(hip.lib().oe_layernorm_bwd_workspace_floats(rows, d), like=like)
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, rowmask, act):
@@ -188,7 +192,7 @@ class LayerNormFn(torch.autograd.Function):
         rows = x.numel() // d
         dx = torch.empty_like(x)
         (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
-        hip.call("oe_layernorm_bwd", dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db)
+        hip.call("oe_layernorm_bwd", dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db, _ln_ws(x, rows, d))
         return dx, rg, rb, None, None, None
 
 
@@ -517,11 +521,12 @@ class ConvModuleFn(torch.autograd.Function):
         dz = gemm_nn(gq, w2m)
         dyc = torch.empty_like(yc)
         (dg, rg), (dbeta, rbeta) = grad_sink(g), grad_sink(b)
-        hip.call("oe_layernorm_bwd", dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta)
+        hip.call("oe_layernorm_bwd", dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta, _ln_ws(dz, B * T, d))
         da = torch.empty_like(a)
         (dwd, rwd), (dbd, rbd) = grad_sink(wd), grad_sink(bd)
         dgpad = torch.zeros(d, device=dy.device) if causal else None
-        hip.call("oe_dwconv_glu_bwd", a, dyc, wd, gpad, B, T, d, K, int(causal), da, dwd, dbd, dgpad)
+        ws = _new(hip.lib().oe_dwconv_glu_bwd_workspace_floats(B, T, d, K), like=dy)
+        hip.call("oe_dwconv_glu_bwd", a, dyc, wd, gpad, B, T, d, K, int(causal), da, dwd, dbd, dgpad, ws)
         dw1 = wgrad(w1, da, xm)
         (db1, rb1) = grad_sink(b1)
         colsum(da, out=db1)

@@ -185,8 +185,9 @@ def test_layernorm_fwd_bwd(rows, d, eps):
     db = torch.zeros(d, device=DEV)
     add = torch.randn(rows, d)
     addd = cu(add)
+    ws = torch.empty(L.oe_layernorm_bwd_workspace_floats(rows, d), device=DEV)
     hip.check(L.oe_layernorm_bwd(hip.ptr(dyd), hip.ptr(xd), hip.ptr(gd), hip.ptr(bd), 0, hip.ptr(stats), rows, d, hip.ptr(md),
-                                 hip.ptr(addd), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.stream()), "ln_bwd")
+                                 hip.ptr(addd), hip.ptr(dx), hip.ptr(dg), hip.ptr(db), hip.ptr(ws), hip.stream()), "ln_bwd")
     sync()
     dx = dx - addd
     torch.testing.assert_close(y.cpu(), y_ref.detach(), rtol=1e-4, atol=1e-5)

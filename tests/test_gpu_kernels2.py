@@ -303,7 +303,8 @@ def test_dwconv_glu_fwd_bwd(causal, K, d, T):
     da = torch.empty(B, T, 2 * d, device=DEV)
     dw, db = torch.zeros(d, K, device=DEV), torch.zeros(d, device=DEV)
     dgp = torch.zeros(d, device=DEV) if causal else None
-    hip.call("oe_dwconv_glu_bwd", ad, gyd, wd, gpd, B, T, d, K, int(causal), da, dw, db, dgp)
+    ws = torch.empty(hip.lib().oe_dwconv_glu_bwd_workspace_floats(B, T, d, K), device=DEV)
+    hip.call("oe_dwconv_glu_bwd", ad, gyd, wd, gpd, B, T, d, K, int(causal), da, dw, db, dgp, ws)
     sync()
     if causal:
         torch.testing.assert_close(dgp.cpu(), gp.grad, rtol=5e-4, atol=2e-4)
