@@ -69,6 +69,8 @@ typedef struct oe_gemm_args {
     const float* residual; long ldr; int res_row_mod; float beta;
     int accumulate; int atomic_out;
     int conv_gather; int conv_t1, conv_f1, conv_t2, conv_f2, conv_c;
+    float* a_colsum; /* optional (precision != 0, k-major A): a_colsum[m] += alpha * sum_k A(m,k), i.e. the bias
+                        gradient fused into the weight-gradient GEMM (adders per address = split_k) */
     int precision;   /* 0: fp32-input MFMA (exact fp32 products); 1: bf16 inputs, fp32 accumulate;
                         3: 3-term bf16 split hi*hi+hi*lo+lo*hi (fp32-grade, ~2^-17 per product) */
 } oe_gemm_args;

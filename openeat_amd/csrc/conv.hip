@@ -299,12 +299,20 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
 
 __global__ __launch_bounds__(256) void dwconv_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int d, int K,
                                                                    float* __restrict__ dw, float* __restrict__ db) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;           // (k, c), c fastest
-    if (idx >= (K + 1) * d) return;
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + cx;                     // (k, c), c fastest
+    const int n = (K + 1) * d;
+    const int b0 = blockIdx.y * 16, b1 = min(nblocks, b0 + 16);
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * (K + 1) * d + idx];
-    const int k = idx / d, c = idx % d;
-    if (k < K) dw[c * K + k] += s; else db[c] += s;
+    if (idx < n) for (int b = b0 + ry; b < b1; b += 4) s += partial[(long)b * n + idx];
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && idx < n) {
+        const float v = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+        const int k = idx / d, c = idx % d;
+        if (k < K) atomicAdd(dw + c * K + k, v); else atomicAdd(db + c, v);
+    }
 }
 
 extern "C" size_t oe_dwconv_glu_bwd_workspace_floats(int B, int T, int d, int K) {
@@ -338,7 +346,7 @@ extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w
     hipLaunchKernelGGL(dwconv_glu_bwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, K,
                        pad_left, da, workspace, dgpad);
     OE_LAUNCH_CHECK("dwconv_glu_bwd");
-    hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 256)), dim3(256), 0, (hipStream_t)stream, workspace,
+    hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 64), oe_cdiv(B * oe_cdiv(T, DW_TT), 16)), dim3(256), 0, (hipStream_t)stream, workspace,
                        B * oe_cdiv(T, DW_TT), d, K, dw, db);
     OE_LAUNCH_CHECK("dwconv_param_reduce");
     return 0;

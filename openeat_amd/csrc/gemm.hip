@@ -211,7 +211,8 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     ep.preact_out = g->preact_out; ep.actgrad_in = g->actgrad_in; ep.ld_aux = g->ld_aux ? g->ld_aux : g->ldc;
     ep.drop_p = g->drop_p; ep.seed = g->seed; ep.seed_dev = g->seed_dev; ep.rowmask = g->rowmask;
     ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
-    ep.accumulate = g->accumulate; ep.atomic = g->atomic_out;
+    ep.accumulate = g->accumulate; ep.atomic = g->atomic_out; ep.a_colsum = g->a_colsum;
+    OE_REQUIRE(!g->a_colsum || (g->precision != 0 && g->a_kmajor && g->conv_gather != OE_GATHER_A), "oe_gemm_f32: a_colsum needs the bf16 path and a k-major A");
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
     OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3, "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);

@@ -35,9 +35,11 @@ template <int ROWS, bool KMAJOR, bool GATHER>
 struct Stage {
     static constexpr int NIDX = KMAJOR ? ROWS * 2 : ROWS * 8;           // work items per tile
     static constexpr int NS = (NIDX + 255) / 256;                      // per thread
+    static constexpr bool PARTIAL = (NIDX % 256) != 0;               // last slot only partly populated
     float4 reg[NS][KMAJOR ? 4 : 1];
     long fix[NS];
     const float* ptr[NS];     // fast path: address of this slot's data for the current K-tile
+    float4 csum[NS];          // k-major only: running sum over k of this slot's 4 rows (fused bias gradient)
 
     __device__ __forceinline__ void init(const OperandDesc& d, long i0, long limit) {
 #pragma unroll
@@ -54,6 +56,42 @@ struct Stage {
     }
     // Fast path (tile fully inside the matrix, vector loads legal, no gather): plain pointers that
     // advance by a wave-uniform stride per K-tile - no bounds checks, no 64-bit index math in the loop.
+    __device__ __forceinline__ void zero_csum() {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) csum[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __device__ __forceinline__ void add_csum() {       // call once per loaded K-tile (k-major operands)
+        if (KMAJOR) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    csum[s].x += reg[s][i].x; csum[s].y += reg[s][i].y; csum[s].z += reg[s][i].z; csum[s].w += reg[s][i].w;
+                }
+        }
+    }
+    // out[i0 + 4*mb + j] += alpha * csum: lanes that differ only in kb (lane bits 0-2) hold partial sums
+    __device__ __forceinline__ void flush_csum(float* out, long i0, long limit, float alpha) {
+        if (KMAJOR) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float4 v = csum[s];
+#pragma unroll
+                for (int o = 1; o < 8; o <<= 1) {
+                    v.x += __shfl_xor(v.x, o, 64); v.y += __shfl_xor(v.y, o, 64);
+                    v.z += __shfl_xor(v.z, o, 64); v.w += __shfl_xor(v.w, o, 64);
+                }
+                const int idx = threadIdx.x + s * 256;
+                if ((idx & 7) == 0 && idx < NIDX) {
+                    const long c = i0 + 4 * (((idx >> 3) & 7) + 8 * (idx >> 6));
+                    if (c < limit) atomicAdd(out + c, v.x * alpha);
+                    if (c + 1 < limit) atomicAdd(out + c + 1, v.y * alpha);
+                    if (c + 2 < limit) atomicAdd(out + c + 2, v.z * alpha);
+                    if (c + 3 < limit) atomicAdd(out + c + 3, v.w * alpha);
+                }
+            }
+        }
+    }
     __device__ __forceinline__ void init_fast(const OperandDesc& d, long i0, int k0) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -66,7 +104,7 @@ struct Stage {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int idx = threadIdx.x + s * 256;
-            if (idx < NIDX) {
+            if (!PARTIAL || idx < NIDX) {
                 if (!KMAJOR) {
                     reg[s][0] = *reinterpret_cast<const float4*>(ptr[s]);
                     ptr[s] += BK2;
@@ -105,7 +143,7 @@ struct Stage {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int idx = threadIdx.x + s * 256;
-            if (idx < NIDX) {
+            if (!PARTIAL || idx < NIDX) {
             if (!KMAJOR) {
                 const int row = idx >> 3, kq = (idx & 7) * 4;
                 bf16x4 h, l;
@@ -131,7 +169,7 @@ struct Stage {
     }
 };
 
-template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B, int TERMS>
+template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B, int TERMS, bool FAST>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
                                                          int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
     // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (private L2s); give each
@@ -166,9 +204,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
 
     Stage<BM, A_KMAJOR, GATHER_A> sa;
     Stage<BN, B_KMAJOR, GATHER_B> sb;
-    // block-uniform: whole tile interior, K-range a multiple of the K-tile, vector loads legal
-    const bool fast = !GATHER_A && !GATHER_B && A.vec_ok && B.vec_ok && (m0 + BM <= M) && (n0 + BN <= N) &&
-                      ((k_end - k_begin) % BK2 == 0);
+    // FAST (chosen on the host): every tile interior, K-ranges multiples of the K-tile, vector loads legal
+    constexpr bool fast = FAST;
     if (fast) {
         sa.init_fast(A, m0, k_begin);
         sb.init_fast(B, n0, k_begin);
@@ -185,9 +222,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const bool do_csum = A_KMAJOR && ep.a_colsum != nullptr && tile_x == 0;      // block-uniform
+    if (A_KMAJOR) sa.zero_csum();
     if (nk > 0) {
         if (fast) { sa.load_fast(A.ld); sb.load_fast(B.ld); }
         else { sa.load(A, m0, M, k_begin, k_end); sb.load(B, n0, N, k_begin, k_end); }
+        if (do_csum) sa.add_csum();
         sa.template store<TERMS>(a_hi(0), a_lo(0));
         sb.template store<TERMS>(b_hi(0), b_lo(0));
     }
@@ -229,16 +269,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
                 }
         }
         if (kt + 1 < nk) {
+            if (do_csum) sa.add_csum();
             sa.template store<TERMS>(a_hi(buf ^ 1), a_lo(buf ^ 1));
             sb.template store<TERMS>(b_hi(buf ^ 1), b_lo(buf ^ 1));
         }
         __syncthreads();
     }
+    if (do_csum) {
+        float al = ep.alpha;
+        if (ep.alpha_dev) al *= *ep.alpha_dev;
+        sa.flush_csum(ep.a_colsum, m0, M, al);
+    }
     gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds_raw), C, ldc, M, N, m0, n0, ep, tile_z);
 }
 
 template <int TM, int TN, bool AK, bool BKM, bool GA, bool GB, int TERMS>
-static int launch_bf16(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int splitk,
+static int launch_bf16_(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int splitk,
                        const EpiParams& ep, hipStream_t st) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     int kc = oe_cdiv(oe_cdiv(K, splitk), BK2) * BK2;
@@ -246,17 +292,22 @@ static int launch_bf16(const OperandDesc& A, const OperandDesc& B, float* C, lon
     int nz = oe_cdiv(K, kc);
     if (nz < 1) nz = 1;
     const int gx = oe_cdiv(N, BN), gy = oe_cdiv(M, BM);
-    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, GA, GB, TERMS>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
+    const bool fast = !GA && !GB && A.vec_ok && B.vec_ok && (M % BM == 0) && (N % BN == 0) && (K % BK2 == 0) && (kc % BK2 == 0);
+    if (!GA && !GB && fast)
+        hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, false, false, TERMS, true>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, GA, GB, TERMS, false>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm (bf16 mfma)");
     return 0;
 }
+#define launch_bf16 launch_bf16_
 
 // called from oe_gemm_f32 (gemm.hip) when args->precision is 1 or 3
 int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk,
                           const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, int terms, hipStream_t st) {
     // largest tile that still gives the 256 CUs ~one block each
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
-    const int tile = (b22 >= 200 && M >= 128 && N >= 128) ? 22 : (b12 >= 160 && N >= 128) ? 12 : 11;
+    const int tile = (b22 >= 400 && M >= 128 && N >= 128) ? 22 : (b12 >= 400 && N >= 128) ? 12 : 11;
 #define OE_DISP(AK, BKM, GA, GB)                                                                                 \
     do {                                                                                                         \
         if (terms == 3) {                                                                                        \

@@ -64,6 +64,7 @@ struct EpiParams {
     float beta;
     int accumulate;
     int atomic;
+    float* a_colsum;   // optional: out[m] += alpha * sum_k A(m,k) for a k-major A (bias gradient fused into wgrad)
 };
 
 

@@ -142,13 +142,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         partial[(long)blockIdx.x * 2 * d + c] = sh[c] + sh[2 * d + c] + sh[4 * d + c] + sh[6 * d + c];
 }
 
+// second stage: 64 columns x 16 partial rows per block, LDS reduce, one atomic per column per block
+// (<= nblocks/16 adders per address)
+#define PR_ROWS 16
 __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int d,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= 2 * d) return;
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int b0 = blockIdx.y * PR_ROWS, b1 = min(nblocks, b0 + PR_ROWS);
     float s = 0.f;
-    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * 2 * d + c];
-    if (c < d) dgamma[c] += s; else dbeta[c - d] += s;
+    if (c < 2 * d) for (int b = b0 + ry; b < b1; b += 4) s += partial[(long)b * 2 * d + c];
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && c < 2 * d) {
+        const float v = sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx];
+        if (c < d) atomicAdd(dgamma + c, v); else atomicAdd(dbeta + (c - d), v);
+    }
 }
 
 extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
@@ -173,7 +183,7 @@ extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* ga
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * d * sizeof(float),
                        (hipStream_t)stream, dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace);
     OE_LAUNCH_CHECK("layernorm_bwd");
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 256)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 64), oe_cdiv(nb, PR_ROWS)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,
                        dgamma, dbeta);
     OE_LAUNCH_CHECK("ln_param_reduce");
     return 0;

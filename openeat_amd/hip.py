@@ -46,6 +46,7 @@ class GemmArgs(C.Structure):
         ("accumulate", C.c_int), ("atomic_out", C.c_int),
         ("conv_gather", C.c_int), ("conv_t1", C.c_int), ("conv_f1", C.c_int), ("conv_t2", C.c_int),
         ("conv_f2", C.c_int), ("conv_c", C.c_int),
+        ("a_colsum", c_fp),
         ("precision", C.c_int),
     ]
 
@@ -162,7 +163,7 @@ def _dev_f32(t: torch.Tensor, name: str):
 # --------------------------------------------------------------------------- #
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
          bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, seed_dev=None, rowmask=None,
-         residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None):
+         residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None, a_colsum=None):
     g = GemmArgs()
     g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
     g.b, g.ldb, g.b_kmajor = b.data_ptr(), ldb, int(b_kmajor)
@@ -183,6 +184,7 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.accumulate, g.atomic_out = int(accumulate), int(atomic_out)
     g.conv_gather = conv_gather
     g.precision = GEMM_PRECISION if precision is None else precision
+    g.a_colsum = None if (a_colsum is None or g.precision == 0) else a_colsum.data_ptr()
     if conv is not None:
         g.conv_t1, g.conv_f1, g.conv_t2, g.conv_f2, g.conv_c = conv
     if PROFILE is not None:

@@ -59,11 +59,11 @@ def _new(*shape, like: torch.Tensor, zero=False):
 # GEMM helpers
 # --------------------------------------------------------------------------- #
 def _split_k(out_rows: int, out_cols: int, k: int) -> int:
-    """Split of the reduction dimension of a weight-gradient GEMM: enough 128x128 output tiles x splits
-    to give each of the 256 CUs a block, with K-chunks of at least 256."""
-    tiles = -(-out_rows // 128) * -(-out_cols // 128)
-    want = -(-256 // max(tiles, 1))
-    return int(max(1, min(want, 64, k // 256 if k >= 512 else 1)))
+    """Split of the reduction dimension of a weight-gradient GEMM (64x64 output tiles x splits ~ 3 blocks
+    per CU, K-chunks of at least 256)."""
+    tiles = -(-out_rows // 64) * -(-out_cols // 64)
+    want = max(1, 768 // max(tiles, 1))
+    return int(max(1, min(want, k // 256 if k >= 512 else 1)))
 
 
 def gemm_nt(x, w, bias=None, out=None, **epi):
@@ -86,14 +86,20 @@ def gemm_nn(dy, w, out=None, **epi):
     return out
 
 
-def gemm_tn(dy, x, out=None, alpha=1.0, alpha_dev=None):
-    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]  (split-K, atomic accumulation into `out`)."""
+def gemm_tn(dy, x, out=None, alpha=1.0, alpha_dev=None, bias_out=None):
+    """dw[N,K] (+)= dy[M,N]^T @ x[M,K]  (split-K, atomic accumulation into `out`).
+    bias_out (optional, [N], accumulated): alpha * column sums of dy - fused into the GEMM on the
+    bf16 paths, a separate column-sum launch on the exact-fp32 path."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = _new(N, K, like=dy, zero=True)
+    fused = bias_out is not None and hip.GEMM_PRECISION != 0
     hip.gemm(dy, x, out, N, K, M, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kmajor=True, b_kmajor=True,
-             split_k=_split_k(N, K, M), atomic_out=True, alpha=alpha, alpha_dev=alpha_dev)
+             split_k=_split_k(N, K, M), atomic_out=True, alpha=alpha, alpha_dev=alpha_dev,
+             a_colsum=bias_out if fused else None)
+    if bias_out is not None and not fused:
+        colsum(dy, alpha, alpha_dev, N, out=bias_out)
     return out
 
 
@@ -127,6 +133,19 @@ def _sink_swapped(param, src, A, Bd, Cd):
         return out
     hip.call("oe_swap_last2", src, A, Bd, Cd, tgt, 1)
     return None
+
+
+def wgrad_bias(w, b, dy, x, alpha=1.0, alpha_dev=None):
+    """Weight and bias gradient of y = x w^T + b from dy in ONE GEMM launch (bias = fused column sums).
+    Returns what autograd should see: (dw, db), each None when it went straight into the arena."""
+    if b is None:
+        return wgrad(w, dy, x, alpha, alpha_dev), None
+    N, K = dy.shape[1], x.shape[1]
+    tw, tb = _arena.grad_target(w), _arena.grad_target(b)
+    ow = tw.view(N, K) if tw is not None else _new(N, K, like=dy, zero=True)
+    ob = tb if tb is not None else _new(N, like=dy, zero=True)
+    gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob)
+    return (None if tw is not None else ow.view(w.shape)), (None if tb is not None else ob)
 
 
 def bgrad(param, dy, alpha=1.0, alpha_dev=None, n=None):
@@ -222,8 +241,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.act != ACT_NONE:
             dy2 = _act_grad(dy2, pre, ctx.act)
         dx = gemm_nn(dy2, w).view(ctx.in_shape) if ctx.needs_input_grad[0] else None
-        dw = wgrad(w, dy2, x2)
-        db = bgrad(ctx.bias_ref, dy2) if ctx.has_bias else None
+        dw, db = wgrad_bias(w, ctx.bias_ref if ctx.has_bias else None, dy2, x2)
         return dx, dw, db, None
 
 
@@ -307,11 +325,9 @@ class FeedForwardFn(torch.autograd.Function):
         dy2 = dy.view(-1, w2.shape[0])
         g2 = dy2 if (p_out == 0 and out_scale == 1.0) else dropout_scale(dy2, out_scale, p_out, s_out)
         b1, b2 = ctx.biases
-        dw2 = wgrad(w2, g2, a)
-        db2 = bgrad(b2, g2)
+        dw2, db2 = wgrad_bias(w2, b2, g2, a)
         dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
-        dw1 = wgrad(w1, dh, x2)
-        db1 = bgrad(b1, dh)
+        dw1, db1 = wgrad_bias(w1, b1, dh, x2)
         dx = gemm_nn(dh, w1).view(in_shape)
         return dx, dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
 
@@ -401,8 +417,7 @@ class AttentionFn(torch.autograd.Function):
         g = dy2 if p_out == 0 else dropout_scale(dy2, 1.0, p_out, s_out)
         att2 = att.view(-1, d)
         bq, bk, bv, bo = ctx.biases
-        dwo = wgrad(wo, g, att2)
-        dbo = bgrad(bo, g)
+        dwo, dbo = wgrad_bias(wo, bo, g, att2)
         datt = gemm_nn(g, wo)
         delta = _new(B, H, T1, like=dy)
         if self_attn:
@@ -440,9 +455,8 @@ class AttentionFn(torch.autograd.Function):
                 n = dy_fused.shape[1]
                 gw = _arena.grad_target(parts_w[0])
                 gw_all = torch.as_strided(gw, (n, x_in.shape[1]), (x_in.shape[1], 1))
-                gemm_tn(dy_fused, x_in, out=gw_all)
                 gb = _arena.grad_target(parts_b[0])
-                colsum(dy_fused, out=torch.as_strided(gb, (n,), (1,)))
+                gemm_tn(dy_fused, x_in, out=gw_all, bias_out=torch.as_strided(gb, (n,), (1,)))
                 return dx_in, [None] * len(parts_w), [None] * len(parts_b)
             dwf, dbf = gemm_tn(dy_fused, x_in), colsum(dy_fused)
             ws, bs, o = [], [], 0
@@ -462,7 +476,7 @@ class AttentionFn(torch.autograd.Function):
             dxkv = None
         else:
             dx = gemm_nn(dq, wq).view(B, T1, d)
-            dwq, dbq = wgrad(wq, dq, xq2), bgrad(bq, dq)
+            dwq, dbq = wgrad_bias(wq, bq, dq, xq2)
             dxkv, (dwk, dwv), (dbk, dbv) = split_or_sink((wk, wv), (bk, bv), dkv, xkv2)
             dxkv = dxkv.view(B, T2, d)
         return (dx, dxkv, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, dwpos, rpu, rpv, None, None,
@@ -516,8 +530,7 @@ class ConvModuleFn(torch.autograd.Function):
         dy2 = dy.view(-1, d)
         w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
         gq = dy2 if (p_out == 0 and rowmask is None) else dropout_scale(dy2, 1.0, p_out, s_out, rowmask)
-        dw2 = wgrad(w2, gq, z)
-        db2 = bgrad(b2, gq)
+        dw2, db2 = wgrad_bias(w2, b2, gq, z)
         dz = gemm_nn(gq, w2m)
         dyc = torch.empty_like(yc)
         (dg, rg), (dbeta, rbeta) = grad_sink(g), grad_sink(b)
@@ -527,9 +540,11 @@ class ConvModuleFn(torch.autograd.Function):
         dgpad = torch.zeros(d, device=dy.device) if causal else None
         ws = _new(hip.lib().oe_dwconv_glu_bwd_workspace_floats(B, T, d, K), like=dy)
         hip.call("oe_dwconv_glu_bwd", a, dyc, wd, gpad, B, T, d, K, int(causal), da, dwd, dbd, dgpad, ws)
-        dw1 = wgrad(w1, da, xm)
         (db1, rb1) = grad_sink(b1)
-        colsum(da, out=db1)
+        tw1 = _arena.grad_target(w1)
+        ow1 = tw1.view(2 * d, d) if tw1 is not None else _new(2 * d, d, like=dy, zero=True)
+        gemm_tn(da, xm, out=ow1, bias_out=db1)
+        dw1 = None if tw1 is not None else ow1.view(w1.shape)
         if causal:
             db1_pad = torch.empty_like(db1)
             hip.call("oe_glu_bwd", b1, dgpad, 1, d, db1_pad)
@@ -586,17 +601,21 @@ class Subsampling4Fn(torch.autograd.Function):
         B, T, Fd, C, T1, F1, T2, F2, d, xscale = ctx.cfg
         do2 = dout.contiguous().view(B * T2, d)
         y2v = y2.view(B * T2, F2 * C)
-        dwlg = gemm_tn(do2, y2v, alpha=xscale)
+        (dbl_buf, dbl) = grad_sink(bl)
+        dwlg = gemm_tn(do2, y2v, alpha=xscale, bias_out=dbl_buf)
         dwl = _sink_swapped(wl, dwlg, d, F2, C)
-        dbl = bgrad(bl, do2, alpha=xscale)
         dy2 = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=y2v, ld_aux=F2 * C).view(B * T2 * F2, C)
         M2 = B * T2 * F2
         conv = (T1, F1, T2, F2, C)
         dw2g = _new(C, 9 * C, like=do2, zero=True)
+        (db2_buf, db2) = grad_sink(b2)
+        fused = hip.GEMM_PRECISION != 0
         hip.gemm(dy2, y1, dw2g, C, 9 * C, M2, lda=C, ldb=0, ldc=9 * C, a_kmajor=True, b_kmajor=True,
-                 split_k=_split_k(C, 9 * C, M2), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B)
+                 split_k=_split_k(C, 9 * C, M2), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
+                 a_colsum=db2_buf if fused else None)
+        if not fused:
+            colsum(dy2, out=db2_buf)
         dw2 = _sink_swapped(w2, dw2g, C, 9, C)
-        db2 = bgrad(b2, dy2)
         dcol = gemm_nn(dy2, w2g)                                   # (M2, 9C)
         dy1 = torch.empty_like(y1)
         hip.call("oe_col2im_relu", dcol, y1, B, T1, F1, C, dy1)
@@ -653,8 +672,7 @@ class CTCHeadFn(torch.autograd.Function):
         g = g.contiguous().view(1)
         dl = dlogits[:, :V]
         dhs = gemm_nn(dl, w, alpha_dev=g).view(B, T, d)
-        dw = wgrad(w, dl, hs2, alpha_dev=g)
-        db = bgrad(ctx.bias_ref, dlogits, alpha_dev=g, n=V)
+        dw, db = wgrad_bias(w, ctx.bias_ref, dl, hs2, alpha_dev=g)
         return dhs, dw, db, None, None, None
 
 
@@ -695,8 +713,7 @@ class LSMHeadFn(torch.autograd.Function):
         g = g.contiguous().view(1)
         dl = dlogits[:, :V]
         dx = gemm_nn(dl, w, alpha_dev=g).view(shape)
-        dw = wgrad(w, dl, x2, alpha_dev=g)
-        db = bgrad(ctx.bias_ref, dlogits, alpha_dev=g, n=V)
+        dw, db = wgrad_bias(w, ctx.bias_ref, dl, x2, alpha_dev=g)
         return dx, dw, db, None, None, None, None
 
 
