@@ -307,7 +307,10 @@ int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, 
                           const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, int terms, hipStream_t st) {
     // largest tile that still gives the 256 CUs ~one block each
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
-    const int tile = (b22 >= 400 && M >= 128 && N >= 128) ? 22 : (b12 >= 400 && N >= 128) ? 12 : 11;
+    // weight gradients (both operands k-major, long reduction): operand re-reads dominate, so take the
+    // 128x128 tile as soon as the grid still covers the chip; elsewhere favour >= ~2 blocks per CU.
+    const bool wg = a_kmajor && b_kmajor;
+    const int tile = (b22 >= (wg ? 200 : 400) && M >= 128 && N >= 128) ? 22 : (b12 >= 400 && N >= 128) ? 12 : 11;
 #define OE_DISP(AK, BKM, GA, GB)                                                                                 \
     do {                                                                                                         \
         if (terms == 3) {                                                                                        \

@@ -89,6 +89,24 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const bool first_split = (tile_z == 0);
     constexpr int EP_LD = 36;
+    if (ep.atomic) {
+        // split-K accumulation: atomics straight from the accumulators.  Register r of a 32x32 tile is two
+        // full 128-byte row segments per wave-instruction (lanes 0-31 / 32-63) - the shape float atomics
+        // run at full rate with; going through the row-major patch would issue 32-byte fragments.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const long col = n0 + wn * (32 * TN) + j * 32 + lrow;
+                const float bias = (col < N && ep.bias && first_split) ? ep.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < M && col < N) atomicAdd(C + row * ldc + col, acc[i][j][r] * alpha + bias);
+                }
+            }
+        return;
+    }
     float* patch = lds + wave * (32 * EP_LD);
     __syncthreads();   // every wave is done with the operand tiles that the patches overlay
     const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && !ep.atomic;

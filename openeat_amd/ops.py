@@ -59,11 +59,17 @@ def _new(*shape, like: torch.Tensor, zero=False):
 # GEMM helpers
 # --------------------------------------------------------------------------- #
 def _split_k(out_rows: int, out_cols: int, k: int) -> int:
-    """Split of the reduction dimension of a weight-gradient GEMM (64x64 output tiles x splits ~ 3 blocks
-    per CU, K-chunks of at least 256)."""
+    """Split of the reduction dimension of a weight-gradient GEMM.  Large outputs use 128x128 tiles
+    (fewer operand re-reads) with just enough splits to cover the 256 CUs; small ones 64x64 tiles with
+    ~3 blocks per CU.  K-chunks stay >= 256 and the atomic traffic (splits x output bytes) bounded."""
+    if hip.GEMM_PRECISION != 0 and out_rows >= 128 and out_cols >= 128:
+        t128 = -(-out_rows // 128) * -(-out_cols // 128)
+        sk = -(-256 // t128)
+        if t128 * sk >= 200 and sk <= 24:
+            return int(max(1, min(sk, k // 256 if k >= 512 else 1)))
     tiles = -(-out_rows // 64) * -(-out_cols // 64)
     want = max(1, 768 // max(tiles, 1))
-    return int(max(1, min(want, k // 256 if k >= 512 else 1)))
+    return int(max(1, min(want, 24, k // 256 if k >= 512 else 1)))
 
 
 def gemm_nt(x, w, bias=None, out=None, **epi):
