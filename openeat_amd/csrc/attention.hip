@@ -50,12 +50,20 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, 
 
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
-// Stage a [32][DPAD] tile (rows r0.., `nrows` valid, D valid columns) into LDS with row stride LD.
-template <int DPAD, int LD>
-__device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs, int r0, int nrows_total, int D,
-                                           float mul) {
+// A [32][DPAD] tile travels global -> registers (issued early) -> LDS (row stride LD, written late):
+// the global latency of tile j+1 hides under the MFMA/softmax work of tile j.
+template <int DPAD>
+struct TileRegs {
+    static constexpr int N = 32 * (DPAD / 4) / ATT_THREADS;
+    float4 v[N];
+};
+
+template <int DPAD>
+__device__ __forceinline__ void tile_load(TileRegs<DPAD>& t, const float* src, long rs, int r0, int nrows_total, int D) {
     const bool vec = (rs % 4 == 0) && ((((uintptr_t)src) & 15) == 0) && (D % 4 == 0);
-    for (int e = threadIdx.x; e < 32 * (DPAD / 4); e += ATT_THREADS) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<DPAD>::N; ++i) {
+        const int e = threadIdx.x + i * ATT_THREADS;
         const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         const int gr = r0 + row;
@@ -64,9 +72,28 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs
             if (vec) val = *reinterpret_cast<const float4*>(p);
             else { val.x = p[0]; if (c4 + 1 < D) val.y = p[1]; if (c4 + 2 < D) val.z = p[2]; if (c4 + 3 < D) val.w = p[3]; }
         }
-        float* d = dst + row * LD + c4;
-        d[0] = val.x * mul; d[1] = val.y * mul; d[2] = val.z * mul; d[3] = val.w * mul;
+        t.v[i] = val;
     }
+}
+
+template <int DPAD, int LD>
+__device__ __forceinline__ void tile_store(const TileRegs<DPAD>& t, float* dst) {
+#pragma unroll
+    for (int i = 0; i < TileRegs<DPAD>::N; ++i) {
+        const int e = threadIdx.x + i * ATT_THREADS;
+        const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
+        float* d = dst + row * LD + c4;
+        d[0] = t.v[i].x; d[1] = t.v[i].y; d[2] = t.v[i].z; d[3] = t.v[i].w;
+    }
+}
+
+// Stage a [32][DPAD] tile synchronously (used where no pipelining is needed).
+template <int DPAD, int LD>
+__device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs, int r0, int nrows_total, int D,
+                                           float mul) {
+    TileRegs<DPAD> t;
+    tile_load<DPAD>(t, src, rs, r0, nrows_total, D);
+    tile_store<DPAD, LD>(t, dst);
 }
 
 // ------------------------------------------------------------------ forward --
@@ -77,6 +104,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
     constexpr int DT = DPAD / 32;
     __shared__ float Ks[32 * LD];
     __shared__ float Vs[32 * LD];
+    __shared__ float kb_s[32];           // per-key bias of the tile; -inf marks a key masked for every query
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lq = lane & 31, lk = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -107,13 +135,31 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
-    const unsigned char* mrow = p.mask ? p.mask + (long)b * p.m_bs + (long)(q_ok ? qi : 0) * p.m_rs : nullptr;
+    // a (B,1,T2) key mask is the same for every query: fold it into the staged per-key bias;
+    // only a full (B,T1,T2) mask (decoder self-attention) is read per (query, key)
+    const bool key_mask = p.mask && p.m_rs == 0;
+    const unsigned char* mrow = (p.mask && !key_mask) ? p.mask + (long)b * p.m_bs + (long)(q_ok ? qi : 0) * p.m_rs : nullptr;
 
+    TileRegs<DPAD> kreg, vreg;
+    float kb_next = 0.f;
+    auto prefetch = [&](int j0) {
+        tile_load<DPAD>(kreg, kb, p.k_rs, j0, p.T2, p.D);
+        tile_load<DPAD>(vreg, vb, p.v_rs, j0, p.T2, p.D);
+        if (threadIdx.x < 32) {
+            const int kj = j0 + threadIdx.x;
+            float v = NEG_INF;
+            if (kj < p.T2 && (!key_mask || p.mask[(long)b * p.m_bs + kj] != 0)) v = p.keybias ? p.keybias[bh * p.T2 + kj] : 0.f;
+            kb_next = v;
+        }
+    };
+    prefetch(0);
     for (int j0 = 0; j0 < p.T2; j0 += 32) {
         __syncthreads();
-        stage_tile<DPAD, LD>(Ks, kb, p.k_rs, j0, p.T2, p.D, 1.f);
-        stage_tile<DPAD, LD>(Vs, vb, p.v_rs, j0, p.T2, p.D, 1.f);
+        tile_store<DPAD, LD>(kreg, Ks);
+        tile_store<DPAD, LD>(vreg, Vs);
+        if (threadIdx.x < 32) kb_s[threadIdx.x] = kb_next;
         __syncthreads();
+        if (j0 + 32 < p.T2) prefetch(j0 + 32);
         // S^T[key, query]
         f32x16 sacc;
 #pragma unroll
@@ -125,12 +171,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
         float tmax = NEG_INF;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int kj = j0 + acc_row(r, lk);
-            bool ok = kj < p.T2;
-            if (ok && mrow) ok = mrow[kj] != 0;
-            float sv = sacc[r];
-            if (ok && p.keybias) sv += p.keybias[bh * p.T2 + kj];
-            sv = ok ? sv : NEG_INF;
+            const int kr = acc_row(r, lk);
+            float sv = sacc[r] + kb_s[kr];                 // -inf for keys past T2 / masked keys
+            if (mrow && j0 + kr < p.T2 && mrow[j0 + kr] == 0) sv = NEG_INF;
             pr[r] = sv;
             tmax = fmaxf(tmax, sv);
         }
@@ -154,9 +197,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
                 for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
             if (p.drop_p > 0.f) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(r, lk));
-                    pr[r] *= dropout_scale(seed_eff, idx, p.drop_p, inv_keep);
+                for (int g = 0; g < 4; ++g) {       // registers 4g..4g+3 are 4 consecutive keys
+                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(4 * g, lk));
+                    if ((idx & 3) == 0) {
+                        const float4 d4 = dropout_scale4(seed_eff, idx >> 2, p.drop_p, inv_keep);
+                        pr[4 * g] *= d4.x; pr[4 * g + 1] *= d4.y; pr[4 * g + 2] *= d4.z; pr[4 * g + 3] *= d4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pr[4 * g + e] *= dropout_scale(seed_eff, idx + e, p.drop_p, inv_keep);
+                    }
                 }
             }
             // O^T[dv, query] += V^T[dv, key] P^T[key, query]
@@ -175,15 +224,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
 #pragma unroll
             for (int s = 0; s < DPAD / 2; ++s)
                 dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[lq * LD + 2 * s + lk], dof[s], dpacc, 0, 0, 0);
+            float dmask[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dmask[r] = 1.f;
+            if (p.drop_p > 0.f) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(4 * g, lk));
+                    if ((idx & 3) == 0) {
+                        const float4 d4 = dropout_scale4(seed_eff, idx >> 2, p.drop_p, inv_keep);
+                        dmask[4 * g] = d4.x; dmask[4 * g + 1] = d4.y; dmask[4 * g + 2] = d4.z; dmask[4 * g + 3] = d4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dmask[4 * g + e] = dropout_scale(seed_eff, idx + e, p.drop_p, inv_keep);
+                    }
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = (pr[r] == NEG_INF) ? 0.f : __expf(pr[r] - lse_i);
-                float dpv = dpacc[r];
-                if (p.drop_p > 0.f) {
-                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(r, lk));
-                    dpv *= dropout_scale(seed_eff, idx, p.drop_p, inv_keep);
-                }
-                pr[r] = pv * (dpv - delta_i);     // dS^T
+                pr[r] = pv * (dpacc[r] * dmask[r] - delta_i);     // dS^T
             }
             // dQ^T[d, query] += K^T[d, key] dS^T[key, query]
 #pragma unroll

@@ -149,13 +149,24 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 }
                 const bool row_dead = ep.rowmask && !ep.rowmask[row];
                 float pre[4];
+                float dm[4] = {1.f, 1.f, 1.f, 1.f};
+                if (ep.drop_p > 0.f) {
+                    const unsigned long long e0 = (unsigned long long)(row * N + col);
+                    if ((e0 & 3) == 0) {           // aligned group: one Philox call for the four columns
+                        const float4 d4 = dropout_scale4(seed, e0 >> 2, ep.drop_p, inv_keep);
+                        dm[0] = d4.x; dm[1] = d4.y; dm[2] = d4.z; dm[3] = d4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) dm[e] = dropout_scale(seed, e0 + e, ep.drop_p, inv_keep);
+                    }
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     float x = v[e] * alpha + bias4[e];
                     pre[e] = x;
                     if (ep.actgrad_in) x *= act_bwd(ep.act, aux[e]);
                     else x = act_fwd(ep.act, x);
-                    if (ep.drop_p > 0.f) x *= dropout_scale(seed, (unsigned long long)(row * N + col + e), ep.drop_p, inv_keep);
+                    x *= dm[e];
                     if (row_dead) x = 0.f;
                     x = res[e] + ep.beta * x;
                     v[e] = x;

@@ -6,6 +6,7 @@
 
 #define LN_MAXV 8   // float4 per lane -> d <= 2048
 
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int rows, int d,
                                                              const unsigned char* __restrict__ rowmask, int act,
@@ -15,17 +16,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     if (row >= rows) return;
     const int nv = d >> 2;
     const float4* xr = reinterpret_cast<const float4*>(x + row * d);
-    float4 v[LN_MAXV];
+    float4 v[NV];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) { v[j] = xr[i]; s += v[j].x + v[j].y + v[j].z + v[j].w; }
     }
     const float mean = wave_sum(s) / d;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) {
             float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) {
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -57,6 +58,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 
 #define LNB_ROWS 32   // rows per block in backward (8 per wave)
 
+template <int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                              const float* __restrict__ stats,
@@ -68,9 +70,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int nv = d >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
-    float4 gam[LN_MAXV], bet[LN_MAXV], dg[LN_MAXV], db[LN_MAXV];
+    float4 gam[NV], bet[NV], dg[NV], db[NV];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         gam[j] = (i < nv) ? g4[i] : make_float4(0, 0, 0, 0);
         bet[j] = (i < nv && act) ? b4[i] : make_float4(0, 0, 0, 0);
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float4* addr = add ? reinterpret_cast<const float4*>(add + row * d) : nullptr;
         if (rowmask && !rowmask[row]) {
 #pragma unroll
-            for (int j = 0; j < LN_MAXV; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 const int i = lane + 64 * j;
                 if (i < nv) dxr[i] = addr ? addr[i] : make_float4(0, 0, 0, 0);
             }
@@ -94,10 +96,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
         const float4* dyr = reinterpret_cast<const float4*>(dy + row * d);
         const float4* xr = reinterpret_cast<const float4*>(x + row * d);
-        float4 g[LN_MAXV], xh[LN_MAXV];
+        float4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < LN_MAXV; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
                 float4 dyv = dyr[i];
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         }
         const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
 #pragma unroll
-        for (int j = 0; j < LN_MAXV; ++j) {
+        for (int j = 0; j < NV; ++j) {
             const int i = lane + 64 * j;
             if (i < nv) {
                 float4 o;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     // cross-wave reduction of the parameter gradients, then one atomic per column per block
     float4* shg = reinterpret_cast<float4*>(sh) + wave * 2 * nv;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         if (i < nv) { shg[i] = dg[j]; shg[nv + i] = db[j]; }
     }
@@ -165,8 +167,10 @@ extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float*
                                 const unsigned char* rowmask, int act, float* y, float* stats, void* stream) {
     OE_REQUIRE(x && gamma && beta && y, "oe_layernorm_fwd: null pointer");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps,
-                       rows, d, rowmask, act, y, stats);
+#define LN_FWD(NVV) hipLaunchKernelGGL(layernorm_fwd_kernel<NVV>, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, \
+                                       beta, eps, rows, d, rowmask, act, y, stats)
+    if (d <= 256) LN_FWD(1); else if (d <= 512) LN_FWD(2); else if (d <= 1024) LN_FWD(4); else LN_FWD(8);
+#undef LN_FWD
     OE_LAUNCH_CHECK("layernorm_fwd");
     return 0;
 }
@@ -180,8 +184,10 @@ extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* ga
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     OE_REQUIRE(workspace, "oe_layernorm_bwd: null workspace");
     const int nb = oe_cdiv(rows, LNB_ROWS);
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), (size_t)8 * d * sizeof(float),
-                       (hipStream_t)stream, dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace);
+#define LN_BWD(NVV) hipLaunchKernelGGL(layernorm_bwd_kernel<NVV>, dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
+                                       dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace)
+    if (d <= 256) LN_BWD(1); else if (d <= 512) LN_BWD(2); else if (d <= 1024) LN_BWD(4); else LN_BWD(8);
+#undef LN_BWD
     OE_LAUNCH_CHECK("layernorm_bwd");
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 64), oe_cdiv(nb, PR_ROWS)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,
                        dgamma, dbeta);

@@ -86,6 +86,14 @@ __device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, floa
     return u >= p ? inv_keep : 0.f;
 }
 
+// four consecutive elements idx4*4 .. idx4*4+3 from ONE Philox call (same values as dropout_scale)
+__device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint64_t idx4, float p, float inv_keep) {
+    const uint4 r = philox4(seed, idx4);
+    const float k = 1.0f / 16777216.0f;
+    return make_float4((float)(r.x >> 8) * k >= p ? inv_keep : 0.f, (float)(r.y >> 8) * k >= p ? inv_keep : 0.f,
+                       (float)(r.z >> 8) * k >= p ? inv_keep : 0.f, (float)(r.w >> 8) * k >= p ? inv_keep : 0.f);
+}
+
 // ---- activations ------------------------------------------------------------
 enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2 };
 
