@@ -23,7 +23,7 @@ def init_from_env(backend: str = None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("OE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
@@ -39,7 +39,8 @@ class GradAllReduce:
         step = -(-n // max(1, n_chunks))
         step = (step + 1023) // 1024 * 1024
         self.chunks = [flat_grad[i:min(n, i + step)] for i in range(0, n, step)]
-        self._avg = hasattr(dist.ReduceOp, "AVG") and flat_grad.is_cuda
+        self._avg = (hasattr(dist.ReduceOp, "AVG") and flat_grad.is_cuda and dist.is_initialized()
+                     and dist.get_backend(process_group) == "nccl")
 
     def broadcast_parameters(self, flat_params: torch.Tensor, src: int = 0):
         """DDP's construction-time parameter broadcast."""

@@ -44,6 +44,7 @@ class TrainEngine:
         self.seed_counter.add_(1)
 
     _capturing = False
+    _split = False
 
     def step(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):
         """Eager step (any shapes)."""
@@ -57,7 +58,10 @@ class TrainEngine:
 
     # ---- HIP-graph path: fixed shapes, no host sync inside the step -----------------------------
     def capture(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
-        assert self.reducer.world == 1, "graph capture of the collective is not enabled; use step() for N > 1"
+        """Capture the step as a HIP graph.  With one rank the whole step (incl. clip + Adam) is one graph;
+        with several ranks the graph holds zero-grad + forward + backward and the gradient all-reduce and
+        the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph)."""
+        self._split = self.reducer.world > 1
         common.STATIC_SHAPES = True
         self.static_shapes = True
         self._static = {k: v.clone() for k, v in example_batch.items()}
@@ -75,7 +79,8 @@ class TrainEngine:
             with torch.cuda.graph(g):
                 self.arena.grad.zero_()
                 self._out = self._fwd_bwd(self._static)
-                self._finish()
+                if not self._split:
+                    self._finish()
         finally:
             self._capturing = False
         self._graph = g
@@ -89,4 +94,6 @@ class TrainEngine:
             self.optimizer.set_lr(lr)
             self.optimizer.lr_dev.fill_(lr)
         self._graph.replay()
+        if self._split:
+            self._finish()
         return self._out
