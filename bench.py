@@ -86,6 +86,31 @@ def cpu_baseline(B, seconds, L, steps):
             "sample": f"B={B} x {seconds:g} s utterances, {steps} timed fwd+bwd+clip+Adam steps after 1 warm-up, dropout 0.1"}
 
 
+def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3):
+    """BASELINE.json configs[3]: attention-rescoring decode of n_utt synthetic utterances on one GPU
+    (ctc_weight 0.5, reverse_weight 0.3 as in examples/aishell/run.sh:69-72; no LM: the reference's
+    LanguageModel cannot be constructed).  RTF = wall seconds / audio seconds, front end included."""
+    model.eval()
+    g = torch.Generator().manual_seed(123)
+    wav = (torch.rand(n_utt, int(16000 * seconds), generator=g) - 0.5).to(dev)
+    times = []
+    hyps = None
+    for it in range(reps + 1):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        feats, nfr = fb(wav)
+        utt_norm(feats, nfr)
+        hyps = model.attention_rescoring_batch(feats, nfr, beam, ctc_weight=0.5, reverse_weight=0.3)
+        torch.cuda.synchronize()
+        if it > 0:
+            times.append(time.perf_counter() - t0)
+    model.train()
+    best = min(times)
+    return {"rtf": best / (n_utt * seconds), "wall_s": best, "utterances": n_utt, "seconds_each": seconds, "beam": beam,
+            "ctc_weight": 0.5, "reverse_weight": 0.3, "lm": None, "mean_hyp_len": sum(len(h) for h in hyps) / len(hyps),
+            "note": "random-init weights: CTC emits near-uniform noise, so hypotheses are ~T' tokens long (worst case for the decoder pass)"}
+
+
 def log(msg):
     if int(os.environ.get("RANK", "0")) == 0:
         print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -101,11 +126,14 @@ def main():
     ap.add_argument("--target-len", type=int, default=30)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=4)
-    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--no-decode", action="store_true", help="skip the attention-rescoring RTF measurement")
+    ap.add_argument("--decode-utts", type=int, default=64)
+    ap.add_argument("--cpu-batch", type=int, default=16)
+    ap.add_argument("--cpu-steps", type=int, default=2)
     args = ap.parse_args()
 
     from openeat_amd import ddp, hip
+    hip.GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "3"))      # default: fp32-grade 3-term bf16 split
     rank, local, world = ddp.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (openeat_amd has no CPU path)"
@@ -204,6 +232,14 @@ def main():
         cpu = cpu_baseline(args.cpu_batch, args.seconds, args.target_len, args.cpu_steps)
         log(f"cpu baseline done: {cpu['value']:.0f} frames/s on {cpu['cores']} threads")
 
+    dec = None
+    if rank == 0 and world == 1 and not args.no_decode:
+        log("decode RTF (attention rescoring, 64 utterances) ...")
+        engine.arena.enabled = False
+        dec = decode_rtf(model, fb, utt_normalize_, args.decode_utts, args.seconds, 10, dev)
+        engine.arena.enabled = True
+        log(f"decode done: RTF {dec['rtf']:.5f} ({dec['wall_s'] * 1e3:.0f} ms for {dec['utterances']} x {args.seconds:g} s)")
+
     if rank == 0:
         line = {"metric": METRIC, "value": value, "unit": "audio-frames/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
@@ -212,7 +248,7 @@ def main():
                                        f"B={args.batch}/GPU x {args.seconds:g} s 16 kHz wav (T={T} frames), L={args.target_len}, "
                                        "CTC+attention joint loss, fbank+fwd+bwd+clip+Adam, dropout 0.1",
                            "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph},
-                "loss": loss, "roofline": roof, "cpu_baseline": cpu}
+                "loss": loss, "roofline": roof, "cpu_baseline": cpu, "decode": dec}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -273,6 +273,14 @@ int oe_fbank(const float* wav, const int* nsamples, int B, long wav_stride, int 
  * (feature_processor.py:5-8: population std, no epsilon). */
 int oe_utt_normalize(float* x, const int* nframes, int B, int Tmax, int F, void* stream);
 
+/* CTC prefix beam search, HOST code (all pointers are host pointers): the per-frame recursion of
+ * asr_model.py:359-396 on the top-`beam` (log-prob, token) pairs of every frame (computed on the
+ * device).  Doubles and insertion-ordered stable pruning as in the reference's Python, so the
+ * n-best list and scores are identical.  out_prefix_host (beam, max_len) int32, out_len_host (beam)
+ * (-1 = fewer than `beam` hypotheses), out_score_host (beam) = log_add(pb, pnb). */
+int oe_ctc_prefix_beam_host(const float* topk_logp_host, const long long* topk_idx_host, int T, int beam,
+                            int max_len, int* out_prefix_host, int* out_len_host, double* out_score_host);
+
 #ifdef __cplusplus
 }
 #endif

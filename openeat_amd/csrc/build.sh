@@ -15,6 +15,14 @@ for f in *.hip; do
     pids+=($!)
   fi
 done
+for f in *.cpp; do
+  o=obj/${f%.cpp}.o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ ../../include/openeat_hip.h -nt "$o" ]; then
+    echo "g++ $f"
+    g++ -O2 -fPIC -std=c++17 -Wall -c "$f" -o "$o" &
+    pids+=($!)
+  fi
+done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libopeneat_hip.so" obj/*.o
 echo "built $OUT/libopeneat_hip.so"

@@ -126,6 +126,7 @@ _SIGNATURES = {
     "oe_lsm_loss_fused": (I, [P, L, L, I, P, I, F, I, F, F, I, P, P, P]),
     "oe_fbank": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, P, P]),
     "oe_utt_normalize": (I, [P, P, I, I, I, P]),
+    "oe_ctc_prefix_beam_host": (I, [P, P, I, I, I, P, P, P]),
     "oe_grad_norm_workspace_floats": (SZ, []),
     "oe_grad_norm": (I, [P, L, P, P, P]),
     "oe_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, P, P, P]),
@@ -233,3 +234,19 @@ def attention_fwd(a: AttnArgs):
 
 def attention_bwd(a: AttnArgs):
     check(lib().oe_attention_bwd(C.byref(a), stream()), "oe_attention_bwd")
+
+
+def ctc_prefix_beam_host(top_logp: torch.Tensor, top_idx: torch.Tensor, beam: int):
+    """top_logp (T, beam) float32 / top_idx (T, beam) int64 CPU tensors -> [(prefix tuple, score)] (native host code)."""
+    import numpy as np
+    lp = top_logp.contiguous().numpy()
+    ix = top_idx.contiguous().numpy()
+    T = lp.shape[0]
+    prefixes = np.zeros((beam, max(T, 1)), dtype=np.int32)
+    lens = np.zeros(beam, dtype=np.int32)
+    scores = np.zeros(beam, dtype=np.float64)
+    rc = lib().oe_ctc_prefix_beam_host(lp.ctypes.data_as(C.c_void_p), ix.ctypes.data_as(C.c_void_p), T, beam, max(T, 1),
+                                       prefixes.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                                       scores.ctypes.data_as(C.c_void_p))
+    check(rc, "oe_ctc_prefix_beam_host")
+    return [(tuple(int(v) for v in prefixes[i, : lens[i]]), float(scores[i])) for i in range(beam) if lens[i] >= 0]

@@ -104,35 +104,15 @@ class ASRModel(torch.nn.Module):
         return [toks[b, : int(n[b])].tolist() for b in range(B)]
 
     def _ctc_prefix_beam_search(self, features, features_length, beam_size: int):
-        """asr_model.py:328-396 (batch of one): log-probs computed on device, the prefix recursion on host."""
+        """asr_model.py:328-396 (batch of one): log-probs and per-frame top-k on the device, the prefix
+        recursion in native host code (oe_ctc_prefix_beam_host: same ordering and float64 arithmetic)."""
         assert features.shape[0] == features_length.shape[0]
         assert features.shape[0] == 1
         encoder_out, _, _ = self._encode(features, features_length)
         ctc_probs = self.ctc.log_softmax(encoder_out).squeeze(0)
         top_p, top_i = ctc_probs.topk(beam_size, dim=1)
-        top_p, top_i = top_p.cpu().tolist(), top_i.cpu().tolist()
-        NEG = -float("inf")
-        cur = [(tuple(), (0.0, NEG))]
-        for t in range(len(top_i)):
-            nxt = defaultdict(lambda: (NEG, NEG))
-            for s, ps in zip(top_i[t], top_p[t]):
-                for prefix, (pb, pnb) in cur:
-                    last = prefix[-1] if prefix else None
-                    if s == 0:
-                        b0, n0 = nxt[prefix]
-                        nxt[prefix] = (log_add([b0, pb + ps, pnb + ps]), n0)
-                    elif s == last:
-                        b0, n0 = nxt[prefix]
-                        nxt[prefix] = (b0, log_add([n0, pnb + ps]))
-                        ext = prefix + (s,)
-                        b1, n1 = nxt[ext]
-                        nxt[ext] = (b1, log_add([n1, pb + ps]))
-                    else:
-                        ext = prefix + (s,)
-                        b1, n1 = nxt[ext]
-                        nxt[ext] = (b1, log_add([n1, pb + ps, pnb + ps]))
-            cur = sorted(nxt.items(), key=lambda kv: log_add(list(kv[1])), reverse=True)[:beam_size]
-        return [(p, log_add([pb, pnb])) for p, (pb, pnb) in cur], encoder_out
+        from openeat_amd import hip
+        return hip.ctc_prefix_beam_host(top_p.cpu(), top_i.cpu(), beam_size), encoder_out
 
     def ctc_prefix_beam_search(self, features, features_length, beam_size: int) -> List[int]:
         hyps, _ = self._ctc_prefix_beam_search(features, features_length, beam_size)
@@ -181,6 +161,61 @@ class ASRModel(torch.nn.Module):
             if score > best:
                 best, best_i = score, i
         return hyps[best_i][0], enc, pre
+
+    @torch.no_grad()
+    def attention_rescoring_batch(self, features: torch.Tensor, features_length: torch.Tensor, beam_size: int,
+                                  ctc_weight: float = 0.0, reverse_weight: float = 0.0) -> List[List[int]]:
+        """Batched form of attention_rescoring (the reference handles one utterance per call,
+        asr_model.py:444): ONE encoder pass and ONE per-frame top-k for the whole batch, the prefix
+        recursion per utterance in native host code on its own valid frames, then ONE bi-decoder pass
+        over all B x beam hypotheses and the same score mix (asr_model.py:504-528)."""
+        from openeat_amd import hip
+        device = features.device
+        B = features.shape[0]
+        encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        lens = encoder_mask.squeeze(1).sum(1)
+        top_p, top_i = self.ctc.log_softmax(encoder_out).topk(beam_size, dim=2)
+        top_p, top_i, lens_h = top_p.cpu(), top_i.cpu(), lens.cpu().tolist()
+        nbest = [hip.ctc_prefix_beam_host(top_p[b, : lens_h[b]], top_i[b, : lens_h[b]], beam_size) for b in range(B)]
+        for b in range(B):                                     # a very short utterance can yield fewer than `beam` prefixes
+            while len(nbest[b]) < beam_size:
+                nbest[b].append((nbest[b][-1][0], -float("inf")))
+        flat = [h for nb in nbest for h in nb]
+        R = B * beam_size
+        hl = torch.tensor([len(h[0]) for h in flat], dtype=torch.long)
+        Lm = max(int(hl.max()), 1)
+        ori = torch.full((R, Lm), self.ignore_id, dtype=torch.long)
+        for i, h in enumerate(flat):
+            if h[0]:
+                ori[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long)
+        ori, hl = ori.to(device), hl.to(device)
+        hyps_pad, _ = add_sos_eos(ori, self.sos, self.eos, self.ignore_id)
+        L = hyps_pad.size(1)
+        hyps_mask = (~make_pad_mask(hl + 1, L)).unsqueeze(1) & subsequent_mask(L, device=device).unsqueeze(0)
+        enc = encoder_out.repeat_interleave(beam_size, dim=0)
+        enc_mask = encoder_mask.repeat_interleave(beam_size, dim=0)
+        r_hyps_pad, _ = add_sos_eos(reverse_pad_list(ori, hl, self.ignore_id), self.sos, self.eos, self.ignore_id)
+        if reverse_weight > 0 and self.decoder.r_num_blocks == 0:
+            raise IndexError("reverse_weight > 0 needs r_decoder_num_blocks > 0 (as in the reference)")
+        l_x, r_x, _ = self.decoder(enc, enc_mask, hyps_pad, r_hyps_pad, hyps_mask)
+        pos = torch.arange(L, device=device).unsqueeze(0)
+        valid = pos < hl.unsqueeze(1)                                            # token positions j < len
+        tok = torch.cat([ori, ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)
+
+        def seq_score(logits, tokens_at):
+            lp = ops.log_softmax_rows(logits)
+            tok_lp = lp.gather(2, tokens_at.unsqueeze(2)).squeeze(2)
+            eos_lp = lp[torch.arange(R, device=device), hl, self.eos]
+            return (tok_lp * valid).sum(1).double() + eos_lp.double()
+
+        score = seq_score(l_x, tok)
+        if reverse_weight > 0:
+            r_tok = torch.cat([reverse_pad_list(ori, hl, self.ignore_id).long(),
+                               ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)
+            score = score * (1 - reverse_weight) + seq_score(r_x, r_tok) * reverse_weight
+        score = score + torch.tensor([h[1] for h in flat], dtype=torch.float64, device=device) * ctc_weight
+        best = score.view(B, beam_size).argmax(1).cpu().tolist()
+        return [list(nbest[b][best[b]][0]) for b in range(B)]
 
     def recognize(self, features: torch.Tensor, features_length: torch.Tensor, beam_size: int = 10) -> torch.Tensor:
         """asr_model.py:205-295: batched attention beam search (incl. the reference's un-reordered cache)."""

@@ -246,3 +246,41 @@ def test_f12_end_to_end_bf16_mfma_modes(prec, loss_rtol, gn_rtol):
         got = float(grads[k].grad.norm())
         assert abs(got - n) <= gn_rtol * max(1.0, abs(n)), (k, got, n)
     assert greedy == meta["greedy"]
+
+
+def test_batched_rescoring_equals_per_utterance_rescoring():
+    """attention_rescoring_batch on a batch == attention_rescoring (the reference's B=1 algorithm, itself
+    checked against the reference's golden pick in F11/F12) applied to each utterance; equal-length
+    utterances so that padding plays no role."""
+    g = load_golden("f12_tiny_conformer")
+    meta = load_golden_json("f12_tiny_conformer")
+    model = ASRModel(80, meta["V"], **meta["kwargs"])
+    model.load_state_dict(g["sd"])
+    model = model.to(DEV).eval()
+    torch.manual_seed(31)
+    feats = torch.randn(4, 83, 80, device=DEV)
+    flen = torch.full((4,), 83, dtype=torch.int32, device=DEV)
+    tok2chr = {t: str(t) for t in range(meta["V"])}
+    with torch.no_grad():
+        batch = model.attention_rescoring_batch(feats, flen, 4, ctc_weight=0.5, reverse_weight=0.3)
+        single = [list(model.attention_rescoring(feats[b:b + 1].contiguous(), flen[b:b + 1], 4, ctc_weight=0.5, reverse_weight=0.3,
+                                                 token2char=tok2chr)[0]) for b in range(4)]
+    assert batch == single
+
+
+def test_native_prefix_beam_matches_python_recursion():
+    from openeat_amd import hip
+    from oracle import asr as O
+    torch.manual_seed(32)
+    for trial in range(10):
+        T, V, beam = 40 + trial, 30, 1 + trial % 5
+        logits = torch.randn(T, V) * 2
+        if trial % 3 == 0:
+            logits = (logits * 2).round() / 2                     # exact ties
+        logp = torch.log_softmax(logits, -1)
+        tp, ti = logp.topk(beam, dim=1)
+        got = hip.ctc_prefix_beam_host(tp, ti, beam)
+        want = O.prefix_beam_from_logp(logp, beam)
+        assert [p for p, _ in got] == [p for p, _ in want]
+        for (_, a), (_, b) in zip(got, want):
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(b))

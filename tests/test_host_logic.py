@@ -127,3 +127,23 @@ def test_product_never_imports_the_oracle():
     code = ("import sys; import openeat_amd.models.asr_model, openeat_amd.ops; "
             "bad=[m for m in sys.modules if m=='oracle' or m.startswith('oracle.')]; assert not bad, bad")
     subprocess.check_call([sys.executable, "-c", code], cwd=os.path.dirname(GOLDEN) + "/..")
+
+
+def test_native_prefix_beam_search_host_code():
+    """oe_ctc_prefix_beam_host is host code: checked on the CPU against the oracle's restatement of
+    asr_model.py:359-396 (incl. exact ties, which exercise the stable pruning order)."""
+    from openeat_amd import hip
+    from oracle import asr as O
+    torch.manual_seed(40)
+    for trial in range(12):
+        T, V, beam = 5 + 7 * trial, 12 + trial, 1 + trial % 6
+        logits = torch.randn(T, V) * (1 + trial % 3)
+        if trial % 2 == 0:
+            logits = (logits * 2).round() / 2
+        logp = torch.log_softmax(logits, -1)
+        tp, ti = logp.topk(beam, dim=1)
+        got = hip.ctc_prefix_beam_host(tp, ti, beam)
+        want = O.prefix_beam_from_logp(logp, beam)
+        assert [p for p, _ in got] == [p for p, _ in want]
+        for (_, a), (_, b) in zip(got, want):
+            assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
