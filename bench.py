@@ -107,8 +107,10 @@ def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3):
     model.train()
     best = min(times)
     return {"rtf": best / (n_utt * seconds), "wall_s": best, "utterances": n_utt, "seconds_each": seconds, "beam": beam,
-            "ctc_weight": 0.5, "reverse_weight": 0.3, "lm": None, "mean_hyp_len": sum(len(h) for h in hyps) / len(hyps),
-            "note": "random-init weights: CTC emits near-uniform noise, so hypotheses are ~T' tokens long (worst case for the decoder pass)"}
+            "ctc_weight": 0.5, "reverse_weight": 0.3, "lm": None, "mean_best_len": sum(len(h) for h in hyps) / len(hyps),
+            "mean_nbest_len": getattr(model, "last_nbest_mean_len", None),
+            "note": "random-init weights: the n-best lists and the rescored pick are whatever an untrained model emits; "
+                    "decoder cost scales with mean_nbest_len"}
 
 
 def log(msg):

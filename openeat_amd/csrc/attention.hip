@@ -368,18 +368,27 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
 }
 
 // delta[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d]
+// thread per (b,i,h) with float4 loads (adjacent threads = adjacent heads = contiguous memory)
 __global__ void attn_delta_kernel(AttnParams p) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)p.B * p.H * p.T1;
+    const long total = (long)p.B * p.T1 * p.H;
     if (idx >= total) return;
-    const int i = (int)(idx % p.T1);
-    const long bh = idx / p.T1;
-    const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+    const int h = (int)(idx % p.H);
+    const long bi = idx / p.H;
+    const int i = (int)(bi % p.T1);
+    const int b = (int)(bi / p.T1);
     const float* a = p.d_o + (long)b * p.o_bs + (long)i * p.o_rs + h * p.D;
     const float* o = p.o_in + (long)b * p.o_bs + (long)i * p.o_rs + h * p.D;
     float s = 0.f;
-    for (int d = 0; d < p.D; ++d) s += a[d] * o[d];
-    p.delta[idx] = s;
+    if ((p.D & 3) == 0 && (((uintptr_t)a | (uintptr_t)o) & 15) == 0) {
+        for (int d = 0; d < p.D; d += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(a + d), y = *reinterpret_cast<const float4*>(o + d);
+            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+    } else {
+        for (int d = 0; d < p.D; ++d) s += a[d] * o[d];
+    }
+    p.delta[((long)b * p.H + h) * p.T1 + i] = s;
 }
 
 static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {

@@ -6,6 +6,35 @@
 
 // ---------------------------------------------------------------- rel-pos ----
 // kp[b,t,h,:] = k[b,t,h,:] + p[t,h,:] ; keybias[b,h,t] = scale*(u_h.k + v_h.p)
+// one wave per (b,t) row of d = H*D floats: coalesced float4 traffic; the per-head dot products are
+// reduced with shuffles over the D/4 lanes of a head when D/4 is a power of two (generic fallback below).
+__global__ __launch_bounds__(256) void relpos_prepare_rows_kernel(const float* __restrict__ k, long k_bs, long k_rs,
+                                                                   const float* __restrict__ p, long p_rs,
+                                                                   const float* __restrict__ u, const float* __restrict__ v, int B,
+                                                                   int T, int H, int D, float scale, float* __restrict__ kp,
+                                                                   float* __restrict__ keybias) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * T) return;
+    const int t = (int)(row % T);
+    const long b = row / T;
+    const int d = H * D, lph = D >> 2;                     // lanes per head
+    const float* kr = k + b * k_bs + (long)t * k_rs;
+    const float* pr = p + (long)t * p_rs;
+    float* out = kp + row * d;
+    for (int c0 = 0; c0 < d; c0 += 256) {
+        const int c = c0 + lane * 4;
+        float s = 0.f;
+        if (c < d) {
+            const float4 kv = *reinterpret_cast<const float4*>(kr + c), pv = *reinterpret_cast<const float4*>(pr + c);
+            const float4 uv = *reinterpret_cast<const float4*>(u + c), vv = *reinterpret_cast<const float4*>(v + c);
+            *reinterpret_cast<float4*>(out + c) = make_float4(kv.x + pv.x, kv.y + pv.y, kv.z + pv.z, kv.w + pv.w);
+            s = uv.x * kv.x + uv.y * kv.y + uv.z * kv.z + uv.w * kv.w + vv.x * pv.x + vv.y * pv.y + vv.z * pv.z + vv.w * pv.w;
+        }
+        for (int o = 1; o < lph; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (c < d && (lane % lph) == 0) keybias[(b * H + c / D) * T + t] = s * scale;
+    }
+}
 __global__ void relpos_prepare_kernel(const float* __restrict__ k, long k_bs, long k_rs, const float* __restrict__ p, long p_rs,
                                       const float* __restrict__ u, const float* __restrict__ v, int B, int T, int H, int D,
                                       float scale, float* __restrict__ kp, float* __restrict__ keybias) {
@@ -59,9 +88,18 @@ extern "C" int oe_relpos_prepare(const float* k, long k_bstride, long k_rstride,
                                  const float* u, const float* v, int B, int T, int H, int D, float scale, float* kp,
                                  float* keybias, void* stream) {
     OE_REQUIRE(k && p && u && v && kp && keybias && B > 0 && T > 0 && H > 0 && D > 0, "oe_relpos_prepare: bad arguments");
-    const long n = (long)B * T * H;
-    hipLaunchKernelGGL(relpos_prepare_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k, k_bstride, k_rstride,
-                       p, p_rstride, u, v, B, T, H, D, scale, kp, keybias);
+    const int lph = D / 4;
+    const bool rows_ok = (D % 4 == 0) && lph >= 1 && lph <= 64 && (lph & (lph - 1)) == 0 && (256 % (4 * lph) == 0 || 4 * lph >= 256) &&
+                         (k_rstride % 4 == 0) && (k_bstride % 4 == 0) && (p_rstride % 4 == 0) &&
+                         (((uintptr_t)k | (uintptr_t)p | (uintptr_t)u | (uintptr_t)v | (uintptr_t)kp) & 15) == 0;
+    if (rows_ok) {
+        hipLaunchKernelGGL(relpos_prepare_rows_kernel, dim3(oe_cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, k,
+                           k_bstride, k_rstride, p, p_rstride, u, v, B, T, H, D, scale, kp, keybias);
+    } else {
+        const long n = (long)B * T * H;
+        hipLaunchKernelGGL(relpos_prepare_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, k, k_bstride, k_rstride,
+                           p, p_rstride, u, v, B, T, H, D, scale, kp, keybias);
+    }
     OE_LAUNCH_CHECK("relpos_prepare");
     return 0;
 }

@@ -40,6 +40,7 @@ struct Stage {
     long fix[NS];
     const float* ptr[NS];     // fast path: address of this slot's data for the current K-tile
     float4 csum[NS];          // k-major only: running sum over k of this slot's 4 rows (fused bias gradient)
+    int gf[NS], gt[NS]; long gb[NS];   // k-major im2col gather: (f, t, b) of this slot's next position (no divisions in the loop)
 
     __device__ __forceinline__ void init(const OperandDesc& d, long i0, long limit) {
 #pragma unroll
@@ -51,6 +52,19 @@ struct Stage {
             } else {
                 const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
                 fix[s] = (idx < NIDX) ? addr_col<GATHER>(d, i0 + 4 * mb) : -1;
+            }
+        }
+    }
+    // position counters of the first row this slot will read (k-major gather only)
+    __device__ __forceinline__ void init_gather_pos(const OperandDesc& d, int k0) {
+        if (KMAJOR && GATHER) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const long r = k0 + 4 * ((threadIdx.x + s * 256) & 7);
+                gf[s] = (int)(r % d.F2);
+                const long q = r / d.F2;
+                gt[s] = (int)(q % d.T2);
+                gb[s] = q / d.T2;
             }
         }
     }
@@ -129,11 +143,27 @@ struct Stage {
                 const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
                 const long c = i0 + 4 * mb;
                 const int nvr = (fix[s] < 0) ? 0 : (int)max(0L, min(4L, limit - c));
+                if (GATHER) {
+                    // im2col rows: walk (f, t, b) forward one output position at a time, carry instead of divide
+                    int f = gf[s], t = gt[s];
+                    long bb = gb[s];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = k0 + 4 * kb + i;
-                    reg[s][i] = (nvr && k < k_end) ? load4(d.p + addr_row<GATHER>(d, k) + fix[s], nvr, d.vec_ok)
-                                                   : make_float4(0, 0, 0, 0);
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k0 + 4 * kb + i;
+                        const long base = ((bb * d.T1 + 2 * t) * (long)d.F1 + 2 * f) * d.C;
+                        reg[s][i] = (nvr && k < k_end) ? load4(d.p + base + fix[s], nvr, d.vec_ok) : make_float4(0, 0, 0, 0);
+                        if (++f == d.F2) { f = 0; if (++t == d.T2) { t = 0; ++bb; } }
+                    }
+                    f += BK2 - 4;                                  // this slot's rows of the next K-tile start 32 further
+                    while (f >= d.F2) { f -= d.F2; if (++t == d.T2) { t = 0; ++bb; } }
+                    gf[s] = f; gt[s] = t; gb[s] = bb;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = k0 + 4 * kb + i;
+                        reg[s][i] = (nvr && k < k_end) ? load4(d.p + addr_row<GATHER>(d, k) + fix[s], nvr, d.vec_ok)
+                                                       : make_float4(0, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -212,6 +242,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDe
     } else {
         sa.init(A, m0, M);
         sb.init(B, n0, N);
+        sa.init_gather_pos(A, k_begin);
+        sb.init_gather_pos(B, k_begin);
     }
 
     f32x16 acc[TM][TN];

@@ -181,6 +181,7 @@ class ASRModel(torch.nn.Module):
             while len(nbest[b]) < beam_size:
                 nbest[b].append((nbest[b][-1][0], -float("inf")))
         flat = [h for nb in nbest for h in nb]
+        self.last_nbest_mean_len = sum(len(h[0]) for h in flat) / max(len(flat), 1)
         R = B * beam_size
         hl = torch.tensor([len(h[0]) for h in flat], dtype=torch.long)
         Lm = max(int(hl.max()), 1)
