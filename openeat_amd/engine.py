@@ -16,8 +16,9 @@ from openeat_amd.utils import common
 
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, grad_clip: float = 5.0, accum_grad: int = 1,
-                 n_allreduce_chunks: int = 4, static_shapes: bool = False):
+                 n_allreduce_chunks: int = 4, static_shapes: bool = False, async_wgrad: bool = True):
         self.model = model
+        ops.ASYNC_WGRAD = bool(async_wgrad)
         self.arena = ParamArena(model).activate()
         self.optimizer = FusedAdam(self.arena, lr=lr, max_grad_norm=grad_clip)
         self.reducer = GradAllReduce(self.arena.grad, n_allreduce_chunks)
@@ -36,6 +37,7 @@ class TrainEngine:
         loss, acc = self.model(**batch)
         loss = loss / self.accum_grad if self.accum_grad != 1 else loss
         loss.backward()
+        ops.join_side_stream()                 # weight-gradient GEMMs running beside the backward chain
         return loss.detach(), None if acc is None else acc.detach()
 
     def _finish(self):

@@ -119,6 +119,57 @@ def colsum(x, alpha=1.0, alpha_dev=None, n=None, out=None):
     return out
 
 
+# ---- weight-gradient GEMMs on a side stream -----------------------------------
+# Nothing downstream of backward consumes a parameter gradient before the optimizer, so (with a
+# ParamArena as the destination) the wgrad GEMMs can run on a second HIP stream beside the
+# activation-gradient chain and fill its bubbles.  The engine joins the streams after backward.
+ASYNC_WGRAD = False
+_side_stream = None
+
+
+def side_stream():
+    global _side_stream
+    if _side_stream is None:
+        _side_stream = torch.cuda.Stream()
+    return _side_stream
+
+
+def join_side_stream():
+    if _side_stream is not None:
+        torch.cuda.current_stream().wait_stream(_side_stream)
+
+
+class _Side:
+    """Run the enclosed launches on the side stream, ordered after everything enqueued so far."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if isinstance(t, torch.Tensor)]
+
+    def __enter__(self):
+        side = side_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        self.cm = torch.cuda.stream(side)
+        self.cm.__enter__()
+
+    def __exit__(self, *exc):
+        self.cm.__exit__(*exc)
+        for t in self.tensors:                 # keep the allocator from recycling inputs the side stream still reads
+            t.record_stream(_side_stream)
+        return False
+
+
+class _Inline:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _wgrad_ctx(to_arena: bool, *tensors):
+    return _Side(*tensors) if (ASYNC_WGRAD and to_arena) else _Inline()
+
+
 # ---- parameter-gradient sinks ------------------------------------------------
 # With a ParamArena active the kernels accumulate into the flat gradient buffer and
 # autograd is told "no gradient" (None); otherwise a fresh tensor is returned.
@@ -126,7 +177,8 @@ def wgrad(param, dy, x, alpha=1.0, alpha_dev=None):
     tgt = _arena.grad_target(param)
     if tgt is None:
         return gemm_tn(dy, x, alpha=alpha, alpha_dev=alpha_dev).view(param.shape)
-    gemm_tn(dy, x, out=tgt.view(dy.shape[1], x.shape[1]), alpha=alpha, alpha_dev=alpha_dev)
+    with _wgrad_ctx(True, dy, x, alpha_dev):
+        gemm_tn(dy, x, out=tgt.view(dy.shape[1], x.shape[1]), alpha=alpha, alpha_dev=alpha_dev)
     return None
 
 
@@ -150,7 +202,8 @@ def wgrad_bias(w, b, dy, x, alpha=1.0, alpha_dev=None):
     tw, tb = _arena.grad_target(w), _arena.grad_target(b)
     ow = tw.view(N, K) if tw is not None else _new(N, K, like=dy, zero=True)
     ob = tb if tb is not None else _new(N, like=dy, zero=True)
-    gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob)
+    with _wgrad_ctx(tw is not None and tb is not None, dy, x, alpha_dev):
+        gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob)
     return (None if tw is not None else ow.view(w.shape)), (None if tb is not None else ob)
 
 
@@ -462,7 +515,8 @@ class AttentionFn(torch.autograd.Function):
                 gw = _arena.grad_target(parts_w[0])
                 gw_all = torch.as_strided(gw, (n, x_in.shape[1]), (x_in.shape[1], 1))
                 gb = _arena.grad_target(parts_b[0])
-                gemm_tn(dy_fused, x_in, out=gw_all, bias_out=torch.as_strided(gb, (n,), (1,)))
+                with _wgrad_ctx(True, dy_fused, x_in):
+                    gemm_tn(dy_fused, x_in, out=gw_all, bias_out=torch.as_strided(gb, (n,), (1,)))
                 return dx_in, [None] * len(parts_w), [None] * len(parts_b)
             dwf, dbf = gemm_tn(dy_fused, x_in), colsum(dy_fused)
             ws, bs, o = [], [], 0
@@ -549,7 +603,8 @@ class ConvModuleFn(torch.autograd.Function):
         (db1, rb1) = grad_sink(b1)
         tw1 = _arena.grad_target(w1)
         ow1 = tw1.view(2 * d, d) if tw1 is not None else _new(2 * d, d, like=dy, zero=True)
-        gemm_tn(da, xm, out=ow1, bias_out=db1)
+        with _wgrad_ctx(tw1 is not None and rb1 is None and not causal, da, xm):
+            gemm_tn(da, xm, out=ow1, bias_out=db1)
         dw1 = None if tw1 is not None else ow1.view(w1.shape)
         if causal:
             db1_pad = torch.empty_like(db1)
