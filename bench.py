@@ -223,8 +223,16 @@ def main():
         prec = hip.GEMM_PRECISION
         peak = PEAK_FP32_MFMA_TFLOPS if prec == 0 else PEAK_BF16_MFMA_TFLOPS
         mfma_flops = flops * (3 if prec == 3 else 1)            # the 3-term split issues 3 MFMAs per algorithmic product
+        traffic = None                                           # HBM bytes per launch from the committed PMC passes
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
+                pmc = json.load(f)
+            if pmc.get("precision") == prec:
+                traffic = pmc["gemm"]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"kernel": KERNEL_NAMES[prec], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": None, "launches_per_step": len(recs),
+                "frac": ach / peak, "traffic": traffic, "launches_per_step": len(recs),
                 "avg_launch_us": secs / max(len(recs), 1) * 1e6, "gemm_ms_per_step": secs * 1e3,
                 "algorithmic_gflop_per_step": flops / 1e9, "mfma_issue_tflops": mfma_flops / secs / 1e12}
 

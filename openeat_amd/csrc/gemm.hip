@@ -13,6 +13,7 @@
 // before the MFMA block of the current one (register staging).
 //
 // Roofline: MFMA-bound.  fp32-input MFMA peak on gfx950 = 157.3 TFLOP/s.
+#include <stdlib.h>
 #include "gemm_common.h"
 #include "../../include/openeat_hip.h"
 

@@ -13,6 +13,7 @@
 // 4-bank slots: 20*r mod 64).  k-major operands are transposed in registers on the way in
 // (4x4 micro-blocks, lane -> (k-block, row-block) = (l&7, l>>3) so that both the 128-byte
 // global segments and the ds_write_b64 pattern are conflict free).
+#include <stdlib.h>
 #include "gemm_common.h"
 #include "../../include/openeat_hip.h"
 
@@ -342,7 +343,9 @@ int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, 
     // weight gradients (both operands k-major, long reduction): operand re-reads dominate, so take the
     // 128x128 tile as soon as the grid still covers the chip; elsewhere favour >= ~2 blocks per CU.
     const bool wg = a_kmajor && b_kmajor;
-    const int tile = (b22 >= (wg ? 200 : 400) && M >= 128 && N >= 128) ? 22 : (b12 >= 400 && N >= 128) ? 12 : 11;
+    int tile = (b22 >= (wg ? 200 : 400) && M >= 128 && N >= 128) ? 22 : (b12 >= 400 && N >= 128) ? 12 : 11;
+    static const int forced_tile = getenv("OE_GEMM_TILE") ? atoi(getenv("OE_GEMM_TILE")) : 0;   // tuning aid (tools/gemm_bench.py)
+    if (forced_tile) tile = forced_tile;
 #define OE_DISP(AK, BKM, GA, GB)                                                                                 \
     do {                                                                                                         \
         if (terms == 3) {                                                                                        \

@@ -10,7 +10,7 @@ from tools.gemm_bench import run  # noqa: E402
 
 if __name__ == "__main__":
     for kind, m, n in (("nt", 7936, 1024), ("nt", 7936, 256), ("nn", 7936, 1024), ("tn", 1024, 256)):
-        for prec in (1, 0):
+        for prec in (3, 1):
             row = []
             ks = (32, 64, 128, 256, 512, 1024, 2048) if kind != "tn" else (512, 1024, 2048, 4096, 7936, 15872)
             for k in ks:
