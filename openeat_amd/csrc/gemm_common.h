@@ -3,8 +3,36 @@
 #pragma once
 #include "oe_common.h"
 
+#include <type_traits>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N).  Used where the body is too large
+// for `#pragma unroll` to be honoured but must index register arrays statically.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+
+// Diagnostic build only (-DOE_GEMM_STAMPS, tools/gemm_stamps.py): per-workgroup s_memtime stamps at the
+// phase boundaries, written to a buffer nothing else reads.  No stamp exists in the shipped library.
+#ifdef OE_GEMM_STAMPS
+static __device__ unsigned long long* oe_stamp_buf = nullptr;   // per translation unit; only gemm_dma.hip sets its copy
+#define OE_STAMP(slot)                                                                                     \
+    do {                                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        unsigned long long t_;                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+        if (oe_stamp_buf && threadIdx.x == 0 && blockIdx.x < 4096) oe_stamp_buf[blockIdx.x * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define OE_STAMP(slot) do { } while (0)
+#endif
 
 struct OperandDesc {
     const float* p;
@@ -71,23 +99,44 @@ struct EpiParams {
 int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk,
                           const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, int terms, hipStream_t st);
 
-// Epilogue shared by both kernels.  `acc` holds TM x TN 32x32 accumulator tiles in the MFMA C/D layout
+// LDS-DMA variant (gemm_dma.hip): returns 1 when the problem does not qualify, else the launch status
+int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep,
+                    bool a_kmajor, bool b_kmajor, bool gather_b, int terms, int tile, hipStream_t st);
+
+// One output value: x = acc*alpha + bias -> (pre-activation kept) -> act fwd, or times act'(aux) in a
+// backward GEMM -> dropout mask -> dead-row zeroing -> res + beta*x.
+__device__ __forceinline__ float epi_value(const EpiParams& ep, float v, float alpha, float bias, float aux, float dm, bool row_dead,
+                                           float res, float& pre) {
+    float x = v * alpha + bias;
+    pre = x;
+    if (ep.actgrad_in) x *= act_bwd(ep.act, aux);
+    else x = act_fwd(ep.act, x);
+    x *= dm;
+    if (row_dead) x = 0.f;
+    return res + ep.beta * x;
+}
+
+// Epilogue shared by the GEMM kernels.  `acc` holds TM x TN 32x32 accumulator tiles in the MFMA C/D layout
 // (col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)); `lds` must provide 4*32*36 floats and all
 // waves of the block must call this together (it synchronises).
+//
+// vmcnt counts loads and stores together, in order: a wait for a load issued after a store also waits for
+// that store to be acknowledged, and hipcc waits vmcnt(0) at every use of a conditionally loaded value
+// once a branch separates load and use.  So the paths below keep their loads out of branches that also
+// hold stores: blocks that are interior and 16-byte aligned take straight-line code with every auxiliary
+// load of a 32x32 tile issued ahead of the tile's stores; only ragged-edge blocks take the bounds-checked path.
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, float* __restrict__ C, long ldc, int M, int N,
                                               long m0, long n0, const EpiParams& ep, int tile_z) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lrow = lane & 31, lk = lane >> 5;
-    // Each wave parks one 32x32 accumulator tile at a time in its own LDS patch
-    // and re-reads it row-major, so that every global access of the epilogue
-    // (C, residual, pre-activation, act-grad input) is a coalesced float4 row.
     float alpha = ep.alpha;
     if (ep.alpha_dev) alpha *= *ep.alpha_dev;
     const float inv_keep = ep.drop_p > 0.f ? 1.f / (1.f - ep.drop_p) : 1.f;
     const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const bool first_split = (tile_z == 0);
+    const bool interior = (m0 + 64 * TM <= M) && (n0 + 64 * TN <= N);          // block-uniform
     constexpr int EP_LD = 36;
     if (ep.atomic) {
         // split-K accumulation: atomics straight from the accumulators.  Register r of a 32x32 tile is two
@@ -98,26 +147,143 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const long col = n0 + wn * (32 * TN) + j * 32 + lrow;
-                const float bias = (col < N && ep.bias && first_split) ? ep.bias[col] : 0.f;
+                float bias = (col < N && ep.bias && first_split) ? ep.bias[col] : 0.f;
+                asm volatile("" : "+v"(bias));      // resolve the load here, not in front of every atomic
+                float* base = C + (m0 + wm * (32 * TM) + i * 32 + 4 * lk) * ldc + col;
+                if (interior) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long row = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (row < M && col < N) atomicAdd(C + row * ldc + col, acc[i][j][r] * alpha + bias);
+                    for (int r = 0; r < 16; ++r) atomicAdd(base + ((r & 3) + 8 * (r >> 2)) * ldc, acc[i][j][r] * alpha + bias);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long row = m0 + wm * (32 * TM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (row < M && col < N) atomicAdd(C + row * ldc + col, acc[i][j][r] * alpha + bias);
+                    }
                 }
             }
         return;
     }
+    // Each wave parks one 32x32 accumulator tile at a time in its own LDS patch and re-reads it row-major,
+    // so that every global access of the epilogue (C, residual, pre-activation, act-grad input) is a
+    // coalesced float4 row segment.
     float* patch = lds + wave * (32 * EP_LD);
     __syncthreads();   // every wave is done with the operand tiles that the patches overlay
-    const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0) && !ep.atomic;
+    OE_STAMP(5);
+    const bool c_vec = (ldc % 4 == 0) && (((uintptr_t)C & 15) == 0);
     const bool aux_vec = (ep.ld_aux % 4 == 0) && (((uintptr_t)ep.preact_out & 15) == 0) && (((uintptr_t)ep.actgrad_in & 15) == 0);
     const bool res_vec = (ep.ldr % 4 == 0) && (((uintptr_t)ep.residual & 15) == 0);
+    const int prow = lane >> 3, pcol = (lane & 7) * 4;       // this lane's (row within a pass, first column) of the patch
+
+    if (interior && c_vec && aux_vec && res_vec && !ep.accumulate) {
+        static_for<0, TM * TN>([&](auto tile_idx) {
+            {
+                constexpr int i = decltype(tile_idx)::value / TN, j = decltype(tile_idx)::value % TN;
+                const long row0 = m0 + wm * (32 * TM) + i * 32 + prow;
+                const long col = n0 + wn * (32 * TN) + j * 32 + pcol;
+                // ---- every load of this tile, before anything of it is stored
+                float4 aux[4], res[4];
+                bool dead[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+                for (int p = 0; p < 4; ++p) { aux[p] = make_float4(0.f, 0.f, 0.f, 0.f); res[p] = aux[p]; dead[p] = false; }
+                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ep.bias && first_split) { b4.x = ep.bias[col]; b4.y = ep.bias[col + 1]; b4.z = ep.bias[col + 2]; b4.w = ep.bias[col + 3]; }
+                if (ep.actgrad_in) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            // the patch is private to this wave: LDS operations of one wave complete in order, so a
-            // wave-level fence (wait for our own LDS traffic, then a compiler barrier) is enough
+                    for (int p = 0; p < 4; ++p) aux[p] = *reinterpret_cast<const float4*>(ep.actgrad_in + (row0 + 8 * p) * ep.ld_aux + col);
+                }
+                if (ep.residual) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const long rr = ep.res_row_mod > 0 ? (row0 + 8 * p) % ep.res_row_mod : row0 + 8 * p;
+                        res[p] = *reinterpret_cast<const float4*>(ep.residual + rr * ep.ldr + col);
+                    }
+                }
+                if (ep.rowmask) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) dead[p] = !ep.rowmask[row0 + 8 * p];
+                }
+                // ---- accumulators -> patch -> row-major float4 (wave-private: a wave-level fence is enough)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) patch[((r & 3) + 8 * (r >> 2) + 4 * lk) * EP_LD + lrow] = acc[i][j][r];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                float4 t[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) t[p] = *reinterpret_cast<const float4*>(patch + (p * 8 + prow) * EP_LD + pcol);
+                if (i == 0 && j == 0) OE_STAMP(6);
+                // ---- values: every feature test is one wave-uniform branch per tile, never per element
+                float4 x[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    x[p] = make_float4(t[p].x * alpha + b4.x, t[p].y * alpha + b4.y, t[p].z * alpha + b4.z, t[p].w * alpha + b4.w);
+                float* cdst = C + row0 * ldc + col;
+                if (ep.preact_out) {
+                    float* pdst = ep.preact_out + row0 * ep.ld_aux + col;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(pdst + 8 * p * ep.ld_aux) = x[p];
+                }
+                if (ep.actgrad_in) {
+                    if (ep.act == OE_ACT_SWISH) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            x[p].x *= act_bwd(OE_ACT_SWISH, aux[p].x); x[p].y *= act_bwd(OE_ACT_SWISH, aux[p].y);
+                            x[p].z *= act_bwd(OE_ACT_SWISH, aux[p].z); x[p].w *= act_bwd(OE_ACT_SWISH, aux[p].w);
+                        }
+                    } else if (ep.act == OE_ACT_RELU) {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            x[p].x = aux[p].x > 0.f ? x[p].x : 0.f; x[p].y = aux[p].y > 0.f ? x[p].y : 0.f;
+                            x[p].z = aux[p].z > 0.f ? x[p].z : 0.f; x[p].w = aux[p].w > 0.f ? x[p].w : 0.f;
+                        }
+                    }
+                } else if (ep.act == OE_ACT_SWISH) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        x[p].x *= sigmoidf_(x[p].x); x[p].y *= sigmoidf_(x[p].y); x[p].z *= sigmoidf_(x[p].z); x[p].w *= sigmoidf_(x[p].w);
+                    }
+                } else if (ep.act == OE_ACT_RELU) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        x[p].x = fmaxf(x[p].x, 0.f); x[p].y = fmaxf(x[p].y, 0.f); x[p].z = fmaxf(x[p].z, 0.f); x[p].w = fmaxf(x[p].w, 0.f);
+                    }
+                }
+                if (ep.drop_p > 0.f) {
+                    const unsigned long long e0 = (unsigned long long)(row0 * N + col);
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        const unsigned long long e = e0 + (unsigned long long)(8 * p) * N;
+                        float4 dm;
+                        if ((e & 3) == 0) dm = dropout_scale4(seed, e >> 2, ep.drop_p, inv_keep);
+                        else {
+                            dm.x = dropout_scale(seed, e, ep.drop_p, inv_keep); dm.y = dropout_scale(seed, e + 1, ep.drop_p, inv_keep);
+                            dm.z = dropout_scale(seed, e + 2, ep.drop_p, inv_keep); dm.w = dropout_scale(seed, e + 3, ep.drop_p, inv_keep);
+                        }
+                        x[p].x *= dm.x; x[p].y *= dm.y; x[p].z *= dm.z; x[p].w *= dm.w;
+                    }
+                }
+                if (ep.rowmask) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) if (dead[p]) x[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (ep.residual || ep.beta != 1.f) {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p)
+                        x[p] = make_float4(res[p].x + ep.beta * x[p].x, res[p].y + ep.beta * x[p].y, res[p].z + ep.beta * x[p].z, res[p].w + ep.beta * x[p].w);
+                }
+#pragma unroll
+                for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(cdst + 8 * p * ldc) = x[p];
+                if (i == 0 && j == 0) OE_STAMP(7);
+            }
+        });
+        return;
+    }
+
+    // ragged-edge / unaligned blocks: bounds-checked
+    static_for<0, TM * TN>([&](auto tile_idx) {
+        {
+            constexpr int i = decltype(tile_idx)::value / TN, j = decltype(tile_idx)::value % TN;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -125,15 +291,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             const long row_base = m0 + wm * (32 * TM) + i * 32;
-            const long col = n0 + wn * (32 * TN) + j * 32 + (lane & 7) * 4;
+            const long col = n0 + wn * (32 * TN) + j * 32 + pcol;
             const int ncol = (int)max(0L, min(4L, (long)N - col));
             float bias4[4] = {0.f, 0.f, 0.f, 0.f};
             if (ep.bias && first_split) for (int e = 0; e < ncol; ++e) bias4[e] = ep.bias[col + e];
             for (int pass = 0; pass < 4; ++pass) {
-                const int lr = pass * 8 + (lane >> 3);
+                const int lr = pass * 8 + prow;
                 const long row = row_base + lr;
                 if (row >= M || ncol == 0) continue;
-                const float4 t4 = *reinterpret_cast<const float4*>(patch + lr * EP_LD + (lane & 7) * 4);
+                const float4 t4 = *reinterpret_cast<const float4*>(patch + lr * EP_LD + pcol);
                 float v[4] = {t4.x, t4.y, t4.z, t4.w};
                 const bool full = (ncol == 4);
                 float aux[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
@@ -161,25 +327,14 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float x = v[e] * alpha + bias4[e];
-                    pre[e] = x;
-                    if (ep.actgrad_in) x *= act_bwd(ep.act, aux[e]);
-                    else x = act_fwd(ep.act, x);
-                    x *= dm[e];
-                    if (row_dead) x = 0.f;
-                    x = res[e] + ep.beta * x;
-                    v[e] = x;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = epi_value(ep, v[e], alpha, bias4[e], aux[e], dm[e], row_dead, res[e], pre[e]);
                 if (ep.preact_out) {
                     float* pp = ep.preact_out + row * ep.ld_aux + col;
                     if (full && aux_vec) *reinterpret_cast<float4*>(pp) = make_float4(pre[0], pre[1], pre[2], pre[3]);
                     else for (int e = 0; e < ncol; ++e) pp[e] = pre[e];
                 }
                 float* dst = C + row * ldc + col;
-                if (ep.atomic) {
-                    for (int e = 0; e < ncol; ++e) atomicAdd(dst + e, v[e]);
-                } else if (full && c_vec) {
+                if (full && c_vec) {
                     float4 o = make_float4(v[0], v[1], v[2], v[3]);
                     if (ep.accumulate) { const float4 c4 = *reinterpret_cast<const float4*>(dst); o.x += c4.x; o.y += c4.y; o.z += c4.z; o.w += c4.w; }
                     *reinterpret_cast<float4*>(dst) = o;
@@ -188,5 +343,5 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 }
             }
         }
-    }
+    });
 }

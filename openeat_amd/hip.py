@@ -20,7 +20,8 @@ PROFILE = None
 # Default GEMM arithmetic: 0 = fp32-input MFMA (exact), 1 = bf16 inputs, 3 = 3-term bf16 split (fp32-grade).
 GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "0"))
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libopeneat_hip.so")
+# OE_HIP_LIB: diagnostic builds only (tools/gemm_stamps.py loads the stamped variant of the library)
+_LIB_PATH = os.environ.get("OE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libopeneat_hip.so")
 _lib = None
 
 ACT = {"none": 0, None: 0, "relu": 1, "swish": 2}

@@ -64,7 +64,7 @@ def _split_k(out_rows: int, out_cols: int, k: int) -> int:
     ~3 blocks per CU.  K-chunks stay >= 256 and the atomic traffic (splits x output bytes) bounded."""
     if hip.GEMM_PRECISION != 0 and out_rows >= 128 and out_cols >= 128:
         t128 = -(-out_rows // 128) * -(-out_cols // 128)
-        sk = -(-256 // t128)
+        sk = max(1, 256 // t128)          # at most one 128x128 block per CU (the ring kernel holds one per CU)
         if t128 * sk >= 200 and sk <= 24:
             return int(max(1, min(sk, k // 256 if k >= 512 else 1)))
     tiles = -(-out_rows // 64) * -(-out_cols // 64)

@@ -1,0 +1,124 @@
+"""GPU: the LDS-DMA ring GEMM (gemm_dma.hip) against float64 on shapes that qualify for it
+(tiles interior, 16-byte aligned, K % 32 == 0).
+
+The library picks the ring only where it measured faster (weight gradients, x @ W with K >= 512); to cover
+every layout / tile / ring-depth case the same checks also run in a child process with OE_GEMM_DMA=2
+(ring wherever the problem qualifies) - the switch is read once per process.
+"""
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda"
+CASES = [(128, 128, 32), (256, 128, 96), (512, 384, 256), (1024, 1024, 160), (192, 64, 64), (512, 256, 1024)]
+PRECS = [(3, 2e-5), (1, 6e-3)]
+
+
+def check_case(prec, rel, M, N, K):
+    """One to 32 K-tiles (shorter than, equal to and longer than the 4-deep ring), the three operand layouts,
+    bias / residual / activation epilogues, split-K atomics and the fused bias gradient."""
+    from openeat_amd import hip
+
+    torch.manual_seed(21)
+    x, w, dy, b = torch.randn(M, K), torch.randn(N, K), torch.randn(M, N), torch.randn(N)
+    res = torch.randn(M, N)
+    xd, wd, dyd, bd, resd = (t.to(DEV) for t in (x, w, dy, b, res))
+
+    def err(got, ref, k):
+        return float((got.cpu().double() - ref).abs().max()) / math.sqrt(k)
+
+    y = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(xd, wd, y, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, residual=resd, ldr=N, beta=0.5, precision=prec)
+    pre = torch.full((M, N), float("nan"), device=DEV)
+    ya = torch.full((M, N), float("nan"), device=DEV)
+    hip.gemm(xd, wd, ya, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, act=2, preact_out=pre, ld_aux=N, precision=prec)
+    # dgrad: dx[M,K'] = dy[M,N] @ W[N,K'] needs K' % 64 == 0 to qualify as an output width
+    Kp = 64 * max(1, K // 64)
+    w2 = torch.randn(N, Kp)
+    w2d = w2.to(DEV)
+    dx = torch.full((M, Kp), float("nan"), device=DEV)
+    hip.gemm(dyd, w2d, dx, M, Kp, N, lda=N, ldb=Kp, ldc=Kp, b_kmajor=True, precision=prec)
+    # same with the activation derivative fused (relu'(aux)) and a row mask
+    auxd = torch.randn(M, Kp, device=DEV)
+    mask = (torch.rand(M) > 0.2).to(torch.uint8).to(DEV)
+    dxa = torch.full((M, Kp), float("nan"), device=DEV)
+    hip.gemm(dyd, w2d, dxa, M, Kp, N, lda=N, ldb=Kp, ldc=Kp, b_kmajor=True, act=1, actgrad_in=auxd, ld_aux=Kp,
+             rowmask=mask, precision=prec)
+    # wgrad dW[N,Kp] = dy^T x2 with the reduction over M split three ways + bias gradient
+    x2 = torch.randn(M, Kp)
+    x2d = x2.to(DEV)
+    dw = torch.zeros(N, Kp, device=DEV)
+    db = torch.zeros(N, device=DEV)
+    sk = 3 if M >= 96 * 3 else 1
+    hip.gemm(dyd, x2d, dw, N, Kp, M, lda=N, ldb=Kp, ldc=Kp, a_kmajor=True, b_kmajor=True, split_k=sk, atomic_out=True,
+             precision=prec, a_colsum=db)
+    torch.cuda.synchronize()
+    lin = x.double() @ w.double().T + b.double()
+    assert err(y, res.double() + 0.5 * lin, K) < rel * 3
+    assert err(pre, lin, K) < rel * 3
+    assert err(ya, lin * torch.sigmoid(lin), K) < rel * 3 * 1.2
+    ref_dx = dy.double() @ w2.double()
+    assert err(dx, ref_dx, N) < rel * 3
+    ref_dxa = ref_dx * (auxd.cpu().double() > 0) * mask.cpu().double()[:, None]
+    assert err(dxa, ref_dxa, N) < rel * 3
+    assert err(dw, dy.double().T @ x2.double(), M) < rel * 3
+    torch.testing.assert_close(db.cpu().double(), dy.double().sum(0), rtol=1e-4, atol=1e-4 * math.sqrt(M))
+
+
+@pytest.mark.parametrize("prec,rel", PRECS)
+@pytest.mark.parametrize("M,N,K", CASES)
+def test_gemm_aligned_shapes_default_dispatch(prec, rel, M, N, K):
+    check_case(prec, rel, M, N, K)
+
+
+@pytest.mark.parametrize("prec,rel", PRECS)
+@pytest.mark.parametrize("Cc,B_,T1,F1,sk", [(64, 4, 33, 17, 1), (64, 4, 33, 17, 3), (128, 2, 65, 17, 2)])
+def test_conv2_weight_gradient_gather_ring(prec, rel, Cc, B_, T1, F1, sk):
+    """conv2 weight gradient with the im2col gather done by the DMA pieces' source addresses: channel counts whose
+    kernel rows (3C floats) are whole column tiles and B*T2*F2 a multiple of the K-tile, against unfold + einsum."""
+    import torch.nn.functional as F
+    from openeat_amd import hip
+
+    torch.manual_seed(5)
+    T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+    Mc = B_ * T2 * F2
+    assert Mc % 32 == 0
+    xc = torch.randn(B_, Cc, T1, F1)
+    x_nhwc = xc.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dyc = torch.randn(Mc, Cc)
+    dycd = dyc.to(DEV)
+    dwg = torch.zeros(Cc, 9 * Cc, device=DEV)
+    db = torch.zeros(Cc, device=DEV)
+    hip.gemm(dycd, x_nhwc, dwg, Cc, 9 * Cc, Mc, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True, split_k=sk,
+             atomic_out=True, conv=(T1, F1, T2, F2, Cc), conv_gather=hip.GATHER_B, precision=prec, a_colsum=db)
+    torch.cuda.synchronize()
+    col = F.unfold(xc.double(), 3, stride=2).transpose(1, 2).reshape(Mc, Cc, 9)      # (m, ci, kh*3+kw)
+    ref_dw = torch.einsum("mo,mck->okc", dyc.double(), col).reshape(Cc, 9 * Cc)
+    assert float((dwg.cpu().double() - ref_dw).abs().max()) / math.sqrt(Mc) < rel * 3
+    torch.testing.assert_close(db.cpu().double(), dyc.double().sum(0), rtol=1e-4, atol=1e-4 * math.sqrt(Mc))
+
+
+def test_gemm_dma_ring_forced_everywhere():
+    env = dict(os.environ, OE_GEMM_DMA="2", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for tile in ("0", "22", "42"):          # 0 = the library's own tile choice
+        env["OE_GEMM_TILE"] = tile
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, f"tile {tile}:\n{r.stdout[-3000:]}\n{r.stderr[-3000:]}"
+        assert "dma-ring cases ok" in r.stdout
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, ROOT)
+    assert os.environ.get("OE_GEMM_DMA") == "2"
+    for prec, rel in PRECS:
+        for M, N, K in CASES:
+            check_case(prec, rel, M, N, K)
+        test_conv2_weight_gradient_gather_ring(prec, rel, 128, 2, 65, 17, 2)      # 128x128 tiles when OE_GEMM_TILE=22
+    print("dma-ring cases ok")

@@ -1,0 +1,13 @@
+import csv, sys, collections, re
+path = sys.argv[1]; steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+agg = collections.defaultdict(lambda: [0, 0.0])
+with open(path) as f:
+    for r in csv.DictReader(f):
+        name = r.get("Kernel_Name") or r.get("Name")
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        name = re.sub(r"\(.*", "", name)[:110]
+        agg[name][0] += 1; agg[name][1] += d
+tot = sum(v[1] for v in agg.values())
+print(f"total kernel time {tot/1e3:.2f} ms over trace; per step {tot/1e3/steps:.2f} ms")
+for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+    print(f"{t/steps/1e3:8.3f} ms/step {c/steps:7.1f} calls/step {t/c:8.1f} us  {n}")
