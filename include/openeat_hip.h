@@ -159,6 +159,9 @@ typedef struct oe_attn_args {
     float* dq; float* dk; float* dv;
     float* dkeybias;
     float* delta;
+    /* matrix-core arithmetic of the score / context products, as oe_gemm_args.precision:
+     * 0 = fp32 MFMA (exact products), 1 = bf16 inputs, 3 = three-term bf16 split (fp32-grade) */
+    int precision;
 } oe_attn_args;
 
 int oe_attention_fwd(const oe_attn_args* args, void* stream);

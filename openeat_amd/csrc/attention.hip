@@ -10,7 +10,9 @@
 // i.e. ordinary attention on keys K' = K+P plus a per-key bias; the host side
 // prepares K' and the bias (oe_relpos_prepare), so one kernel serves both forms.
 //
-// Matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32).  Layout trick: the forward
+// Matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32, args->precision 0) or v_mfma_f32_32x32x16_bf16 with the
+// operands split to bf16 in registers (precision 1: plain bf16 products, 3: three-term split, fp32-grade; same
+// meaning as oe_gemm_args.precision).  Layout trick: the forward
 // and dQ kernels compute the TRANSPOSED score tile S^T = K Q^T, so the query
 // sits on the lane (softmax statistics are per-lane scalars) and the key on
 // the accumulator rows, which is exactly the B-operand layout of the following
@@ -23,7 +25,52 @@
 #include "../../include/openeat_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define NEG_INF (-INFINITY)
+
+// ---- bf16 matrix-core variants (TERMS = 1: bf16 products; TERMS = 3: hi*hi + hi*lo + lo*hi, fp32-grade) ----
+// v_mfma_f32_32x32x16_bf16: lane (i = lane&31, g = lane>>5) supplies 8 consecutive k-slots 8g..8g+7 of row i (A) /
+// column i (B).  The k-slot -> (feature | key | query) assignment is free as long as A and B agree, so
+//   * products over features take slots = 8 consecutive features (row fragment, A from an LDS tile row);
+//   * products over the 32 keys / queries of a tile take slot e of step s = accumulator row acc_row(8s+e, g): the
+//     B operand is then simply registers 8s..8s+7 of the score tile this lane already holds (P never leaves
+//     registers, as in the fp32 kernels), and A is read from LDS at those rows (column fragment).
+// The tiles stay fp32 in LDS; fragments are split to bf16 hi (+ lo) in registers.
+template <int TERMS> struct BFrag { bf16x8 hi, lo; };
+
+template <int TERMS>
+__device__ __forceinline__ void bsplit(const float (&x)[8], BFrag<TERMS>& f) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        f.hi[e] = (__bf16)x[e];
+        if (TERMS == 3) f.lo[e] = (__bf16)(x[e] - (float)f.hi[e]);
+    }
+}
+template <int TERMS>
+__device__ __forceinline__ f32x16 bmma(const BFrag<TERMS>& a, const BFrag<TERMS>& b, f32x16 c) {
+    if (TERMS == 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+// A[row][16s + 8g + e] of an LDS tile with row stride LD
+template <int TERMS, int LD>
+__device__ __forceinline__ void row_frag(const float* tile, int row, int s, int g, BFrag<TERMS>& f) {
+    float x[8];
+    const float* p = tile + row * LD + 16 * s + 8 * g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = p[e];
+    bsplit<TERMS>(x, f);
+}
+// A[acc_row(8s + e, g)][col] of an LDS tile: the rows this lane's accumulator registers 8s..8s+7 stand for
+template <int TERMS, int LD>
+__device__ __forceinline__ void col_frag(const float* tile, int col, int s, int g, BFrag<TERMS>& f) {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) x[e] = tile[((e & 3) + 8 * (2 * s + (e >> 2)) + 4 * g) * LD + col];
+    bsplit<TERMS>(x, f);
+}
 #define ATT_WAVES 2
 #define ATT_THREADS (64 * ATT_WAVES)
 
@@ -98,10 +145,11 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs
 
 // ------------------------------------------------------------------ forward --
 // MODE 0: forward (writes O, LSE).  MODE 1: dQ (reads dO, LSE, delta; writes dQ).
-template <int DPAD, int MODE>
+template <int DPAD, int MODE, int TERMS>
 __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
     constexpr int LD = DPAD + 1;
     constexpr int DT = DPAD / 32;
+    constexpr int KS = DPAD / 16;            // bf16 k-steps over the features
     __shared__ float Ks[32 * LD];
     __shared__ float Vs[32 * LD];
     __shared__ float kb_s[32];           // per-key bias of the tile; -inf marks a key masked for every query
@@ -117,13 +165,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
     const long bh = (long)b * p.H + h;
 
     // Q^T fragments (B operand of S^T = K Q^T), pre-scaled; for dQ also dO^T fragments
-    float qf[DPAD / 2];
-    float dof[MODE == 1 ? DPAD / 2 : 1];
+    float qf[TERMS == 0 ? DPAD / 2 : 1];
+    float dof[(TERMS == 0 && MODE == 1) ? DPAD / 2 : 1];
+    BFrag<TERMS == 0 ? 1 : TERMS> qfr[TERMS == 0 ? 1 : KS], dofr[(TERMS != 0 && MODE == 1) ? KS : 1];
+    if constexpr (TERMS == 0) {
 #pragma unroll
-    for (int s = 0; s < DPAD / 2; ++s) {
-        const int d = 2 * s + lk;
-        qf[s] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
-        if (MODE == 1) dof[s] = (q_ok && d < p.D) ? p.d_o[(long)b * p.o_bs + (long)qi * p.o_rs + h * p.D + d] : 0.f;
+        for (int s = 0; s < DPAD / 2; ++s) {
+            const int d = 2 * s + lk;
+            qf[s] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
+            if (MODE == 1) dof[s] = (q_ok && d < p.D) ? p.d_o[(long)b * p.o_bs + (long)qi * p.o_rs + h * p.D + d] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float x[8], y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = 16 * s + 8 * lk + e;
+                x[e] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
+                if (MODE == 1) y[e] = (q_ok && d < p.D) ? p.d_o[(long)b * p.o_bs + (long)qi * p.o_rs + h * p.D + d] : 0.f;
+            }
+            bsplit<TERMS>(x, qfr[s]);
+            if (MODE == 1) bsplit<TERMS>(y, dofr[s]);
+        }
     }
     float m_run = NEG_INF, l_run = 0.f;
     float lse_i = 0.f, delta_i = 0.f;
@@ -164,9 +228,18 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        if constexpr (TERMS == 0) {
 #pragma unroll
-        for (int s = 0; s < DPAD / 2; ++s)
-            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LD + 2 * s + lk], qf[s], sacc, 0, 0, 0);
+            for (int s = 0; s < DPAD / 2; ++s)
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[lq * LD + 2 * s + lk], qf[s], sacc, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                BFrag<TERMS> a;
+                row_frag<TERMS, LD>(Ks, lq, s, lk, a);
+                sacc = bmma<TERMS>(a, qfr[s], sacc);
+            }
+        }
         float pr[16];
         float tmax = NEG_INF;
 #pragma unroll
@@ -209,21 +282,47 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
                 }
             }
             // O^T[dv, query] += V^T[dv, key] P^T[key, query]
+            if constexpr (TERMS == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int krow = acc_row(r, lk);
+                for (int r = 0; r < 16; ++r) {
+                    const int krow = acc_row(r, lk);
 #pragma unroll
-                for (int t = 0; t < DT; ++t)
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[krow * LD + t * 32 + lq], pr[r], oacc[t], 0, 0, 0);
+                    for (int t = 0; t < DT; ++t)
+                        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[krow * LD + t * 32 + lq], pr[r], oacc[t], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = pr[8 * s + e];
+                    BFrag<TERMS> pf;
+                    bsplit<TERMS>(x, pf);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        BFrag<TERMS> a;
+                        col_frag<TERMS, LD>(Vs, t * 32 + lq, s, lk, a);
+                        oacc[t] = bmma<TERMS>(a, pf, oacc[t]);
+                    }
+                }
             }
         } else {
             // P^T = exp(S^T - lse); dP^T[key, query] = V[key,:] . dO[query,:]
             f32x16 dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) dpacc[r] = 0.f;
+            if constexpr (TERMS == 0) {
 #pragma unroll
-            for (int s = 0; s < DPAD / 2; ++s)
-                dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[lq * LD + 2 * s + lk], dof[s], dpacc, 0, 0, 0);
+                for (int s = 0; s < DPAD / 2; ++s)
+                    dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[lq * LD + 2 * s + lk], dof[s], dpacc, 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    BFrag<TERMS> a;
+                    row_frag<TERMS, LD>(Vs, lq, s, lk, a);
+                    dpacc = bmma<TERMS>(a, dofr[s], dpacc);
+                }
+            }
             float dmask[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dmask[r] = 1.f;
@@ -246,12 +345,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
                 pr[r] = pv * (dpacc[r] * dmask[r] - delta_i);     // dS^T
             }
             // dQ^T[d, query] += K^T[d, key] dS^T[key, query]
+            if constexpr (TERMS == 0) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int krow = acc_row(r, lk);
+                for (int r = 0; r < 16; ++r) {
+                    const int krow = acc_row(r, lk);
 #pragma unroll
-                for (int t = 0; t < DT; ++t)
-                    oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LD + t * 32 + lq], pr[r], oacc[t], 0, 0, 0);
+                    for (int t = 0; t < DT; ++t)
+                        oacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[krow * LD + t * 32 + lq], pr[r], oacc[t], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float x[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = pr[8 * s + e];
+                    BFrag<TERMS> df;
+                    bsplit<TERMS>(x, df);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        BFrag<TERMS> a;
+                        col_frag<TERMS, LD>(Ks, t * 32 + lq, s, lk, a);
+                        oacc[t] = bmma<TERMS>(a, df, oacc[t]);
+                    }
+                }
             }
         }
     }
@@ -277,10 +393,11 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------- dK / dV -------
-template <int DPAD>
+template <int DPAD, int TERMS>
 __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams p) {
     constexpr int LD = DPAD + 1;
     constexpr int DT = DPAD / 32;
+    constexpr int KS = DPAD / 16;
     __shared__ float Qs[32 * LD];
     __shared__ float Os[32 * LD];      // dO tile
     __shared__ float lse_s[32], delta_s[32];
@@ -293,13 +410,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
     const float* qb = p.q + (long)b * p.q_bs + h * p.D;
     const float* dob = p.d_o + (long)b * p.o_bs + h * p.D;
     const long bh = (long)b * p.H + h;
-    float kf[DPAD / 2], vf[DPAD / 2];
+    float kf[TERMS == 0 ? DPAD / 2 : 1], vf[TERMS == 0 ? DPAD / 2 : 1];
+    BFrag<TERMS == 0 ? 1 : TERMS> kfr[TERMS == 0 ? 1 : KS], vfr[TERMS == 0 ? 1 : KS];
+    if constexpr (TERMS == 0) {
 #pragma unroll
-    for (int s = 0; s < DPAD / 2; ++s) {
-        const int d = 2 * s + lk;
-        const bool ok = k_ok && d < p.D;
-        kf[s] = ok ? p.k[(long)b * p.k_bs + (long)kj * p.k_rs + h * p.D + d] * p.scale : 0.f;
-        vf[s] = ok ? p.v[(long)b * p.v_bs + (long)kj * p.v_rs + h * p.D + d] : 0.f;
+        for (int s = 0; s < DPAD / 2; ++s) {
+            const int d = 2 * s + lk;
+            const bool ok = k_ok && d < p.D;
+            kf[s] = ok ? p.k[(long)b * p.k_bs + (long)kj * p.k_rs + h * p.D + d] * p.scale : 0.f;
+            vf[s] = ok ? p.v[(long)b * p.v_bs + (long)kj * p.v_rs + h * p.D + d] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float x[8], y[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int d = 16 * s + 8 * lk + e;
+                const bool ok = k_ok && d < p.D;
+                x[e] = ok ? p.k[(long)b * p.k_bs + (long)kj * p.k_rs + h * p.D + d] * p.scale : 0.f;
+                y[e] = ok ? p.v[(long)b * p.v_bs + (long)kj * p.v_rs + h * p.D + d] : 0.f;
+            }
+            bsplit<TERMS>(x, kfr[s]);
+            bsplit<TERMS>(y, vfr[s]);
+        }
     }
     const float kbias = (p.keybias && k_ok) ? p.keybias[bh * p.T2 + kj] : 0.f;
     f32x16 dkacc[DT], dvacc[DT];
@@ -324,10 +458,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+        if constexpr (TERMS == 0) {
 #pragma unroll
-        for (int s = 0; s < DPAD / 2; ++s) {
-            sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[lj * LD + 2 * s + lk], kf[s], sacc, 0, 0, 0);
-            dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[lj * LD + 2 * s + lk], vf[s], dpacc, 0, 0, 0);
+            for (int s = 0; s < DPAD / 2; ++s) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[lj * LD + 2 * s + lk], kf[s], sacc, 0, 0, 0);
+                dpacc = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[lj * LD + 2 * s + lk], vf[s], dpacc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                BFrag<TERMS> a;
+                row_frag<TERMS, LD>(Qs, lj, s, lk, a);
+                sacc = bmma<TERMS>(a, kfr[s], sacc);
+                row_frag<TERMS, LD>(Os, lj, s, lk, a);
+                dpacc = bmma<TERMS>(a, vfr[s], dpacc);
+            }
         }
         float pd[16], ds[16];
 #pragma unroll
@@ -343,13 +488,33 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
             ds[r] = pv * (dpacc[r] * dscale - delta_s[qr]);        // dS
             dbias += ds[r];
         }
+        if constexpr (TERMS == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = acc_row(r, lk);
+            for (int r = 0; r < 16; ++r) {
+                const int qr = acc_row(r, lk);
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                dvacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[qr * LD + t * 32 + lj], pd[r], dvacc[t], 0, 0, 0);
-                dkacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qr * LD + t * 32 + lj], ds[r], dkacc[t], 0, 0, 0);
+                for (int t = 0; t < DT; ++t) {
+                    dvacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Os[qr * LD + t * 32 + lj], pd[r], dvacc[t], 0, 0, 0);
+                    dkacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Qs[qr * LD + t * 32 + lj], ds[r], dkacc[t], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float x[8], y[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { x[e] = pd[8 * s + e]; y[e] = ds[8 * s + e]; }
+                BFrag<TERMS> pf, df;
+                bsplit<TERMS>(x, pf);
+                bsplit<TERMS>(y, df);
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    BFrag<TERMS> a;
+                    col_frag<TERMS, LD>(Os, t * 32 + lj, s, lk, a);
+                    dvacc[t] = bmma<TERMS>(a, pf, dvacc[t]);
+                    col_frag<TERMS, LD>(Qs, t * 32 + lj, s, lk, a);
+                    dkacc[t] = bmma<TERMS>(a, df, dkacc[t]);
+                }
             }
         }
     }
@@ -398,6 +563,7 @@ static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {
         return -1;
     }
     if (!(a->drop_p >= 0.f && a->drop_p < 1.f)) { oe_set_error("%s: drop_p out of range", who); return -1; }
+    if (!(a->precision == 0 || a->precision == 1 || a->precision == 3)) { oe_set_error("%s: precision must be 0, 1 or 3", who); return -1; }
     p.q = a->q; p.q_bs = a->q_bstride; p.q_rs = a->q_rstride;
     p.k = a->k; p.k_bs = a->k_bstride; p.k_rs = a->k_rstride;
     p.v = a->v; p.v_bs = a->v_bstride; p.v_rs = a->v_rstride;
@@ -417,8 +583,13 @@ extern "C" int oe_attention_fwd(const oe_attn_args* a, void* stream) {
     OE_REQUIRE(a->out && a->lse, "oe_attention_fwd: null out/lse");
     dim3 grid(oe_cdiv(p.T1, 32 * ATT_WAVES), p.H, p.B);
     hipStream_t st = (hipStream_t)stream;
-    if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0>), grid, dim3(ATT_THREADS), 0, st, p);
-    else hipLaunchKernelGGL((attn_qtile_kernel<64, 0>), grid, dim3(ATT_THREADS), 0, st, p);
+#define ATT_FWD(TT)                                                                                       \
+    do {                                                                                                  \
+        if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0, TT>), grid, dim3(ATT_THREADS), 0, st, p); \
+        else hipLaunchKernelGGL((attn_qtile_kernel<64, 0, TT>), grid, dim3(ATT_THREADS), 0, st, p);        \
+    } while (0)
+    if (a->precision == 3) ATT_FWD(3); else if (a->precision == 1) ATT_FWD(1); else ATT_FWD(0);
+#undef ATT_FWD
     OE_LAUNCH_CHECK("oe_attention_fwd");
     return 0;
 }
@@ -432,13 +603,18 @@ extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
     hipLaunchKernelGGL(attn_delta_kernel, dim3(oe_cdiv(rows, 256)), dim3(256), 0, st, p);
     OE_LAUNCH_CHECK("attn_delta");
     dim3 gq(oe_cdiv(p.T1, 32 * ATT_WAVES), p.H, p.B), gk(oe_cdiv(p.T2, 32 * ATT_WAVES), p.H, p.B);
-    if (p.D <= 32) {
-        hipLaunchKernelGGL((attn_qtile_kernel<32, 1>), gq, dim3(ATT_THREADS), 0, st, p);
-        hipLaunchKernelGGL((attn_ktile_bwd_kernel<32>), gk, dim3(ATT_THREADS), 0, st, p);
-    } else {
-        hipLaunchKernelGGL((attn_qtile_kernel<64, 1>), gq, dim3(ATT_THREADS), 0, st, p);
-        hipLaunchKernelGGL((attn_ktile_bwd_kernel<64>), gk, dim3(ATT_THREADS), 0, st, p);
-    }
+#define ATT_BWD(TT)                                                                                       \
+    do {                                                                                                  \
+        if (p.D <= 32) {                                                                                  \
+            hipLaunchKernelGGL((attn_qtile_kernel<32, 1, TT>), gq, dim3(ATT_THREADS), 0, st, p);          \
+            hipLaunchKernelGGL((attn_ktile_bwd_kernel<32, TT>), gk, dim3(ATT_THREADS), 0, st, p);         \
+        } else {                                                                                          \
+            hipLaunchKernelGGL((attn_qtile_kernel<64, 1, TT>), gq, dim3(ATT_THREADS), 0, st, p);          \
+            hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, TT>), gk, dim3(ATT_THREADS), 0, st, p);         \
+        }                                                                                                 \
+    } while (0)
+    if (a->precision == 3) ATT_BWD(3); else if (a->precision == 1) ATT_BWD(1); else ATT_BWD(0);
+#undef ATT_BWD
     OE_LAUNCH_CHECK("oe_attention_bwd");
     return 0;
 }

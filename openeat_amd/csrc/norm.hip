@@ -56,9 +56,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     }
 }
 
-#define LNB_ROWS 32   // rows per block in backward (8 per wave)
+#define LNB_ROWS 16   // rows per block in backward (4 per wave, all loaded before the first is reduced)
 
-template <int NV>
+// Backward is a latency chain per row (load dy/x -> two wave reductions -> store); with one row in flight per
+// wave the 3*rows*d*4 bytes move at a fraction of the HBM rate.  Each wave therefore issues the loads of its
+// RB rows back to back and only then reduces them one by one.
+template <int NV, int RB>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                              const float* __restrict__ stats,
@@ -79,55 +82,71 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         dg[j] = make_float4(0, 0, 0, 0);
         db[j] = make_float4(0, 0, 0, 0);
     }
-    const long r0 = (long)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
-    for (int rr = 0; rr < LNB_ROWS / 4; ++rr) {
-        const long row = r0 + rr;
-        if (row >= rows) break;
-        float4* dxr = reinterpret_cast<float4*>(dx + row * d);
-        const float4* addr = add ? reinterpret_cast<const float4*>(add + row * d) : nullptr;
-        if (rowmask && !rowmask[row]) {
+    const long w0 = (long)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
+    for (int rb = 0; rb < LNB_ROWS / 4; rb += RB) {
+        // ---- loads of RB rows (rows past the end re-read the last row; nothing of them is used or stored)
+        float4 dyv[RB][NV], xv[RB][NV], av[RB][NV];
+        float mean[RB], rstd[RB];
+        bool live[RB], valid[RB];
+#pragma unroll
+        for (int k = 0; k < RB; ++k) {
+            const long row = w0 + rb + k;
+            valid[k] = row < rows;
+            const long rc = valid[k] ? row : rows - 1;
+            live[k] = valid[k] && !(rowmask && !rowmask[rc]);
+            mean[k] = stats[rc * 2];
+            rstd[k] = stats[rc * 2 + 1];
+            const float4* dyr = reinterpret_cast<const float4*>(dy + rc * d);
+            const float4* xr = reinterpret_cast<const float4*>(x + rc * d);
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i = lane + 64 * j;
-                if (i < nv) dxr[i] = addr ? addr[i] : make_float4(0, 0, 0, 0);
+                const int ic = i < nv ? i : 0;
+                dyv[k][j] = dyr[ic];
+                xv[k][j] = xr[ic];
+                av[k][j] = add ? reinterpret_cast<const float4*>(add + rc * d)[ic] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            continue;
         }
-        const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-        const float4* dyr = reinterpret_cast<const float4*>(dy + row * d);
-        const float4* xr = reinterpret_cast<const float4*>(x + row * d);
-        float4 g[NV], xh[NV];
-        float s1 = 0.f, s2 = 0.f;
+        // ---- one row at a time: reductions, dx, parameter-gradient partials
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
-            if (i < nv) {
-                float4 dyv = dyr[i];
-                const float4 xv = xr[i];
-                xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+        for (int k = 0; k < RB; ++k) {
+            float4* dxr = reinterpret_cast<float4*>(dx + (w0 + rb + k) * d);
+            float4 g[NV], xh[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + 64 * j;
+                const bool on = live[k] && i < nv;
+                float4 t = dyv[k][j];
+                const float4 v = xv[k][j];
+                xh[j] = make_float4((v.x - mean[k]) * rstd[k], (v.y - mean[k]) * rstd[k], (v.z - mean[k]) * rstd[k], (v.w - mean[k]) * rstd[k]);
                 if (act) {   // y = act(ln): chain through the activation at the recomputed pre-activation
-                    dyv.x *= act_bwd(act, xh[j].x * gam[j].x + bet[j].x); dyv.y *= act_bwd(act, xh[j].y * gam[j].y + bet[j].y);
-                    dyv.z *= act_bwd(act, xh[j].z * gam[j].z + bet[j].z); dyv.w *= act_bwd(act, xh[j].w * gam[j].w + bet[j].w);
+                    t.x *= act_bwd(act, xh[j].x * gam[j].x + bet[j].x); t.y *= act_bwd(act, xh[j].y * gam[j].y + bet[j].y);
+                    t.z *= act_bwd(act, xh[j].z * gam[j].z + bet[j].z); t.w *= act_bwd(act, xh[j].w * gam[j].w + bet[j].w);
                 }
-                g[j] = make_float4(dyv.x * gam[j].x, dyv.y * gam[j].y, dyv.z * gam[j].z, dyv.w * gam[j].w);
+                if (!on) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = t; }      // masked rows may hold anything
+                g[j] = make_float4(t.x * gam[j].x, t.y * gam[j].y, t.z * gam[j].z, t.w * gam[j].w);
                 s1 += g[j].x + g[j].y + g[j].z + g[j].w;
                 s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
-                dg[j].x += dyv.x * xh[j].x; dg[j].y += dyv.y * xh[j].y; dg[j].z += dyv.z * xh[j].z; dg[j].w += dyv.w * xh[j].w;
-                db[j].x += dyv.x; db[j].y += dyv.y; db[j].z += dyv.z; db[j].w += dyv.w;
+                dg[j].x += t.x * xh[j].x; dg[j].y += t.y * xh[j].y; dg[j].z += t.z * xh[j].z; dg[j].w += t.w * xh[j].w;
+                db[j].x += t.x; db[j].y += t.y; db[j].z += t.z; db[j].w += t.w;
             }
-        }
-        const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+            const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+            if (valid[k]) {
 #pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const int i = lane + 64 * j;
-            if (i < nv) {
-                float4 o;
-                o.x = rstd * (g[j].x - c1 - xh[j].x * c2);
-                o.y = rstd * (g[j].y - c1 - xh[j].y * c2);
-                o.z = rstd * (g[j].z - c1 - xh[j].z * c2);
-                o.w = rstd * (g[j].w - c1 - xh[j].w * c2);
-                if (addr) { const float4 a4 = addr[i]; o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w; }
-                dxr[i] = o;
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + 64 * j;
+                    if (i < nv) {
+                        float4 o = av[k][j];
+                        if (live[k]) {
+                            o.x += rstd[k] * (g[j].x - c1 - xh[j].x * c2);
+                            o.y += rstd[k] * (g[j].y - c1 - xh[j].y * c2);
+                            o.z += rstd[k] * (g[j].z - c1 - xh[j].z * c2);
+                            o.w += rstd[k] * (g[j].w - c1 - xh[j].w * c2);
+                        }
+                        dxr[i] = o;
+                    }
+                }
             }
         }
     }
@@ -184,9 +203,9 @@ extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* ga
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     OE_REQUIRE(workspace, "oe_layernorm_bwd: null workspace");
     const int nb = oe_cdiv(rows, LNB_ROWS);
-#define LN_BWD(NVV) hipLaunchKernelGGL(layernorm_bwd_kernel<NVV>, dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
-                                       dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace)
-    if (d <= 256) LN_BWD(1); else if (d <= 512) LN_BWD(2); else if (d <= 1024) LN_BWD(4); else LN_BWD(8);
+#define LN_BWD(NVV, RBB) hipLaunchKernelGGL((layernorm_bwd_kernel<NVV, RBB>), dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
+                                            dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace)
+    if (d <= 256) LN_BWD(1, 4); else if (d <= 512) LN_BWD(2, 2); else if (d <= 1024) LN_BWD(4, 1); else LN_BWD(8, 1);
 #undef LN_BWD
     OE_LAUNCH_CHECK("layernorm_bwd");
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 64), oe_cdiv(nb, PR_ROWS)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,

@@ -65,6 +65,7 @@ class AttnArgs(C.Structure):
         ("scale", C.c_float),
         ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("seed_dev", c_fp),
         ("d_out", c_fp), ("dq", c_fp), ("dk", c_fp), ("dv", c_fp), ("dkeybias", c_fp), ("delta", c_fp),
+        ("precision", C.c_int),
     ]
 
 
@@ -212,8 +213,9 @@ def call(name, *args):
 
 def attn_args(q, k, v, out, lse, B, H, T1, T2, D, scale, *, q_strides, k_strides, v_strides, o_strides, mask=None,
               mask_strides=(0, 0), keybias=None, drop_p=0.0, seed=0, seed_dev=None, d_out=None, dq=None, dk=None, dv=None,
-              dkeybias=None, delta=None):
+              dkeybias=None, delta=None, precision=None):
     a = AttnArgs()
+    a.precision = GEMM_PRECISION if precision is None else precision
     dp = lambda t: None if t is None else t.data_ptr()
     a.q, (a.q_bstride, a.q_rstride) = dp(q), q_strides
     a.k, (a.k_bstride, a.k_rstride) = dp(k), k_strides

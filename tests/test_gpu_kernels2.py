@@ -46,7 +46,10 @@ def ref_attention(q, k, v, mask, keybias, scale):
     (1, 4, 130, 130, 64, "none", False),
     (2, 4, 40, 40, 36, "key", True),
 ])
-def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias):
+@pytest.mark.parametrize("prec", [0, 3, 1])
+def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias, prec):
+    """prec 0: exact fp32 matrix-core products; 3: three-term bf16 split (same tolerances: fp32-grade);
+    1: plain bf16 products (tolerance ~2^-8 relative on each product)."""
     torch.manual_seed(11)
     q = torch.randn(B, T1, H, D, requires_grad=True)
     k = torch.randn(B, T2, H, D, requires_grad=True)
@@ -83,20 +86,20 @@ def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias):
     mstr = (0, 0) if mask is None else (mask.shape[1] * T2, 0 if mask.shape[1] == 1 else T2)
     kbd = None if kb is None else cu(kb.detach())
     a = hip.attn_args(qd, kd, vd, out, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=ks, v_strides=vs,
-                      o_strides=(T1 * d, d), mask=md, mask_strides=mstr, keybias=kbd)
+                      o_strides=(T1 * d, d), mask=md, mask_strides=mstr, keybias=kbd, precision=prec)
     hip.attention_fwd(a)
     sync()
-    torch.testing.assert_close(out.cpu(), out_ref.detach(), **TOL)
+    torch.testing.assert_close(out.cpu(), out_ref.detach(), **(TOL if prec != 1 else dict(rtol=3e-2, atol=3e-2)))
 
     wd = cu(w)
     dkb = torch.empty(B, H, T2, device=DEV) if bias else None
     delta = torch.empty(B, H, T1, device=DEV)
     a2 = hip.attn_args(qd, kd, vd, out, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=ks, v_strides=vs,
                        o_strides=(T1 * d, d), mask=md, mask_strides=mstr, keybias=kbd, d_out=wd, dq=dqd, dk=dkd, dv=dvd,
-                       dkeybias=dkb, delta=delta)
+                       dkeybias=dkb, delta=delta, precision=prec)
     hip.attention_bwd(a2)
     sync()
-    g = dict(rtol=5e-4, atol=5e-5)
+    g = dict(rtol=5e-4, atol=5e-5) if prec != 1 else dict(rtol=5e-2, atol=8e-2)
     torch.testing.assert_close(dqd.cpu().reshape(B, T1, H, D), q.grad, **g)
     torch.testing.assert_close(dkd.cpu().reshape(B, T2, H, D), k.grad, **g)
     torch.testing.assert_close(dvd.cpu().reshape(B, T2, H, D), v.grad, **g)
