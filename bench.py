@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--target-len", type=int, default=30)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-table", action="store_true", help="log the per-problem GEMM timing table of one step to stderr")
     ap.add_argument("--no-decode", action="store_true", help="skip the attention-rescoring RTF measurement")
     ap.add_argument("--decode-utts", type=int, default=64)
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -220,6 +221,15 @@ def main():
         flops = sum(r[2] for r in recs)
         secs = sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
         ach = flops / secs / 1e12
+        if args.gemm_table:                                      # per-problem breakdown of the step's GEMM launches (stderr)
+            by = {}
+            for r in recs:
+                c = by.setdefault(r[3], [0, 0.0, r[2]])
+                c[0] += 1
+                c[1] += r[0].elapsed_time(r[1]) * 1e3
+            log("GEMM problems of one step (m, n, k, a_kmajor, b_kmajor, gather, split_k): launches, us each, ms total, TFLOP/s")
+            for key, (cnt, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+                log(f"  {str(key):44s} x{cnt:3d} {us / cnt:9.1f} us {us / 1e3:7.3f} ms {fl * cnt / us / 1e6:7.1f}")
         prec = hip.GEMM_PRECISION
         peak = PEAK_FP32_MFMA_TFLOPS if prec == 0 else PEAK_BF16_MFMA_TFLOPS
         mfma_flops = flops * (3 if prec == 3 else 1)            # the 3-term split issues 3 MFMAs per algorithmic product

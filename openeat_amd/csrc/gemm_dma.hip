@@ -118,12 +118,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < PA; ++j) {
         const int g = wave * PA + j;
+        // rows / columns past the matrix edge re-read the last valid ones: their products land in accumulator
+        // rows the (bounds-checked) epilogue of an edge block never stores
         if (!A_KMAJOR) {
             const int row = 8 * g + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
-            srcA[j] = Ap + (m0 + row) * lda + k_begin + chunk * 4;
+            srcA[j] = Ap + min(m0 + row, (long)M - 1) * lda + k_begin + chunk * 4;
         } else {
             const int off = g * 256 + lane * 4;
-            srcA[j] = Ap + (long)(k_begin + off / BM) * lda + m0 + (off % BM);
+            srcA[j] = Ap + (long)(k_begin + off / BM) * lda + min(m0 + (off % BM), (long)M - 4);
         }
     }
 #pragma unroll
@@ -131,10 +133,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float* __restrict__
         const int g = wave * PB + j;
         if (!B_KMAJOR) {
             const int row = 8 * g + (lane >> 3), chunk = (lane & 7) ^ ((row >> 1) & 7);
-            srcB[j] = Bp + (n0 + row) * ldb + k_begin + chunk * 4;
+            srcB[j] = Bp + min(n0 + row, (long)N - 1) * ldb + k_begin + chunk * 4;
         } else if (!GATHER_B) {
             const int off = g * 256 + lane * 4;
-            srcB[j] = Bp + (long)(k_begin + off / BN) * ldb + n0 + (off % BN);
+            srcB[j] = Bp + (long)(k_begin + off / BN) * ldb + min(n0 + (off % BN), (long)N - 4);
         } else {
             const int off = g * 256 + lane * 4;
             kposB[j] = k_begin + off / BN;
@@ -227,7 +229,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
-            if (fhalf == 0) atomicAdd(ep.a_colsum + m0 + wm * 32 * TM + i * 32 + frow, v * al);
+            const long row = m0 + wm * 32 * TM + i * 32 + frow;
+            if (fhalf == 0 && row < M) atomicAdd(ep.a_colsum + row, v * al);
         }
     }
     gemm_epilogue<TM, TN>(acc, lds, C, ldc, M, N, m0, n0, ep, tile_z);
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float* __restrict__
 template <int TM, int TN, bool AK, bool BKM, int TERMS, int NST, bool GB = false>
 static int launch_dma(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int kc, int nz,
                       const EpiParams& ep, hipStream_t st) {
-    const int gx = N / (64 * TN), gy = M / (64 * TM);
+    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 64 * TM);
     hipLaunchKernelGGL((gemm_dma_kernel<TM, TN, AK, BKM, TERMS, NST, GB>), dim3(gx * gy * nz), dim3(256), 0, st, A.p, A.ld, B.p, B.ld, C, ldc,
                        M, N, K, kc, gx, gy, ep, B);
     OE_LAUNCH_CHECK("oe_gemm (bf16 mfma, lds-dma)");
@@ -256,10 +259,17 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     // Measured on MI355X (tools/gemm_bench.py, M = 7936): the ring wins where the register-staged kernel pays a
     // transpose per K-tile and the K-loop is long - weight gradients (both operands k-major) and x @ W with
     // K >= 512; short-K x @ W^T problems are epilogue/launch bound and run faster at 2-4 co-resident blocks per CU.
-    if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512)) return 1;
+    // ... and problems too small to put more than one 64x64 block on a CU: nothing overlaps a block's own memory
+    // latency there except the ring (decoder-side GEMMs, M = B*(L+1) rows; linear_pos, M = T rows).
+    const bool small = (long)oe_cdiv(M, 64) * oe_cdiv(N, 64) * sk <= 256;
+    if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small) return 1;
     if (tile == 12) tile = 11;
     const int bm = 64 * (tile / 10), bn = 64 * (tile % 10);
-    if (!A.vec_ok || !B.vec_ok || M % bm || N % bn || K % DBK) return 1;
+    // pieces are 16 bytes: K a multiple of the K-tile; a k-major operand's row length (M resp. N) a multiple of 4.
+    // Ragged M / N edges are clamped in the kernel; the gather path keeps whole tiles.
+    if (!A.vec_ok || !B.vec_ok || K % DBK || M < 4 || N < 4) return 1;
+    if ((a_kmajor && M % 4) || (b_kmajor && N % 4)) return 1;
+    if (gather_b && (M % bm || N % bn)) return 1;
     if (gather_b) {
         // conv2 weight gradient: a 128-column tile must stay inside one kernel row (3C contiguous floats),
         // positions must be exact in float (div_small), C a multiple of 4 for the 16-byte pieces

@@ -195,7 +195,7 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
         e0.record()
         check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
         e1.record()
-        PROFILE.append((e0, e1, 2.0 * m * n * k))
+        PROFILE.append((e0, e1, 2.0 * m * n * k, (m, n, k, int(a_kmajor), int(b_kmajor), int(conv_gather), int(split_k))))
         return
     check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
 

@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
-CASES = [(128, 128, 32), (256, 128, 96), (512, 384, 256), (1024, 1024, 160), (192, 64, 64), (512, 256, 1024)]
+CASES = [(128, 128, 32), (256, 128, 96), (512, 384, 256), (1024, 1024, 160), (192, 64, 64), (512, 256, 1024),
+         # ragged M / N edges (clamped source rows, bounds-checked epilogue on the edge blocks): the decoder's 992 rows, ...
+         (992, 256, 256), (250, 100, 64), (76, 36, 96), (992, 1024, 256), (248, 256, 256)]
 PRECS = [(3, 2e-5), (1, 6e-3)]
 
 
