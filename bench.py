@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-table", action="store_true", help="log the per-problem GEMM timing table of one step to stderr")
+    ap.add_argument("--dropout", type=float, default=None, help="tuning aid: override the config's dropout 0.1 (the reported line is only valid at the default)")
     ap.add_argument("--no-decode", action="store_true", help="skip the attention-rescoring RTF measurement")
     ap.add_argument("--decode-utts", type=int, default=64)
     ap.add_argument("--cpu-batch", type=int, default=16)
@@ -151,7 +152,11 @@ def main():
 
     log(f"world={world} device={torch.cuda.get_device_name(dev)}")
     torch.manual_seed(777)
-    model = ASRModel(80, V, **MODEL_CONF).to(dev).train()
+    conf = dict(MODEL_CONF)
+    if args.dropout is not None:
+        conf["dropout_rate"] = args.dropout
+        log(f"NOTE: dropout overridden to {args.dropout} - not the BASELINE config, tuning only")
+    model = ASRModel(80, V, **conf).to(dev).train()
     engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True)
     fb = Fbank(80, device=dev)
     wav, tgt, tlen = synth_batch(args.batch, args.seconds, args.target_len, seed=rank, device=dev)
@@ -268,6 +273,7 @@ def main():
                                        f"B={args.batch}/GPU x {args.seconds:g} s 16 kHz wav (T={T} frames), L={args.target_len}, "
                                        "CTC+attention joint loss, fbank+fwd+bwd+clip+Adam, dropout 0.1",
                            "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph},
+                **({"invalid": f"dropout overridden to {args.dropout}"} if args.dropout is not None else {}),
                 "loss": loss, "roofline": roof, "cpu_baseline": cpu, "decode": dec}
         print(json.dumps(line))
     if world > 1:

@@ -110,15 +110,17 @@ int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
  * executor.py:56).  blank = 0.
  *   logits  (B, T, ldv>=V) batch-major, row stride ldv
  *   hlens   (B) valid frames, targets (B, Lmax) int32 (entries >= tlen ignored)
- *   out: nll (B) with infeasible -> 0, loss_sum[0] = sum_b nll_b,
+ *   utt_weight (B) or NULL: per-utterance weight w_b (NULL = 1).  CTC(length_normalized_loss=True)
+ *        (ctc.py:24-25: CTCLoss(reduction='mean')) is w_b = 1 / max(tlen_b, 1) and a further / B on the host.
+ *   out: nll (B) unweighted, infeasible -> 0;  loss_sum[0] = sum_b w_b * nll_b,
  *        dlogits (B, T, ldv) = grad_scale * d loss_sum / d logits (may alias
  *        logits; padded frames / infeasible utterances exactly 0), or NULL.
  *   workspace: float[ oe_ctc_workspace_floats(B,T,Lmax) ].
  * ------------------------------------------------------------------------- */
 size_t oe_ctc_workspace_floats(int B, int T, int Lmax);
 int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
-                      int Lmax, const int* tlens, float grad_scale, float* nll, float* loss_sum, float* dlogits,
-                      float* workspace, void* stream);
+                      int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll, float* loss_sum,
+                      float* dlogits, float* workspace, void* stream);
 
 /* CTC greedy search on device (asr_model.py:318-325 + common.py:187-196):
  * argmax over V per frame (lowest index wins ties, = topk(1)), frames >= hlen

@@ -198,10 +198,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
                                                         int Lmax, const int* __restrict__ tlens, int Sp,
                                                         const float* __restrict__ lse, const float* __restrict__ lp,
                                                         const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                        const float* __restrict__ ll_in, float scale, float* dlogits) {
+                                                        const float* __restrict__ ll_in, float scale,
+                                                        const float* __restrict__ utt_weight, float* dlogits) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // gam[S], then lab[S] (as int)
     const long row = blockIdx.x;
     const int b = (int)(row / T), t = (int)(row % T);
+    if (utt_weight) scale *= utt_weight[b];
     const float* p = logits + row * ldv;
     float* g = dlogits + row * ldv;
     const float ll = ll_in[b];
@@ -246,9 +248,9 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
 }
 
-__global__ void ctc_sum_kernel(const float* __restrict__ nll, int B, float* __restrict__ out) {
+__global__ void ctc_sum_kernel(const float* __restrict__ nll, const float* __restrict__ utt_weight, int B, float* __restrict__ out) {
     float s = 0.f;
-    for (int i = threadIdx.x; i < B; i += 64) s += nll[i];
+    for (int i = threadIdx.x; i < B; i += 64) s += utt_weight ? nll[i] * utt_weight[i] : nll[i];
     s = wave_sum(s);
     if (threadIdx.x == 0) out[0] = s;
 }
@@ -259,8 +261,8 @@ extern "C" size_t oe_ctc_workspace_floats(int B, int T, int Lmax) {
 }
 
 extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
-                                 int Lmax, const int* tlens, float grad_scale, float* nll, float* loss_sum, float* dlogits,
-                                 float* workspace, void* stream) {
+                                 int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll,
+                                 float* loss_sum, float* dlogits, float* workspace, void* stream) {
     OE_REQUIRE(logits && hlens && tlens && nll && workspace, "oe_ctc_loss_fused: null pointer");
     OE_REQUIRE(targets || Lmax == 0, "oe_ctc_loss_fused: null targets");
     OE_REQUIRE(B > 0 && T > 0 && V > 1 && Lmax >= 0 && ldv >= V, "oe_ctc_loss_fused: bad shape B=%d T=%d V=%d Lmax=%d ldv=%ld",
@@ -283,12 +285,12 @@ extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, in
 #undef AB
     OE_LAUNCH_CHECK("ctc_alphabeta");
     if (loss_sum) {
-        hipLaunchKernelGGL(ctc_sum_kernel, dim3(1), dim3(64), 0, st, nll, B, loss_sum);
+        hipLaunchKernelGGL(ctc_sum_kernel, dim3(1), dim3(64), 0, st, nll, utt_weight, B, loss_sum);
         OE_LAUNCH_CHECK("ctc_sum");
     }
     if (dlogits) {
         hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)rows), dim3(256), (size_t)Sp * 8, st, logits, ldv, T, V, hlens,
-                           targets, Lmax, tlens, Sp, lse, lp, alpha, beta, ll, grad_scale, dlogits);
+                           targets, Lmax, tlens, Sp, lse, lp, alpha, beta, ll, grad_scale, utt_weight, dlogits);
         OE_LAUNCH_CHECK("ctc_grad");
     }
     return 0;

@@ -7,15 +7,14 @@ from openeat_amd import ops
 class CTC(torch.nn.Module):
     def __init__(self, odim: int, encoder_output_size: int, length_normalized_loss: bool = False):
         super().__init__()
-        if length_normalized_loss:
-            raise NotImplementedError("CTCLoss(reduction='mean') has no gfx950 path yet; every shipped config uses 'sum'")
+        self.length_normalized_loss = bool(length_normalized_loss)      # ctc.py:24: CTCLoss(reduction='mean')
         self.ctc_lo = torch.nn.Linear(encoder_output_size, odim)
         self.odim = odim
 
     def forward(self, hs_pad: torch.Tensor, hlens: torch.Tensor, ys_pad: torch.Tensor, ys_lens: torch.Tensor):
-        """ctc.py:27-45: projection, log-softmax, CTC loss (sum, zero_infinity) / batch - one fused op
-        whose backward is already computed when forward returns."""
-        return ops.ctc_head(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias, hlens, ys_pad, ys_lens)
+        """ctc.py:27-45: projection, log-softmax, CTC loss (sum or length-normalised mean, zero_infinity) / batch -
+        one fused op whose backward is already computed when forward returns."""
+        return ops.ctc_head(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias, hlens, ys_pad, ys_lens, self.length_normalized_loss)
 
     def logits(self, hs_pad: torch.Tensor) -> torch.Tensor:
         return ops.linear(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias)

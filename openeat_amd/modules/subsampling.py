@@ -1,5 +1,5 @@
-"""Conv2d subsampling front end (/root/reference/openeat/modules/subsampling.py).
-Only the 1/4 variant used by every shipped config has a HIP path so far."""
+"""Input layers (/root/reference/openeat/modules/subsampling.py): the 1/4 conv2d subsampling of every shipped
+config and the linear (no subsampling) layer.  The 1/6 and 1/8 variants have no HIP path yet."""
 from typing import Tuple
 
 import torch
@@ -49,5 +49,21 @@ class Conv2dSubsampling8(_NoKernelYet):
     pass
 
 
-class LinearNoSubsampling(_NoKernelYet):
-    pass
+class LinearNoSubsampling(BaseSubsampling):
+    """subsampling.py:23-62: Linear(idim, odim) -> LayerNorm(odim, eps 1e-12) -> positional encoding; the mask and
+    the time axis pass through unchanged.  Parameter names as in the reference: out.0 (Linear), out.1 (LayerNorm)."""
+
+    def __init__(self, idim: int, odim: int, pos_enc_class: torch.nn.Module):
+        super().__init__()
+        self.out = torch.nn.Sequential(torch.nn.Linear(idim, odim), torch.nn.LayerNorm(odim, eps=1e-12))
+        self.pos_enc = pos_enc_class
+        self.right_context = 0
+        self.subsampling_rate = 1
+
+    def forward(self, x: torch.Tensor, x_mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        lin, norm = self.out[0], self.out[1]
+        y = ops.linear(x, lin.weight, lin.bias)
+        y = ops.layer_norm(y, norm.weight, norm.bias, norm.eps)
+        pos = self.pos_enc.table(x.device, x.size(1))
+        y = ops.scale_add(y, self.pos_enc.xscale, pos if self.pos_enc.kind == "abs_pos" else None)
+        return y, x_mask, pos

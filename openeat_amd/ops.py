@@ -335,6 +335,31 @@ def activation(x, act):
     return ActivationFn.apply(x, act)
 
 
+class ScaleAddFn(torch.autograd.Function):
+    """out = alpha * x (+ add broadcast over the batch): the x*sqrt(d) (+pe) of embedding.py:44-60,75-88 where it
+    is not fused into a producing GEMM (LinearNoSubsampling)."""
+
+    @staticmethod
+    def forward(ctx, x, alpha, add):
+        x = _chk(x, "scale_add input")
+        out = torch.empty_like(x)
+        add_b = None if add is None else _chk(add.expand_as(x), "scale_add addend")
+        hip.call("oe_axpby", x, add_b, x.numel(), float(alpha), 1.0, None, out)
+        ctx.alpha = float(alpha)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        hip.call("oe_axpby", dy, None, dy.numel(), ctx.alpha, 0.0, None, dx)
+        return dx, None, None
+
+
+def scale_add(x, alpha, add=None):
+    return ScaleAddFn.apply(x, alpha, add)
+
+
 class CmvnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mean, istd):
@@ -702,7 +727,7 @@ class CTCHeadFn(torch.autograd.Function):
     gradient; the logits buffer is overwritten by d loss/d logits (never read again)."""
 
     @staticmethod
-    def forward(ctx, hs, w, b, hlens, ys, ylens):
+    def forward(ctx, hs, w, b, hlens, ys, ylens, length_normalized=False):
         hs = _chk(hs, "ctc input")
         B, T, d = hs.shape
         V = w.shape[0]
@@ -720,11 +745,14 @@ class CTCHeadFn(torch.autograd.Function):
         ws = _new(hip.lib().oe_ctc_workspace_floats(B, T, Lmax), like=hs)
         nll = _new(B, like=hs)
         tot = _new(1, like=hs)
-        hip.call("oe_ctc_loss_fused", logits, Vp, B, T, V, hl32, ys32, Lmax, yl32, 1.0 / B, nll, tot, logits, ws)
+        # reduction 'sum' then / B (ctc.py:43-44); 'mean' = mean_b(nll_b / max(len_b, 1)), then / B as well
+        uw = (1.0 / yl32.clamp(min=1).to(torch.float32)) if length_normalized else None
+        denom = float(B * B) if length_normalized else float(B)
+        hip.call("oe_ctc_loss_fused", logits, Vp, B, T, V, hl32, ys32, Lmax, yl32, 1.0 / denom, uw, nll, tot, logits, ws)
         ctx.save_for_backward(hs2, w, logits)
         ctx.shape = (B, T, d, V)
         ctx.bias_ref = b
-        return tot[0] / B
+        return tot[0] / denom
 
     @staticmethod
     def backward(ctx, g):
@@ -734,11 +762,11 @@ class CTCHeadFn(torch.autograd.Function):
         dl = dlogits[:, :V]
         dhs = gemm_nn(dl, w, alpha_dev=g).view(B, T, d)
         dw, db = wgrad_bias(w, ctx.bias_ref, dl, hs2, alpha_dev=g)
-        return dhs, dw, db, None, None, None
+        return dhs, dw, db, None, None, None, None
 
 
-def ctc_head(hs, w, b, hlens, ys, ylens):
-    return CTCHeadFn.apply(hs, w, b, hlens, ys, ylens)
+def ctc_head(hs, w, b, hlens, ys, ylens, length_normalized=False):
+    return CTCHeadFn.apply(hs, w, b, hlens, ys, ylens, length_normalized)
 
 
 class LSMHeadFn(torch.autograd.Function):

@@ -202,6 +202,14 @@ def subsample4(sd, cfg: Config, x: Tensor, mask: Tensor):
     return y, mask[:, :, :-2:2][:, :, :-2:2], pos
 
 
+def linear_no_subsampling(sd, cfg: Config, x: Tensor, mask: Tensor):
+    """modules/subsampling.py:23-62 (LinearNoSubsampling): Linear -> LayerNorm(eps 1e-12) -> positional encoding."""
+    p = "encoder.embed."
+    y = _ln(_lin(x, sd, p + "out.0"), sd, p + "out.1", 1e-12)
+    y, pos = position_encode(cfg, y)
+    return y, mask, pos
+
+
 def position_encode(cfg_or_kind, y: Tensor, d_model: Optional[int] = None):
     """modules/embedding.py:44-60 (abs) / :75-88 (rel)."""
     kind = cfg_or_kind if isinstance(cfg_or_kind, str) else cfg_or_kind.pos_enc_layer_type
@@ -316,8 +324,11 @@ def encoder(sd, cfg: Config, feats: Tensor, masks: Tensor, training: bool = Fals
     x = feats
     if cfg.has_cmvn:  # modules/cmvn.py:35-46
         x = (x - sd["encoder.global_cmvn.mean"]) * sd["encoder.global_cmvn.istd"]
-    assert cfg.input_layer == "conv2d"
-    x, masks, pos = subsample4(sd, cfg, x, masks)
+    if cfg.input_layer == "linear":         # modules/encoder.py:150-151
+        x, masks, pos = linear_no_subsampling(sd, cfg, x, masks)
+    else:
+        assert cfg.input_layer == "conv2d"
+        x, masks, pos = subsample4(sd, cfg, x, masks)
     n_unique = cfg.encoder_num_blocks // cfg.encoder_num_blocks_share
     for i in range(n_unique):
         for _ in range(cfg.encoder_num_blocks_share):

@@ -203,6 +203,27 @@ def f5_f6_encoder():
                       "grad": {**grads_of(enc, "encoder."), "x": x.grad}, "grad_layer": gl_named})
 
 
+def f16_encoder_linear_input():
+    """TransformerEncoder(input_layer='linear') (encoder.py:150-151, subsampling.py:23-62), both positional encodings."""
+    for kind, name in (("abs_pos", "f16_encoder_linear_abs"), ("rel_pos", "f16_encoder_linear_rel")):
+        torch.manual_seed(116)
+        if kind == "rel_pos":
+            enc = TransformerEncoder(24, "linear", "rel_pos", 32, 0.0, 4, 64, "swish", True, True, 15, False,
+                                     False, 64, 0.1, num_blocks=1)
+        else:
+            enc = TransformerEncoder(24, "linear", "abs_pos", 32, 0.0, 4, 64, "relu", False, False, 15, False,
+                                     False, 64, 0.1, num_blocks=1)
+        randomize(enc, 16)
+        lens = [19, 12, 5]
+        x = torch.randn(3, 19, 24, requires_grad=True)
+        mask = ragged_mask(lens, 19)
+        y, ymask, pos = enc(x, mask)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        save(name, **{"in": {"x": x, "mask": mask, "w": w}, "sd": sd_of(enc, "encoder."),
+                      "out": {"y": y, "mask": ymask, "pos": pos}, "grad": {**grads_of(enc, "encoder."), "x": x.grad}})
+
+
 def f7_ctc():
     torch.manual_seed(107)
     V, D, B, T = 20, 16, 5, 12
@@ -225,6 +246,29 @@ def f7_ctc():
     save("f07_ctc", **{"in": {"hs": hs, "hlens": hlens, "ys": ys, "ylens": ylens}, "sd": sd_of(m, "ctc."),
                        "out": {"loss": loss, "per_utt": per_utt, "logits": logits},
                        "grad": {**grads_of(m, "ctc."), "hs": hs.grad, "logits": logits.grad}})
+
+
+def f14_ctc_length_normalized():
+    """CTC(length_normalized_loss=True): CTCLoss(reduction='mean') = mean_b(nll_b / max(len_b, 1)), then / B again
+    (ctc.py:24-25,43-44)."""
+    torch.manual_seed(114)
+    V, D, B, T = 20, 16, 5, 12
+    m = CTC(V, D, length_normalized_loss=True)
+    randomize(m, 14)
+    hs = torch.randn(B, T, D, requires_grad=True)
+    hlens = torch.tensor([12, 9, 3, 12, 7])
+    ys = torch.tensor([[3, 4, 4, 5, 1], [7, 7, 2, -1, -1], [2, 3, 4, 5, -1], [-1, -1, -1, -1, -1], [6, 6, 6, -1, -1]],
+                      dtype=torch.int32)
+    ylens = torch.tensor([5, 3, 4, 0, 3], dtype=torch.int32)
+    logits = m.ctc_lo(hs)
+    logits.retain_grad()
+    loss = m.ctc_loss(logits.transpose(0, 1).log_softmax(2), ys, hlens, ylens) / B
+    loss.backward()
+    loss2 = m(hs.detach(), hlens, ys, ylens)
+    assert torch.allclose(loss, loss2)
+    save("f14_ctc_lennorm", **{"in": {"hs": hs, "hlens": hlens, "ys": ys, "ylens": ylens}, "sd": sd_of(m, "ctc."),
+                               "out": {"loss": loss, "logits": logits},
+                               "grad": {**grads_of(m, "ctc."), "hs": hs.grad, "logits": logits.grad}})
 
 
 def f8_lsm():
@@ -360,6 +404,15 @@ def f11_f12_e2e():
          lens=[95, 70, 43], tlens=[7, 5, 3], V=40, seed=12)
 
 
+def f15_e2e_length_normalized():
+    _e2e("f15_tiny_conformer_lennorm",
+         dict(encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+              linear_units=64, dropout_rate=0.0, activation_type="swish", macaron_style=True, use_cnn_module=True,
+              cnn_module_kernel=15, pos_enc_layer_type="rel_pos", ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3,
+              length_normalized_loss=True),
+         lens=[95, 70, 43], tlens=[7, 5, 3], V=40, seed=15)
+
+
 def f13_misc():
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.Adam([p], lr=1e-3)
@@ -381,5 +434,10 @@ def f13_misc():
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
-    f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
-    f10_helpers(); f11_f12_e2e(); f13_misc()
+    if len(sys.argv) > 1:                       # regenerate only the named groups, e.g. `make_fixtures.py f14_ctc_length_normalized`
+        for fn in sys.argv[1:]:
+            globals()[fn]()
+    else:
+        f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
+        f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
+        f16_encoder_linear_input()

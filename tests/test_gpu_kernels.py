@@ -197,7 +197,7 @@ def test_layernorm_fwd_bwd(rows, d, eps):
 
 
 # -------------------------------------------------------------------- CTC ----
-def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False):
+def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_weight=None):
     B, T, V = logits.shape
     ldv = ldv or V
     buf = torch.zeros(B, T, ldv, device=DEV)
@@ -209,8 +209,9 @@ def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False):
     nll = torch.empty(B, device=DEV)
     tot = torch.empty(1, device=DEV)
     dl = buf if inplace else torch.full((B, T, ldv), float("nan"), device=DEV)
+    uw = None if utt_weight is None else cu(utt_weight.float())
     hip.check(L.oe_ctc_loss_fused(hip.ptr(buf), ldv, B, T, V, hip.ptr(hl), hip.ptr(yd), Lmax, hip.ptr(yl), scale,
-                                  hip.ptr(nll), hip.ptr(tot), hip.ptr(dl), hip.ptr(ws), hip.stream()), "ctc")
+                                  hip.ptr(uw), hip.ptr(nll), hip.ptr(tot), hip.ptr(dl), hip.ptr(ws), hip.stream()), "ctc")
     sync()
     return nll.cpu(), tot.cpu(), dl[:, :, :V].cpu()
 

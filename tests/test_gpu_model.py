@@ -117,6 +117,24 @@ def build_encoder(name, sd):
     return load_into(enc, sd, "encoder.")
 
 
+@pytest.mark.parametrize("name", ["f16_encoder_linear_abs", "f16_encoder_linear_rel"])
+def test_f16_encoder_linear_input_layer(name):
+    g = load_golden(name)
+    if name.endswith("rel"):
+        enc = TransformerEncoder(24, "linear", "rel_pos", 32, 0.0, 4, 64, "swish", True, True, 15, False, False, 64, 0.1, num_blocks=1)
+    else:
+        enc = TransformerEncoder(24, "linear", "abs_pos", 32, 0.0, 4, 64, "relu", False, False, 15, False, False, 64, 0.1, num_blocks=1)
+    enc = load_into(enc, g["sd"], "encoder.")
+    x = g["in"]["x"].to(DEV).requires_grad_()
+    y, mask, pos = enc(x, g["in"]["mask"].to(DEV))
+    close(y, g["out"]["y"], rtol=5e-4, atol=2e-4, msg="y")
+    assert torch.equal(mask.cpu(), g["out"]["mask"])
+    close(pos, g["out"]["pos"], msg="pos")
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    close(x.grad, g["grad"]["x"], rtol=2e-3, atol=3e-4, msg="dx")
+    check_param_grads(enc, g["grad"], "encoder.", rtol=3e-3, rel_floor=1e-3)
+
+
 @pytest.mark.parametrize("name", ["f06_encoder_conformer", "f06_encoder_conformer_cmvn", "f06_encoder_transformer"])
 def test_f05_f06_encoder(name):
     g = load_golden(name)
@@ -146,6 +164,17 @@ def test_f07_ctc_module():
     close(hs.grad, g["grad"]["hs"], rtol=1e-3, atol=1e-5, msg="dhs")
     check_param_grads(m, g["grad"], "ctc.")
     close(m.logits(g["in"]["hs"].to(DEV)), g["out"]["logits"], msg="logits")
+
+
+def test_f14_ctc_module_length_normalized():
+    g = load_golden("f14_ctc_lennorm")
+    m = load_into(CTC(20, 16, length_normalized_loss=True), g["sd"], "ctc.")
+    hs = g["in"]["hs"].to(DEV).requires_grad_()
+    loss = m(hs, g["in"]["hlens"].to(DEV), g["in"]["ys"].to(DEV), g["in"]["ylens"].to(DEV))
+    close(loss, g["out"]["loss"], msg="loss")
+    loss.backward()
+    close(hs.grad, g["grad"]["hs"], rtol=1e-3, atol=1e-5, msg="dhs")
+    check_param_grads(m, g["grad"], "ctc.")
 
 
 def test_f08_label_smoothing_module():
@@ -181,7 +210,7 @@ def test_f09_bidecoder_and_incremental_decoding():
             close(p, g["out"]["steps"][step - 1], rtol=2e-4, atol=1e-4, msg=f"step{step}")
 
 
-E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False}
+E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False}
 
 
 @pytest.mark.parametrize("name", list(E2E))

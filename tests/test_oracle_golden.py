@@ -97,6 +97,29 @@ ENC_CFGS = {
 }
 
 
+LINEAR_IN = {
+    "f16_encoder_linear_abs": dict(pos_enc_layer_type="abs_pos", activation_type="relu", macaron_style=False, use_cnn_module=False),
+    "f16_encoder_linear_rel": dict(pos_enc_layer_type="rel_pos", activation_type="swish", macaron_style=True, use_cnn_module=True),
+}
+
+
+@pytest.mark.parametrize("name", list(LINEAR_IN))
+def test_f16_encoder_linear_input_layer(name):
+    """TransformerEncoder(input_layer='linear'): subsampling.py:23-62 in front of one encoder layer."""
+    g = load_golden(name)
+    cfg = O.Config(input_size=24, d_model=32, attention_heads=4, linear_units=64, dropout_rate=0.0, encoder_num_blocks=1,
+                   input_layer="linear", **LINEAR_IN[name])
+    sd = req(g["sd"])
+    x = g["in"]["x"].clone().requires_grad_()
+    y, m, pos = O.encoder(sd, cfg, x, g["in"]["mask"])
+    torch.testing.assert_close(y, g["out"]["y"], rtol=2e-4, atol=5e-5)
+    assert torch.equal(m, g["out"]["mask"])
+    torch.testing.assert_close(pos, g["out"]["pos"])
+    (y * g["in"]["w"]).sum().backward()
+    check_grads(sd, g["grad"], tol=dict(rtol=1e-3, atol=2e-4))
+    torch.testing.assert_close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4)
+
+
 @pytest.mark.parametrize("name", list(ENC_CFGS))
 def test_f05_f06_encoder(name):
     g = load_golden(name)
@@ -141,6 +164,26 @@ def test_f07_ctc_loss_and_grad():
     np.testing.assert_allclose(dlog / B, g["grad"]["logits"].numpy(), rtol=1e-4, atol=2e-6)
     assert np.all(g["grad"]["logits"].numpy()[2] == 0.0)               # and no gradient
     assert np.all(g["grad"]["logits"].numpy()[1, 9:] == 0.0)           # padded frames: exactly 0
+
+
+def test_f14_ctc_length_normalized():
+    """CTC(length_normalized_loss=True): CTCLoss(reduction='mean') then / B (ctc.py:24-25,43-44)."""
+    g = load_golden("f14_ctc_lennorm")
+    cfg = O.Config(vocab_size=20, d_model=16, length_normalized_loss=True)
+    sd = req(g["sd"])
+    hs = g["in"]["hs"].clone().requires_grad_()
+    loss = O.ctc_loss(sd, cfg, hs, g["in"]["hlens"], g["in"]["ys"], g["in"]["ylens"])
+    torch.testing.assert_close(loss, g["out"]["loss"], **TOL)
+    loss.backward()
+    check_grads(sd, g["grad"])
+    torch.testing.assert_close(hs.grad, g["grad"]["hs"], **TOL)
+    # the independent alpha/beta restatement with per-utterance weights 1 / max(len, 1) and the two / B
+    nll, dlog = ctc_np.ctc_nll_and_grad(g["out"]["logits"].numpy(), g["in"]["hlens"].numpy(),
+                                        g["in"]["ys"].numpy(), g["in"]["ylens"].numpy())
+    B = hs.shape[0]
+    w = 1.0 / np.maximum(g["in"]["ylens"].numpy(), 1)
+    np.testing.assert_allclose((nll * w).sum() / (B * B), float(g["out"]["loss"]), rtol=1e-5)
+    np.testing.assert_allclose(dlog * w[:, None, None] / (B * B), g["grad"]["logits"].numpy(), rtol=1e-4, atol=2e-6)
 
 
 def test_f08_label_smoothing_and_accuracy():
@@ -198,7 +241,7 @@ def test_f10_helper_tables():
         assert a == b or abs(a - b) < 1e-12
 
 
-E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False}
+E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False}
 
 
 @pytest.mark.parametrize("name", list(E2E))
