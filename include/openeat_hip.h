@@ -77,19 +77,6 @@ typedef struct oe_gemm_args {
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);
 
-/* The same product on operands that are already split into bf16 planes: hi = bf16(x), lo = bf16(x - hi) (lo planes
- * only for precision 3).  A is (m, k) and B is (n, k), both row-major with k contiguous; args->lda / ldb are the
- * plane row strides in elements (multiples of 8), args->a / b are ignored, a_kmajor = b_kmajor = 0, no conv gather,
- * k a multiple of 32.  x @ W and weight gradients use planes written transposed (oe_split_bf16 transpose = 1).
- * Epilogue, split_k / atomic_out and precision (1 or 3) as in oe_gemm_f32. */
-int oe_gemm_planes(const oe_gemm_args* args, const void* a_hi, const void* a_lo, const void* b_hi, const void* b_lo,
-                   void* stream);
-/* fp32 (rows, cols), row stride ldx -> bf16 planes; transpose = 0: planes are (rows, cols), 1: (cols, rows);
- * ld_out = plane row stride in elements; lo may be NULL (precision 1).  cols, ldx, ld_out multiples of 4
- * (and rows, when transposing). */
-int oe_split_bf16(const float* x, long ldx, long rows, int cols, int transpose, void* hi, void* lo, long ld_out,
-                  void* stream);
-
 /* column sums: out[n] (+)= alpha * sum_m x[m,n]  - bias gradients of every
  * Linear (autograd of aten::addmm).  alpha_dev optional device scalar. */
 int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const float* alpha_dev,

@@ -101,8 +101,6 @@ _SIGNATURES = {
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
     "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
-    "oe_gemm_planes": (I, [P, P, P, P, P, P]),
-    "oe_split_bf16": (I, [P, L, L, I, I, P, P, L, P]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
     "oe_attention_fwd": (I, [C.POINTER(AttnArgs), P]),
