@@ -36,6 +36,24 @@ def grad_target(param: torch.Tensor) -> Optional[torch.Tensor]:
     return a.by_ptr.get(param.data_ptr())
 
 
+def arena_units(model: torch.nn.Module):
+    """(unit name, module) in forward order for the ASR model; any other module is one unit."""
+    enc = getattr(model, "encoder", None)
+    if enc is None or not hasattr(enc, "encoders") or not hasattr(enc, "embed"):
+        return [("all", model)]
+    units = []
+    if getattr(enc, "global_cmvn", None) is not None:
+        units.append(("embed", enc.global_cmvn))
+    units.append(("embed", enc.embed))
+    for i, layer in enumerate(enc.encoders):
+        units.append((f"enc{i}", layer))
+    units.append(("enc_norm", enc.after_norm))
+    for name in ("ctc", "decoder"):
+        if getattr(model, name, None) is not None:
+            units.append(("heads", getattr(model, name)))
+    return units
+
+
 class ParamArena:
     ALIGN = 4  # floats (16 bytes)
 
@@ -43,21 +61,29 @@ class ParamArena:
         from openeat_amd.modules.attention import MultiHeadedAttention
         params: List[torch.nn.Parameter] = []
         seen = set()
+        self.unit_of: List[str] = []          # unit name of every parameter, in arena order
 
-        def add(p):
+        def add(p, unit):
             if p is not None and p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 params.append(p)
+                self.unit_of.append(unit)
 
-        # attention modules first lay out [Wq Wk Wv][bq bk bv] contiguously
-        for mod in model.modules():
-            if isinstance(mod, MultiHeadedAttention):
-                for lin in (mod.linear_q, mod.linear_k, mod.linear_v):
-                    add(lin.weight)
-                for lin in (mod.linear_q, mod.linear_k, mod.linear_v):
-                    add(lin.bias)
-        for p in model.parameters():
-            add(p)
+        # The arena is laid out in units that follow the forward order (input layer, encoder layer 0..n-1, final norm,
+        # heads): backward finishes them in reverse, so "everything from unit u on" is a contiguous tail that can go
+        # to the gradient all-reduce while the earlier units are still being differentiated (ddp.GradAllReduce).
+        # Inside a unit every attention module first lays out [Wq Wk Wv][bq bk bv] contiguously (fused QKV GEMM).
+        for unit, mod in arena_units(model):
+            for m in mod.modules():
+                if isinstance(m, MultiHeadedAttention):
+                    for lin in (m.linear_q, m.linear_k, m.linear_v):
+                        add(lin.weight, unit)
+                    for lin in (m.linear_q, m.linear_k, m.linear_v):
+                        add(lin.bias, unit)
+            for p_ in mod.parameters():
+                add(p_, unit)
+        for p_ in model.parameters():           # anything the unit walk did not reach
+            add(p_, "rest")
         assert params, "model has no trainable parameters"
         dev = params[0].device
         assert dev.type == "cuda", "move the model to the GPU before building the arena"
@@ -70,6 +96,9 @@ class ParamArena:
         self.flat = torch.zeros(total, device=dev)
         self.grad = torch.zeros(total, device=dev)
         self.params = params
+        self.unit_start: Dict[str, int] = {}      # first float of each unit (units are contiguous, in forward order)
+        for u, o in zip(self.unit_of, offs):
+            self.unit_start.setdefault(u, o)
         self.by_ptr: Dict[int, torch.Tensor] = {}
         self.enabled = True
         with torch.no_grad():

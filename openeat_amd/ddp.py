@@ -3,10 +3,13 @@
 
 One process per GPU.  Gradients live in one flat fp32 arena, so the exchange is
 a handful of large all-reduces over contiguous memory (no bucketing copies, no
-per-parameter hooks).  The arena is cut into `n_chunks` slices that are issued
-back to back on a side stream; RCCL pipelines them over the 7 xGMI links.  The
-sum is divided by the world size inside the collective (ReduceOp.AVG), which is
-DDP's gradient averaging.
+per-parameter hooks).  The arena is laid out in forward order, so the part whose
+gradients are final at any point of backward is a contiguous tail: `reduce_tail`
+(called from two tensor hooks: gradient of the encoder output ready = heads done,
+gradient of the middle encoder layer's input ready = upper half done) sends that
+tail to RCCL while the rest of backward keeps running; `__call__` after backward
+sends what is left in `n_chunks` slices and waits.  The sum is divided by the
+world size inside the collective (ReduceOp.AVG), which is DDP's gradient averaging.
 """
 from __future__ import annotations
 
@@ -38,7 +41,10 @@ class GradAllReduce:
         n = flat_grad.numel()
         step = -(-n // max(1, n_chunks))
         step = (step + 1023) // 1024 * 1024
+        self.n_chunks = max(1, n_chunks)
         self.chunks = [flat_grad[i:min(n, i + step)] for i in range(0, n, step)]
+        self._done_from = n            # floats [_done_from, n) have already been handed to the collective this step
+        self._works = []
         self._avg = (hasattr(dist.ReduceOp, "AVG") and flat_grad.is_cuda and dist.is_initialized()
                      and dist.get_backend(process_group) == "nccl")
 
@@ -47,16 +53,35 @@ class GradAllReduce:
         if self.world > 1:
             dist.broadcast(flat_params, src=src, group=self.group)
 
+    def _issue(self, t: torch.Tensor):
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+
+    def reduce_tail(self, start: int):
+        """Gradients of floats [start, end of what is still pending) are final: start their all-reduce now (async; the
+        collective is ordered after everything already enqueued on the current stream)."""
+        if self.world == 1 or start >= self._done_from:
+            return
+        if start > 0:
+            start = (start + 1023) // 1024 * 1024      # 4 KiB aligned slices; the few floats skipped go with the next tail
+            if start >= self._done_from:
+                return
+        self._issue(self.grad[start:self._done_from])
+        self._done_from = start
+
     def __call__(self):
+        """After backward: reduce what no hook has sent yet, wait for everything, average."""
         if self.world == 1:
             return
-        works = []
-        for c in self.chunks:
-            if self._avg:
-                works.append(dist.all_reduce(c, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-            else:
-                works.append(dist.all_reduce(c, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w in works:
+        n = self._done_from
+        if n > 0:
+            step = -(-n // self.n_chunks)
+            step = (step + 1023) // 1024 * 1024
+            for i in range(0, n, step):
+                self._issue(self.grad[i:min(n, i + step)])
+        for w in self._works:
             w.wait()
+        self._works = []
+        self._done_from = self.grad.numel()
         if not self._avg:
             self.grad.div_(self.world)

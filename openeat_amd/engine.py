@@ -23,6 +23,8 @@ class TrainEngine:
         self.optimizer = FusedAdam(self.arena, lr=lr, max_grad_norm=grad_clip)
         self.reducer = GradAllReduce(self.arena.grad, n_allreduce_chunks)
         self.reducer.broadcast_parameters(self.arena.flat)
+        if self.reducer.world > 1:
+            self._install_overlap_hooks()
         self.accum_grad = accum_grad
         self.static_shapes = static_shapes
         dev = self.arena.flat.device
@@ -31,6 +33,27 @@ class TrainEngine:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._static: Dict[str, torch.Tensor] = {}
         self._out = None
+
+    def _install_overlap_hooks(self):
+        """Start the gradient all-reduce of the arena tail whose gradients are final while backward is still running:
+        after the heads (gradient of the encoder output ready) and after the upper half of the encoder layers."""
+        us = self.arena.unit_start
+        enc = getattr(self.model, "encoder", None)
+        if enc is None or "heads" not in us:
+            return
+
+        def tail_from(unit):
+            def cb():
+                if self._capturing:             # a HIP-graph capture holds no collectives: all of it goes after the graph
+                    return
+                ops.join_side_stream()          # weight-gradient GEMMs of the finished units run on the side stream
+                self.reducer.reduce_tail(us[unit])
+            return cb
+
+        self.model.grad_ready_hooks = {"encoder_out": tail_from("heads")}
+        n = len(enc.encoders)
+        if n >= 2 and f"enc{n // 2}" in us:
+            enc.grad_ready_hooks = {n // 2: tail_from(f"enc{n // 2}")}
 
     # one micro-step: loss (already divided by accum_grad) and its backward
     def _fwd_bwd(self, batch):

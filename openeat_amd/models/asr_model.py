@@ -65,6 +65,10 @@ class ASRModel(torch.nn.Module):
         assert (features.shape[0] == features_length.shape[0] == targets.shape[0] == targets_length.shape[0]), \
             (features.shape, features_length.shape, targets.shape, targets_length.shape)
         encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        hooks = getattr(self, "grad_ready_hooks", None)          # set by TrainEngine for multi-GPU overlap
+        if hooks and encoder_out.requires_grad:
+            cb = hooks["encoder_out"]
+            encoder_out.register_hook(lambda g, cb=cb: cb())      # returns None: the gradient is not modified
         encoder_out_lens = encoder_mask.squeeze(1).sum(1)
         loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
         if self.ctc_weight < 1:

@@ -87,7 +87,10 @@ class TransformerEncoder(torch.nn.Module):
             xs = self.global_cmvn(xs)
         xs, masks, pos_emb = self.embed(xs, masks)
         m8 = masks.to(torch.uint8).contiguous()
-        for layer in self.encoders:
+        hooks = getattr(self, "grad_ready_hooks", None)           # {layer index: callback}, set by TrainEngine (multi-GPU)
+        for i, layer in enumerate(self.encoders):
+            if hooks and i in hooks and xs.requires_grad:
+                xs.register_hook(lambda g, cb=hooks[i]: cb())     # gradient of layer i's input ready = layers >= i done
             for _ in range(self.num_blocks_share):
                 xs, _ = layer(xs, m8, pos_emb)
         xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)

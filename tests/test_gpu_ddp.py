@@ -1,0 +1,108 @@
+"""GPU, two ranks (both on cuda:0, gloo so that no second GPU / RCCL is needed): one TrainEngine step per rank on
+different minibatches must leave both ranks with identical parameters, equal to what a single process gets by
+averaging the two ranks' gradients before the same clip + Adam update (DistributedDataParallel semantics,
+train_ddp.py:212-219), including the all-reduce phases that start inside backward."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONF = dict(encoder_num_blocks=4, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4, linear_units=64,
+            dropout_rate=0.0, activation_type="swish", macaron_style=True, use_cnn_module=True, cnn_module_kernel=15,
+            pos_enc_layer_type="rel_pos", ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3)
+V = 40
+
+
+def _batch(seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    B, T, L = 3, 83, 6
+    feats = torch.randn(B, T, 80, generator=g)
+    flen = torch.tensor([83, 64, 41], dtype=torch.int32)
+    tgt = torch.randint(2, V - 1, (B, L), generator=g, dtype=torch.int32)
+    tlen = torch.tensor([6, 4, 3], dtype=torch.int32)
+    for b in range(B):
+        tgt[b, int(tlen[b]):] = -1
+    return dict(features=feats.to(dev), features_length=flen.to(dev), targets=tgt.to(dev), targets_length=tlen.to(dev))
+
+
+def _model(dev):
+    from openeat_amd.models.asr_model import ASRModel
+    torch.manual_seed(7)
+    return ASRModel(80, V, **CONF).to(dev).train()
+
+
+def worker():
+    sys.path.insert(0, ROOT)
+    from openeat_amd import ddp
+    from openeat_amd.engine import TrainEngine
+    rank, _, world = ddp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    model = _model(dev)
+    eng = TrainEngine(model, lr=1e-2, grad_clip=5.0)
+    assert eng.reducer.world == 2 and hasattr(model, "grad_ready_hooks") and hasattr(model.encoder, "grad_ready_hooks")
+    issued = []
+    orig = eng.reducer.reduce_tail
+    eng.reducer.reduce_tail = lambda start: (issued.append(start), orig(start))[1]
+    loss, _ = eng.step(_batch(100 + rank, dev))
+    torch.cuda.synchronize()
+    assert len(issued) == 2 and issued[0] > issued[1] > 0, issued          # heads first, then the upper encoder half
+    out = {"flat": eng.arena.flat.detach().cpu(), "loss": float(loss), "issued": issued}
+    torch.save(out, os.environ["OE_TEST_OUT"] + f".{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_matches_gradient_averaging(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ddp_out")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2",
+                   OE_TEST_OUT=out, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-4000:]
+    got = [torch.load(out + f".{r}") for r in range(2)]
+    assert torch.equal(got[0]["flat"], got[1]["flat"])                       # both ranks hold the same parameters
+
+    # single process: average the two ranks' gradients, then the same clip + Adam
+    from openeat_amd.engine import TrainEngine
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    eng = TrainEngine(model, lr=1e-2, grad_clip=5.0)
+    grads = []
+    for r in range(2):
+        eng.arena.zero_grad()
+        eng._fwd_bwd(_batch(100 + r, dev))
+        grads.append(eng.arena.grad.clone())
+    eng.arena.grad.copy_((grads[0] + grads[1]) / 2)
+    eng.optimizer.step()
+    torch.cuda.synchronize()
+    ref = eng.arena.flat.detach().cpu()
+    # Adam's first step moves every parameter by ~lr * sign(g): compare the updates, tolerance a fraction of lr
+    torch.manual_seed(7)
+    init = _model(dev)
+    from openeat_amd.arena import ParamArena
+    eng.arena.deactivate()
+    init_flat = ParamArena(init).flat.detach().cpu()
+    du_ref, du_got = ref - init_flat, got[0]["flat"] - init_flat
+    assert float(du_ref.abs().max()) > 5e-3                                   # the step did move the parameters
+    bad = (du_ref - du_got).abs() > 2e-3 * 1e-2 + 0.02 * du_ref.abs()
+    # parameters whose averaged gradient is ~0 get a sign-of-noise update from Adam: allow a small fraction of those
+    assert float(bad.float().mean()) < 2e-3, float(bad.float().mean())
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker":
+    worker()
