@@ -110,6 +110,13 @@ class TrainEngine:
             self._capturing = False
         self._graph = g
 
+    def drop_graph(self):
+        """Forget the captured graph (and give its memory pool back): subsequent steps are eager again."""
+        self._graph = None
+        self._out = None
+        self._static = {}
+        torch.cuda.empty_cache()
+
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
         assert self._graph is not None
         if batch is not None:
