@@ -285,6 +285,11 @@ int oe_utt_normalize(float* x, const int* nframes, int B, int Tmax, int F, void*
  * (-1 = fewer than `beam` hypotheses), out_score_host (beam) = log_add(pb, pnb). */
 int oe_ctc_prefix_beam_host(const float* topk_logp_host, const long long* topk_idx_host, int T, int beam,
                             int max_len, int* out_prefix_host, int* out_len_host, double* out_score_host);
+/* The same for B utterances at once, spread over n_threads host threads (<= 0: all cores): inputs (B, Tmax, beam) with
+ * lens[b] valid frames each; outputs (B, beam, max_len) / (B, beam) / (B, beam). */
+int oe_ctc_prefix_beam_host_batch(const float* topk_logp_host, const long long* topk_idx_host, int B, int Tmax,
+                                  const int* lens_host, int beam, int max_len, int* out_prefix_host, int* out_len_host,
+                                  double* out_score_host, int n_threads);
 
 #ifdef __cplusplus
 }

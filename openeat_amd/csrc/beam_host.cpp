@@ -11,7 +11,9 @@
 #include <cstdint>
 #include <cstring>
 #include <limits>
-#include <map>
+#include <atomic>
+#include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/openeat_hip.h"
@@ -32,10 +34,96 @@ inline double log_add2(double a, double b) {
     return m + std::log(std::exp(a - m) + std::exp(b - m));
 }
 
+// Prefixes live in a trie: a node is (parent, token); two prefixes are equal iff they are the same node, so the
+// per-frame dictionary of the reference (keyed by the token tuple) becomes a map keyed by the node id and every
+// candidate update is O(1) instead of a comparison of two token sequences.
+struct Trie {
+    std::vector<int> parent, token, length;
+    std::unordered_map<uint64_t, int> child;
+    Trie() { parent.push_back(-1); token.push_back(-1); length.push_back(0); }
+    int extend(int node, int tok) {
+        const uint64_t key = ((uint64_t)(uint32_t)node << 32) | (uint32_t)tok;
+        auto it = child.find(key);
+        if (it != child.end()) return it->second;
+        const int id = (int)parent.size();
+        parent.push_back(node); token.push_back(tok); length.push_back(length[node] + 1);
+        child.emplace(key, id);
+        return id;
+    }
+};
+
 struct Hyp {
-    std::vector<int> prefix;
+    int node;
     double pb, pnb;
 };
+
+// one utterance; returns 0 or -1 (prefix longer than max_len)
+int beam_one(const float* topk_logp, const long long* topk_idx, int T, int beam, int max_len, int* out_prefix, int* out_len,
+             double* out_score) {
+    Trie trie;
+    std::vector<Hyp> cur(1, Hyp{0, 0.0, NEG}), nxt, pruned;
+    std::unordered_map<int, int> index;                    // node -> position in nxt (nxt keeps the insertion order)
+    auto slot = [&](int node) -> Hyp& {
+        auto it = index.find(node);
+        if (it != index.end()) return nxt[it->second];
+        index.emplace(node, (int)nxt.size());
+        nxt.push_back(Hyp{node, NEG, NEG});
+        return nxt.back();
+    };
+    std::vector<double> key;
+    std::vector<int> order;
+    for (int t = 0; t < T; ++t) {
+        nxt.clear();
+        index.clear();
+        for (int j = 0; j < beam; ++j) {
+            const int s = (int)topk_idx[(long)t * beam + j];
+            const double ps = (double)topk_logp[(long)t * beam + j];
+            for (size_t h = 0; h < cur.size(); ++h) {
+                const int node = cur[h].node;
+                const double pb = cur[h].pb, pnb = cur[h].pnb;
+                const int last = trie.token[node];          // -1 for the empty prefix
+                if (s == 0) {
+                    Hyp& e = slot(node);
+                    e.pb = log_add3(e.pb, pb + ps, pnb + ps);
+                } else if (s == last) {
+                    {
+                        Hyp& e = slot(node);
+                        e.pnb = log_add2(e.pnb, pnb + ps);
+                    }
+                    Hyp& e2 = slot(trie.extend(node, s));
+                    e2.pnb = log_add2(e2.pnb, pb + ps);
+                } else {
+                    Hyp& e2 = slot(trie.extend(node, s));
+                    e2.pnb = log_add3(e2.pnb, pb + ps, pnb + ps);
+                }
+            }
+        }
+        // sorted(items, key=log_add(pb, pnb), reverse=True): CPython implements reverse=True as
+        // reverse / stable ascending sort / reverse, which keeps ties in their ORIGINAL order
+        key.resize(nxt.size());
+        order.resize(nxt.size());
+        for (size_t i = 0; i < nxt.size(); ++i) { key[i] = log_add2(nxt[i].pb, nxt[i].pnb); order[i] = (int)i; }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
+        const size_t keep = std::min<size_t>(beam, order.size());
+        pruned.clear();
+        for (size_t i = 0; i < keep; ++i) pruned.push_back(nxt[order[i]]);
+        cur.swap(pruned);
+    }
+    for (int i = 0; i < beam; ++i) {
+        if (i < (int)cur.size()) {
+            const int n = trie.length[cur[i].node];
+            if (n > max_len) return -1;
+            out_len[i] = n;
+            int node = cur[i].node;
+            for (int k = n - 1; k >= 0; --k) { out_prefix[(long)i * max_len + k] = trie.token[node]; node = trie.parent[node]; }
+            out_score[i] = log_add2(cur[i].pb, cur[i].pnb);
+        } else {
+            out_len[i] = -1;
+            out_score[i] = NEG;
+        }
+    }
+    return 0;
+}
 }  // namespace
 
 extern "C" int oe_ctc_prefix_beam_host(const float* topk_logp_host, const long long* topk_idx_host, int T, int beam,
@@ -45,77 +133,39 @@ extern "C" int oe_ctc_prefix_beam_host(const float* topk_logp_host, const long l
         oe_set_error("oe_ctc_prefix_beam_host: bad arguments");
         return -1;
     }
-    std::vector<Hyp> cur(1);
-    cur[0].pb = 0.0;
-    cur[0].pnb = NEG;
-    std::vector<Hyp> nxt;
-    std::map<std::vector<int>, int> index;                 // prefix -> position in nxt (insertion order kept by nxt)
-    auto slot = [&](const std::vector<int>& p) -> Hyp& {
-        auto it = index.find(p);
-        if (it != index.end()) return nxt[it->second];
-        index.emplace(p, (int)nxt.size());
-        nxt.push_back(Hyp{p, NEG, NEG});
-        return nxt.back();
+    if (beam_one(topk_logp_host, topk_idx_host, T, beam, max_len, out_prefix_host, out_len_host, out_score_host)) {
+        oe_set_error("oe_ctc_prefix_beam_host: prefix longer than max_len=%d", max_len);
+        return -1;
+    }
+    return 0;
+}
+
+// B utterances at once, spread over host threads (utterances are independent: asr_model.py:444 handles one per call).
+extern "C" int oe_ctc_prefix_beam_host_batch(const float* topk_logp_host, const long long* topk_idx_host, int B, int Tmax,
+                                             const int* lens_host, int beam, int max_len, int* out_prefix_host,
+                                             int* out_len_host, double* out_score_host, int n_threads) {
+    if (!topk_logp_host || !topk_idx_host || !lens_host || !out_prefix_host || !out_len_host || !out_score_host || B <= 0 ||
+        Tmax < 0 || beam <= 0 || max_len < 0) {
+        oe_set_error("oe_ctc_prefix_beam_host_batch: bad arguments");
+        return -1;
+    }
+    for (int b = 0; b < B; ++b)
+        if (lens_host[b] < 0 || lens_host[b] > Tmax) { oe_set_error("oe_ctc_prefix_beam_host_batch: lens[%d] out of range", b); return -1; }
+    if (n_threads <= 0) n_threads = std::min(16, (int)std::thread::hardware_concurrency());   // a one-GPU share of the host
+    n_threads = std::max(1, std::min(n_threads, std::min(B, 64)));
+    std::atomic<int> next(0), failed(0);
+    auto work = [&]() {
+        for (int b = next.fetch_add(1); b < B; b = next.fetch_add(1)) {
+            const long in_off = (long)b * Tmax * beam;
+            if (beam_one(topk_logp_host + in_off, topk_idx_host + in_off, lens_host[b], beam, max_len,
+                         out_prefix_host + (long)b * beam * max_len, out_len_host + (long)b * beam, out_score_host + (long)b * beam))
+                failed.store(1);
+        }
     };
-    std::vector<int> ext;
-    for (int t = 0; t < T; ++t) {
-        nxt.clear();
-        index.clear();
-        for (int j = 0; j < beam; ++j) {
-            const int s = (int)topk_idx_host[(long)t * beam + j];
-            const double ps = (double)topk_logp_host[(long)t * beam + j];
-            for (size_t h = 0; h < cur.size(); ++h) {
-                // copy what we need: slot() may reallocate nxt, but cur is a separate vector
-                const std::vector<int>& prefix = cur[h].prefix;
-                const double pb = cur[h].pb, pnb = cur[h].pnb;
-                const int last = prefix.empty() ? -1 : prefix.back();
-                if (s == 0) {
-                    Hyp& e = slot(prefix);
-                    e.pb = log_add3(e.pb, pb + ps, pnb + ps);
-                } else if (s == last) {
-                    {
-                        Hyp& e = slot(prefix);
-                        e.pnb = log_add2(e.pnb, pnb + ps);
-                    }
-                    ext = prefix;
-                    ext.push_back(s);
-                    Hyp& e2 = slot(ext);
-                    e2.pnb = log_add2(e2.pnb, pb + ps);
-                } else {
-                    ext = prefix;
-                    ext.push_back(s);
-                    Hyp& e2 = slot(ext);
-                    e2.pnb = log_add3(e2.pnb, pb + ps, pnb + ps);
-                }
-            }
-        }
-        // sorted(items, key=log_add(pb, pnb), reverse=True): CPython implements reverse=True as
-        // reverse / stable ascending sort / reverse, which keeps ties in their ORIGINAL order
-        std::vector<double> key(nxt.size());
-        for (size_t i = 0; i < nxt.size(); ++i) key[i] = log_add2(nxt[i].pb, nxt[i].pnb);
-        std::vector<int> order(nxt.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b]; });
-        const size_t keep = std::min<size_t>(beam, order.size());
-        std::vector<Hyp> pruned;
-        pruned.reserve(keep);
-        for (size_t i = 0; i < keep; ++i) pruned.push_back(std::move(nxt[order[i]]));
-        cur.swap(pruned);
-    }
-    for (int i = 0; i < beam; ++i) {
-        if (i < (int)cur.size()) {
-            const int n = (int)cur[i].prefix.size();
-            if (n > max_len) {
-                oe_set_error("oe_ctc_prefix_beam_host: prefix longer than max_len=%d", max_len);
-                return -1;
-            }
-            out_len_host[i] = n;
-            if (n) std::memcpy(out_prefix_host + (long)i * max_len, cur[i].prefix.data(), (size_t)n * sizeof(int));
-            out_score_host[i] = log_add2(cur[i].pb, cur[i].pnb);
-        } else {
-            out_len_host[i] = -1;
-            out_score_host[i] = NEG;
-        }
-    }
+    std::vector<std::thread> pool;
+    for (int i = 1; i < n_threads; ++i) pool.emplace_back(work);
+    work();
+    for (auto& th : pool) th.join();
+    if (failed.load()) { oe_set_error("oe_ctc_prefix_beam_host_batch: prefix longer than max_len=%d", max_len); return -1; }
     return 0;
 }

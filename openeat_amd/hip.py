@@ -129,6 +129,7 @@ _SIGNATURES = {
     "oe_fbank": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, P, P]),
     "oe_utt_normalize": (I, [P, P, I, I, I, P]),
     "oe_ctc_prefix_beam_host": (I, [P, P, I, I, I, P, P, P]),
+    "oe_ctc_prefix_beam_host_batch": (I, [P, P, I, I, P, I, I, P, P, P, I]),
     "oe_grad_norm_workspace_floats": (SZ, []),
     "oe_grad_norm": (I, [P, L, P, P, P]),
     "oe_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, P, P, P]),
@@ -237,6 +238,25 @@ def attention_fwd(a: AttnArgs):
 
 def attention_bwd(a: AttnArgs):
     check(lib().oe_attention_bwd(C.byref(a), stream()), "oe_attention_bwd")
+
+
+def ctc_prefix_beam_host_batch(top_logp: torch.Tensor, top_idx: torch.Tensor, lens, beam: int, n_threads: int = 0):
+    """top_logp (B, T, beam) float32 / top_idx (B, T, beam) int64 CPU tensors, lens[b] valid frames ->
+    per utterance [(prefix tuple, score)] (native host code, utterances spread over host threads)."""
+    import numpy as np
+    lp = np.ascontiguousarray(top_logp.numpy())
+    ix = np.ascontiguousarray(top_idx.numpy())
+    B, T = lp.shape[0], lp.shape[1]
+    ln = np.ascontiguousarray(np.asarray(lens, dtype=np.int32))
+    ml = max(T, 1)
+    prefixes = np.zeros((B, beam, ml), dtype=np.int32)
+    plen = np.zeros((B, beam), dtype=np.int32)
+    scores = np.zeros((B, beam), dtype=np.float64)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().oe_ctc_prefix_beam_host_batch(vp(lp), vp(ix), B, T, vp(ln), beam, ml, vp(prefixes), vp(plen), vp(scores), n_threads),
+          "oe_ctc_prefix_beam_host_batch")
+    return [[(tuple(int(v) for v in prefixes[b, i, : plen[b, i]]), float(scores[b, i])) for i in range(beam) if plen[b, i] >= 0]
+            for b in range(B)]
 
 
 def ctc_prefix_beam_host(top_logp: torch.Tensor, top_idx: torch.Tensor, beam: int):

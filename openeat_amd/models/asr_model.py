@@ -180,7 +180,7 @@ class ASRModel(torch.nn.Module):
         lens = encoder_mask.squeeze(1).sum(1)
         top_p, top_i = self.ctc.log_softmax(encoder_out).topk(beam_size, dim=2)
         top_p, top_i, lens_h = top_p.cpu(), top_i.cpu(), lens.cpu().tolist()
-        nbest = [hip.ctc_prefix_beam_host(top_p[b, : lens_h[b]], top_i[b, : lens_h[b]], beam_size) for b in range(B)]
+        nbest = hip.ctc_prefix_beam_host_batch(top_p, top_i, lens_h, beam_size)
         for b in range(B):                                     # a very short utterance can yield fewer than `beam` prefixes
             while len(nbest[b]) < beam_size:
                 nbest[b].append((nbest[b][-1][0], -float("inf")))

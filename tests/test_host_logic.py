@@ -147,3 +147,28 @@ def test_native_prefix_beam_search_host_code():
         assert [p for p, _ in got] == [p for p, _ in want]
         for (_, a), (_, b) in zip(got, want):
             assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+
+
+def test_native_prefix_beam_search_batch_matches_per_utterance_and_oracle():
+    """The threaded batch entry (ragged lengths, long emitting utterances) gives, per utterance, exactly what the
+    single-utterance entry and the oracle give."""
+    from openeat_amd import hip
+    from oracle import asr as O
+    torch.manual_seed(41)
+    B, T, V, beam = 9, 60, 30, 5
+    logits = torch.randn(B, T, V) * 3
+    logits[:, :, 0] -= 2.0                      # few blanks: prefixes grow to tens of tokens
+    logits[4] = (logits[4] * 2).round() / 2     # exact ties
+    logp = torch.log_softmax(logits, -1)
+    lens = [60, 1, 37, 60, 59, 0, 12, 60, 45]
+    tp, ti = logp.topk(beam, dim=2)
+    got = hip.ctc_prefix_beam_host_batch(tp, ti, lens, beam, n_threads=4)
+    assert len(got) == B
+    for b in range(B):
+        one = hip.ctc_prefix_beam_host(tp[b, : lens[b]].contiguous(), ti[b, : lens[b]].contiguous(), beam)
+        assert got[b] == one
+        want = O.prefix_beam_from_logp(logp[b, : lens[b]], beam)
+        assert [p for p, _ in got[b]] == [p for p, _ in want]
+        for (_, a), (_, w) in zip(got[b], want):
+            assert abs(a - w) <= 1e-12 * max(1.0, abs(w))
+    assert max(len(p) for p, _ in got[0]) > 20
