@@ -278,6 +278,16 @@ int oe_fbank(const float* wav, const int* nsamples, int B, long wav_stride, int 
  * (feature_processor.py:5-8: population std, no epsilon). */
 int oe_utt_normalize(float* x, const int* nframes, int B, int Tmax, int F, void* stream);
 
+/* SpecAugment masks (feature_processor.py:10-43) on the padded batch, in place: for utterance b the frames
+ * [t_masks[b][k][0], t_masks[b][k][1]) and the bins [f_masks[b][k][0], f_masks[b][k][1]) become `value`
+ * (SPEC_MASK = 0); only the utterance's own nframes[b] frames are touched.  The (start, end) pairs are drawn on
+ * the host in the reference's order (openeat_amd/augment.py), which makes the result bit-identical for a given seed. */
+int oe_spec_augment(float* x, const int* nframes, int B, int Tmax, int F, const int* t_masks, int nt, const int* f_masks,
+                    int nf, float value, void* stream);
+/* Spec-substitute (feature_processor.py:45-64): subs (B, ns, 3) = (start, end, pos); rows [start, end) are replaced
+ * by rows [start - pos, end - pos), one substitution after the other; end - start <= max_rows. */
+int oe_spec_substitute(float* x, int B, int Tmax, int F, const int* subs, int ns, int max_rows, void* stream);
+
 /* CTC prefix beam search, HOST code (all pointers are host pointers): the per-frame recursion of
  * asr_model.py:359-396 on the top-`beam` (log-prob, token) pairs of every frame (computed on the
  * device).  Doubles and insertion-ordered stable pruning as in the reference's Python, so the

@@ -128,6 +128,8 @@ _SIGNATURES = {
     "oe_lsm_loss_fused": (I, [P, L, L, I, P, I, F, I, F, F, I, P, P, P]),
     "oe_fbank": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, P, P]),
     "oe_utt_normalize": (I, [P, P, I, I, I, P]),
+    "oe_spec_augment": (I, [P, P, I, I, I, P, I, P, I, F, P]),
+    "oe_spec_substitute": (I, [P, I, I, I, P, I, I, P]),
     "oe_ctc_prefix_beam_host": (I, [P, P, I, I, I, P, P, P]),
     "oe_ctc_prefix_beam_host_batch": (I, [P, P, I, I, P, I, I, P, P, P, I]),
     "oe_grad_norm_workspace_floats": (SZ, []),

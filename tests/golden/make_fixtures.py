@@ -224,6 +224,23 @@ def f16_encoder_linear_input():
                       "out": {"y": y, "mask": ymask, "pos": pos}, "grad": {**grads_of(enc, "encoder."), "x": x.grad}})
 
 
+def f17_spec_augment():
+    """feature_processor.py:10-64 in CollateFunc's order (dataset.py:203-209) with a fixed python-random seed."""
+    import random
+    from openeat.dataset.feature_processor import _spec_augmentation, _spec_substitute
+    rng = np.random.RandomState(17)
+    xs = [rng.randn(t, 80).astype(np.float32) for t in (57, 40, 23)]
+    sub_conf = dict(max_t=20, num_t_sub=3)
+    aug_conf = dict(num_t_mask=2, num_f_mask=2, max_t=50, max_f=10)         # conf/train.yaml:51-56
+    random.seed(17)
+    ys = [_spec_substitute(x, **sub_conf) for x in xs]
+    ys = [_spec_augmentation(y, **aug_conf) for y in ys]
+    random.seed(18)
+    zs = [_spec_augmentation(x, num_t_mask=3, num_f_mask=1, max_t=10, max_f=30) for x in xs]
+    save("f17_spec_augment", **{"in": {f"x{i}": x for i, x in enumerate(xs)}, "out": {f"y{i}": y for i, y in enumerate(ys)},
+                                "out_aug_only": {f"z{i}": z for i, z in enumerate(zs)}})
+
+
 def f7_ctc():
     torch.manual_seed(107)
     V, D, B, T = 20, 16, 5, 12
@@ -440,4 +457,4 @@ if __name__ == "__main__":
     else:
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
-        f16_encoder_linear_input()
+        f16_encoder_linear_input(); f17_spec_augment()

@@ -192,3 +192,42 @@ def test_arena_with_bf16_gemms_and_fused_bias_gradients(prec):
         scale = max(1e-3, float(p1.grad.abs().max()))
         err = float((p2.grad - p1.grad).abs().max()) / scale
         assert err <= (5e-3 if prec == 3 else 0.25), (k, err)
+
+
+def test_spec_augment_on_device_matches_reference_bit_for_bit():
+    """SpecAugment + spec-substitute on the padded batch (kernels in augment.hip, draws on the host in the reference's
+    order): identical to the reference's per-utterance numpy result for the same random seed; padding untouched."""
+    import random
+    from conftest import load_golden
+    from openeat_amd.augment import spec_augment_, spec_substitute_
+    g = load_golden("f17_spec_augment")
+    xs = [g["in"][f"x{i}"] for i in range(3)]
+    lens = [x.shape[0] for x in xs]
+    Tmax = max(lens) + 5
+
+    def batch():
+        b = torch.full((3, Tmax, 80), 7.0)
+        for i, x in enumerate(xs):
+            b[i, : lens[i]] = x
+        return b.to(DEV)
+    random.seed(17)
+    y = spec_augment_(spec_substitute_(batch(), lens, max_t=20, num_t_sub=3), lens, num_t_mask=2, num_f_mask=2, max_t=50, max_f=10).cpu()
+    for i in range(3):
+        assert torch.equal(y[i, : lens[i]], g["out"][f"y{i}"])
+        assert bool((y[i, lens[i]:] == 7.0).all())
+    random.seed(18)
+    z = spec_augment_(batch(), lens, num_t_mask=3, num_f_mask=1, max_t=10, max_f=30).cpu()
+    for i in range(3):
+        assert torch.equal(z[i, : lens[i]], g["out_aug_only"][f"z{i}"])
+    # config-2 size (32 x 998 x 80): masked cells are exactly the union of the drawn stripes
+    torch.manual_seed(0)
+    big = torch.randn(32, 998, 80, device=DEV) + 3.0
+    ref = big.clone()
+    random.seed(5)
+    out = spec_augment_(big, [998] * 32).cpu()
+    zero = out == 0
+    assert 0.02 < float(zero.float().mean()) < 0.35
+    assert torch.equal(out[~zero], ref.cpu()[~zero])
+    rows_all = zero.all(2)
+    cols_all = zero.all(1)
+    assert bool((zero == (rows_all[:, :, None] | cols_all[:, None, :])).all())

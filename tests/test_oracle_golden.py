@@ -297,3 +297,20 @@ def test_fbank_cross_check_transformers():
                             log_mel="log", mel_floor=1.192092955078125e-07, remove_dc_offset=True).T
     assert mine.shape == (98, 80) and theirs.shape == (98, 80)
     np.testing.assert_allclose(mine.numpy(), theirs, rtol=2e-4, atol=2e-3)
+
+
+def test_f17_spec_augment_and_substitute():
+    """oracle/augment.py against the reference's own output for the same python-random seed."""
+    import random
+    from oracle import augment as A
+    g = load_golden("f17_spec_augment")
+    xs = [g["in"][f"x{i}"].numpy() for i in range(3)]
+    random.seed(17)
+    ys = A.collate_augment(xs, dict(max_t=20, num_t_sub=3), dict(num_t_mask=2, num_f_mask=2, max_t=50, max_f=10))
+    for i, y in enumerate(ys):
+        assert np.array_equal(y, g["out"][f"y{i}"].numpy())
+    random.seed(18)
+    zs = A.collate_augment(xs, None, dict(num_t_mask=3, num_f_mask=1, max_t=10, max_f=30))
+    for i, z in enumerate(zs):
+        assert np.array_equal(z, g["out_aug_only"][f"z{i}"].numpy())
+    assert any((y == 0).all(axis=1).any() for y in ys)              # some frame really is masked
