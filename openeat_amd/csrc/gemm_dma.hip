@@ -261,8 +261,10 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     // K >= 512; short-K x @ W^T problems are epilogue/launch bound and run faster at 2-4 co-resident blocks per CU.
     // ... and problems too small to put more than one 64x64 block on a CU: nothing overlaps a block's own memory
     // latency there except the ring (decoder-side GEMMs, M = B*(L+1) rows; linear_pos, M = T rows).
+    // ... and very wide outputs (the vocabulary projections): many column blocks re-read the same rows of A.
     const bool small = (long)oe_cdiv(M, 64) * oe_cdiv(N, 64) * sk <= 256;
-    if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small) return 1;
+    const bool wide = N >= 2048 && !a_kmajor;
+    if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small && !wide) return 1;
     if (tile == 12) tile = 11;
     const int bm = 64 * (tile / 10), bn = 64 * (tile % 10);
     // pieces are 16 bytes: K a multiple of the K-tile; a k-major operand's row length (M resp. N) a multiple of 4.
@@ -287,11 +289,19 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     int kc = oe_cdiv(oe_cdiv(K, sk), DBK) * DBK;
     if (kc <= 0) kc = DBK;
     const int nz = oe_cdiv(K, kc);
+    // ring depth: long reductions keep three tiles in flight at one 128x128 block per CU (96 KiB of LDS); short ones
+    // (K of a few tiles) do better with two stages = two blocks per CU, whose prologues/epilogues overlap
+    static const int forced_nst = getenv("OE_DMA_NST") ? atoi(getenv("OE_DMA_NST")) : 0;       // tuning
+    const int nst = forced_nst ? forced_nst : (tile == 11 ? 4 : (kc >= 512 ? 3 : 2));   // 64x64 tiles: 4 stages are still 64 KiB
 #define OE_DMA_T(AK, BKM, T)                                                                                         \
     do {                                                                                                             \
         if (tile == 42) return launch_dma<4, 2, AK, BKM, T, 3>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
+        if (tile == 22 && nst == 2) return launch_dma<2, 2, AK, BKM, T, 2>(A, B, C, ldc, M, N, K, kc, nz, ep, st);   \
+        if (tile == 22 && nst == 3) return launch_dma<2, 2, AK, BKM, T, 3>(A, B, C, ldc, M, N, K, kc, nz, ep, st);   \
         if (tile == 22) return launch_dma<2, 2, AK, BKM, T, 4>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
         if (tile == 21) return launch_dma<2, 1, AK, BKM, T, 4>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
+        if (tile == 11 && nst == 2) return launch_dma<1, 1, AK, BKM, T, 2>(A, B, C, ldc, M, N, K, kc, nz, ep, st);   \
+        if (tile == 11 && nst == 3) return launch_dma<1, 1, AK, BKM, T, 3>(A, B, C, ldc, M, N, K, kc, nz, ep, st);   \
         if (tile == 11) return launch_dma<1, 1, AK, BKM, T, 4>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
         return 1;                                                                                                    \
     } while (0)
