@@ -136,7 +136,7 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the attention-rescoring RTF measurement")
     ap.add_argument("--decode-utts", type=int, default=64)
     ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     args = ap.parse_args()
 
     from openeat_amd import ddp, hip
