@@ -71,8 +71,9 @@ __device__ __forceinline__ void col_frag(const float* tile, int col, int s, int 
     for (int e = 0; e < 8; ++e) x[e] = tile[((e & 3) + 8 * (2 * s + (e >> 2)) + 4 * g) * LD + col];
     bsplit<TERMS>(x, f);
 }
-#define ATT_WAVES 2
-#define ATT_THREADS (64 * ATT_WAVES)
+#define ATT_WAVES 2                       // 32-row tiles (queries, or keys in the dK/dV kernel) per block
+#define ATT_GROUP (64 * ATT_WAVES)        // threads of one wave group: they stage and consume the same LDS tiles
+#define ATT_MAX_SPLIT 2                   // wave groups that share the reduction loop of a tile (template parameter SPLIT)
 
 struct AttnParams {
     const float* q; long q_bs, q_rs;     // batch stride, row (time) stride; head h at +h*D
@@ -97,11 +98,18 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, 
 
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
+// Work split.  B*H*ceil(T/32) tiles are only ~1000 waves at the path's sizes - one per SIMD, each a serial chain
+// over the other sequence axis.  A tile's chain can be cut in SPLIT parts run by different wave groups of the same
+// block (keys for forward / dQ, queries for dK/dV) and merged through LDS at the end (online-softmax merge of
+// (m, l, O) for the forward, plain sums for the gradients); thread t belongs to group t / ATT_GROUP.  Measured at
+// config 2: the forward gains 22 % from SPLIT = 2, the two backward kernels (VALU-bound on the bf16 fragment
+// splits, so a second wave per SIMD only competes for the same pipe) lose 7-14 % and stay at SPLIT = 1.
+//
 // A [32][DPAD] tile travels global -> registers (issued early) -> LDS (row stride LD, written late):
 // the global latency of tile j+1 hides under the MFMA/softmax work of tile j.
 template <int DPAD>
 struct TileRegs {
-    static constexpr int N = 32 * (DPAD / 4) / ATT_THREADS;
+    static constexpr int N = 32 * (DPAD / 4) / ATT_GROUP;
     float4 v[N];
 };
 
@@ -110,7 +118,7 @@ __device__ __forceinline__ void tile_load(TileRegs<DPAD>& t, const float* src, l
     const bool vec = (rs % 4 == 0) && ((((uintptr_t)src) & 15) == 0) && (D % 4 == 0);
 #pragma unroll
     for (int i = 0; i < TileRegs<DPAD>::N; ++i) {
-        const int e = threadIdx.x + i * ATT_THREADS;
+        const int e = (threadIdx.x % ATT_GROUP) + i * ATT_GROUP;
         const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
         float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
         const int gr = r0 + row;
@@ -127,7 +135,7 @@ template <int DPAD, int LD>
 __device__ __forceinline__ void tile_store(const TileRegs<DPAD>& t, float* dst) {
 #pragma unroll
     for (int i = 0; i < TileRegs<DPAD>::N; ++i) {
-        const int e = threadIdx.x + i * ATT_THREADS;
+        const int e = (threadIdx.x % ATT_GROUP) + i * ATT_GROUP;
         const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
         float* d = dst + row * LD + c4;
         d[0] = t.v[i].x; d[1] = t.v[i].y; d[2] = t.v[i].z; d[3] = t.v[i].w;
@@ -145,15 +153,18 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs
 
 // ------------------------------------------------------------------ forward --
 // MODE 0: forward (writes O, LSE).  MODE 1: dQ (reads dO, LSE, delta; writes dQ).
-template <int DPAD, int MODE, int TERMS>
-__global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
+template <int DPAD, int MODE, int TERMS, int SPLIT>
+__global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParams p) {
     constexpr int LD = DPAD + 1;
     constexpr int DT = DPAD / 32;
     constexpr int KS = DPAD / 16;            // bf16 k-steps over the features
-    __shared__ float Ks[32 * LD];
-    __shared__ float Vs[32 * LD];
-    __shared__ float kb_s[32];           // per-key bias of the tile; -inf marks a key masked for every query
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float KVs[SPLIT][2][32 * LD];         // [group][K | V] tiles; reused as the merge buffer at the end
+    __shared__ float kbs[SPLIT][32];                 // per-key bias of the tile; -inf marks a key masked for every query
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % ATT_WAVES, grp = threadIdx.x / ATT_GROUP;
+    const int gtid = threadIdx.x % ATT_GROUP;
+    float* Ks = KVs[grp][0];
+    float* Vs = KVs[grp][1];
+    float* kb_s = kbs[grp];
     const int lq = lane & 31, lk = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int q0 = (blockIdx.x * ATT_WAVES + wave) * 32;
@@ -209,21 +220,26 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
     auto prefetch = [&](int j0) {
         tile_load<DPAD>(kreg, kb, p.k_rs, j0, p.T2, p.D);
         tile_load<DPAD>(vreg, vb, p.v_rs, j0, p.T2, p.D);
-        if (threadIdx.x < 32) {
-            const int kj = j0 + threadIdx.x;
+        if (gtid < 32) {
+            const int kj = j0 + gtid;
             float v = NEG_INF;
             if (kj < p.T2 && (!key_mask || p.mask[(long)b * p.m_bs + kj] != 0)) v = p.keybias ? p.keybias[bh * p.T2 + kj] : 0.f;
             kb_next = v;
         }
     };
-    prefetch(0);
-    for (int j0 = 0; j0 < p.T2; j0 += 32) {
+    // this group's share of the key tiles: [grp * per, (grp + 1) * per); tiles past T2 are all-masked (bias -inf) and
+    // every group runs the same number of iterations (block-wide barriers inside)
+    const int per = (((p.T2 + 31) >> 5) + SPLIT - 1) / SPLIT;
+    const int j_begin = grp * per * 32;
+    prefetch(j_begin);
+    for (int it = 0; it < per; ++it) {
+        const int j0 = j_begin + it * 32;
         __syncthreads();
         tile_store<DPAD, LD>(kreg, Ks);
         tile_store<DPAD, LD>(vreg, Vs);
-        if (threadIdx.x < 32) kb_s[threadIdx.x] = kb_next;
+        if (gtid < 32) kb_s[gtid] = kb_next;
         __syncthreads();
-        if (j0 + 32 < p.T2) prefetch(j0 + 32);
+        if (it + 1 < per) prefetch(j0 + 32);
         // S^T[key, query]
         f32x16 sacc;
 #pragma unroll
@@ -371,8 +387,35 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
             }
         }
     }
-    // ---- write back: lane = query, accumulator rows = feature index
+    if constexpr (SPLIT == 2) {
+        // ---- merge the key halves: group 1 parks (m, l, O^T) / dQ^T in LDS, group 0 combines and writes
+        __syncthreads();                               // every wave is done with the K/V tiles the buffer overlays
+        float* mb = &KVs[0][0][0] + wave * (DPAD * 32 + 64);      // [DPAD rows][32 queries] + m[32] + l[32] per q-tile
+        if (grp == 1) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mb[(t * 32 + acc_row(r, lk)) * 32 + lq] = oacc[t][r];
+            if (MODE == 0 && lk == 0) { mb[DPAD * 32 + lq] = m_run; mb[DPAD * 32 + 32 + lq] = l_run; }
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        float a1 = 1.f, a2 = 1.f;
+        if (MODE == 0) {
+            const float m2 = mb[DPAD * 32 + lq], l2 = mb[DPAD * 32 + 32 + lq];
+            const float m = fmaxf(m_run, m2);
+            a1 = (m_run == NEG_INF) ? 0.f : __expf(m_run - m);
+            a2 = (m2 == NEG_INF) ? 0.f : __expf(m2 - m);
+            l_run = l_run * a1 + l2 * a2;
+            m_run = m;
+        }
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[t][r] = oacc[t][r] * a1 + mb[(t * 32 + acc_row(r, lk)) * 32 + lq] * a2;
+    }
     if (!q_ok) return;
+    // ---- write back: lane = query, accumulator rows = feature index
     float mul;
     float* dst;
     if (MODE == 0) {
@@ -393,15 +436,19 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_qtile_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------- dK / dV -------
-template <int DPAD, int TERMS>
-__global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams p) {
+template <int DPAD, int TERMS, int SPLIT>
+__global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnParams p) {
     constexpr int LD = DPAD + 1;
     constexpr int DT = DPAD / 32;
     constexpr int KS = DPAD / 16;
-    __shared__ float Qs[32 * LD];
-    __shared__ float Os[32 * LD];      // dO tile
-    __shared__ float lse_s[32], delta_s[32];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ float QOs[SPLIT][2][32 * LD];         // [group][Q | dO] tiles; reused as the merge buffer at the end
+    __shared__ float lds_s[SPLIT][2][32];            // [group][lse | delta]
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % ATT_WAVES, grp = threadIdx.x / ATT_GROUP;
+    const int gtid = threadIdx.x % ATT_GROUP;
+    float* Qs = QOs[grp][0];
+    float* Os = QOs[grp][1];
+    float* lse_s = lds_s[grp][0];
+    float* delta_s = lds_s[grp][1];
     const int lj = lane & 31, lk = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int k0 = (blockIdx.x * ATT_WAVES + wave) * 32;
@@ -445,16 +492,28 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
     const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
     const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
 
-    for (int i0 = 0; i0 < p.T1; i0 += 32) {
-        __syncthreads();
-        stage_tile<DPAD, LD>(Qs, qb, p.q_rs, i0, p.T1, p.D, 1.f);
-        stage_tile<DPAD, LD>(Os, dob, p.o_rs, i0, p.T1, p.D, 1.f);
-        if (threadIdx.x < 32) {
-            const int qi = i0 + threadIdx.x;
-            lse_s[threadIdx.x] = qi < p.T1 ? p.lse[bh * p.T1 + qi] : 0.f;
-            delta_s[threadIdx.x] = qi < p.T1 ? p.delta[bh * p.T1 + qi] : 0.f;
+    // this group's share of the query tiles; tiles past T1 contribute nothing (ok = false for every element)
+    const int per = (((p.T1 + 31) >> 5) + SPLIT - 1) / SPLIT;
+    TileRegs<DPAD> qreg, oreg;
+    float lse_next = 0.f, delta_next = 0.f;
+    auto prefetch = [&](int i0) {
+        tile_load<DPAD>(qreg, qb, p.q_rs, i0, p.T1, p.D);
+        tile_load<DPAD>(oreg, dob, p.o_rs, i0, p.T1, p.D);
+        if (gtid < 32) {
+            const int qi = i0 + gtid;
+            lse_next = qi < p.T1 ? p.lse[bh * p.T1 + qi] : 0.f;
+            delta_next = qi < p.T1 ? p.delta[bh * p.T1 + qi] : 0.f;
         }
+    };
+    prefetch(grp * per * 32);
+    for (int it = 0; it < per; ++it) {
+        const int i0 = (grp * per + it) * 32;
         __syncthreads();
+        tile_store<DPAD, LD>(qreg, Qs);
+        tile_store<DPAD, LD>(oreg, Os);
+        if (gtid < 32) { lse_s[gtid] = lse_next; delta_s[gtid] = delta_next; }
+        __syncthreads();
+        if (it + 1 < per) prefetch(i0 + 32);
         f32x16 sacc, dpacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
@@ -519,6 +578,32 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_ktile_bwd_kernel(AttnParams 
         }
     }
     dbias += __shfl_xor(dbias, 32, 64);
+    if constexpr (SPLIT == 2) {
+        // ---- merge the query halves: group 1 parks dK^T, dV^T and the bias gradient in LDS, group 0 adds
+        __syncthreads();
+        float* mb = &QOs[0][0][0] + wave * (2 * DPAD * 32);        // [dK | dV][DPAD rows][32 keys] per key tile
+        float* mbias = &lds_s[0][0][0] + wave * 32;
+        if (grp == 1) {
+#pragma unroll
+            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    mb[(t * 32 + acc_row(r, lk)) * 32 + lj] = dkacc[t][r];
+                    mb[DPAD * 32 + (t * 32 + acc_row(r, lk)) * 32 + lj] = dvacc[t][r];
+                }
+            if (lk == 0) mbias[lj] = dbias;
+        }
+        __syncthreads();
+        if (grp == 1) return;
+        dbias += mbias[lj];
+#pragma unroll
+        for (int t = 0; t < DT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                dkacc[t][r] += mb[(t * 32 + acc_row(r, lk)) * 32 + lj];
+                dvacc[t][r] += mb[DPAD * 32 + (t * 32 + acc_row(r, lk)) * 32 + lj];
+            }
+    }
     if (!k_ok) return;
     if (p.dkeybias && lk == 0) p.dkeybias[bh * p.T2 + kj] = dbias;
     float* dkd = p.dk + (long)b * p.k_bs + (long)kj * p.k_rs + h * p.D;
@@ -585,8 +670,8 @@ extern "C" int oe_attention_fwd(const oe_attn_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
 #define ATT_FWD(TT)                                                                                       \
     do {                                                                                                  \
-        if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0, TT>), grid, dim3(ATT_THREADS), 0, st, p); \
-        else hipLaunchKernelGGL((attn_qtile_kernel<64, 0, TT>), grid, dim3(ATT_THREADS), 0, st, p);        \
+        if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0, TT, 2>), grid, dim3(ATT_GROUP * 2), 0, st, p); \
+        else hipLaunchKernelGGL((attn_qtile_kernel<64, 0, TT, 2>), grid, dim3(ATT_GROUP * 2), 0, st, p);        \
     } while (0)
     if (a->precision == 3) ATT_FWD(3); else if (a->precision == 1) ATT_FWD(1); else ATT_FWD(0);
 #undef ATT_FWD
@@ -606,11 +691,11 @@ extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
 #define ATT_BWD(TT)                                                                                       \
     do {                                                                                                  \
         if (p.D <= 32) {                                                                                  \
-            hipLaunchKernelGGL((attn_qtile_kernel<32, 1, TT>), gq, dim3(ATT_THREADS), 0, st, p);          \
-            hipLaunchKernelGGL((attn_ktile_bwd_kernel<32, TT>), gk, dim3(ATT_THREADS), 0, st, p);         \
+            hipLaunchKernelGGL((attn_qtile_kernel<32, 1, TT, 1>), gq, dim3(ATT_GROUP), 0, st, p);         \
+            hipLaunchKernelGGL((attn_ktile_bwd_kernel<32, TT, 1>), gk, dim3(ATT_GROUP), 0, st, p);        \
         } else {                                                                                          \
-            hipLaunchKernelGGL((attn_qtile_kernel<64, 1, TT>), gq, dim3(ATT_THREADS), 0, st, p);          \
-            hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, TT>), gk, dim3(ATT_THREADS), 0, st, p);         \
+            hipLaunchKernelGGL((attn_qtile_kernel<64, 1, TT, 1>), gq, dim3(ATT_GROUP), 0, st, p);         \
+            hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, TT, 1>), gk, dim3(ATT_GROUP), 0, st, p);        \
         }                                                                                                 \
     } while (0)
     if (a->precision == 3) ATT_BWD(3); else if (a->precision == 1) ATT_BWD(1); else ATT_BWD(0);
