@@ -246,7 +246,18 @@ def main():
         recs, hip.PROFILE = hip.PROFILE, None
         recs = recs[len(recs) // 2:]                            # second step only
         flops = sum(r[2] for r in recs)
-        secs = sum(r[0].elapsed_time(r[1]) for r in recs) * 1e-3
+        # an event pair itself occupies the queue for a few microseconds: measure empty pairs the same way (GPU parked,
+        # pairs back to back) and take that out of every launch interval
+        torch.cuda._sleep(int(1.0e8))
+        empty = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            empty.append((e0, e1))
+        torch.cuda.synchronize()
+        pair_ms = sorted(a.elapsed_time(b) for a, b in empty)[len(empty) // 2]
+        secs = sum(max(r[0].elapsed_time(r[1]) - pair_ms, 0.0) for r in recs) * 1e-3
         ach = flops / secs / 1e12
         if args.gemm_table:                                      # per-problem breakdown of the step's GEMM launches (stderr)
             by = {}
@@ -271,7 +282,8 @@ def main():
         roof = {"kernel": KERNEL_NAMES[prec], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                 "frac": ach / peak, "traffic": traffic, "launches_per_step": len(recs),
                 "avg_launch_us": secs / max(len(recs), 1) * 1e6, "gemm_ms_per_step": secs * 1e3,
-                "algorithmic_gflop_per_step": flops / 1e9, "mfma_issue_tflops": mfma_flops / secs / 1e12}
+                "algorithmic_gflop_per_step": flops / 1e9, "mfma_issue_tflops": mfma_flops / secs / 1e12,
+                "event_pair_overhead_us": pair_ms * 1e3}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -4,6 +4,8 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 with open(path) as f:
     for r in csv.DictReader(f):
         name = r.get("Kernel_Name") or r.get("Name")
+        if "spin_kernel" in name:          # torch.cuda._sleep: parks the GPU during bench.py's event-bracketed steps
+            continue
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         name = re.sub(r"\(.*", "", name)[:110]
         agg[name][0] += 1; agg[name][1] += d
