@@ -28,6 +28,25 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define NEG_INF (-INFINITY)
 
+// Diagnostic build only (-DOE_GEMM_STAMPS, tools/attn_stamps.py): s_memtime sums per phase of the forward kernel.
+#ifdef OE_GEMM_STAMPS
+static __device__ unsigned long long* oe_attn_stamp_buf = nullptr;
+extern "C" int oe_debug_set_attn_stamp_buffer(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(oe_attn_stamp_buf), &p, sizeof(p));
+}
+#define ATT_NOW(var)                                                                         \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#define ATT_ACC(slot, t0)                                                                    \
+    do { unsigned long long t1_; ATT_NOW(t1_); att_acc[slot] += t1_ - t0; t0 = t1_; } while (0)
+#else
+#define ATT_NOW(var) do { } while (0)
+#define ATT_ACC(slot, t0) do { } while (0)
+#endif
+
 // ---- bf16 matrix-core variants (TERMS = 1: bf16 products; TERMS = 3: hi*hi + hi*lo + lo*hi, fp32-grade) ----
 // v_mfma_f32_32x32x16_bf16: lane (i = lane&31, g = lane>>5) supplies 8 consecutive k-slots 8g..8g+7 of row i (A) /
 // column i (B).  The k-slot -> (feature | key | query) assignment is free as long as A and B agree, so
@@ -98,6 +117,54 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, 
 
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
+// ---- dropout of the attention weights -------------------------------------------------------------------------
+// Element (b, h, query i, key j) has index idx = ((b*H + h)*T1 + i)*T2 + j.  Philox call idx >> 3 yields eight 16-bit
+// fields for the eight consecutive elements of its block; element idx keeps iff field (idx & 7) >= thr, thr =
+// round(p * 65536) (the keep scale is 65536 / (65536 - thr), the exact inverse of the realised keep probability).
+// RNG was ~half of the forward and most of the dK/dV kernel when every lane generated the numbers for its own
+// registers; the lanes of a wave now share calls (T2 % 8 == 0: a block never straddles two query rows):
+//   * forward / dQ (lane = query, registers = keys): the lanes lk = 0 / 1 of a query hold the two halves of each
+//     8-key block - each computes two of the four blocks of a 32-key tile and swaps halves with its partner;
+//   * dK/dV (lane = key, registers = 16 queries): the eight lanes of a key block need the same 16 calls (one per
+//     query row) - each computes two and the fields are fetched with lane shuffles.
+// Any other T2 takes the per-element path (one call per element; same mask by definition).
+struct DropParams { unsigned thr; float inv_keep; };
+__device__ __forceinline__ DropParams drop_params(float p) {
+    DropParams d;
+    d.thr = (unsigned)(p * 65536.f + 0.5f);
+    d.inv_keep = 65536.f / (65536.f - (float)d.thr);
+    return d;
+}
+__device__ __forceinline__ float drop_field(unsigned w, int half, const DropParams& d) {
+    return ((w >> (16 * half)) & 0xFFFFu) >= d.thr ? d.inv_keep : 0.f;
+}
+__device__ __forceinline__ float drop_elem(unsigned long long seed, unsigned long long idx, const DropParams& d) {
+    const uint4 r = philox4(seed, idx >> 3);
+    const int f = (int)(idx & 7);
+    const unsigned w = (f >> 1) == 0 ? r.x : (f >> 1) == 1 ? r.y : (f >> 1) == 2 ? r.z : r.w;
+    return drop_field(w, f & 1, d);
+}
+// forward / dQ: scales for this lane's 16 registers (keys j0 + acc_row(r, lk)) of query row `rowbase / T2`
+__device__ __forceinline__ void drop_tile_qlane(unsigned long long seed, unsigned long long rowbase, int j0, int lk, bool aligned,
+                                                const DropParams& d, float (&m)[16]) {
+    if (aligned) {
+        const unsigned long long blk = (rowbase + j0) >> 3;
+        const uint4 ca = philox4(seed, blk + lk), cb = philox4(seed, blk + 2 + lk);     // blocks g = lk and g = 2 + lk
+        const unsigned r0 = __shfl_xor(lk ? ca.x : ca.z, 32, 64), r1 = __shfl_xor(lk ? ca.y : ca.w, 32, 64);
+        const unsigned r2 = __shfl_xor(lk ? cb.x : cb.z, 32, 64), r3 = __shfl_xor(lk ? cb.y : cb.w, 32, 64);
+        unsigned w[4][2];                                                                 // [block g][word of this lane's half]
+        w[0][0] = lk ? r0 : ca.x; w[0][1] = lk ? r1 : ca.y;
+        w[1][0] = lk ? ca.z : r0; w[1][1] = lk ? ca.w : r1;
+        w[2][0] = lk ? r2 : cb.x; w[2][1] = lk ? r3 : cb.y;
+        w[3][0] = lk ? cb.z : r2; w[3][1] = lk ? cb.w : r3;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = drop_field(w[r >> 2][(r & 3) >> 1], r & 1, d);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m[r] = drop_elem(seed, rowbase + j0 + acc_row(r, lk), d);
+    }
+}
+
 // Work split.  B*H*ceil(T/32) tiles are only ~1000 waves at the path's sizes - one per SIMD, each a serial chain
 // over the other sequence axis.  A tile's chain can be cut in SPLIT parts run by different wave groups of the same
 // block (keys for forward / dQ, queries for dK/dV) and merged through LDS at the end (online-softmax merge of
@@ -153,8 +220,10 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs
 
 // ------------------------------------------------------------------ forward --
 // MODE 0: forward (writes O, LSE).  MODE 1: dQ (reads dO, LSE, delta; writes dQ).
+// (second launch bound = waves per SIMD the register allocation must leave room for: the split forward needs two
+// of its four-wave blocks per CU to have all 512 blocks of config 2 resident at once)
 template <int DPAD, int MODE, int TERMS, int SPLIT>
-__global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(AttnParams p) {
     constexpr int LD = DPAD + 1;
     constexpr int DT = DPAD / 32;
     constexpr int KS = DPAD / 16;            // bf16 k-steps over the features
@@ -208,13 +277,20 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParam
     for (int t = 0; t < DT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
-    const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const DropParams dpar = drop_params(p.drop_p);
+    const bool drop_aligned = (p.T2 % 8) == 0;
+    const unsigned long long drop_rowbase = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2;
     const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
     // a (B,1,T2) key mask is the same for every query: fold it into the staged per-key bias;
     // only a full (B,T1,T2) mask (decoder self-attention) is read per (query, key)
     const bool key_mask = p.mask && p.m_rs == 0;
     const unsigned char* mrow = (p.mask && !key_mask) ? p.mask + (long)b * p.m_bs + (long)(q_ok ? qi : 0) * p.m_rs : nullptr;
 
+#ifdef OE_GEMM_STAMPS
+    unsigned long long att_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, att_t = 0, att_t0 = 0;
+    ATT_NOW(att_t0);
+    att_t = att_t0;
+#endif
     TileRegs<DPAD> kreg, vreg;
     float kb_next = 0.f;
     auto prefetch = [&](int j0) {
@@ -232,14 +308,18 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParam
     const int per = (((p.T2 + 31) >> 5) + SPLIT - 1) / SPLIT;
     const int j_begin = grp * per * 32;
     prefetch(j_begin);
+    ATT_ACC(0, att_t);                                  // prologue: Q fragments, first prefetch issue
     for (int it = 0; it < per; ++it) {
         const int j0 = j_begin + it * 32;
         __syncthreads();
+        ATT_ACC(1, att_t);                              // wait at the first barrier
         tile_store<DPAD, LD>(kreg, Ks);
         tile_store<DPAD, LD>(vreg, Vs);
         if (gtid < 32) kb_s[gtid] = kb_next;
         __syncthreads();
+        ATT_ACC(2, att_t);                              // tile store (waits for the prefetched data) + second barrier
         if (it + 1 < per) prefetch(j0 + 32);
+        ATT_ACC(3, att_t);                              // prefetch issue
         // S^T[key, query]
         f32x16 sacc;
 #pragma unroll
@@ -256,6 +336,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParam
                 sacc = bmma<TERMS>(a, qfr[s], sacc);
             }
         }
+        ATT_ACC(4, att_t);                              // S fragments + MFMAs (issue)
         float pr[16];
         float tmax = NEG_INF;
 #pragma unroll
@@ -285,18 +366,12 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParam
 #pragma unroll
                 for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
             if (p.drop_p > 0.f) {
+                float dm[16];
+                drop_tile_qlane(seed_eff, drop_rowbase, j0, lk, drop_aligned, dpar, dm);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {       // registers 4g..4g+3 are 4 consecutive keys
-                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(4 * g, lk));
-                    if ((idx & 3) == 0) {
-                        const float4 d4 = dropout_scale4(seed_eff, idx >> 2, p.drop_p, inv_keep);
-                        pr[4 * g] *= d4.x; pr[4 * g + 1] *= d4.y; pr[4 * g + 2] *= d4.z; pr[4 * g + 3] *= d4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) pr[4 * g + e] *= dropout_scale(seed_eff, idx + e, p.drop_p, inv_keep);
-                    }
-                }
+                for (int r = 0; r < 16; ++r) pr[r] *= dm[r];
             }
+            ATT_ACC(5, att_t);                          // softmax (waits for the S MFMAs)
             // O^T[dv, query] += V^T[dv, key] P^T[key, query]
             if constexpr (TERMS == 0) {
 #pragma unroll
@@ -342,19 +417,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParam
             float dmask[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dmask[r] = 1.f;
-            if (p.drop_p > 0.f) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const unsigned long long idx = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2 + (j0 + acc_row(4 * g, lk));
-                    if ((idx & 3) == 0) {
-                        const float4 d4 = dropout_scale4(seed_eff, idx >> 2, p.drop_p, inv_keep);
-                        dmask[4 * g] = d4.x; dmask[4 * g + 1] = d4.y; dmask[4 * g + 2] = d4.z; dmask[4 * g + 3] = d4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dmask[4 * g + e] = dropout_scale(seed_eff, idx + e, p.drop_p, inv_keep);
-                    }
-                }
-            }
+            if (p.drop_p > 0.f) drop_tile_qlane(seed_eff, drop_rowbase, j0, lk, drop_aligned, dpar, dmask);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = (pr[r] == NEG_INF) ? 0.f : __expf(pr[r] - lse_i);
@@ -387,6 +450,14 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_qtile_kernel(AttnParam
             }
         }
     }
+    ATT_ACC(6, att_t);                                  // last PV issue -> here (loop exit)
+#ifdef OE_GEMM_STAMPS
+    if (oe_attn_stamp_buf && MODE == 0 && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y < 4 && blockIdx.z < 32) {
+        unsigned long long* o = oe_attn_stamp_buf + (blockIdx.z * 4 + blockIdx.y) * 8;
+        for (int i = 0; i < 7; ++i) o[i] = att_acc[i];
+        o[7] = att_t - att_t0;
+    }
+#endif
     if constexpr (SPLIT == 2) {
         // ---- merge the key halves: group 1 parks (m, l, O^T) / dQ^T in LDS, group 0 combines and writes
         __syncthreads();                               // every wave is done with the K/V tiles the buffer overlays
@@ -489,7 +560,8 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
     float dbias = 0.f;
-    const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
+    const DropParams dpar = drop_params(p.drop_p);
+    const bool drop_aligned = (p.T2 % 8) == 0;
     const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
 
     // this group's share of the query tiles; tiles past T1 contribute nothing (ok = false for every element)
@@ -533,7 +605,31 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
                 dpacc = bmma<TERMS>(a, vfr[s], dpacc);
             }
         }
-        float pd[16], ds[16];
+        float pd[16], ds[16], dsc[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dsc[r] = 1.f;
+        if (p.drop_p > 0.f) {
+            if (drop_aligned) {
+                // the 8 lanes of a key block share 16 calls (one per query row of the tile): lane c computes rows c, c + 8
+                const int c = lj & 7;
+                const unsigned long long kblk = (unsigned long long)(k0 + (lj & ~7));
+                const unsigned long long rowa = (unsigned long long)(bh * p.T1 + min(i0 + acc_row(c, lk), p.T1 - 1)) * p.T2;
+                const unsigned long long rowb = (unsigned long long)(bh * p.T1 + min(i0 + acc_row(c + 8, lk), p.T1 - 1)) * p.T2;
+                const uint4 wa = philox4(seed_eff, (rowa + kblk) >> 3), wb = philox4(seed_eff, (rowb + kblk) >> 3);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int src = (lane & ~7) | (r & 7);
+                    const uint4 ws = (r < 8) ? wa : wb;
+                    const unsigned x0 = __shfl(ws.x, src, 64), x1 = __shfl(ws.y, src, 64), x2 = __shfl(ws.z, src, 64), x3 = __shfl(ws.w, src, 64);
+                    const unsigned w = (c >> 1) == 0 ? x0 : (c >> 1) == 1 ? x1 : (c >> 1) == 2 ? x2 : x3;
+                    dsc[r] = drop_field(w, c & 1, dpar);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    dsc[r] = drop_elem(seed_eff, ((unsigned long long)(bh * p.T1 + min(i0 + acc_row(r, lk), p.T1 - 1))) * p.T2 + min(kj, p.T2 - 1), dpar);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = acc_row(r, lk);
@@ -541,8 +637,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
             bool ok = k_ok && qi < p.T1;
             if (ok && p.mask) ok = p.mask[(long)b * p.m_bs + (long)qi * p.m_rs + kj] != 0;
             const float pv = ok ? __expf(sacc[r] + kbias - lse_s[qr]) : 0.f;
-            float dscale = 1.f;
-            if (p.drop_p > 0.f) dscale = dropout_scale(seed_eff, ((unsigned long long)(bh * p.T1 + min(qi, p.T1 - 1))) * p.T2 + min(kj, p.T2 - 1), p.drop_p, inv_keep);
+            const float dscale = dsc[r];
             pd[r] = pv * dscale;                                   // dropped attention weights
             ds[r] = pv * (dpacc[r] * dscale - delta_s[qr]);        // dS
             dbias += ds[r];
