@@ -118,32 +118,14 @@ __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, 
 __device__ __forceinline__ int acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
 // ---- dropout of the attention weights -------------------------------------------------------------------------
-// Element (b, h, query i, key j) has index idx = ((b*H + h)*T1 + i)*T2 + j.  Philox call idx >> 3 yields eight 16-bit
-// fields for the eight consecutive elements of its block; element idx keeps iff field (idx & 7) >= thr, thr =
-// round(p * 65536) (the keep scale is 65536 / (65536 - thr), the exact inverse of the realised keep probability).
-// RNG was ~half of the forward and most of the dK/dV kernel when every lane generated the numbers for its own
+// Element (b, h, query i, key j) has index idx = ((b*H + h)*T1 + i)*T2 + j; mask definition in oe_common.h
+// (call idx >> 3, 16-bit field idx & 7).  RNG was ~half of the forward and most of the dK/dV kernel when every lane generated the numbers for its own
 // registers; the lanes of a wave now share calls (T2 % 8 == 0: a block never straddles two query rows):
 //   * forward / dQ (lane = query, registers = keys): the lanes lk = 0 / 1 of a query hold the two halves of each
 //     8-key block - each computes two of the four blocks of a 32-key tile and swaps halves with its partner;
 //   * dK/dV (lane = key, registers = 16 queries): the eight lanes of a key block need the same 16 calls (one per
 //     query row) - each computes two and the fields are fetched with lane shuffles.
 // Any other T2 takes the per-element path (one call per element; same mask by definition).
-struct DropParams { unsigned thr; float inv_keep; };
-__device__ __forceinline__ DropParams drop_params(float p) {
-    DropParams d;
-    d.thr = (unsigned)(p * 65536.f + 0.5f);
-    d.inv_keep = 65536.f / (65536.f - (float)d.thr);
-    return d;
-}
-__device__ __forceinline__ float drop_field(unsigned w, int half, const DropParams& d) {
-    return ((w >> (16 * half)) & 0xFFFFu) >= d.thr ? d.inv_keep : 0.f;
-}
-__device__ __forceinline__ float drop_elem(unsigned long long seed, unsigned long long idx, const DropParams& d) {
-    const uint4 r = philox4(seed, idx >> 3);
-    const int f = (int)(idx & 7);
-    const unsigned w = (f >> 1) == 0 ? r.x : (f >> 1) == 1 ? r.y : (f >> 1) == 2 ? r.z : r.w;
-    return drop_field(w, f & 1, d);
-}
 // forward / dQ: scales for this lane's 16 registers (keys j0 + acc_row(r, lk)) of query row `rowbase / T2`
 __device__ __forceinline__ void drop_tile_qlane(unsigned long long seed, unsigned long long rowbase, int j0, int lk, bool aligned,
                                                 const DropParams& d, float (&m)[16]) {

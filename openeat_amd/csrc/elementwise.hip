@@ -160,23 +160,25 @@ extern "C" int oe_glu_bwd(const float* a, const float* dy, long rows, int d, flo
 __global__ void dropout_scale_kernel(const float* x, long n, int cols, float alpha, float p, unsigned long long seed,
                                      const unsigned long long* __restrict__ seed_dev,
                                      const unsigned char* __restrict__ rowmask, float* out, int vec) {
-    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;       // group of 4 consecutive elements
-    const long i = i4 * 4;
+    const long i8 = (long)blockIdx.x * blockDim.x + threadIdx.x;       // block of 8 consecutive elements = one Philox call
+    const long i = i8 * 8;
     if (i >= n) return;
     if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
-    float4 m = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (p > 0.f) m = dropout_scale4(seed, (unsigned long long)i4, p, 1.f / (1.f - p));
-    const float mm[4] = {m.x, m.y, m.z, m.w};
-    if (vec && i + 3 < n) {
-        const float4 v = *reinterpret_cast<const float4*>(x + i);
-        float o[4] = {v.x * alpha * mm[0], v.y * alpha * mm[1], v.z * alpha * mm[2], v.w * alpha * mm[3]};
-        if (rowmask) {
+    float mm[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (p > 0.f) drop_block8(seed, (unsigned long long)i8, drop_params(p), mm);
+    if (vec && i + 7 < n) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (!rowmask[(i + e) / cols]) o[e] = 0.f;
+        for (int h = 0; h < 2; ++h) {
+            const float4 v = *reinterpret_cast<const float4*>(x + i + 4 * h);
+            float o[4] = {v.x * alpha * mm[4 * h], v.y * alpha * mm[4 * h + 1], v.z * alpha * mm[4 * h + 2], v.w * alpha * mm[4 * h + 3]};
+            if (rowmask) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!rowmask[(i + 4 * h + e) / cols]) o[e] = 0.f;
+            }
+            *reinterpret_cast<float4*>(out + i + 4 * h) = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *reinterpret_cast<float4*>(out + i) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
-        for (int e = 0; e < 4 && i + e < n; ++e) {
+        for (int e = 0; e < 8 && i + e < n; ++e) {
             float v = x[i + e] * alpha * mm[e];
             if (rowmask && !rowmask[(i + e) / cols]) v = 0.f;
             out[i + e] = v;
@@ -187,7 +189,7 @@ extern "C" int oe_dropout_scale(const float* x, long n, int cols, float alpha, f
                                 const unsigned long long* seed_dev, const unsigned char* rowmask, float* out, void* stream) {
     OE_REQUIRE(x && out && n > 0 && cols > 0 && p >= 0.f && p < 1.f, "oe_dropout_scale: bad arguments");
     const int vec = ((((uintptr_t)x) | ((uintptr_t)out)) & 15) == 0;
-    hipLaunchKernelGGL(dropout_scale_kernel, dim3(oe_cdiv((n + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, n, cols, alpha,
+    hipLaunchKernelGGL(dropout_scale_kernel, dim3(oe_cdiv((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, n, cols, alpha,
                        p, seed, seed_dev, rowmask, out, vec);
     OE_LAUNCH_CHECK("dropout_scale");
     return 0;

@@ -133,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     const int lrow = lane & 31, lk = lane >> 5;
     float alpha = ep.alpha;
     if (ep.alpha_dev) alpha *= *ep.alpha_dev;
-    const float inv_keep = ep.drop_p > 0.f ? 1.f / (1.f - ep.drop_p) : 1.f;
+    const DropParams dpar = drop_params(ep.drop_p);
     const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const bool first_split = (tile_z == 0);
     const bool interior = (m0 + 64 * TM <= M) && (n0 + 64 * TN <= N);          // block-uniform
@@ -251,16 +251,31 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 }
                 if (ep.drop_p > 0.f) {
                     const unsigned long long e0 = (unsigned long long)(row0 * N + col);
+                    if ((N & 7) == 0) {
+                        // lanes 2i / 2i+1 hold the two halves of an 8-element block in every pass: the even lane draws the
+                        // calls of passes 0 and 2, the odd lane those of passes 1 and 3, and they swap the other half
+                        const int odd = lane & 1;
+                        const unsigned long long b0 = (e0 - 4 * odd) + (unsigned long long)(8 * odd) * N;     // block of pass `odd`
+                        const uint4 ca = philox4(seed, b0 >> 3), cb = philox4(seed, (b0 + (unsigned long long)16 * N) >> 3);
+                        const unsigned r0 = __shfl_xor(odd ? ca.x : ca.z, 1, 64), r1 = __shfl_xor(odd ? ca.y : ca.w, 1, 64);
+                        const unsigned r2 = __shfl_xor(odd ? cb.x : cb.z, 1, 64), r3 = __shfl_xor(odd ? cb.y : cb.w, 1, 64);
+                        unsigned w[4][2];                                   // [pass][word of this lane's half]
+                        w[0][0] = odd ? r0 : ca.x; w[0][1] = odd ? r1 : ca.y;
+                        w[1][0] = odd ? ca.z : r0; w[1][1] = odd ? ca.w : r1;
+                        w[2][0] = odd ? r2 : cb.x; w[2][1] = odd ? r3 : cb.y;
+                        w[3][0] = odd ? cb.z : r2; w[3][1] = odd ? cb.w : r3;
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const unsigned long long e = e0 + (unsigned long long)(8 * p) * N;
-                        float4 dm;
-                        if ((e & 3) == 0) dm = dropout_scale4(seed, e >> 2, ep.drop_p, inv_keep);
-                        else {
-                            dm.x = dropout_scale(seed, e, ep.drop_p, inv_keep); dm.y = dropout_scale(seed, e + 1, ep.drop_p, inv_keep);
-                            dm.z = dropout_scale(seed, e + 2, ep.drop_p, inv_keep); dm.w = dropout_scale(seed, e + 3, ep.drop_p, inv_keep);
+                        for (int p = 0; p < 4; ++p) {
+                            x[p].x *= drop_field(w[p][0], 0, dpar); x[p].y *= drop_field(w[p][0], 1, dpar);
+                            x[p].z *= drop_field(w[p][1], 0, dpar); x[p].w *= drop_field(w[p][1], 1, dpar);
                         }
-                        x[p].x *= dm.x; x[p].y *= dm.y; x[p].z *= dm.z; x[p].w *= dm.w;
+                    } else {
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) {
+                            const unsigned long long e = e0 + (unsigned long long)(8 * p) * N;
+                            x[p].x *= drop_elem(seed, e, dpar); x[p].y *= drop_elem(seed, e + 1, dpar);
+                            x[p].z *= drop_elem(seed, e + 2, dpar); x[p].w *= drop_elem(seed, e + 3, dpar);
+                        }
                     }
                 }
                 if (ep.rowmask) {
@@ -318,13 +333,8 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 float dm[4] = {1.f, 1.f, 1.f, 1.f};
                 if (ep.drop_p > 0.f) {
                     const unsigned long long e0 = (unsigned long long)(row * N + col);
-                    if ((e0 & 3) == 0) {           // aligned group: one Philox call for the four columns
-                        const float4 d4 = dropout_scale4(seed, e0 >> 2, ep.drop_p, inv_keep);
-                        dm[0] = d4.x; dm[1] = d4.y; dm[2] = d4.z; dm[3] = d4.w;
-                    } else {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) dm[e] = dropout_scale(seed, e0 + e, ep.drop_p, inv_keep);
-                    }
+                    for (int e = 0; e < 4; ++e) dm[e] = drop_elem(seed, e0 + e, dpar);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = epi_value(ep, v[e], alpha, bias4[e], aux[e], dm[e], row_dead, res[e], pre[e]);

@@ -76,22 +76,33 @@ __device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
     }
     return make_uint4(c0, c1, c2, c3);
 }
-// keep-mask scale for element `idx` (idx = flat element index of the tensor the
-// dropout is applied to): returns 0 or 1/(1-p).
-__device__ __forceinline__ float dropout_scale(uint64_t seed, uint64_t idx, float p, float inv_keep) {
-    uint4 r = philox4(seed, idx >> 2);
-    uint32_t w = (idx & 3) == 0 ? r.x : (idx & 3) == 1 ? r.y : (idx & 3) == 2 ? r.z : r.w;
-    // uniform in [0,1): keep iff u >= p
-    float u = (float)(w >> 8) * (1.0f / 16777216.0f);
-    return u >= p ? inv_keep : 0.f;
+// Dropout masks.  Element idx of the tensor a mask applies to belongs to Philox call idx >> 3, which yields eight
+// 16-bit fields for the eight consecutive elements of its block; the element is kept iff field (idx & 7) >= thr with
+// thr = round(p * 65536), and kept values are scaled by 65536 / (65536 - thr) - the exact inverse of the realised
+// keep probability (p = 0.1 -> 0.100006).  One call serves eight elements: consumers that hold fewer (a float4 per
+// lane in the GEMM epilogue, four keys per lane in attention) share calls between neighbouring lanes.
+struct DropParams { unsigned thr; float inv_keep; };
+__device__ __forceinline__ DropParams drop_params(float p) {
+    DropParams d;
+    d.thr = (unsigned)(p * 65536.f + 0.5f);
+    d.inv_keep = 65536.f / (65536.f - (float)d.thr);
+    return d;
 }
-
-// four consecutive elements idx4*4 .. idx4*4+3 from ONE Philox call (same values as dropout_scale)
-__device__ __forceinline__ float4 dropout_scale4(uint64_t seed, uint64_t idx4, float p, float inv_keep) {
-    const uint4 r = philox4(seed, idx4);
-    const float k = 1.0f / 16777216.0f;
-    return make_float4((float)(r.x >> 8) * k >= p ? inv_keep : 0.f, (float)(r.y >> 8) * k >= p ? inv_keep : 0.f,
-                       (float)(r.z >> 8) * k >= p ? inv_keep : 0.f, (float)(r.w >> 8) * k >= p ? inv_keep : 0.f);
+__device__ __forceinline__ float drop_field(unsigned w, int half, const DropParams& d) {
+    return ((w >> (16 * half)) & 0xFFFFu) >= d.thr ? d.inv_keep : 0.f;
+}
+// one element on its own (ragged edges / unaligned rows): a whole call for one field
+__device__ __forceinline__ float drop_elem(unsigned long long seed, unsigned long long idx, const DropParams& d) {
+    const uint4 r = philox4(seed, idx >> 3);
+    const int f = (int)(idx & 7);
+    const unsigned w = (f >> 1) == 0 ? r.x : (f >> 1) == 1 ? r.y : (f >> 1) == 2 ? r.z : r.w;
+    return drop_field(w, f & 1, d);
+}
+// the eight elements of block idx8 from one call
+__device__ __forceinline__ void drop_block8(unsigned long long seed, unsigned long long idx8, const DropParams& d, float (&m)[8]) {
+    const uint4 r = philox4(seed, idx8);
+    m[0] = drop_field(r.x, 0, d); m[1] = drop_field(r.x, 1, d); m[2] = drop_field(r.y, 0, d); m[3] = drop_field(r.y, 1, d);
+    m[4] = drop_field(r.z, 0, d); m[5] = drop_field(r.z, 1, d); m[6] = drop_field(r.w, 0, d); m[7] = drop_field(r.w, 1, d);
 }
 
 // ---- activations ------------------------------------------------------------

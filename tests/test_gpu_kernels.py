@@ -120,6 +120,26 @@ def test_gemm_dropout_epilogue_statistics_and_determinism():
     torch.testing.assert_close(a[a != 0], torch.full_like(a[a != 0], 1 / 0.9), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("prec", [0, 3])
+@pytest.mark.parametrize("M,N,K", [(512, 256, 32), (300, 200, 64), (130, 36, 32), (992, 1024, 256)])
+def test_dropout_mask_is_the_same_in_every_consumer(M, N, K, prec):
+    """The GEMM epilogue (interior blocks share Philox calls between lane pairs, edge blocks go element by element,
+    N % 8 != 0 likewise) and the stand-alone dropout kernel (eight elements per thread) must realise the same mask
+    for the same seed: forward fuses it into the producing GEMM, backward applies it with oe_dropout_scale."""
+    torch.manual_seed(6)
+    x, w = cu(torch.randn(M, K)), cu(torch.randn(N, K))
+    plain = torch.empty(M, N, device=DEV)
+    fused = torch.empty(M, N, device=DEV)
+    hip.gemm(x, w, plain, M, N, K, lda=K, ldb=K, ldc=N, precision=prec)
+    hip.gemm(x, w, fused, M, N, K, lda=K, ldb=K, ldc=N, drop_p=0.3, seed=4242, precision=prec)
+    after = torch.empty_like(plain)
+    hip.call("oe_dropout_scale", plain, plain.numel(), N, 1.0, 0.3, 4242, None, None, after)
+    sync()
+    assert torch.equal(fused == 0, after == 0)
+    torch.testing.assert_close(fused, after, rtol=1e-6, atol=1e-6)
+    assert abs((fused != 0).float().mean().item() - 0.7) < 0.02
+
+
 def test_gemm_conv2_implicit_forward_and_wgrad():
     """Conv2d(C,C,3,stride 2) over NHWC as an implicit GEMM (subsampling.py:79)."""
     torch.manual_seed(4)
