@@ -30,17 +30,20 @@ class DecoderLayer(nn.Module):
     def forward(self, tgt: torch.Tensor, tgt_mask: torch.Tensor, memory: torch.Tensor, memory_mask: torch.Tensor,
                 cache: Optional[torch.Tensor] = None):
         p = self.dropout.p
-        residual = tgt
-        y = self._ln(self.norm1, tgt)
+        fork = lambda norm, t: ops.pre_norm(t, norm.weight, norm.bias, norm.eps)    # (residual, LN(t)) from one op
         if cache is None:
+            residual, y = fork(self.norm1, tgt)
             x = self.self_attn(y, y, y, tgt_mask, residual=residual, out_dropout=p)
         else:
             assert cache.shape == (tgt.shape[0], tgt.shape[1] - 1, self.size)
+            residual = tgt
+            y = self._ln(self.norm1, tgt)
             q = y[:, -1:, :].contiguous()
             x = self.self_attn(q, y, y, tgt_mask[:, -1:, :], residual=residual[:, -1:, :].contiguous(), out_dropout=p)
-        y = self._ln(self.norm2, x)
-        x = self.src_attn(y, memory, memory, memory_mask, residual=x, out_dropout=p)
-        x = self.feed_forward(self._ln(self.norm3, x), residual=x, out_scale=1.0, out_dropout=p)
+        r, y = fork(self.norm2, x)
+        x = self.src_attn(y, memory, memory, memory_mask, residual=r, out_dropout=p)
+        r, y = fork(self.norm3, x)
+        x = self.feed_forward(y, residual=r, out_scale=1.0, out_dropout=p)
         if cache is not None:
             x = torch.cat([cache, x], dim=1)
         return x

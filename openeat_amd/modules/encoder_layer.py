@@ -38,20 +38,27 @@ class EncoderLayer(nn.Module):
     def _ln(norm: nn.LayerNorm, x, rowmask=None):
         return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, rowmask)
 
+    @staticmethod
+    def _fork(norm: nn.LayerNorm, x, rowmask=None):
+        """(residual, LN(x)): the two branches of a pre-norm block from one op (their gradients meet in one kernel)."""
+        return ops.pre_norm(x, norm.weight, norm.bias, norm.eps, rowmask)
+
     def forward(self, x: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor):
         p = self.dropout.p
         if self.feed_forward_macaron is not None:
-            x = self.feed_forward_macaron(self._ln(self.norm_ff_macaron, x), residual=x, out_scale=self.ff_scale, out_dropout=p)
-        y = self._ln(self.norm_mha, x)
-        x = self.self_attn(y, y, y, masks, pos_emb, residual=x, out_dropout=p)
+            r, y = self._fork(self.norm_ff_macaron, x)
+            x = self.feed_forward_macaron(y, residual=r, out_scale=self.ff_scale, out_dropout=p)
+        r, y = self._fork(self.norm_mha, x)
+        x = self.self_attn(y, y, y, masks, pos_emb, residual=r, out_dropout=p)
         if self.conv_module is not None:
             m8 = masks if masks.dtype == torch.uint8 else masks.to(torch.uint8)
             rowmask = m8.contiguous().view(-1)
             # the reference zeroes padded frames of norm_conv's output in place (convolution.py:88-89):
             # fused into the LayerNorm kernel, so the module skips its own input-mask pass.
-            y = self._ln(self.norm_conv, x, rowmask)
-            x = self.conv_module(y, m8, residual=x, out_dropout=p, input_masked=True)
-        x = self.feed_forward(self._ln(self.norm_ff, x), residual=x, out_scale=self.ff_scale, out_dropout=p)
+            r, y = self._fork(self.norm_conv, x, rowmask)
+            x = self.conv_module(y, m8, residual=r, out_dropout=p, input_masked=True)
+        r, y = self._fork(self.norm_ff, x)
+        x = self.feed_forward(y, residual=r, out_scale=self.ff_scale, out_dropout=p)
         if self.conv_module is not None:
             x = self._ln(self.norm_final, x)
         return x, masks

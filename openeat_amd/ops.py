@@ -278,6 +278,42 @@ def layer_norm(x, gamma, beta, eps, rowmask=None, act=ACT_NONE):
     return LayerNormFn.apply(x, gamma, beta, eps, rowmask, act)
 
 
+class PreNormFn(torch.autograd.Function):
+    """The fork of a pre-norm residual block, x -> (x, LN(x)) (encoder_layer.py:79-83 etc.: `residual = x;
+    x = norm(x)`).  Owning both branches lets backward produce d x = d residual + LN'(d y) in the LayerNorm
+    backward kernel itself (its `add` input) instead of a separate elementwise add by autograd."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, rowmask):
+        x = _chk(x, "pre_norm")
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        stats = _new(rows, 2, like=x)
+        hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
+        ctx.save_for_backward(x, gamma, beta, stats, rowmask)
+        return x.view_as(x), y
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, gamma, beta, stats, rowmask = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None, None
+        d = x.shape[-1]
+        rows = x.numel() // d
+        dx = torch.empty_like(x)
+        (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
+        add = None if dres is None else dres.contiguous()
+        hip.call("oe_layernorm_bwd", dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db,
+                 _ln_ws(x, rows, d))
+        return dx, rg, rb, None, None
+
+
+def pre_norm(x, gamma, beta, eps, rowmask=None):
+    """-> (residual, normed): use `residual` for the skip connection of the block."""
+    return PreNormFn.apply(x, gamma, beta, eps, rowmask)
+
+
 # --------------------------------------------------------------------------- #
 # Linear (single GEMM with bias / activation)
 # --------------------------------------------------------------------------- #
