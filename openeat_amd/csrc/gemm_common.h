@@ -163,6 +163,37 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
             }
         return;
     }
+    // Plain outputs (alpha, bias, activation, optional pre-activation copy; nothing to load, no dropout): store straight
+    // from the accumulators.  Register r of a 32x32 tile is two full 128-byte row segments per wave-instruction, so the
+    // LDS round trip of the general path buys nothing here.
+    if (interior && !ep.accumulate && !ep.actgrad_in && !ep.residual && !ep.rowmask && ep.drop_p <= 0.f && ep.beta == 1.f) {
+        static_for<0, TM * TN>([&](auto tile_idx) {
+            constexpr int i = decltype(tile_idx)::value / TN, j = decltype(tile_idx)::value % TN;
+            const long col = n0 + wn * (32 * TN) + j * 32 + lrow;
+            const float bias = (ep.bias && first_split) ? ep.bias[col] : 0.f;
+            const long rbase = m0 + wm * (32 * TM) + i * 32 + 4 * lk;
+            float* cbase = C + rbase * ldc + col;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[i][j][r] * alpha + bias;
+            if (ep.preact_out) {
+                float* pbase = ep.preact_out + rbase * ep.ld_aux + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pbase[((r & 3) + 8 * (r >> 2)) * ep.ld_aux] = v[r];
+            }
+            if (ep.act == OE_ACT_SWISH) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] *= sigmoidf_(v[r]);
+            } else if (ep.act == OE_ACT_RELU) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cbase[((r & 3) + 8 * (r >> 2)) * ldc] = v[r];
+        });
+        return;
+    }
+
     // Each wave parks one 32x32 accumulator tile at a time in its own LDS patch and re-reads it row-major,
     // so that every global access of the epilogue (C, residual, pre-activation, act-grad input) is a
     // coalesced float4 row segment.
