@@ -87,11 +87,14 @@ def cpu_baseline(B, seconds, L, steps):
             "sample": f"B={B} x {seconds:g} s utterances, {steps} timed fwd+bwd+clip+Adam steps after 1 warm-up, dropout 0.1"}
 
 
-def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3):
+def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3, lm=None, lm_weight=0.0):
     """BASELINE.json configs[3]: attention-rescoring decode of n_utt synthetic utterances on one GPU
-    (ctc_weight 0.5, reverse_weight 0.3 as in examples/aishell/run.sh:69-72; no LM: the reference's
-    LanguageModel cannot be constructed).  RTF = wall seconds / audio seconds, front end included."""
+    (ctc_weight 0.5, reverse_weight 0.3 as in examples/aishell/run.sh:69-72; LM = the build-defined 6-layer d=256
+    Transformer LM, lm_weight 0.3: the reference's own LanguageModel cannot be constructed).
+    RTF = wall seconds / audio seconds, front end included."""
     model.eval()
+    if lm is not None:
+        lm.eval()
     g = torch.Generator().manual_seed(123)
     wav = (torch.rand(n_utt, int(16000 * seconds), generator=g) - 0.5).to(dev)
     times = []
@@ -101,14 +104,16 @@ def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3):
         t0 = time.perf_counter()
         feats, nfr = fb(wav)
         utt_norm(feats, nfr)
-        hyps = model.attention_rescoring_batch(feats, nfr, beam, ctc_weight=0.5, reverse_weight=0.3)
+        hyps = model.attention_rescoring_batch(feats, nfr, beam, ctc_weight=0.5, reverse_weight=0.3, lm=lm, lm_weight=lm_weight)
         torch.cuda.synchronize()
         if it > 0:
             times.append(time.perf_counter() - t0)
     model.train()
     best = min(times)
     return {"rtf": best / (n_utt * seconds), "wall_s": best, "utterances": n_utt, "seconds_each": seconds, "beam": beam,
-            "ctc_weight": 0.5, "reverse_weight": 0.3, "lm": None, "mean_best_len": sum(len(h) for h in hyps) / len(hyps),
+            "ctc_weight": 0.5, "reverse_weight": 0.3,
+            "lm": None if lm is None else "6-layer d=256 h=4 ff=1024 Transformer LM (seeded init), shallow fusion", "lm_weight": lm_weight,
+            "mean_best_len": sum(len(h) for h in hyps) / len(hyps),
             "mean_nbest_len": getattr(model, "last_nbest_mean_len", None),
             "note": "seeded random-init weights: the n-best lists and the rescored pick are whatever an untrained model emits "
                     "(an untrained CTC head emits far more tokens than speech has - the prefix recursion and the decoder "
@@ -297,8 +302,10 @@ def main():
         engine.arena.enabled = False
         torch.manual_seed(4)                                     # configs[3]: "weights = seeded init", not the model trained above
         dec_model = ASRModel(80, V, **MODEL_CONF).to(dev)
-        dec = decode_rtf(dec_model, fb, utt_normalize_, args.decode_utts, args.seconds, 10, dev)
-        del dec_model
+        from openeat_amd.models.language_model import LanguageModel
+        lm = LanguageModel(V, encoder_num_blocks=6, d_model=256, attention_heads=4, linear_units=1024).to(dev)
+        dec = decode_rtf(dec_model, fb, utt_normalize_, args.decode_utts, args.seconds, 10, dev, lm=lm, lm_weight=0.3)
+        del dec_model, lm
         engine.arena.enabled = True
         log(f"decode done: RTF {dec['rtf']:.5f} ({dec['wall_s'] * 1e3:.0f} ms for {dec['utterances']} x {args.seconds:g} s)")
 

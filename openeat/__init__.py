@@ -7,7 +7,7 @@ import importlib
 import sys
 
 _SUBMODULES = [
-    "models", "models.asr_model",
+    "models", "models.asr_model", "models.language_model",
     "modules", "modules.attention", "modules.cmvn", "modules.convolution", "modules.ctc", "modules.decoder",
     "modules.decoder_layer", "modules.embedding", "modules.encoder", "modules.encoder_layer",
     "modules.label_smoothing_loss", "modules.positionwise_feed_forward", "modules.subsampling", "modules.swish",

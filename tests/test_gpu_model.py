@@ -313,3 +313,87 @@ def test_native_prefix_beam_matches_python_recursion():
         assert [p for p, _ in got] == [p for p, _ in want]
         for (_, a), (_, b) in zip(got, want):
             assert abs(a - b) <= 1e-12 * max(1.0, abs(b))
+
+
+# ------------------------------------------------------------------ language model + shallow fusion -----
+from oracle import asr as O  # noqa: E402  (the checker for the LM: the reference's class cannot be constructed)
+
+LM_CONF = dict(d_model=32, attention_heads=4, linear_units=64, dropout_rate=0.0, encoder_num_blocks=2, activation_type="swish")
+
+
+def _lm_and_cfg(V, seed=31):
+    from openeat_amd.models.language_model import LanguageModel
+    torch.manual_seed(seed)
+    lm = LanguageModel(V, **LM_CONF)
+    with torch.no_grad():
+        for p_ in lm.parameters():
+            p_.copy_(torch.randn_like(p_) * 0.2)
+    cfg = O.Config(vocab_size=V, macaron_style=False, use_cnn_module=False, pos_enc_layer_type="abs_pos", **LM_CONF)
+    return lm, cfg
+
+
+def test_language_model_matches_cpu_restatement():
+    """The re-specified LM (the reference class cannot be constructed - PARITY UNPINNED against it) vs
+    oracle.language_model_logits: logits, label-smoothing loss, accuracy and every parameter gradient."""
+    V = 40
+    lm, cfg = _lm_and_cfg(V)
+    sd = {k: v.detach().clone().requires_grad_() for k, v in lm.state_dict().items()}
+    lm = lm.to(DEV).train()
+    tgt = torch.tensor([[3, 7, 7, 2, 9], [5, 1, 4, -1, -1], [8, -1, -1, -1, -1]])
+    tl = torch.tensor([5, 3, 1])
+    loss, acc = lm(tgt.to(DEV), tgt.to(DEV), tl.to(DEV))
+    ys_in, ys_out = O.with_sos_eos(tgt, V - 1, V - 1, -1)
+    ref_logits = O.language_model_logits(sd, cfg, ys_in, tl + 1)
+    cfg_l = O.Config(vocab_size=V, lsm_weight=0.1)
+    ref_loss = O.label_smoothing_loss(cfg_l, ref_logits, ys_out)
+    close(loss, ref_loss.detach(), rtol=2e-4, atol=2e-4, msg="lm loss")
+    with torch.no_grad():
+        close(lm._forward_encoder(ys_in.to(DEV), (tl + 1).to(DEV)), ref_logits.detach(), rtol=1e-3, atol=2e-4, msg="lm logits")
+    close(acc, O.token_accuracy(ref_logits.detach().reshape(-1, V), ys_out, -1), rtol=1e-6, atol=1e-6, msg="lm acc")
+    loss.backward()
+    ref_loss.backward()
+    for k, p_ in lm.named_parameters():
+        g, r = p_.grad.cpu(), sd[k].grad
+        assert float((g - r).abs().max()) <= 3e-3 * max(float(r.abs().max()), 1e-3) + 1e-5, k
+
+
+def test_attention_rescoring_with_neural_lm_fusion():
+    """asr_model.py:490-527 with the LM term: the HIP model + HIP LM pick the hypothesis the CPU restatement picks, in
+    the one-utterance API and in the batched one, and the LM weight really changes the choice somewhere."""
+    g = load_golden("f12_tiny_conformer")
+    meta = load_golden_json("f12_tiny_conformer")
+    V = meta["V"]
+    model = ASRModel(80, V, **meta["kwargs"])
+    model.load_state_dict(g["sd"])
+    model = model.to(DEV).eval()
+    lm, lm_cfg = _lm_and_cfg(V, seed=33)
+    lm_sd = {k: v.detach().clone() for k, v in lm.state_dict().items()}
+    lm = lm.to(DEV).eval()
+    cfg = O.Config(input_size=80, vocab_size=V, **meta["kwargs"])
+    feats, flen = g["in"]["feats"], g["in"]["flen"]
+    tok2chr = {t: str(t) for t in range(V)}
+    picks_lm, picks_plain = [], []
+    with torch.no_grad():
+        for b in range(feats.shape[0]):
+            n = int(flen[b])
+            f1, l1 = feats[b:b + 1, :n].contiguous(), flen[b:b + 1]
+            for w, acc_ in ((8.0, picks_lm), (0.0, picks_plain)):
+                want, _, _ = O.attention_rescoring(g["sd"], cfg, f1, l1, meta["beam"], 0.5, 0.3, lm=(lm_sd, lm_cfg), lm_weight=w)
+                got, _, _ = model.attention_rescoring(f1.to(DEV), l1.to(DEV), meta["beam"], ctc_weight=0.5, reverse_weight=0.3,
+                                                      lm=lm, lm_weight=w, token2char=tok2chr)
+                assert list(got) == list(want), (b, w)
+                acc_.append(list(got))
+        # batched API on equal-length utterances (padding plays no role, as in the test above) == one by one
+        torch.manual_seed(35)
+        fe = torch.randn(4, 83, 80, device=DEV)
+        fl = torch.full((4,), 83, dtype=torch.int32, device=DEV)
+        batch = model.attention_rescoring_batch(fe, fl, 4, ctc_weight=0.5, reverse_weight=0.3, lm=lm, lm_weight=8.0)
+        single = [list(model.attention_rescoring(fe[b:b + 1].contiguous(), fl[b:b + 1], 4, ctc_weight=0.5, reverse_weight=0.3,
+                                                 lm=lm, lm_weight=8.0, token2char=tok2chr)[0]) for b in range(4)]
+        # the LM term is live: log-probabilities are negative, so an overwhelming LM weight picks a shortest hypothesis
+        f0, l0 = feats[:1, : int(flen[0])].contiguous().to(DEV), flen[:1].to(DEV)
+        nbest, _ = model._ctc_prefix_beam_search(f0, l0, meta["beam"])
+        short, _, _ = model.attention_rescoring(f0, l0, meta["beam"], ctc_weight=0.5, reverse_weight=0.3, lm=lm, lm_weight=1e4,
+                                                token2char=tok2chr)
+    assert batch == single
+    assert len(short) == min(len(h) for h, _ in nbest) < max(len(h) for h, _ in nbest)
