@@ -185,29 +185,49 @@ def main():
 
     engine.model = WithFrontend(model)
     batch = {"wav": wav, "targets": tgt, "targets_length": tlen}
-    # Step launch mode.  N > 1 runs the step eagerly (the collectives start inside backward, from autograd hooks).
-    # At N = 1 both modes are tried during warm-up and the faster one is timed: graph replay has no host work, but the
-    # eager step overlaps the side-stream weight-gradient GEMMs with the backward chain (the captured graph runs its
-    # parallel branches one after the other on this ROCm), and the host keeps ahead of the GPU either way.
+    # Step launch mode: both are tried during warm-up and the faster one is timed (the decision is the same on every
+    # rank: MAX over ranks of each timing).  Graph replay has no host work; the eager step is host-bound on some boxes
+    # but overlaps more: at N = 1 the side-stream weight gradients, at N > 1 the gradient all-reduce, which the autograd
+    # hooks start inside backward (with a graph the collectives run after the replayed forward+backward instead).
     log("first eager step ...")
     l0 = engine.step(batch)[0]
     torch.cuda.synchronize()
     log(f"first eager step done, loss={float(l0):.4f}")
     eager = lambda: engine.step(batch)
-    use_graph = False
-    if world == 1 and not args.no_graph:
-        def trial(f, n=10):
+
+    def agree(ms):                                   # same number on every rank
+        if world == 1:
+            return ms
+        t = torch.tensor([ms], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        return float(t)
+
+    def trial(f, n, give_up_ms=None):
+        f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        f()
+        torch.cuda.synchronize()
+        first = agree((time.perf_counter() - t) * 1e3)
+        if give_up_ms is not None and first > give_up_ms:       # hopeless (e.g. a host-staged collective backend): stop here
+            return first
+        t = time.perf_counter()
+        for _ in range(n):
             f()
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            for _ in range(n):
-                f()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t) / n * 1e3
-        t_eager = trial(eager)                      # before the capture: the graph's private memory pool changes allocator state
-        engine.capture(batch, warmup=max(1, args.warmup))
-        log("HIP graph captured")
-        t_graph = trial(engine.replay)
+        torch.cuda.synchronize()
+        return agree((time.perf_counter() - t) / n * 1e3)
+
+    use_graph = False
+    if not args.no_graph:
+        n_trial = 10 if world == 1 else 5
+        t_eager = trial(eager, n_trial)              # before the capture: the graph's private memory pool changes allocator state
+        try:
+            engine.capture(batch, warmup=max(1, args.warmup))
+            log("HIP graph captured")
+            t_graph = trial(engine.replay, n_trial, give_up_ms=3.0 * t_eager)
+        except Exception as e:                        # capture trouble must never cost the run: stay eager
+            log(f"graph capture/replay failed ({type(e).__name__}: {e}); staying eager")
+            t_graph = float("inf")
         use_graph = args.force_graph or t_graph <= t_eager
         log(f"warm-up calibration: eager {t_eager:.2f} ms/step, graph replay {t_graph:.2f} ms/step -> timing {'graph' if use_graph else 'eager'}")
         if not use_graph:
