@@ -682,73 +682,96 @@ def conv_module(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residu
 # --------------------------------------------------------------------------- #
 # Conv2d subsampling (1/4) + output Linear + positional scaling
 # --------------------------------------------------------------------------- #
-class Subsampling4Fn(torch.autograd.Function):
-    """subsampling.py:110-116 + embedding.py:44-60/75-88.  Activations are kept
-    NHWC so the second conv is an implicit GEMM and the flatten before the
-    Linear is free; the checkpoint's OIHW / channel-major weights are
-    re-laid-out on the fly (tiny)."""
+class ConvSubsamplingFn(torch.autograd.Function):
+    """subsampling.py:110-116 (Conv2dSubsampling4) / :248-253 (Conv2dSubsampling8) + embedding.py:44-60/75-88:
+    Conv2d(1,C,3,2)+ReLU -> n x [Conv2d(C,C,3,2)+ReLU] -> channel-major flatten -> Linear -> x*sqrt(d) (+pe).
+    Activations are kept NHWC so every C->C conv is an implicit GEMM (im2col gather in the operand load) and the
+    flatten before the Linear is free; the checkpoint's OIHW / channel-major weights are re-laid-out on the fly (tiny).
+    Arguments after the fixed ones: (w_k, b_k) of the n C->C conv stages, in forward order."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, wl, bl, pe, xscale):
+    def forward(ctx, x, w1, b1, wl, bl, pe, xscale, *stage_params):
         x = _chk(x, "subsampling input")
         B, T, Fd = x.shape
         C = w1.shape[0]
-        T1, F1 = (T - 3) // 2 + 1, (Fd - 3) // 2 + 1
-        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
         d = wl.shape[0]
-        assert wl.shape[1] == C * F2, "Linear input size does not match the conv output"
-        y1 = _new(B, T1, F1, C, like=x)
-        hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y1)
-        w2g = _new(C, 9 * C, like=x)                               # [co][kh][kw][ci]
-        hip.call("oe_swap_last2", w2, C, C, 9, w2g, 0)
-        M2 = B * T2 * F2
-        y2 = _new(M2, C, like=x)
-        conv = (T1, F1, T2, F2, C)
-        hip.gemm(y1, w2g, y2, M2, C, 9 * C, lda=0, ldb=9 * C, ldc=C, bias=b2, act=ACT_RELU, conv=conv,
-                 conv_gather=hip.GATHER_A)
-        wlg = _new(d, F2 * C, like=x)                              # columns reordered to (f, c)
-        hip.call("oe_swap_last2", wl, d, C, F2, wlg, 0)
-        y2v = y2.view(B * T2, F2 * C)
-        pe2 = None if pe is None else _chk(pe, "pe").reshape(-1, d)[:T2]
-        out = gemm_nt(y2v, wlg, bl, beta=xscale, residual=pe2, ldr=0 if pe2 is None else d, res_row_mod=0 if pe2 is None else T2)
-        ctx.save_for_backward(x, y1, w2g, y2, wlg)
-        ctx.params = (w1, b1, w2, b2, wl, bl)
-        ctx.cfg = (B, T, Fd, C, T1, F1, T2, F2, d, xscale)
-        return out.view(B, T2, d)
+        n = len(stage_params) // 2
+        dims = [((T - 3) // 2 + 1, (Fd - 3) // 2 + 1)]
+        y = _new(B, dims[0][0], dims[0][1], C, like=x)
+        hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y)
+        acts, wgs = [y], []
+        for k in range(n):
+            wk, bk = stage_params[2 * k], stage_params[2 * k + 1]
+            Ti, Fi = dims[-1]
+            To, Fo = (Ti - 3) // 2 + 1, (Fi - 3) // 2 + 1
+            assert To > 0 and Fo > 0, "input too short for the subsampling stack"
+            wg = _new(C, 9 * C, like=x)                             # [co][kh][kw][ci]
+            hip.call("oe_swap_last2", wk, C, C, 9, wg, 0)
+            yo = _new(B * To * Fo, C, like=x)
+            hip.gemm(acts[-1], wg, yo, B * To * Fo, C, 9 * C, lda=0, ldb=9 * C, ldc=C, bias=bk, act=ACT_RELU,
+                     conv=(Ti, Fi, To, Fo, C), conv_gather=hip.GATHER_A)
+            dims.append((To, Fo))
+            acts.append(yo.view(B, To, Fo, C))
+            wgs.append(wg)
+        TL, FL = dims[-1]
+        assert wl.shape[1] == C * FL, "Linear input size does not match the conv output"
+        wlg = _new(d, FL * C, like=x)                               # columns reordered to (f, c)
+        hip.call("oe_swap_last2", wl, d, C, FL, wlg, 0)
+        ylv = acts[-1].view(B * TL, FL * C)
+        pe2 = None if pe is None else _chk(pe, "pe").reshape(-1, d)[:TL]
+        out = gemm_nt(ylv, wlg, bl, beta=xscale, residual=pe2, ldr=0 if pe2 is None else d, res_row_mod=0 if pe2 is None else TL)
+        ctx.save_for_backward(x, wlg, *acts, *wgs)
+        ctx.params = (w1, b1, wl, bl, stage_params)
+        ctx.cfg = (B, T, Fd, C, d, xscale, n, dims)
+        return out.view(B, TL, d)
 
     @staticmethod
     def backward(ctx, dout):
-        x, y1, w2g, y2, wlg = ctx.saved_tensors
-        w1, b1, w2, b2, wl, bl = ctx.params
-        B, T, Fd, C, T1, F1, T2, F2, d, xscale = ctx.cfg
-        do2 = dout.contiguous().view(B * T2, d)
-        y2v = y2.view(B * T2, F2 * C)
+        B, T, Fd, C, d, xscale, n, dims = ctx.cfg
+        x, wlg = ctx.saved_tensors[0], ctx.saved_tensors[1]
+        acts = ctx.saved_tensors[2:2 + n + 1]
+        wgs = ctx.saved_tensors[2 + n + 1:]
+        w1, b1, wl, bl, stage_params = ctx.params
+        TL, FL = dims[-1]
+        do2 = dout.contiguous().view(B * TL, d)
+        ylv = acts[-1].view(B * TL, FL * C)
         (dbl_buf, dbl) = grad_sink(bl)
-        dwlg = gemm_tn(do2, y2v, alpha=xscale, bias_out=dbl_buf)
-        dwl = _sink_swapped(wl, dwlg, d, F2, C)
-        dy2 = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=y2v, ld_aux=F2 * C).view(B * T2 * F2, C)
-        M2 = B * T2 * F2
-        conv = (T1, F1, T2, F2, C)
-        dw2g = _new(C, 9 * C, like=do2, zero=True)
-        (db2_buf, db2) = grad_sink(b2)
+        dwlg = gemm_tn(do2, ylv, alpha=xscale, bias_out=dbl_buf)
+        dwl = _sink_swapped(wl, dwlg, d, FL, C)
+        # gradient w.r.t. the last conv's pre-activation: the Linear's dgrad with the ReLU mask fused
+        dy = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=ylv, ld_aux=FL * C).view(B * TL * FL, C)
         fused = hip.GEMM_PRECISION != 0
-        hip.gemm(dy2, y1, dw2g, C, 9 * C, M2, lda=C, ldb=0, ldc=9 * C, a_kmajor=True, b_kmajor=True,
-                 split_k=_split_k(C, 9 * C, M2), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
-                 a_colsum=db2_buf if fused else None)
-        if not fused:
-            colsum(dy2, out=db2_buf)
-        dw2 = _sink_swapped(w2, dw2g, C, 9, C)
-        dcol = gemm_nn(dy2, w2g)                                   # (M2, 9C)
-        dy1 = torch.empty_like(y1)
-        hip.call("oe_col2im_relu", dcol, y1, B, T1, F1, C, dy1)
-        del dcol
+        stage_grads = [None] * (2 * n)
+        for k in range(n - 1, -1, -1):
+            wk, bk = stage_params[2 * k], stage_params[2 * k + 1]
+            (Ti, Fi), (To, Fo) = dims[k], dims[k + 1]
+            Mo = B * To * Fo
+            conv = (Ti, Fi, To, Fo, C)
+            yin = acts[k]
+            dwg = _new(C, 9 * C, like=do2, zero=True)
+            (dbk_buf, dbk) = grad_sink(bk)
+            hip.gemm(dy, yin, dwg, C, 9 * C, Mo, lda=C, ldb=0, ldc=9 * C, a_kmajor=True, b_kmajor=True,
+                     split_k=_split_k(C, 9 * C, Mo), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
+                     a_colsum=dbk_buf if fused else None)
+            if not fused:
+                colsum(dy, out=dbk_buf)
+            stage_grads[2 * k], stage_grads[2 * k + 1] = _sink_swapped(wk, dwg, C, 9, C), dbk
+            dcol = gemm_nn(dy, wgs[k])                               # (Mo, 9C)
+            dyin = torch.empty_like(yin)
+            hip.call("oe_col2im_relu", dcol, yin, B, Ti, Fi, C, dyin)   # col2im + the ReLU mask of this stage's input
+            del dcol
+            dy = dyin.view(B * Ti * Fi, C)
         (dw1, rw1), (db1, rb1) = grad_sink(w1), grad_sink(b1)
-        hip.call("oe_conv1_wgrad", x, dy1, B, T, Fd, C, dw1, db1)
-        return None, rw1, rb1, dw2, db2, dwl, dbl, None, None
+        hip.call("oe_conv1_wgrad", x, dy.view(B, dims[0][0], dims[0][1], C), B, T, Fd, C, dw1, db1)
+        return (None, rw1, rb1, dwl, dbl, None, None) + tuple(stage_grads)
 
 
 def subsampling4(x, w1, b1, w2, b2, wl, bl, pe, xscale):
-    return Subsampling4Fn.apply(x, w1, b1, w2, b2, wl, bl, pe, xscale)
+    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, w2, b2)
+
+
+def subsampling8(x, w1, b1, w2, b2, w3, b3, wl, bl, pe, xscale):
+    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, w2, b2, w3, b3)
 
 
 # --------------------------------------------------------------------------- #

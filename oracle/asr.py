@@ -202,6 +202,18 @@ def subsample4(sd, cfg: Config, x: Tensor, mask: Tensor):
     return y, mask[:, :, :-2:2][:, :, :-2:2], pos
 
 
+def subsample8(sd, cfg: Config, x: Tensor, mask: Tensor):
+    """modules/subsampling.py:185-253 (Conv2dSubsampling8) + embedding.py."""
+    p = "encoder.embed."
+    y = x.unsqueeze(1)
+    for k in (0, 2, 4):
+        y = F.relu(F.conv2d(y, sd[p + f"conv.{k}.weight"], sd[p + f"conv.{k}.bias"], stride=2))
+    b, c, t, f = y.shape
+    y = _lin(y.transpose(1, 2).contiguous().view(b, t, c * f), sd, p + "linear")
+    y, pos = position_encode(cfg, y)
+    return y, mask[:, :, :-2:2][:, :, :-2:2][:, :, :-2:2], pos
+
+
 def linear_no_subsampling(sd, cfg: Config, x: Tensor, mask: Tensor):
     """modules/subsampling.py:23-62 (LinearNoSubsampling): Linear -> LayerNorm(eps 1e-12) -> positional encoding."""
     p = "encoder.embed."
@@ -326,6 +338,8 @@ def encoder(sd, cfg: Config, feats: Tensor, masks: Tensor, training: bool = Fals
         x = (x - sd["encoder.global_cmvn.mean"]) * sd["encoder.global_cmvn.istd"]
     if cfg.input_layer == "linear":         # modules/encoder.py:150-151
         x, masks, pos = linear_no_subsampling(sd, cfg, x, masks)
+    elif cfg.input_layer == "conv2d8":      # modules/encoder.py:156-157
+        x, masks, pos = subsample8(sd, cfg, x, masks)
     else:
         assert cfg.input_layer == "conv2d"
         x, masks, pos = subsample4(sd, cfg, x, masks)
