@@ -191,3 +191,36 @@ def test_greedy_full_size_is_collapsed_argmax():
                 want.append(t)
             prev = t
         assert ot[b_, : int(ol[b_])].tolist() == want
+
+
+def test_config5_shape_trains_a_step():
+    """BASELINE.json configs[4] architecture (24L Conformer d=512, h=8, ff=2048, K=15; 192.5 M parameters at V=3246) on
+    16 s utterances: two engine steps run, the loss is finite and decreases with lr 1e-3 on the same batch, every
+    gradient is finite.  (Kernel dispatch differs from config 2: LayerNorm with two float4 per lane, 512-channel
+    convolutions, 8 heads, 2048-wide FFN tiles.)"""
+    from openeat_amd.engine import TrainEngine
+    from openeat_amd.models.asr_model import ASRModel
+    torch.manual_seed(0)
+    conf = dict(encoder_num_blocks=24, decoder_num_blocks=3, r_decoder_num_blocks=3, d_model=512, attention_heads=8, linear_units=2048,
+                dropout_rate=0.1, input_layer="conv2d", pos_enc_layer_type="rel_pos", activation_type="swish", macaron_style=True,
+                use_cnn_module=True, cnn_module_kernel=15, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3)
+    model = ASRModel(80, V, **conf).to(DEV).train()
+    n_par = sum(p.numel() for p in model.parameters())
+    assert abs(n_par - 192.5e6) < 1.5e6, n_par
+    eng = TrainEngine(model, lr=1e-3, grad_clip=5.0)
+    Bs, Ts = 4, 1598
+    feats = torch.randn(Bs, Ts, 80, device=DEV)
+    flen = torch.tensor([1598, 1400, 1111, 803], dtype=torch.int32, device=DEV)
+    tgt = torch.randint(2, V - 1, (Bs, 40), dtype=torch.int32, device=DEV)
+    tlen = torch.tensor([40, 33, 25, 12], dtype=torch.int32, device=DEV)
+    for b_ in range(Bs):
+        tgt[b_, int(tlen[b_]):] = -1
+    batch = dict(features=feats, features_length=flen, targets=tgt, targets_length=tlen)
+    l0, _ = eng.step(batch)
+    assert torch.isfinite(eng.arena.grad).all()
+    l1, _ = eng.step(batch)
+    l2, _ = eng.step(batch)
+    torch.cuda.synchronize()
+    assert all(math.isfinite(float(l)) for l in (l0, l1, l2)), (float(l0), float(l1), float(l2))
+    assert float(l2) < float(l0)
+    eng.arena.deactivate()
