@@ -93,7 +93,9 @@ class TrainEngine:
         # The graph is captured as ONE chain: parallel branches (the side-stream weight gradients of the eager step)
         # are replayed on several hardware queues with cross-queue waits, and measured slower than the plain chain
         # (24.3 vs 22.5 ms/step); the eager step keeps its side stream.
-        async_wgrad, ops.ASYNC_WGRAD = ops.ASYNC_WGRAD, False
+        import os
+        async_wgrad = ops.ASYNC_WGRAD
+        ops.ASYNC_WGRAD = ops.ASYNC_WGRAD and os.environ.get("OE_GRAPH_FORK", "0") == "1"      # tuning: keep the fork in the graph
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
