@@ -193,6 +193,8 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     OE_REQUIRE(!(g->atomic_out && (g->act || g->residual || g->preact_out || g->actgrad_in || g->drop_p > 0.f || g->beta != 1.f)),
                "oe_gemm_f32: atomic_out supports only alpha/bias epilogues");
     OE_REQUIRE(g->drop_p >= 0.f && g->drop_p < 1.f, "oe_gemm_f32: drop_p out of range");
+    OE_REQUIRE(g->act == OE_ACT_NONE || g->act == OE_ACT_RELU || g->act == OE_ACT_SWISH,
+               "oe_gemm_f32: only relu (1) and swish (2) are fused into the epilogue; apply act %d with oe_act_fwd / oe_act_grad", g->act);
     hipStream_t st = (hipStream_t)stream;
     OperandDesc A{}, B{};
     A.p = g->a; A.ld = g->lda; A.vec_ok = vec_ok(g->a, g->lda);

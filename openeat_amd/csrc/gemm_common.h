@@ -109,8 +109,10 @@ __device__ __forceinline__ float epi_value(const EpiParams& ep, float v, float a
                                            float res, float& pre) {
     float x = v * alpha + bias;
     pre = x;
-    if (ep.actgrad_in) x *= act_bwd(ep.act, aux);
-    else x = act_fwd(ep.act, x);
+    // only relu and swish are fused into GEMM epilogues (oe_gemm_f32 rejects the others; the host applies those
+    // with oe_act_fwd / oe_act_grad) - the transcendental-heavy ones would cost every GEMM kernel registers
+    if (ep.actgrad_in) x *= (ep.act == OE_ACT_RELU) ? (aux > 0.f ? 1.f : 0.f) : (ep.act == OE_ACT_SWISH) ? act_bwd(OE_ACT_SWISH, aux) : 1.f;
+    else x = (ep.act == OE_ACT_RELU) ? fmaxf(x, 0.f) : (ep.act == OE_ACT_SWISH) ? x * sigmoidf_(x) : x;
     x *= dm;
     if (row_dead) x = 0.f;
     return res + ep.beta * x;

@@ -106,16 +106,27 @@ __device__ __forceinline__ void drop_block8(unsigned long long seed, unsigned lo
 }
 
 // ---- activations ------------------------------------------------------------
-enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2 };
+// ids follow the reference's table (utils/common.py:160-173): relu, swish, tanh, hardtanh, selu, gelu (erf form)
+enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2, OE_ACT_TANH = 3, OE_ACT_HARDTANH = 4, OE_ACT_SELU = 5, OE_ACT_GELU = 6 };
+#define OE_SELU_ALPHA 1.6732632423543772848170429916717f
+#define OE_SELU_SCALE 1.0507009873554804934193349852946f
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float act_fwd(int act, float x) {
     if (act == OE_ACT_RELU) return fmaxf(x, 0.f);
     if (act == OE_ACT_SWISH) return x * sigmoidf_(x);
+    if (act == OE_ACT_TANH) return tanhf(x);
+    if (act == OE_ACT_HARDTANH) return fminf(fmaxf(x, -1.f), 1.f);
+    if (act == OE_ACT_SELU) return OE_SELU_SCALE * (x > 0.f ? x : OE_SELU_ALPHA * (expf(x) - 1.f));
+    if (act == OE_ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     return x;
 }
 __device__ __forceinline__ float act_bwd(int act, float x) {  // d act / dx at pre-activation x
     if (act == OE_ACT_RELU) return x > 0.f ? 1.f : 0.f;
     if (act == OE_ACT_SWISH) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+    if (act == OE_ACT_TANH) { float t = tanhf(x); return 1.f - t * t; }
+    if (act == OE_ACT_HARDTANH) return (x > -1.f && x < 1.f) ? 1.f : 0.f;
+    if (act == OE_ACT_SELU) return OE_SELU_SCALE * (x > 0.f ? 1.f : OE_SELU_ALPHA * expf(x));
+    if (act == OE_ACT_GELU) return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
     return 1.f;
 }

@@ -24,7 +24,7 @@ GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "0"))
 _LIB_PATH = os.environ.get("OE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libopeneat_hip.so")
 _lib = None
 
-ACT = {"none": 0, None: 0, "relu": 1, "swish": 2}
+ACT = {"none": 0, None: 0, "relu": 1, "swish": 2, "tanh": 3, "hardtanh": 4, "selu": 5, "gelu": 6}
 GATHER_NONE, GATHER_A, GATHER_B = 0, 1, 2
 
 c_fp = C.c_void_p

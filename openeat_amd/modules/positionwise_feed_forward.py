@@ -5,11 +5,18 @@ from openeat_amd import ops
 
 
 def act_id_of(activation: torch.nn.Module) -> int:
-    if isinstance(activation, torch.nn.ReLU):
-        return ops.ACT_RELU
-    if getattr(activation, "act_id", None) is not None:
+    """The kernel id of one of the reference's activation modules (utils/common.py:160-173)."""
+    if getattr(activation, "act_id", None) is not None:          # Swish
         return activation.act_id
-    raise NotImplementedError(f"activation {type(activation).__name__} has no gfx950 kernel yet")
+    table = ((torch.nn.ReLU, ops.ACT_RELU), (torch.nn.Tanh, ops.ACT_TANH), (torch.nn.SELU, ops.ACT_SELU))
+    for cls, aid in table:
+        if isinstance(activation, cls):
+            return aid
+    if isinstance(activation, torch.nn.Hardtanh) and activation.min_val == -1.0 and activation.max_val == 1.0:
+        return ops.ACT_HARDTANH
+    if isinstance(activation, torch.nn.GELU) and getattr(activation, "approximate", "none") == "none":
+        return ops.ACT_GELU
+    raise NotImplementedError(f"activation {activation!r} has no gfx950 kernel")
 
 
 class PositionwiseFeedForward(torch.nn.Module):

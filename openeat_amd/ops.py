@@ -17,8 +17,12 @@ import torch
 from . import hip
 from . import arena as _arena
 
-ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
-ACT_IDS = {"relu": ACT_RELU, "swish": ACT_SWISH, "none": ACT_NONE}
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, ACT_HARDTANH, ACT_SELU, ACT_GELU = 0, 1, 2, 3, 4, 5, 6      # oe_common.h
+ACT_IDS = {"relu": ACT_RELU, "swish": ACT_SWISH, "tanh": ACT_TANH, "hardtanh": ACT_HARDTANH, "selu": ACT_SELU, "gelu": ACT_GELU,
+           "none": ACT_NONE}
+# fused into GEMM epilogues; the others (never used by a shipped config) run as separate elementwise kernels so that
+# their erf / tanh / exp code does not cost every GEMM kernel registers
+GEMM_FUSED_ACTS = (ACT_NONE, ACT_RELU, ACT_SWISH)
 
 
 # --------------------------------------------------------------------------- #
@@ -323,7 +327,12 @@ class LinearFn(torch.autograd.Function):
         x = _chk(x, "linear")
         x2 = x.reshape(-1, x.shape[-1])
         pre = _new(x2.shape[0], w.shape[0], like=x) if act != ACT_NONE else None
-        y = gemm_nt(x2, w, b, act=act, preact_out=pre, ld_aux=w.shape[0])
+        if act in GEMM_FUSED_ACTS:
+            y = gemm_nt(x2, w, b, act=act, preact_out=pre, ld_aux=w.shape[0])
+        else:
+            gemm_nt(x2, w, b, out=pre)
+            y = torch.empty_like(pre)
+            hip.call("oe_act_fwd", pre, pre.numel(), act, y)
         ctx.save_for_backward(x2, w, pre)
         ctx.act, ctx.has_bias, ctx.in_shape = act, b is not None, x.shape
         ctx.bias_ref = b
@@ -428,7 +437,14 @@ class FeedForwardFn(torch.autograd.Function):
         M, ff = x2.shape[0], w1.shape[0]
         s_in, s_out = (next_seed() if p_in > 0 else 0), (next_seed() if p_out > 0 else 0)
         pre = _new(M, ff, like=x)
-        a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+        if act in GEMM_FUSED_ACTS:
+            a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+        else:
+            gemm_nt(x2, w1, b1, out=pre)
+            a = torch.empty_like(pre)
+            hip.call("oe_act_fwd", pre, pre.numel(), act, a)
+            if p_in > 0:
+                a = dropout_scale(a, 1.0, p_in, s_in)
         res2 = None if residual is None else _chk(residual, "residual").reshape(-1, w2.shape[0])
         y = gemm_nt(a, w2, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, residual=res2,
                     ldr=0 if res2 is None else res2.stride(0), beta=out_scale)
@@ -446,7 +462,13 @@ class FeedForwardFn(torch.autograd.Function):
         g2 = dy2 if (p_out == 0 and out_scale == 1.0) else dropout_scale(dy2, out_scale, p_out, s_out)
         b1, b2 = ctx.biases
         dw2, db2 = wgrad_bias(w2, b2, g2, a)
-        dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+        if act in GEMM_FUSED_ACTS:
+            dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+        else:
+            dh = gemm_nn(g2, w2)
+            if p_in > 0:
+                dh = dropout_scale(dh, 1.0, p_in, s_in)
+            dh = _act_grad(dh, pre, act)
         dw1, db1 = wgrad_bias(w1, b1, dh, x2)
         dx = gemm_nn(dh, w1).view(in_shape)
         return dx, dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None

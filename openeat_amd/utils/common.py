@@ -101,9 +101,8 @@ def log_add(args: List[float]) -> float:
 
 
 def get_activation(act):
-    """common.py:160-173.  The HIP path implements swish and relu."""
+    """common.py:160-173 (same table; unknown names raise KeyError as there)."""
     from openeat_amd.modules.swish import Swish
-    table = {"relu": torch.nn.ReLU, "swish": Swish}
-    if act not in table:
-        raise NotImplementedError(f"activation '{act}' has no gfx950 kernel yet (available: {sorted(table)})")
+    table = {"hardtanh": torch.nn.Hardtanh, "tanh": torch.nn.Tanh, "relu": torch.nn.ReLU, "selu": torch.nn.SELU, "swish": Swish,
+             "gelu": torch.nn.GELU}
     return table[act]()

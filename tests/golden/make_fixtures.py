@@ -239,6 +239,22 @@ def f18_encoder_conv2d8():
                                    "out": {"y": y, "mask": ymask, "pos": pos}, "grad": {**grads_of(enc, "encoder."), "x": x.grad}})
 
 
+def f19_activations():
+    """One Conformer block (macaron FFNs + conv module use the activation) for the other entries of the reference's
+    activation table (utils/common.py:160-173): tanh, hardtanh, selu, gelu."""
+    for act in ("tanh", "hardtanh", "selu", "gelu"):
+        torch.manual_seed(119)
+        enc = TransformerEncoder(24, "linear", "rel_pos", 32, 0.0, 4, 64, act, True, True, 15, False, False, 64, 0.1, num_blocks=1)
+        randomize(enc, 19)
+        x = torch.randn(3, 19, 24, requires_grad=True)
+        mask = ragged_mask([19, 12, 5], 19)
+        y, ymask, pos = enc(x, mask)
+        w = torch.randn_like(y)
+        (y * w).sum().backward()
+        save(f"f19_encoder_act_{act}", **{"in": {"x": x, "mask": mask, "w": w}, "sd": sd_of(enc, "encoder."),
+                                           "out": {"y": y}, "grad": {**grads_of(enc, "encoder."), "x": x.grad}})
+
+
 def f17_spec_augment():
     """feature_processor.py:10-64 in CollateFunc's order (dataset.py:203-209) with a fixed python-random seed."""
     import random
@@ -472,4 +488,4 @@ if __name__ == "__main__":
     else:
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
-        f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8()
+        f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations()

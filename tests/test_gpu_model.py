@@ -135,6 +135,20 @@ def test_f16_encoder_linear_input_layer(name):
     check_param_grads(enc, g["grad"], "encoder.", rtol=3e-3, rel_floor=1e-3)
 
 
+@pytest.mark.parametrize("act", ["tanh", "hardtanh", "selu", "gelu"])
+def test_f19_other_activations(act):
+    """The rest of the reference's activation table (utils/common.py:160-173) through the fused FFN / conv-module ops."""
+    g = load_golden(f"f19_encoder_act_{act}")
+    enc = TransformerEncoder(24, "linear", "rel_pos", 32, 0.0, 4, 64, act, True, True, 15, False, False, 64, 0.1, num_blocks=1)
+    enc = load_into(enc, g["sd"], "encoder.")
+    x = g["in"]["x"].to(DEV).requires_grad_()
+    y, _, _ = enc(x, g["in"]["mask"].to(DEV))
+    close(y, g["out"]["y"], rtol=5e-4, atol=2e-4, msg="y")
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    close(x.grad, g["grad"]["x"], rtol=2e-3, atol=3e-4, msg="dx")
+    check_param_grads(enc, g["grad"], "encoder.", rtol=3e-3, rel_floor=1e-3)
+
+
 def test_f18_encoder_conv2d8_input_layer():
     g = load_golden("f18_encoder_conv2d8")
     enc = TransformerEncoder(80, "conv2d8", "rel_pos", 32, 0.0, 4, 64, "swish", True, True, 15, False, False, 64, 0.1, num_blocks=1)

@@ -120,6 +120,20 @@ def test_f16_encoder_linear_input_layer(name):
     torch.testing.assert_close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("act", ["tanh", "hardtanh", "selu", "gelu"])
+def test_f19_other_activations(act):
+    g = load_golden(f"f19_encoder_act_{act}")
+    cfg = O.Config(input_size=24, d_model=32, attention_heads=4, linear_units=64, dropout_rate=0.0, encoder_num_blocks=1,
+                   input_layer="linear", pos_enc_layer_type="rel_pos", activation_type=act, macaron_style=True, use_cnn_module=True)
+    sd = req(g["sd"])
+    x = g["in"]["x"].clone().requires_grad_()
+    y, _, _ = O.encoder(sd, cfg, x, g["in"]["mask"])
+    torch.testing.assert_close(y, g["out"]["y"], rtol=2e-4, atol=5e-5)
+    (y * g["in"]["w"]).sum().backward()
+    check_grads(sd, g["grad"], tol=dict(rtol=1e-3, atol=2e-4))
+    torch.testing.assert_close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4)
+
+
 def test_f18_encoder_conv2d8_input_layer():
     """TransformerEncoder(input_layer='conv2d8'): subsampling.py:185-253 (three 3x3 stride-2 convs, 1/8 frame rate)."""
     g = load_golden("f18_encoder_conv2d8")
