@@ -12,12 +12,12 @@ from openeat_amd.modules.embedding import PositionalEncoding
 from openeat_amd.modules.positionwise_feed_forward import PositionwiseFeedForward
 
 
-def _dec_layers(d, dropout_rate, heads, units, use_adapter, n):
-    if use_adapter:
-        raise NotImplementedError("adapters are outside the accelerated path")
+def _dec_layers(d, dropout_rate, heads, units, use_adapter, n, down_size=64, scalar=0.1):
+    from openeat_amd.modules.adapter import Adapter
     return torch.nn.ModuleList([
         DecoderLayer(d, MultiHeadedAttention(heads, d, dropout_rate), MultiHeadedAttention(heads, d, dropout_rate),
-                     PositionwiseFeedForward(d, units, dropout_rate), None, dropout_rate) for _ in range(n)])
+                     PositionwiseFeedForward(d, units, dropout_rate),
+                     Adapter(d, dropout_rate, down_size, scalar) if use_adapter else None, dropout_rate) for _ in range(n)])
 
 
 class Decoder(torch.nn.Module):
@@ -29,7 +29,7 @@ class Decoder(torch.nn.Module):
         super().__init__()
         self.num_blocks_share = num_blocks_share
         self.decoders = _dec_layers(d_model, dropout_rate, attention_heads, linear_units, use_adapter,
-                                    num_blocks // num_blocks_share)
+                                    num_blocks // num_blocks_share, down_size, scalar)
 
     def forward(self, tgt, tgt_mask, memory, memory_mask):
         x = tgt
@@ -49,7 +49,7 @@ class TransformerDecoder(torch.nn.Module):
         self.num_blocks_share = num_blocks_share
         self.embed = torch.nn.Sequential(torch.nn.Embedding(vocab_size, d_model), PositionalEncoding(d_model))
         self.decoders = _dec_layers(d_model, dropout_rate, attention_heads, linear_units, use_adapter,
-                                    num_blocks // num_blocks_share)
+                                    num_blocks // num_blocks_share, down_size, scalar)
         self.after_norm = torch.nn.LayerNorm(d_model, eps=1e-12)
         self.output_layer = torch.nn.Linear(d_model, vocab_size)
 

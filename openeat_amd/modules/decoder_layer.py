@@ -11,13 +11,11 @@ class DecoderLayer(nn.Module):
     def __init__(self, size: int, self_attn: nn.Module, src_attn: nn.Module, feed_forward: nn.Module,
                  adapter: Optional[nn.Module] = None, dropout_rate: float = 0.1):
         super().__init__()
-        if adapter is not None:
-            raise NotImplementedError("adapters are outside the accelerated path")
         self.size = size
         self.self_attn = self_attn
         self.src_attn = src_attn
         self.feed_forward = feed_forward
-        self.adapter = None
+        self.adapter = adapter
         self.norm1 = nn.LayerNorm(size, eps=1e-12)
         self.norm2 = nn.LayerNorm(size, eps=1e-12)
         self.norm3 = nn.LayerNorm(size, eps=1e-12)
@@ -42,8 +40,11 @@ class DecoderLayer(nn.Module):
             x = self.self_attn(q, y, y, tgt_mask[:, -1:, :], residual=residual[:, -1:, :].contiguous(), out_dropout=p)
         r, y = fork(self.norm2, x)
         x = self.src_attn(y, memory, memory, memory_mask, residual=r, out_dropout=p)
+        adapt_x = self.adapter(x) if self.adapter is not None else None      # decoder_layer.py:98-101
         r, y = fork(self.norm3, x)
         x = self.feed_forward(y, residual=r, out_scale=1.0, out_dropout=p)
+        if adapt_x is not None:
+            x = ops.add(x, adapt_x)                                           # decoder_layer.py:106
         if cache is not None:
             x = torch.cat([cache, x], dim=1)
         return x

@@ -14,9 +14,8 @@ from openeat_amd.utils.common import get_activation
 
 
 def _layers(d_model, dropout_rate, attention_heads, linear_units, activation_type, macaron_style, use_cnn_module,
-            cnn_module_kernel, causal, use_adapter, n_unique):
-    if use_adapter:
-        raise NotImplementedError("adapters are outside the accelerated path")
+            cnn_module_kernel, causal, use_adapter, n_unique, down_size=64, scalar=0.1):
+    from openeat_amd.modules.adapter import Adapter
     attn_cls = RelPositionMultiHeadedAttention if use_cnn_module else MultiHeadedAttention
 
     def ff():
@@ -25,7 +24,8 @@ def _layers(d_model, dropout_rate, attention_heads, linear_units, activation_typ
     return torch.nn.ModuleList([
         EncoderLayer(d_model, ff() if macaron_style else None, attn_cls(attention_heads, d_model, dropout_rate),
                      ConvolutionModule(d_model, cnn_module_kernel, get_activation(activation_type), causal)
-                     if use_cnn_module else None, ff(), None, dropout_rate)
+                     if use_cnn_module else None, ff(),
+                     Adapter(d_model, dropout_rate, down_size, scalar) if use_adapter else None, dropout_rate)
         for _ in range(n_unique)])
 
 
@@ -40,7 +40,8 @@ class Encoder(torch.nn.Module):
         self._output_size = d_model
         self.num_blocks_share = num_blocks_share
         self.encoders = _layers(d_model, dropout_rate, attention_heads, linear_units, activation_type, macaron_style,
-                                use_cnn_module, cnn_module_kernel, causal, use_adapter, num_blocks // num_blocks_share)
+                                use_cnn_module, cnn_module_kernel, causal, use_adapter, num_blocks // num_blocks_share,
+                                down_size, scalar)
         self.after_norm = torch.nn.LayerNorm(d_model, eps=1e-5)
 
     def output_size(self) -> int:
@@ -75,7 +76,8 @@ class TransformerEncoder(torch.nn.Module):
         self.global_cmvn = global_cmvn
         self.embed = sub[input_layer](input_size, d_model, pos[pos_enc_layer_type](d_model))
         self.encoders = _layers(d_model, dropout_rate, attention_heads, linear_units, activation_type, macaron_style,
-                                use_cnn_module, cnn_module_kernel, causal, use_adapter, num_blocks // num_blocks_share)
+                                use_cnn_module, cnn_module_kernel, causal, use_adapter, num_blocks // num_blocks_share,
+                                down_size, scalar)
         self.after_norm = torch.nn.LayerNorm(d_model, eps=1e-5)
 
     def output_size(self) -> int:

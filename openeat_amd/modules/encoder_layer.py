@@ -14,14 +14,12 @@ class EncoderLayer(nn.Module):
                  conv_module: Optional[nn.Module], feed_forward: nn.Module, adapter: Optional[nn.Module],
                  dropout_rate: float = 0.1):
         super().__init__()
-        if adapter is not None:
-            raise NotImplementedError("adapters are off in every shipped config and outside the accelerated path")
         self.size = size
         self.feed_forward_macaron = feed_forward_macaron
         self.self_attn = self_attn
         self.conv_module = conv_module
         self.feed_forward = feed_forward
-        self.adapter = None
+        self.adapter = adapter
         self.ff_scale = 1
         if feed_forward_macaron is not None:
             self.ff_scale = 0.5
@@ -57,8 +55,11 @@ class EncoderLayer(nn.Module):
             # fused into the LayerNorm kernel, so the module skips its own input-mask pass.
             r, y = self._fork(self.norm_conv, x, rowmask)
             x = self.conv_module(y, m8, residual=r, out_dropout=p, input_masked=True)
+        adapt_x = self.adapter(x) if self.adapter is not None else None      # encoder_layer.py:97-100
         r, y = self._fork(self.norm_ff, x)
         x = self.feed_forward(y, residual=r, out_scale=self.ff_scale, out_dropout=p)
+        if adapt_x is not None:
+            x = ops.add(x, adapt_x)                                           # encoder_layer.py:108
         if self.conv_module is not None:
             x = self._ln(self.norm_final, x)
         return x, masks

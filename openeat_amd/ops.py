@@ -405,6 +405,25 @@ def scale_add(x, alpha, add=None):
     return ScaleAddFn.apply(x, alpha, add)
 
 
+class AddFn(torch.autograd.Function):
+    """x + y with both gradients passed through (encoder_layer.py:108 / decoder_layer.py:106: `x = x + adapt_x`)."""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = _chk(x, "add"), _chk(y, "add")
+        out = torch.empty_like(x)
+        hip.call("oe_axpby", x, y, x.numel(), 1.0, 1.0, None, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, d
+
+
+def add(x, y):
+    return AddFn.apply(x, y)
+
+
 class CmvnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mean, istd):

@@ -52,6 +52,10 @@ class Config:
     reverse_weight: float = 0.0
     length_normalized_loss: bool = False
     ignore_id: int = IGNORE_ID
+    encoder_use_adapter: bool = False      # models/asr_model.py:56-58; the adapter is applied wherever its weights exist
+    decoder_use_adapter: bool = False
+    down_size: int = 64
+    scalar: float = 0.1
     has_cmvn: bool = False
 
     @property
@@ -304,9 +308,16 @@ def conv_module(sd, pfx: str, cfg: Config, x: Tensor, mask_pad: Tensor, act) -> 
     return y.transpose(1, 2)
 
 
+def adapter(sd, pfx: str, x: Tensor, scale: float, pd: float, training: bool) -> Tensor:
+    """modules/adapter.py:30-35."""
+    y = _ln(x, sd, pfx + ".norm", 1e-12)
+    y = _lin(_drop(F.relu(_lin(y, sd, pfx + ".down_proj")), pd, training), sd, pfx + ".up_proj")
+    return x + scale * _drop(y, pd, training)
+
+
 def encoder_layer(sd, pfx: str, cfg: Config, x: Tensor, mask: Tensor, pos_emb: Tensor,
                   training: bool = False) -> Tensor:
-    """modules/encoder_layer.py:64-112 (adapter branch is off in every config)."""
+    """modules/encoder_layer.py:64-112."""
     act = _act(cfg.activation_type)
     pd = cfg.dropout_rate
     h = cfg.attention_heads
@@ -324,8 +335,10 @@ def encoder_layer(sd, pfx: str, cfg: Config, x: Tensor, mask: Tensor, pos_emb: T
     if cfg.use_cnn_module:
         y = conv_module(sd, pfx + ".conv_module", cfg, _ln(x, sd, pfx + ".norm_conv", 1e-12), mask, act)
         x = x + _drop(y, pd, training)
+    adapt_x = adapter(sd, pfx + ".adapter", x, cfg.scalar, pd, training) if (pfx + ".adapter.norm.weight") in sd else 0.0
     y = feed_forward(sd, pfx + ".feed_forward", _ln(x, sd, pfx + ".norm_ff", 1e-12), act, pd, training)
     x = x + ff_scale * _drop(y, pd, training)
+    x = x + adapt_x                                       # encoder_layer.py:97-108
     if cfg.use_cnn_module:
         x = _ln(x, sd, pfx + ".norm_final", 1e-12)
     return x
@@ -396,8 +409,10 @@ def decoder_layer(sd, pfx: str, cfg: Config, tgt: Tensor, tgt_mask: Tensor, memo
     x = residual + _drop(mha(sd, pfx + ".self_attn", h, q, y, y, q_mask, pd, training), pd, training)
     y = _ln(x, sd, pfx + ".norm2", 1e-12)
     x = x + _drop(mha(sd, pfx + ".src_attn", h, y, memory, memory, memory_mask, pd, training), pd, training)
+    adapt_x = adapter(sd, pfx + ".adapter", x, cfg.scalar, pd, training) if (pfx + ".adapter.norm.weight") in sd else 0.0
     y = _ln(x, sd, pfx + ".norm3", 1e-12)
     x = x + _drop(feed_forward(sd, pfx + ".feed_forward", y, F.relu, pd, training), pd, training)
+    x = x + adapt_x                                       # decoder_layer.py:98-106
     if cache is not None:
         x = torch.cat([cache, x], dim=1)
     return x

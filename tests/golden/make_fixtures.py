@@ -461,6 +461,16 @@ def f15_e2e_length_normalized():
          lens=[95, 70, 43], tlens=[7, 5, 3], V=40, seed=15)
 
 
+def f20_e2e_adapters():
+    """Tiny Conformer with adapters in every encoder and decoder layer (modules/adapter.py; asr_model.py:56-58)."""
+    _e2e("f20_tiny_conformer_adapters",
+         dict(encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+              linear_units=64, dropout_rate=0.0, activation_type="swish", macaron_style=True, use_cnn_module=True,
+              cnn_module_kernel=15, pos_enc_layer_type="rel_pos", ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3,
+              encoder_use_adapter=True, decoder_use_adapter=True, down_size=16, scalar=0.25),
+         lens=[95, 70, 43], tlens=[7, 5, 3], V=40, seed=20)
+
+
 def f13_misc():
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.Adam([p], lr=1e-3)
@@ -488,4 +498,4 @@ if __name__ == "__main__":
     else:
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
-        f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations()
+        f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations(); f20_e2e_adapters()

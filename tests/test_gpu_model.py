@@ -235,7 +235,8 @@ def test_f09_bidecoder_and_incremental_decoding():
             close(p, g["out"]["steps"][step - 1], rtol=2e-4, atol=1e-4, msg=f"step{step}")
 
 
-E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False}
+E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False,
+       "f20_tiny_conformer_adapters": False}
 
 
 @pytest.mark.parametrize("name", list(E2E))

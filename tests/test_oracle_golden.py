@@ -270,7 +270,8 @@ def test_f10_helper_tables():
         assert a == b or abs(a - b) < 1e-12
 
 
-E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False}
+E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False,
+       "f20_tiny_conformer_adapters": False}
 
 
 @pytest.mark.parametrize("name", list(E2E))
