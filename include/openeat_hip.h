@@ -68,11 +68,13 @@ typedef struct oe_gemm_args {
     const unsigned char* rowmask;
     const float* residual; long ldr; int res_row_mod; float beta;
     int accumulate; int atomic_out;
-    int conv_gather; int conv_t1, conv_f1, conv_t2, conv_f2, conv_c;
+    int conv_gather; int conv_t1, conv_f1, conv_t2, conv_f2, conv_c;   /* implicit conv: input (B,t1,f1,c) NHWC -> (B,t2,f2) positions */
     float* a_colsum; /* optional (precision != 0, k-major A): a_colsum[m] += alpha * sum_k A(m,k), i.e. the bias
                         gradient fused into the weight-gradient GEMM (adders per address = split_k) */
     int precision;   /* 0: fp32-input MFMA (exact fp32 products); 1: bf16 inputs, fp32 accumulate;
                         3: 3-term bf16 split hi*hi+hi*lo+lo*hi (fp32-grade, ~2^-17 per product) */
+    int conv_k, conv_s;   /* kernel size / stride of the gathered conv; 0 = 3 / 2 (Conv2dSubsampling4/8); 5 / 3 is
+                             Conv2dSubsampling6's second conv (subsampling.py:136) */
 } oe_gemm_args;
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);
@@ -228,6 +230,9 @@ int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int F, int C, 
  * ReLU mask of the layer below (autograd of subsampling.py:78-79):
  * dcol (B*T2*F2, 9C) = dy @ W[co][kh][kw][ci]  ->  dx (B,T1,F1,C) * (y1 > 0). */
 int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, int C, float* dx, void* stream);
+/* the same for a KS x KS kernel with stride S (oe_col2im_relu = 3, 2) */
+int oe_col2im_relu_ks(const float* dcol, const float* y1, int B, int T1, int F1, int C, int KS, int S, float* dx,
+                      void* stream);
 
 /* GLU + depthwise Conv1d(K, groups=d) of the Conformer conv module
  * (convolution.py:104-107): a (B,T,2d) -> y (B,T,d); w (d,1,K); causal => left

@@ -133,7 +133,8 @@ extern "C" int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int
 // dx[b,t1,f1,c] = (y1[b,t1,f1,c] > 0) * sum_{kh,kw : t=(t1-kh)/2, f=(f1-kw)/2 integral, in range}
 //                 dcol[(b,t,f)][(kh*3+kw)*C + c]
 __global__ __launch_bounds__(256) void col2im_relu_kernel(const float* __restrict__ dcol, const float* __restrict__ y1, int B,
-                                                           int T1, int F1, int T2, int F2, int C, float* __restrict__ dx) {
+                                                           int T1, int F1, int T2, int F2, int C, int KS, int S,
+                                                           float* __restrict__ dx) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
     const int cv = C >> 2;
     const long total = (long)B * T1 * F1 * cv;
@@ -144,16 +145,14 @@ __global__ __launch_bounds__(256) void col2im_relu_kernel(const float* __restric
     const int t1 = (int)((pos / F1) % T1);
     const long b = pos / ((long)F1 * T1);
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
+    for (int kh = 0; kh < KS; ++kh) {
         const int tt = t1 - kh;
-        if (tt < 0 || (tt & 1) || (tt >> 1) >= T2) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
+        if (tt < 0 || (tt % S) || (tt / S) >= T2) continue;
+        for (int kw = 0; kw < KS; ++kw) {
             const int ff = f1 - kw;
-            if (ff < 0 || (ff & 1) || (ff >> 1) >= F2) continue;
-            const long m = (b * T2 + (tt >> 1)) * F2 + (ff >> 1);
-            const float4 v = *reinterpret_cast<const float4*>(dcol + m * (9L * C) + (kh * 3 + kw) * C + c);
+            if (ff < 0 || (ff % S) || (ff / S) >= F2) continue;
+            const long m = (b * T2 + (tt / S)) * F2 + (ff / S);
+            const float4 v = *reinterpret_cast<const float4*>(dcol + m * ((long)KS * KS * C) + (kh * KS + kw) * C + c);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
     }
@@ -162,14 +161,18 @@ __global__ __launch_bounds__(256) void col2im_relu_kernel(const float* __restric
     *reinterpret_cast<float4*>(dx + pos * C + c) = s;
 }
 
-extern "C" int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, int C, float* dx, void* stream) {
-    OE_REQUIRE(dcol && y1 && dx && B > 0 && T1 >= 3 && F1 >= 3 && C > 0 && C % 4 == 0, "oe_col2im_relu: bad arguments");
-    const int T2 = (T1 - 3) / 2 + 1, F2 = (F1 - 3) / 2 + 1;
+extern "C" int oe_col2im_relu_ks(const float* dcol, const float* y1, int B, int T1, int F1, int C, int KS, int S, float* dx,
+                                 void* stream) {
+    OE_REQUIRE(dcol && y1 && dx && B > 0 && KS >= 1 && S >= 1 && T1 >= KS && F1 >= KS && C > 0 && C % 4 == 0, "oe_col2im_relu: bad arguments");
+    const int T2 = (T1 - KS) / S + 1, F2 = (F1 - KS) / S + 1;
     const long total = (long)B * T1 * F1 * (C / 4);
     hipLaunchKernelGGL(col2im_relu_kernel, dim3(oe_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dcol, y1, B, T1, F1, T2,
-                       F2, C, dx);
+                       F2, C, KS, S, dx);
     OE_LAUNCH_CHECK("col2im_relu");
     return 0;
+}
+extern "C" int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1, int F1, int C, float* dx, void* stream) {
+    return oe_col2im_relu_ks(dcol, y1, B, T1, F1, C, 3, 2, dx, stream);
 }
 
 // -------------------------------------------------------- GLU + depthwise ----

@@ -203,10 +203,13 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     if (ga || gb) {
         OperandDesc& X = ga ? A : B;
         X.T1 = g->conv_t1; X.F1 = g->conv_f1; X.T2 = g->conv_t2; X.F2 = g->conv_f2; X.C = g->conv_c;
+        X.KS = g->conv_k > 0 ? g->conv_k : 3;             // 0 = the 3x3 stride-2 conv of Conv2dSubsampling4/8
+        X.S = g->conv_s > 0 ? g->conv_s : 2;
         OE_REQUIRE(X.C > 0 && X.C % 4 == 0, "oe_gemm_f32: conv gather needs C %% 4 == 0");
-        OE_REQUIRE(X.T2 == (X.T1 - 3) / 2 + 1 && X.F2 == (X.F1 - 3) / 2 + 1, "oe_gemm_f32: conv gather dims inconsistent");
+        OE_REQUIRE(X.T1 >= X.KS && X.F1 >= X.KS && X.T2 == (X.T1 - X.KS) / X.S + 1 && X.F2 == (X.F1 - X.KS) / X.S + 1,
+                   "oe_gemm_f32: conv gather dims inconsistent");
         X.vec_ok = ((uintptr_t)X.p % 16 == 0);
-        OE_REQUIRE(ga ? (!g->a_kmajor && g->k == 9 * X.C) : (g->b_kmajor && g->n == 9 * X.C),
+        OE_REQUIRE(ga ? (!g->a_kmajor && g->k == X.KS * X.KS * X.C) : (g->b_kmajor && g->n == X.KS * X.KS * X.C),
                    "oe_gemm_f32: conv gather layout mismatch");
     }
     EpiParams ep{};

@@ -151,7 +151,7 @@ struct Stage {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int k = k0 + 4 * kb + i;
-                        const long base = ((bb * d.T1 + 2 * t) * (long)d.F1 + 2 * f) * d.C;
+                        const long base = ((bb * d.T1 + d.S * t) * (long)d.F1 + d.S * f) * d.C;
                         reg[s][i] = (nvr && k < k_end) ? load4(d.p + base + fix[s], nvr, d.vec_ok) : make_float4(0, 0, 0, 0);
                         if (++f == d.F2) { f = 0; if (++t == d.T2) { t = 0; ++bb; } }
                     }

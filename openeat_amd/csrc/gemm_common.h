@@ -38,8 +38,8 @@ struct OperandDesc {
     const float* p;
     long ld;
     int vec_ok;     // 16-byte vector loads are legal (pointer/ld alignment)
-    // conv2 im2col gather (NHWC input (B,T1,F1,C), 3x3 stride 2, output (B,T2,F2)):
-    int T1, F1, T2, F2, C;
+    // conv im2col gather (NHWC input (B,T1,F1,C), KS x KS kernel, stride S, output (B,T2,F2)):
+    int T1, F1, T2, F2, C, KS, S;
 };
 
 template <bool GATHER>
@@ -49,12 +49,12 @@ __device__ __forceinline__ long addr_row(const OperandDesc& d, long r) {
     long q = r / d.F2;
     int t = (int)(q % d.T2);
     long b = q / d.T2;
-    return ((b * d.T1 + 2 * t) * (long)d.F1 + 2 * f) * d.C;
+    return ((b * d.T1 + d.S * t) * (long)d.F1 + d.S * f) * d.C;
 }
 template <bool GATHER>
 __device__ __forceinline__ long addr_col(const OperandDesc& d, long c) {
     if (!GATHER) return c;
-    int seg = 3 * d.C;
+    int seg = d.KS * d.C;
     int kh = (int)(c / seg);
     return (long)kh * d.F1 * d.C + (c - (long)kh * seg);
 }

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const float* __restrict__
                 int f, t;
                 const int q = div_small(kposB[j], Bd.F2, rF2, f);
                 const int b = div_small(q, Bd.T2, rT2, t);
-                dma16(srcB[j] + (((long)b * Bd.T1 + 2 * t) * Bd.F1 + 2 * f) * Bd.C, sb + j * 1024u);
+                dma16(srcB[j] + (((long)b * Bd.T1 + Bd.S * t) * Bd.F1 + Bd.S * f) * Bd.C, sb + j * 1024u);
                 kposB[j] += DBK;
             }
         }
@@ -273,9 +273,9 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     if ((a_kmajor && M % 4) || (b_kmajor && N % 4)) return 1;
     if (gather_b && (M % bm || N % bn)) return 1;
     if (gather_b) {
-        // conv2 weight gradient: a 128-column tile must stay inside one kernel row (3C contiguous floats),
+        // conv weight gradient: a column tile must stay inside one kernel row (KS*C contiguous floats),
         // positions must be exact in float (div_small), C a multiple of 4 for the 16-byte pieces
-        if (!(a_kmajor && b_kmajor) || (3 * B.C) % bn || B.C % 4 || K >= (1 << 24) || (tile != 22 && tile != 11)) return 1;
+        if (!(a_kmajor && b_kmajor) || (B.KS * B.C) % bn || B.C % 4 || K >= (1 << 24) || (tile != 22 && tile != 11)) return 1;
         int kc = oe_cdiv(oe_cdiv(K, sk), DBK) * DBK;
         if (kc <= 0) kc = DBK;
         const int nz = oe_cdiv(K, kc);

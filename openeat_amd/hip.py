@@ -49,6 +49,7 @@ class GemmArgs(C.Structure):
         ("conv_f2", C.c_int), ("conv_c", C.c_int),
         ("a_colsum", c_fp),
         ("precision", C.c_int),
+        ("conv_k", C.c_int), ("conv_s", C.c_int),
     ]
 
 
@@ -121,6 +122,7 @@ _SIGNATURES = {
     "oe_conv1_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
     "oe_col2im_relu": (I, [P, P, I, I, I, I, P, P]),
+    "oe_col2im_relu_ks": (I, [P, P, I, I, I, I, I, I, P, P]),
     "oe_dwconv_glu_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P]),
     "oe_dwconv_glu_bwd_workspace_floats": (SZ, [I, I, I, I]),
     "oe_dwconv_glu_bwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
@@ -191,8 +193,9 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.conv_gather = conv_gather
     g.precision = GEMM_PRECISION if precision is None else precision
     g.a_colsum = None if (a_colsum is None or g.precision == 0) else a_colsum.data_ptr()
-    if conv is not None:
-        g.conv_t1, g.conv_f1, g.conv_t2, g.conv_f2, g.conv_c = conv
+    if conv is not None:                         # (T1, F1, T2, F2, C) or (T1, F1, T2, F2, C, kernel size, stride)
+        g.conv_t1, g.conv_f1, g.conv_t2, g.conv_f2, g.conv_c = conv[:5]
+        g.conv_k, g.conv_s = (conv[5], conv[6]) if len(conv) > 5 else (0, 0)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -1,6 +1,6 @@
 """Input layers (/root/reference/openeat/modules/subsampling.py): the 1/4 conv2d subsampling of every shipped
-config, the 1/8 variant (one more 3x3 stride-2 stage of the same implicit-GEMM kind) and the linear (no subsampling)
-layer.  The 1/6 variant (5x5 stride 3) has no HIP path yet."""
+config, the 1/6 (a 5x5 stride-3 second conv) and 1/8 (one more 3x3 stride-2 stage) variants on the same implicit-GEMM
+op, and the linear (no subsampling) layer."""
 from typing import Tuple
 
 import torch
@@ -37,13 +37,26 @@ class Conv2dSubsampling4(BaseSubsampling):
         return y, x_mask[:, :, :-2:2][:, :, :-2:2], pos
 
 
-class _NoKernelYet(BaseSubsampling):
-    def __init__(self, *a, **k):
-        raise NotImplementedError(f"{type(self).__name__}: no gfx950 kernel yet; use input_layer='conv2d'")
+class Conv2dSubsampling6(BaseSubsampling):
+    """subsampling.py:119-182.  Parameter names as in the reference: conv.0 (d,1,3,3), conv.2 (d,d,5,5),
+    linear (d, d*(((idim-1)//2-2)//3))."""
 
+    def __init__(self, idim: int, odim: int, pos_enc_class: torch.nn.Module):
+        super().__init__()
+        self.conv = torch.nn.Sequential(
+            torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(), torch.nn.Conv2d(odim, odim, 5, 3), torch.nn.ReLU())
+        self.linear = torch.nn.Linear(odim * (((idim - 1) // 2 - 2) // 3), odim)
+        self.pos_enc = pos_enc_class
+        self.subsampling_rate = 6
+        self.right_context = 14
 
-class Conv2dSubsampling6(_NoKernelYet):
-    pass
+    def forward(self, x: torch.Tensor, x_mask: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        t_out = ((x.size(1) - 1) // 2 - 2) // 3
+        pos = self.pos_enc.table(x.device, t_out)
+        pe = pos if self.pos_enc.kind == "abs_pos" else None
+        c0, c2 = self.conv[0], self.conv[2]
+        y = ops.subsampling6(x, c0.weight, c0.bias, c2.weight, c2.bias, self.linear.weight, self.linear.bias, pe, self.pos_enc.xscale)
+        return y, x_mask[:, :, :-2:2][:, :, :-4:3], pos
 
 
 class Conv2dSubsampling8(BaseSubsampling):

@@ -724,19 +724,21 @@ def conv_module(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residu
 # Conv2d subsampling (1/4) + output Linear + positional scaling
 # --------------------------------------------------------------------------- #
 class ConvSubsamplingFn(torch.autograd.Function):
-    """subsampling.py:110-116 (Conv2dSubsampling4) / :248-253 (Conv2dSubsampling8) + embedding.py:44-60/75-88:
-    Conv2d(1,C,3,2)+ReLU -> n x [Conv2d(C,C,3,2)+ReLU] -> channel-major flatten -> Linear -> x*sqrt(d) (+pe).
+    """subsampling.py:110-116 (Conv2dSubsampling4) / :176-182 (6) / :248-253 (8) + embedding.py:44-60/75-88:
+    Conv2d(1,C,3,2)+ReLU -> n x [Conv2d(C,C,k,s)+ReLU] -> channel-major flatten -> Linear -> x*sqrt(d) (+pe);
+    `geoms` = ((k, s), ...) of the n C->C stages ((3,2) for 1/4, (5,3) for 1/6, (3,2),(3,2) for 1/8).
     Activations are kept NHWC so every C->C conv is an implicit GEMM (im2col gather in the operand load) and the
     flatten before the Linear is free; the checkpoint's OIHW / channel-major weights are re-laid-out on the fly (tiny).
     Arguments after the fixed ones: (w_k, b_k) of the n C->C conv stages, in forward order."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, wl, bl, pe, xscale, *stage_params):
+    def forward(ctx, x, w1, b1, wl, bl, pe, xscale, geoms, *stage_params):
         x = _chk(x, "subsampling input")
         B, T, Fd = x.shape
         C = w1.shape[0]
         d = wl.shape[0]
         n = len(stage_params) // 2
+        assert len(geoms) == n
         dims = [((T - 3) // 2 + 1, (Fd - 3) // 2 + 1)]
         y = _new(B, dims[0][0], dims[0][1], C, like=x)
         hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y)
@@ -744,13 +746,15 @@ class ConvSubsamplingFn(torch.autograd.Function):
         for k in range(n):
             wk, bk = stage_params[2 * k], stage_params[2 * k + 1]
             Ti, Fi = dims[-1]
-            To, Fo = (Ti - 3) // 2 + 1, (Fi - 3) // 2 + 1
-            assert To > 0 and Fo > 0, "input too short for the subsampling stack"
-            wg = _new(C, 9 * C, like=x)                             # [co][kh][kw][ci]
-            hip.call("oe_swap_last2", wk, C, C, 9, wg, 0)
+            ks, st = geoms[k]
+            To, Fo = (Ti - ks) // st + 1, (Fi - ks) // st + 1
+            assert Ti >= ks and Fi >= ks and To > 0 and Fo > 0, "input too short for the subsampling stack"
+            kk = ks * ks
+            wg = _new(C, kk * C, like=x)                            # [co][kh][kw][ci]
+            hip.call("oe_swap_last2", wk, C, C, kk, wg, 0)
             yo = _new(B * To * Fo, C, like=x)
-            hip.gemm(acts[-1], wg, yo, B * To * Fo, C, 9 * C, lda=0, ldb=9 * C, ldc=C, bias=bk, act=ACT_RELU,
-                     conv=(Ti, Fi, To, Fo, C), conv_gather=hip.GATHER_A)
+            hip.gemm(acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
+                     conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A)
             dims.append((To, Fo))
             acts.append(yo.view(B, To, Fo, C))
             wgs.append(wg)
@@ -763,12 +767,12 @@ class ConvSubsamplingFn(torch.autograd.Function):
         out = gemm_nt(ylv, wlg, bl, beta=xscale, residual=pe2, ldr=0 if pe2 is None else d, res_row_mod=0 if pe2 is None else TL)
         ctx.save_for_backward(x, wlg, *acts, *wgs)
         ctx.params = (w1, b1, wl, bl, stage_params)
-        ctx.cfg = (B, T, Fd, C, d, xscale, n, dims)
+        ctx.cfg = (B, T, Fd, C, d, xscale, n, dims, geoms)
         return out.view(B, TL, d)
 
     @staticmethod
     def backward(ctx, dout):
-        B, T, Fd, C, d, xscale, n, dims = ctx.cfg
+        B, T, Fd, C, d, xscale, n, dims, geoms = ctx.cfg
         x, wlg = ctx.saved_tensors[0], ctx.saved_tensors[1]
         acts = ctx.saved_tensors[2:2 + n + 1]
         wgs = ctx.saved_tensors[2 + n + 1:]
@@ -786,33 +790,39 @@ class ConvSubsamplingFn(torch.autograd.Function):
         for k in range(n - 1, -1, -1):
             wk, bk = stage_params[2 * k], stage_params[2 * k + 1]
             (Ti, Fi), (To, Fo) = dims[k], dims[k + 1]
+            ks, st = geoms[k]
+            kk = ks * ks
             Mo = B * To * Fo
-            conv = (Ti, Fi, To, Fo, C)
+            conv = (Ti, Fi, To, Fo, C, ks, st)
             yin = acts[k]
-            dwg = _new(C, 9 * C, like=do2, zero=True)
+            dwg = _new(C, kk * C, like=do2, zero=True)
             (dbk_buf, dbk) = grad_sink(bk)
-            hip.gemm(dy, yin, dwg, C, 9 * C, Mo, lda=C, ldb=0, ldc=9 * C, a_kmajor=True, b_kmajor=True,
-                     split_k=_split_k(C, 9 * C, Mo), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
+            hip.gemm(dy, yin, dwg, C, kk * C, Mo, lda=C, ldb=0, ldc=kk * C, a_kmajor=True, b_kmajor=True,
+                     split_k=_split_k(C, kk * C, Mo), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
                      a_colsum=dbk_buf if fused else None)
             if not fused:
                 colsum(dy, out=dbk_buf)
-            stage_grads[2 * k], stage_grads[2 * k + 1] = _sink_swapped(wk, dwg, C, 9, C), dbk
-            dcol = gemm_nn(dy, wgs[k])                               # (Mo, 9C)
+            stage_grads[2 * k], stage_grads[2 * k + 1] = _sink_swapped(wk, dwg, C, kk, C), dbk
+            dcol = gemm_nn(dy, wgs[k])                               # (Mo, k*k*C)
             dyin = torch.empty_like(yin)
-            hip.call("oe_col2im_relu", dcol, yin, B, Ti, Fi, C, dyin)   # col2im + the ReLU mask of this stage's input
+            hip.call("oe_col2im_relu_ks", dcol, yin, B, Ti, Fi, C, ks, st, dyin)   # col2im + the ReLU mask of this stage's input
             del dcol
             dy = dyin.view(B * Ti * Fi, C)
         (dw1, rw1), (db1, rb1) = grad_sink(w1), grad_sink(b1)
         hip.call("oe_conv1_wgrad", x, dy.view(B, dims[0][0], dims[0][1], C), B, T, Fd, C, dw1, db1)
-        return (None, rw1, rb1, dwl, dbl, None, None) + tuple(stage_grads)
+        return (None, rw1, rb1, dwl, dbl, None, None, None) + tuple(stage_grads)
 
 
 def subsampling4(x, w1, b1, w2, b2, wl, bl, pe, xscale):
-    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, w2, b2)
+    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, ((3, 2),), w2, b2)
+
+
+def subsampling6(x, w1, b1, w2, b2, wl, bl, pe, xscale):
+    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, ((5, 3),), w2, b2)
 
 
 def subsampling8(x, w1, b1, w2, b2, w3, b3, wl, bl, pe, xscale):
-    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, w2, b2, w3, b3)
+    return ConvSubsamplingFn.apply(x, w1, b1, wl, bl, pe, xscale, ((3, 2), (3, 2)), w2, b2, w3, b3)
 
 
 # --------------------------------------------------------------------------- #

@@ -206,6 +206,18 @@ def subsample4(sd, cfg: Config, x: Tensor, mask: Tensor):
     return y, mask[:, :, :-2:2][:, :, :-2:2], pos
 
 
+def subsample6(sd, cfg: Config, x: Tensor, mask: Tensor):
+    """modules/subsampling.py:119-182 (Conv2dSubsampling6) + embedding.py."""
+    p = "encoder.embed."
+    y = x.unsqueeze(1)
+    y = F.relu(F.conv2d(y, sd[p + "conv.0.weight"], sd[p + "conv.0.bias"], stride=2))
+    y = F.relu(F.conv2d(y, sd[p + "conv.2.weight"], sd[p + "conv.2.bias"], stride=3))
+    b, c, t, f = y.shape
+    y = _lin(y.transpose(1, 2).contiguous().view(b, t, c * f), sd, p + "linear")
+    y, pos = position_encode(cfg, y)
+    return y, mask[:, :, :-2:2][:, :, :-4:3], pos
+
+
 def subsample8(sd, cfg: Config, x: Tensor, mask: Tensor):
     """modules/subsampling.py:185-253 (Conv2dSubsampling8) + embedding.py."""
     p = "encoder.embed."
@@ -353,6 +365,8 @@ def encoder(sd, cfg: Config, feats: Tensor, masks: Tensor, training: bool = Fals
         x, masks, pos = linear_no_subsampling(sd, cfg, x, masks)
     elif cfg.input_layer == "conv2d8":      # modules/encoder.py:156-157
         x, masks, pos = subsample8(sd, cfg, x, masks)
+    elif cfg.input_layer == "conv2d6":      # modules/encoder.py:154-155
+        x, masks, pos = subsample6(sd, cfg, x, masks)
     else:
         assert cfg.input_layer == "conv2d"
         x, masks, pos = subsample4(sd, cfg, x, masks)

@@ -255,6 +255,21 @@ def f19_activations():
                                            "out": {"y": y}, "grad": {**grads_of(enc, "encoder."), "x": x.grad}})
 
 
+def f21_encoder_conv2d6():
+    """TransformerEncoder(input_layer='conv2d6') (encoder.py:154-155, subsampling.py:119-182), ragged lengths."""
+    torch.manual_seed(121)
+    enc = TransformerEncoder(80, "conv2d6", "abs_pos", 32, 0.0, 4, 64, "relu", False, False, 15, False, False, 64, 0.1, num_blocks=1)
+    randomize(enc, 21)
+    lens = [131, 97, 60]
+    x = torch.randn(3, 131, 80, requires_grad=True)
+    mask = ragged_mask(lens, 131)
+    y, ymask, pos = enc(x, mask)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    save("f21_encoder_conv2d6", **{"in": {"x": x, "mask": mask, "w": w}, "sd": sd_of(enc, "encoder."),
+                                   "out": {"y": y, "mask": ymask, "pos": pos}, "grad": {**grads_of(enc, "encoder."), "x": x.grad}})
+
+
 def f17_spec_augment():
     """feature_processor.py:10-64 in CollateFunc's order (dataset.py:203-209) with a fixed python-random seed."""
     import random
@@ -498,4 +513,4 @@ if __name__ == "__main__":
     else:
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
-        f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations(); f20_e2e_adapters()
+        f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations(); f20_e2e_adapters(); f21_encoder_conv2d6()

@@ -149,6 +149,17 @@ def test_f19_other_activations(act):
     check_param_grads(enc, g["grad"], "encoder.", rtol=3e-3, rel_floor=1e-3)
 
 
+def test_f21_encoder_conv2d6_input_layer():
+    g = load_golden("f21_encoder_conv2d6")
+    enc = TransformerEncoder(80, "conv2d6", "abs_pos", 32, 0.0, 4, 64, "relu", False, False, 15, False, False, 64, 0.1, num_blocks=1)
+    enc = load_into(enc, g["sd"], "encoder.")
+    y, mask, pos = enc(g["in"]["x"].to(DEV), g["in"]["mask"].to(DEV))
+    close(y, g["out"]["y"], rtol=5e-4, atol=2e-4, msg="y")
+    assert torch.equal(mask.cpu(), g["out"]["mask"])
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    check_param_grads(enc, g["grad"], "encoder.", rtol=3e-3, rel_floor=1e-3)
+
+
 def test_f18_encoder_conv2d8_input_layer():
     g = load_golden("f18_encoder_conv2d8")
     enc = TransformerEncoder(80, "conv2d8", "rel_pos", 32, 0.0, 4, 64, "swish", True, True, 15, False, False, 64, 0.1, num_blocks=1)

@@ -134,6 +134,21 @@ def test_f19_other_activations(act):
     torch.testing.assert_close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4)
 
 
+def test_f21_encoder_conv2d6_input_layer():
+    """TransformerEncoder(input_layer='conv2d6'): subsampling.py:119-182 (3x3 stride 2, then 5x5 stride 3)."""
+    g = load_golden("f21_encoder_conv2d6")
+    cfg = O.Config(input_size=80, d_model=32, attention_heads=4, linear_units=64, dropout_rate=0.0, encoder_num_blocks=1,
+                   input_layer="conv2d6", pos_enc_layer_type="abs_pos", activation_type="relu", macaron_style=False, use_cnn_module=False)
+    sd = req(g["sd"])
+    x = g["in"]["x"].clone().requires_grad_()
+    y, m, pos = O.encoder(sd, cfg, x, g["in"]["mask"])
+    torch.testing.assert_close(y, g["out"]["y"], rtol=2e-4, atol=5e-5)
+    assert torch.equal(m, g["out"]["mask"]) and y.shape[1] == 21
+    (y * g["in"]["w"]).sum().backward()
+    check_grads(sd, g["grad"], tol=dict(rtol=1e-3, atol=2e-4))
+    torch.testing.assert_close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4)
+
+
 def test_f18_encoder_conv2d8_input_layer():
     """TransformerEncoder(input_layer='conv2d8'): subsampling.py:185-253 (three 3x3 stride-2 convs, 1/8 frame rate)."""
     g = load_golden("f18_encoder_conv2d8")
