@@ -201,7 +201,7 @@ struct Stage {
 };
 
 template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, bool GATHER_A, bool GATHER_B, int TERMS, bool FAST>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, OperandDesc B, float* __restrict__ C, long ldc,
                                                          int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
     // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (private L2s); give each
     // XCD one contiguous range of tiles (x fastest) so blocks sharing an operand strip hit the same L2.

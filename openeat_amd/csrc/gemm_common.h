@@ -208,33 +208,45 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     const int prow = lane >> 3, pcol = (lane & 7) * 4;       // this lane's (row within a pass, first column) of the patch
 
     if (interior && c_vec && aux_vec && res_vec && !ep.accumulate) {
+        // auxiliary inputs (act-grad source, residual, row mask) are double-buffered across the wave's tiles: tile t+1's
+        // loads are issued while tile t is still in its LDS round trip, so their HBM latency hides behind tile t's
+        // math and stores instead of standing in front of tile t+1's
+        float4 auxb[2][4], resb[2][4];
+        bool deadb[2][4];
+        auto issue_loads = [&](int i, int j, float4 (&aux)[4], float4 (&res)[4], bool (&dead)[4]) {
+            const long row0 = m0 + wm * (32 * TM) + i * 32 + prow;
+            const long col = n0 + wn * (32 * TN) + j * 32 + pcol;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) { aux[p] = make_float4(0.f, 0.f, 0.f, 0.f); res[p] = aux[p]; dead[p] = false; }
+            if (ep.actgrad_in) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) aux[p] = *reinterpret_cast<const float4*>(ep.actgrad_in + (row0 + 8 * p) * ep.ld_aux + col);
+            }
+            if (ep.residual) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const long rr = ep.res_row_mod > 0 ? (row0 + 8 * p) % ep.res_row_mod : row0 + 8 * p;
+                    res[p] = *reinterpret_cast<const float4*>(ep.residual + rr * ep.ldr + col);
+                }
+            }
+            if (ep.rowmask) {
+#pragma unroll
+                for (int p = 0; p < 4; ++p) dead[p] = !ep.rowmask[row0 + 8 * p];
+            }
+        };
+        issue_loads(0, 0, auxb[0], resb[0], deadb[0]);
         static_for<0, TM * TN>([&](auto tile_idx) {
             {
-                constexpr int i = decltype(tile_idx)::value / TN, j = decltype(tile_idx)::value % TN;
+                constexpr int tix = decltype(tile_idx)::value;
+                constexpr int i = tix / TN, j = tix % TN;
                 const long row0 = m0 + wm * (32 * TM) + i * 32 + prow;
                 const long col = n0 + wn * (32 * TN) + j * 32 + pcol;
-                // ---- every load of this tile, before anything of it is stored
-                float4 aux[4], res[4];
-                bool dead[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) { aux[p] = make_float4(0.f, 0.f, 0.f, 0.f); res[p] = aux[p]; dead[p] = false; }
+                float4 (&aux)[4] = auxb[tix & 1];
+                float4 (&res)[4] = resb[tix & 1];
+                bool (&dead)[4] = deadb[tix & 1];
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (ep.bias && first_split) { b4.x = ep.bias[col]; b4.y = ep.bias[col + 1]; b4.z = ep.bias[col + 2]; b4.w = ep.bias[col + 3]; }
-                if (ep.actgrad_in) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) aux[p] = *reinterpret_cast<const float4*>(ep.actgrad_in + (row0 + 8 * p) * ep.ld_aux + col);
-                }
-                if (ep.residual) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) {
-                        const long rr = ep.res_row_mod > 0 ? (row0 + 8 * p) % ep.res_row_mod : row0 + 8 * p;
-                        res[p] = *reinterpret_cast<const float4*>(ep.residual + rr * ep.ldr + col);
-                    }
-                }
-                if (ep.rowmask) {
-#pragma unroll
-                    for (int p = 0; p < 4; ++p) dead[p] = !ep.rowmask[row0 + 8 * p];
-                }
+                if constexpr (tix + 1 < TM * TN) issue_loads((tix + 1) / TN, (tix + 1) % TN, auxb[(tix + 1) & 1], resb[(tix + 1) & 1], deadb[(tix + 1) & 1]);
                 // ---- accumulators -> patch -> row-major float4 (wave-private: a wave-level fence is enough)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();

@@ -83,7 +83,7 @@ __device__ __forceinline__ int div_small(int k, int d, float rd, int& rem) {
 // output position k = (b, t2, f2) of an NHWC activation; only its start address differs from a plain row, and a
 // DMA piece takes a per-lane source address anyway, so the gather costs two small divisions per piece and tile.
 template <int TM, int TN, bool A_KMAJOR, bool B_KMAJOR, int TERMS, int NST, bool GATHER_B = false>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
+__global__ __launch_bounds__(256, (NST == 2 && TM * TN <= 4) ? 2 : 1) void gemm_dma_kernel(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
                                                         float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk,
                                                         int gx, int gy, EpiParams ep, OperandDesc Bd) {
     int tile_x, tile_y, tile_z;
