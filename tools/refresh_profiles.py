@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Copy the artifacts of `tools/final_profiles.sh <tag>` from gpurun_out/final into profiles/ and rebuild the summaries."""
+import csv
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(src, "pmc"), "5", "3", tag], stdout=subprocess.DEVNULL)
+shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_p3.csv")
+rows = [r for r in csv.DictReader(open(f"{src}/trace/{tag}_kernel_stats.csv")) if "spin_kernel" not in r["Name"]]
+steps = 10.0
+tot = sum(int(r["TotalDurationNs"]) for r in rows)
+gem = [r for r in rows if "gemm_" in r["Name"]]
+gt, gc = sum(int(r["TotalDurationNs"]) for r in gem), sum(int(r["Calls"]) for r in gem)
+line = json.load(open(f"{src}/{tag}_bench_p3.json"))
+ro = line["roofline"]
+with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
+    f.write("# Round 1 - rocprofv3 kernel stats, bench config 2, precision 3 (final kernels of the round)\n\n")
+    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-decode --no-graph --steps 5 --warmup 2` "
+            "(10 optimizer steps in the trace: first step + 2 warm-up + 5 timed + 2 event-bracketed; the two `spin_kernel` launches that park the "
+            f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p3.csv`.\n\n")
+    f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
+            f"**GEMM class (`gemm_dma_kernel` + `gemm_bf16_kernel`, the kernels behind `oe_gemm_f32`): {gc / steps:.0f} launches/step, "
+            f"{gt / 1e6 / steps:.2f} ms/step, average launch {gt / gc / 1e3:.2f} us = {1574.63445504 / (gt / 1e6 / steps):.1f} TFLOP/s algorithmic** - "
+            f"bench.py's live HIP-event figure (event-pair overhead calibrated out) is {ro['gemm_ms_per_step']:.2f} ms/step, "
+            f"{ro['avg_launch_us']:.2f} us average, {ro['achieved']:.1f} TFLOP/s.\n\n")
+    f.write("| kernel | calls/step | avg us | ms/step | % |\n|---|---|---|---|---|\n")
+    for r in rows[:40]:
+        n = re.sub(r"\(.*", "", r["Name"])[:90]
+        f.write(f"| `{n}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {int(r['TotalDurationNs']) / 1e6 / steps:.3f} | "
+                f"{100 * int(r['TotalDurationNs']) / tot:.2f} |\n")
+for a, b in ((f"{tag}_bench_p3.json", f"{tag}_bench_p3.json"), (f"{tag}_bench_p3.err", f"{tag}_bench_p3.log"), (f"{tag}_gemm_bench.txt", f"{tag}_gemm_bench.txt"),
+             (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p3.txt")):
+    shutil.copy(f"{src}/{a}", f"{dst}/{b}")
+pm = json.load(open(f"{dst}/{tag}_pmc_hbm_traffic.json"))
+print(f"bench {line['ms_per_step']:.2f} ms/step {line['value']:.0f} frames/s graph={line['config']['hip_graph']}")
+print(f"roofline live {ro['achieved']:.1f} TF/s {ro['gemm_ms_per_step']:.2f} ms {ro['avg_launch_us']:.2f} us | rocprof {1574.63445504 / (gt / 1e6 / steps):.1f} TF/s "
+      f"{gt / 1e6 / steps:.2f} ms {gt / gc / 1e3:.2f} us | all kernels {tot / 1e6 / steps:.2f} ms")
+print(f"cpu {line['cpu_baseline']['value']:.0f} | decode rtf {line['decode']['rtf']:.6f} wall {line['decode']['wall_s'] * 1e3:.0f} ms")
+print(f"pmc gemm {pm['gemm']['hbm_bytes_per_step'] / 1e9:.2f} GB/step {pm['gemm']['hbm_bytes_per_launch'] / 1e6:.1f} MB/launch all {pm['all_kernels']['hbm_bytes_per_step'] / 1e9:.2f} GB/step")
