@@ -292,6 +292,9 @@ int oe_spec_augment(float* x, const int* nframes, int B, int Tmax, int F, const 
 /* Spec-substitute (feature_processor.py:45-64): subs (B, ns, 3) = (start, end, pos); rows [start, end) are replaced
  * by rows [start - pos, end - pos), one substitution after the other; end - start <= max_rows. */
 int oe_spec_substitute(float* x, int B, int Tmax, int F, const int* subs, int ns, int max_rows, void* stream);
+/* Feature dither (dataset.py:197-201): x += (u - 0.5) * a, u ~ U[0,1) from Philox(seed, element); only each utterance's
+ * own nframes[b] frames.  Distribution parity with the reference (which uses numpy's global generator), not bit parity. */
+int oe_feature_dither(float* x, const int* nframes, int B, int Tmax, int F, float a, unsigned long long seed, void* stream);
 
 /* CTC prefix beam search, HOST code (all pointers are host pointers): the per-frame recursion of
  * asr_model.py:359-396 on the top-`beam` (log-prob, token) pairs of every frame (computed on the

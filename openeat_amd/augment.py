@@ -14,6 +14,19 @@ import torch
 from openeat_amd import hip
 
 
+def feature_dither_(feats: torch.Tensor, nframes: Sequence[int], feature_dither: float) -> torch.Tensor:
+    """dataset.py:197-201: a = random.uniform(0, feature_dither) once per batch, then x += (U[0,1) - 0.5) * a.
+    `a` is drawn with python's random exactly as the reference does; the per-element uniforms come from the device
+    generator (the reference's come from numpy's global state), so this is distribution parity."""
+    if feature_dither == 0.0:
+        return feats
+    a = random.uniform(0, feature_dither)
+    B, Tmax, F = feats.shape
+    nf = torch.as_tensor([int(n) for n in nframes], dtype=torch.int32).to(feats.device)
+    hip.call("oe_feature_dither", feats, nf, B, Tmax, F, float(a), random.getrandbits(63))
+    return feats
+
+
 def spec_substitute_(feats: torch.Tensor, nframes: Sequence[int], max_t: int = 20, num_t_sub: int = 3) -> torch.Tensor:
     """feature_processor.py:45-64, in place on (B, Tmax, F): per utterance num_t_sub times
     start = randint(0, T-1); length = randint(1, max_t); end = min(T, start+length); pos = randint(0, start);

@@ -40,6 +40,35 @@ __global__ __launch_bounds__(256) void spec_substitute_kernel(float* __restrict_
     }
 }
 
+// Feature dither (dataset.py:197-201): x += (u - 0.5) * a with u ~ U[0,1) per element, on each utterance's own frames.
+// The reference draws u with numpy's global generator; here it is Philox (seed, element index): same distribution, not
+// the same numbers.
+__global__ __launch_bounds__(256) void feature_dither_kernel(float* __restrict__ x, const int* __restrict__ nframes, int Tmax, int F,
+                                                              float a, unsigned long long seed) {
+    const int b = blockIdx.y;
+    const int Tb = nframes ? min(nframes[b], Tmax) : Tmax;
+    const long n4 = ((long)Tb * F + 3) / 4;
+    float* base = x + (long)b * Tmax * F;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint4 r = philox4(seed, (unsigned long long)b * Tmax * F / 4 + i);
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long k = i * 4 + e;
+            if (k < (long)Tb * F) base[k] += ((float)(w[e] >> 8) * (1.0f / 16777216.0f) - 0.5f) * a;
+        }
+    }
+}
+
+extern "C" int oe_feature_dither(float* x, const int* nframes, int B, int Tmax, int F, float a, unsigned long long seed, void* stream) {
+    OE_REQUIRE(x && B > 0 && Tmax > 0 && F > 0, "oe_feature_dither: bad arguments");
+    if (a == 0.f) return 0;
+    const int nb = (int)min((long)oe_cdiv((long)Tmax * F / 4 + 1, 256), 64L);
+    hipLaunchKernelGGL(feature_dither_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, x, nframes, Tmax, F, a, seed);
+    OE_LAUNCH_CHECK("oe_feature_dither");
+    return 0;
+}
+
 extern "C" int oe_spec_augment(float* x, const int* nframes, int B, int Tmax, int F, const int* t_masks, int nt, const int* f_masks,
                                int nf, float value, void* stream) {
     OE_REQUIRE(x && B > 0 && Tmax > 0 && F > 0 && nt >= 0 && nf >= 0 && (nt == 0 || t_masks) && (nf == 0 || f_masks),

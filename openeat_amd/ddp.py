@@ -5,9 +5,9 @@ One process per GPU.  Gradients live in one flat fp32 arena, so the exchange is
 a handful of large all-reduces over contiguous memory (no bucketing copies, no
 per-parameter hooks).  The arena is laid out in forward order, so the part whose
 gradients are final at any point of backward is a contiguous tail: `reduce_tail`
-(called from two tensor hooks: gradient of the encoder output ready = heads done,
-gradient of the middle encoder layer's input ready = upper half done) sends that
-tail to RCCL while the rest of backward keeps running; `__call__` after backward
+(called from tensor hooks: gradient of the encoder output ready = heads done, then
+the gradient of the input of the encoder layers at the quarter points of the stack)
+sends that tail to RCCL while the rest of backward keeps running; `__call__` after backward
 sends what is left in `n_chunks` slices and waits.  The sum is divided by the
 world size inside the collective (ReduceOp.AVG), which is DDP's gradient averaging.
 """

@@ -36,7 +36,8 @@ class TrainEngine:
 
     def _install_overlap_hooks(self):
         """Start the gradient all-reduce of the arena tail whose gradients are final while backward is still running:
-        after the heads (gradient of the encoder output ready) and after the upper half of the encoder layers."""
+        after the heads (gradient of the encoder output ready) and at the quarter points of the encoder stack; what is
+        left after backward is the first quarter of the encoder and the input layer."""
         us = self.arena.unit_start
         enc = getattr(self.model, "encoder", None)
         if enc is None or "heads" not in us:
@@ -52,8 +53,8 @@ class TrainEngine:
 
         self.model.grad_ready_hooks = {"encoder_out": tail_from("heads")}
         n = len(enc.encoders)
-        if n >= 2 and f"enc{n // 2}" in us:
-            enc.grad_ready_hooks = {n // 2: tail_from(f"enc{n // 2}")}
+        cuts = sorted({(n * q) // 4 for q in (1, 2, 3)} - {0})      # quarter points of the encoder stack
+        enc.grad_ready_hooks = {i: tail_from(f"enc{i}") for i in cuts if f"enc{i}" in us}
 
     # one micro-step: loss (already divided by accum_grad) and its backward
     def _fwd_bwd(self, batch):

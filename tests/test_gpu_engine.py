@@ -231,3 +231,25 @@ def test_spec_augment_on_device_matches_reference_bit_for_bit():
     rows_all = zero.all(2)
     cols_all = zero.all(1)
     assert bool((zero == (rows_all[:, :, None] | cols_all[:, None, :])).all())
+
+
+def test_feature_dither_on_device_distribution():
+    """dataset.py:197-201: x + (U[0,1) - 0.5) * a with a = random.uniform(0, feature_dither): amplitude drawn like the
+    reference, noise uniform in [-a/2, a/2) with the right moments, padding untouched, deterministic for a seed."""
+    import random
+    from openeat_amd.augment import feature_dither_
+    lens = [998, 700, 333, 998]
+    base = torch.zeros(4, 998, 80, device=DEV)
+    random.seed(9)
+    a = random.uniform(0, 0.5)
+    random.seed(9)
+    y = feature_dither_(base.clone(), lens, 0.5).cpu()
+    random.seed(9)
+    y2 = feature_dither_(base.clone(), lens, 0.5).cpu()
+    assert torch.equal(y, y2)
+    for b, n in enumerate(lens):
+        v = y[b, :n]
+        assert float(v.min()) >= -a / 2 - 1e-6 and float(v.max()) < a / 2 + 1e-6
+        assert abs(float(v.mean())) < a * 0.01 and abs(float(v.var()) - a * a / 12) < a * a / 12 * 0.03
+        assert bool((y[b, n:] == 0).all())
+    assert not torch.equal(y[0, :333], y[2, :333])
