@@ -109,7 +109,10 @@ class TrainEngine:
             g = torch.cuda.CUDAGraph()
             self._capturing = True
             try:
-                with torch.cuda.graph(g):
+                # with a process group alive, another thread (the collective backend's watchdog) may touch the device
+                # while we capture: only this thread's calls belong to the capture
+                mode = "thread_local" if self.reducer.world > 1 else "global"
+                with torch.cuda.graph(g, capture_error_mode=mode):
                     self.arena.grad.zero_()
                     self._out = self._fwd_bwd(self._static)
                     if not self._split:
