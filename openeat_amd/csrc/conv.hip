@@ -177,10 +177,11 @@ extern "C" int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1,
 
 // -------------------------------------------------------- GLU + depthwise ----
 #define DW_TT 16
-#define DW_MAXK 31
+#define DW_MAXK 31      // largest kernel size; the kernels are instantiated for K <= 7, 15, 31 (per-tap loops are unrolled)
 // y[b,t,c] = bias[c] + sum_k w[c][k] * g[b, t - pad_left + k, c],  g = a[:, :d] * sigmoid(a[:, d:])
 // gpad (optional, [d]): value of g on the virtual frames t < 0.  The causal variant of the reference pads
 // its input BEFORE the pointwise conv (convolution.py:92-93), so those frames carry GLU(pointwise bias).
+template <int KT>
 __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                               const float* __restrict__ bias, const float* __restrict__ gpad,
                                                               int T, int d, int K, int pad_left, float* __restrict__ y) {
@@ -189,32 +190,54 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
     const int t0 = blockIdx.x * DW_TT;
     const int rows = DW_TT + K - 1;
     const int dv = d >> 2;
-    for (int e = threadIdx.x; e < rows * dv; e += 256) {
-        const int r = e / dv, c = (e % dv) * 4;
-        const int t = t0 - pad_left + r;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (t >= 0 && t < T) {
-            const float* ap = a + ((long)b * T + t) * 2 * d;
-            const float4 xv = *reinterpret_cast<const float4*>(ap + c);
-            const float4 gv = *reinterpret_cast<const float4*>(ap + d + c);
-            g = make_float4(xv.x * sigmoidf_(gv.x), xv.y * sigmoidf_(gv.y), xv.z * sigmoidf_(gv.z), xv.w * sigmoidf_(gv.w));
-        } else if (t < 0 && gpad) {
-            g = *reinterpret_cast<const float4*>(gpad + c);
+    // staging: four window elements per thread at a time, their global loads issued together (one at a time, each load's
+    // HBM latency would be exposed in turn)
+    for (int e0 = threadIdx.x; e0 < rows * dv; e0 += 256 * 4) {
+        float4 xv[4], gv[4];
+        int kind[4];                                   // 0: zero, 1: from a, 2: pad value
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            kind[u] = 0;
+            xv[u] = gv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < rows * dv) {
+                const int r = e / dv, c = (e % dv) * 4;
+                const int t = t0 - pad_left + r;
+                if (t >= 0 && t < T) {
+                    const float* ap = a + ((long)b * T + t) * 2 * d;
+                    xv[u] = *reinterpret_cast<const float4*>(ap + c);
+                    gv[u] = *reinterpret_cast<const float4*>(ap + d + c);
+                    kind[u] = 1;
+                } else if (t < 0 && gpad) {
+                    xv[u] = *reinterpret_cast<const float4*>(gpad + c);
+                    kind[u] = 2;
+                }
+            }
         }
-        *reinterpret_cast<float4*>(win + r * d + c) = g;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            if (e < rows * dv) {
+                const int r = e / dv, c = (e % dv) * 4;
+                float4 g = xv[u];
+                if (kind[u] == 1)
+                    g = make_float4(xv[u].x * sigmoidf_(gv[u].x), xv[u].y * sigmoidf_(gv[u].y), xv[u].z * sigmoidf_(gv[u].z), xv[u].w * sigmoidf_(gv[u].w));
+                *reinterpret_cast<float4*>(win + r * d + c) = g;
+            }
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
-        float wk[DW_MAXK];
+        float wk[KT];
 #pragma unroll
-        for (int k = 0; k < DW_MAXK; ++k) wk[k] = k < K ? w[c * K + k] : 0.f;
+        for (int k = 0; k < KT; ++k) wk[k] = k < K ? w[c * K + k] : 0.f;
         const float bc = bias[c];
         for (int tt = 0; tt < DW_TT; ++tt) {
             const int t = t0 + tt;
             if (t >= T) break;
             float s = bc;
 #pragma unroll
-            for (int k = 0; k < DW_MAXK; ++k) if (k < K) s += wk[k] * win[(tt + k) * d + c];
+            for (int k = 0; k < KT; ++k) if (k < K) s += wk[k] * win[(tt + k) * d + c];
             y[((long)b * T + t) * d + c] = s;
         }
     }
@@ -222,6 +245,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
 
 // da (B*T, 2d) = GLU'(a, dg),  dg[t,c] = sum_k w[c][k] * dy[t + pad_left - k, c]
 // dw[c][k] += sum_t dy[t,c] * g[t - pad_left + k, c] ; db[c] += sum_t dy[t,c]
+template <int KT>
 __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
                                                               const float* __restrict__ w, const float* __restrict__ gpad,
                                                               int T, int d, int K, int pad_left,
@@ -234,30 +258,61 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * DW_TT;
     const int dv = d >> 2;
-    for (int e = threadIdx.x; e < rows * dv; e += 256) {
-        const int r = e / dv, c = (e % dv) * 4;
-        const int tg = t0 - pad_left + r;
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tg >= 0 && tg < T) {
-            const float* ap = a + ((long)b * T + tg) * 2 * d;
-            const float4 xv = *reinterpret_cast<const float4*>(ap + c);
-            const float4 gv = *reinterpret_cast<const float4*>(ap + d + c);
-            g = make_float4(xv.x * sigmoidf_(gv.x), xv.y * sigmoidf_(gv.y), xv.z * sigmoidf_(gv.z), xv.w * sigmoidf_(gv.w));
-        } else if (tg < 0 && gpad) {
-            g = *reinterpret_cast<const float4*>(gpad + c);
+    // staging: four window elements per thread at a time, all their global loads issued together
+    for (int e0 = threadIdx.x; e0 < rows * dv; e0 += 256 * 4) {
+        float4 xv[4], gv[4], qv[4];
+        int kind[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            kind[u] = 0;
+            xv[u] = gv[u] = qv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < rows * dv) {
+                const int r = e / dv, c = (e % dv) * 4;
+                const int tg = t0 - pad_left + r;
+                if (tg >= 0 && tg < T) {
+                    const float* ap = a + ((long)b * T + tg) * 2 * d;
+                    xv[u] = *reinterpret_cast<const float4*>(ap + c);
+                    gv[u] = *reinterpret_cast<const float4*>(ap + d + c);
+                    kind[u] = 1;
+                } else if (tg < 0 && gpad) {
+                    xv[u] = *reinterpret_cast<const float4*>(gpad + c);
+                    kind[u] = 2;
+                }
+                const int td = t0 + pad_left - (K - 1) + r;
+                if (td >= 0 && td < T) qv[u] = *reinterpret_cast<const float4*>(dy + ((long)b * T + td) * d + c);
+            }
         }
-        *reinterpret_cast<float4*>(gwin + r * d + c) = g;
-        const int td = t0 + pad_left - (K - 1) + r;
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (td >= 0 && td < T) q = *reinterpret_cast<const float4*>(dy + ((long)b * T + td) * d + c);
-        *reinterpret_cast<float4*>(dwin + r * d + c) = q;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = e0 + u * 256;
+            if (e < rows * dv) {
+                const int r = e / dv, c = (e % dv) * 4;
+                float4 g = xv[u];
+                if (kind[u] == 1)
+                    g = make_float4(xv[u].x * sigmoidf_(gv[u].x), xv[u].y * sigmoidf_(gv[u].y), xv[u].z * sigmoidf_(gv[u].z), xv[u].w * sigmoidf_(gv[u].w));
+                *reinterpret_cast<float4*>(gwin + r * d + c) = g;
+                *reinterpret_cast<float4*>(dwin + r * d + c) = qv[u];
+            }
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < d; c += 256) {
-        float wk[DW_MAXK], dwk[DW_MAXK];
+        float wk[KT], dwk[KT];
 #pragma unroll
-        for (int k = 0; k < DW_MAXK; ++k) { wk[k] = k < K ? w[c * K + k] : 0.f; dwk[k] = 0.f; }
+        for (int k = 0; k < KT; ++k) { wk[k] = k < K ? w[c * K + k] : 0.f; dwk[k] = 0.f; }
         float dbs = 0.f;
+        // this channel's (x, gate) of the tile's frames, all loads in flight at once: inside the frame loop they would be
+        // one dependent global round trip per frame (the loop body also stores)
+        float xs[DW_TT], gs[DW_TT];
+#pragma unroll
+        for (int tt = 0; tt < DW_TT; ++tt) {
+            const int t = min(t0 + tt, T - 1);
+            const float* ap = a + ((long)b * T + t) * 2 * d;
+            xs[tt] = ap[c];
+            gs[tt] = ap[d + c];
+        }
+#pragma unroll
         for (int tt = 0; tt < DW_TT; ++tt) {
             const int t = t0 + tt;
             if (t >= T) break;
@@ -265,10 +320,9 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             //   row(td) = td - (t0 + pad_left - (K-1));  td = t + pad_left - k  ->  row = tt + (K-1) - k
             float dg = 0.f;
 #pragma unroll
-            for (int k = 0; k < DW_MAXK; ++k) if (k < K) dg += wk[k] * dwin[(tt + (K - 1) - k) * d + c];
+            for (int k = 0; k < KT; ++k) if (k < K) dg += wk[k] * dwin[(tt + (K - 1) - k) * d + c];
             // GLU backward at (t, c)
-            const float* ap = a + ((long)b * T + t) * 2 * d;
-            const float xv = ap[c], gv = ap[d + c];
+            const float xv = xs[tt], gv = gs[tt];
             const float sg = sigmoidf_(gv);
             float* dap = da + ((long)b * T + t) * 2 * d;
             dap[c] = dg * sg;
@@ -277,12 +331,12 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             const float dyt = dwin[(tt + (K - 1) - pad_left) * d + c];
             dbs += dyt;
 #pragma unroll
-            for (int k = 0; k < DW_MAXK; ++k) if (k < K) dwk[k] += dyt * gwin[(tt + k) * d + c];
+            for (int k = 0; k < KT; ++k) if (k < K) dwk[k] += dyt * gwin[(tt + k) * d + c];
         }
         // per-block partials [blk][K+1][d] (coalesced over c); reduced in fixed order afterwards
         float* pp = partial + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (K + 1)) * d + c;
 #pragma unroll
-        for (int k = 0; k < DW_MAXK; ++k) if (k < K) pp[(long)k * d] = dwk[k];
+        for (int k = 0; k < KT; ++k) if (k < K) pp[(long)k * d] = dwk[k];
         pp[(long)K * d] = dbs;
         // gradient of the pad value: virtual frames tau in [-pad_left, -1] (first time tile only; its dy
         // window starts at frame pad_left-(K-1) <= 0):  dg[tau] = sum_k w[k] dy[tau + pad_left - k]
@@ -291,7 +345,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             const int td0 = pad_left - (K - 1);
             for (int tau = -pad_left; tau < 0; ++tau)
 #pragma unroll
-                for (int k = 0; k < DW_MAXK; ++k) {
+                for (int k = 0; k < KT; ++k) {
                     const int td = tau + pad_left - k;
                     if (k < K && td >= 0 && td - td0 < rows) acc += wk[k] * dwin[(td - td0) * d + c];
                 }
@@ -330,9 +384,14 @@ extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bi
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
     const size_t lds = (size_t)(DW_TT + K - 1) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_fwd: window does not fit LDS (d=%d)", d);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dwconv_glu_fwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, gpad, T, d, K,
-                       pad_left, y);
+#define DW_FWD(KT)                                                                                                           \
+    do {                                                                                                                     \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(dwconv_glu_fwd_kernel<KT>, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, gpad, T, d, \
+                           K, pad_left, y);                                                                                  \
+    } while (0)
+    if (K <= 7) DW_FWD(7); else if (K <= 15) DW_FWD(15); else DW_FWD(31);
+#undef DW_FWD
     OE_LAUNCH_CHECK("dwconv_glu_fwd");
     return 0;
 }
@@ -345,9 +404,14 @@ extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
     const size_t lds = (size_t)2 * (DW_TT + K - 1) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_bwd: window does not fit LDS (d=%d)", d);
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(dwconv_glu_bwd_kernel, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, K,
-                       pad_left, da, workspace, dgpad);
+#define DW_BWD(KT)                                                                                                           \
+    do {                                                                                                                     \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(dwconv_glu_bwd_kernel<KT>, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, \
+                           K, pad_left, da, workspace, dgpad);                                                               \
+    } while (0)
+    if (K <= 7) DW_BWD(7); else if (K <= 15) DW_BWD(15); else DW_BWD(31);
+#undef DW_BWD
     OE_LAUNCH_CHECK("dwconv_glu_bwd");
     hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 64), oe_cdiv(B * oe_cdiv(T, DW_TT), 16)), dim3(256), 0, (hipStream_t)stream, workspace,
                        B * oe_cdiv(T, DW_TT), d, K, dw, db);
