@@ -175,13 +175,31 @@ extern "C" int oe_col2im_relu(const float* dcol, const float* y1, int B, int T1,
     return oe_col2im_relu_ks(dcol, y1, B, T1, F1, C, 3, 2, dx, stream);
 }
 
+// Diagnostic build only (-DOE_GEMM_STAMPS): phase stamps of the depthwise-conv backward (tools/dwconv_stamps.py)
+#ifdef OE_GEMM_STAMPS
+static __device__ unsigned long long* oe_dw_stamp_buf = nullptr;
+extern "C" int oe_debug_set_dw_stamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(oe_dw_stamp_buf), &p, sizeof(p)); }
+#define DW_STAMP(slot)                                                                                         \
+    do {                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                           \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if (oe_dw_stamp_buf && threadIdx.x == 0 && blockIdx.y < 8) oe_dw_stamp_buf[(blockIdx.y * 16 + (blockIdx.x & 15)) * 8 + (slot)] = t_; \
+    } while (0)
+#else
+#define DW_STAMP(slot) do { } while (0)
+#endif
+
 // -------------------------------------------------------- GLU + depthwise ----
 #define DW_TT 16
 #define DW_MAXK 31      // largest kernel size; the kernels are instantiated for K <= 7, 15, 31 (per-tap loops are unrolled)
 // y[b,t,c] = bias[c] + sum_k w[c][k] * g[b, t - pad_left + k, c],  g = a[:, :d] * sigmoid(a[:, d:])
 // gpad (optional, [d]): value of g on the virtual frames t < 0.  The causal variant of the reference pads
 // its input BEFORE the pointwise conv (convolution.py:92-93), so those frames carry GLU(pointwise bias).
-template <int KT>
+// KT = compile-time bound of the kernel size; EXACT: K == KT, so the per-tap loops carry no runtime test (with a test
+// every tap became a scalar branch and every LDS read its own wait)
+template <int KT, bool EXACT>
 __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                               const float* __restrict__ bias, const float* __restrict__ gpad,
                                                               int T, int d, int K, int pad_left, float* __restrict__ y) {
@@ -230,22 +248,22 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
     for (int c = threadIdx.x; c < d; c += 256) {
         float wk[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) wk[k] = k < K ? w[c * K + k] : 0.f;
+        for (int k = 0; k < KT; ++k) wk[k] = (EXACT || k < K) ? w[c * K + k] : 0.f;
         const float bc = bias[c];
+#pragma unroll
         for (int tt = 0; tt < DW_TT; ++tt) {
             const int t = t0 + tt;
-            if (t >= T) break;
             float s = bc;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) if (k < K) s += wk[k] * win[(tt + k) * d + c];
-            y[((long)b * T + t) * d + c] = s;
+            for (int k = 0; k < KT; ++k) if (EXACT || k < K) s += wk[k] * win[(tt + k) * d + c];
+            if (t < T) y[((long)b * T + t) * d + c] = s;
         }
     }
 }
 
 // da (B*T, 2d) = GLU'(a, dg),  dg[t,c] = sum_k w[c][k] * dy[t + pad_left - k, c]
 // dw[c][k] += sum_t dy[t,c] * g[t - pad_left + k, c] ; db[c] += sum_t dy[t,c]
-template <int KT>
+template <int KT, bool EXACT>
 __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __restrict__ a, const float* __restrict__ dy,
                                                               const float* __restrict__ w, const float* __restrict__ gpad,
                                                               int T, int d, int K, int pad_left,
@@ -258,12 +276,14 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * DW_TT;
     const int dv = d >> 2;
-    // staging: four window elements per thread at a time, all their global loads issued together
-    for (int e0 = threadIdx.x; e0 < rows * dv; e0 += 256 * 4) {
-        float4 xv[4], gv[4], qv[4];
-        int kind[4];
+    DW_STAMP(0);
+    // staging: eight window elements per thread at a time (the whole window at d = 256, K = 15), all their global
+    // loads issued together
+    for (int e0 = threadIdx.x; e0 < rows * dv; e0 += 256 * 8) {
+        float4 xv[8], gv[8], qv[8];
+        int kind[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * 256;
             kind[u] = 0;
             xv[u] = gv[u] = qv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -284,7 +304,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int e = e0 + u * 256;
             if (e < rows * dv) {
                 const int r = e / dv, c = (e % dv) * 4;
@@ -296,11 +316,13 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             }
         }
     }
+    DW_STAMP(1);
     __syncthreads();
+    DW_STAMP(2);
     for (int c = threadIdx.x; c < d; c += 256) {
         float wk[KT], dwk[KT];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) { wk[k] = k < K ? w[c * K + k] : 0.f; dwk[k] = 0.f; }
+        for (int k = 0; k < KT; ++k) { wk[k] = (EXACT || k < K) ? w[c * K + k] : 0.f; dwk[k] = 0.f; }
         float dbs = 0.f;
         // this channel's (x, gate) of the tile's frames, all loads in flight at once: inside the frame loop they would be
         // one dependent global round trip per frame (the loop body also stores)
@@ -312,15 +334,16 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             xs[tt] = ap[c];
             gs[tt] = ap[d + c];
         }
+        DW_STAMP(3);
 #pragma unroll
         for (int tt = 0; tt < DW_TT; ++tt) {
             const int t = t0 + tt;
-            if (t >= T) break;
+            if (t < T) {                  // (a predicate, not a break: the loop must unroll so that xs / gs stay registers)
             // dy[t] sits at window row tt + (K-1) - pad_left ... relative to dwin start t0 + pad_left - (K-1):
             //   row(td) = td - (t0 + pad_left - (K-1));  td = t + pad_left - k  ->  row = tt + (K-1) - k
             float dg = 0.f;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) if (k < K) dg += wk[k] * dwin[(tt + (K - 1) - k) * d + c];
+            for (int k = 0; k < KT; ++k) if (EXACT || k < K) dg += wk[k] * dwin[(tt + (K - 1) - k) * d + c];
             // GLU backward at (t, c)
             const float xv = xs[tt], gv = gs[tt];
             const float sg = sigmoidf_(gv);
@@ -331,13 +354,16 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
             const float dyt = dwin[(tt + (K - 1) - pad_left) * d + c];
             dbs += dyt;
 #pragma unroll
-            for (int k = 0; k < KT; ++k) if (k < K) dwk[k] += dyt * gwin[(tt + k) * d + c];
+            for (int k = 0; k < KT; ++k) if (EXACT || k < K) dwk[k] += dyt * gwin[(tt + k) * d + c];
+            }
         }
+        DW_STAMP(4);
         // per-block partials [blk][K+1][d] (coalesced over c); reduced in fixed order afterwards
         float* pp = partial + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * (K + 1)) * d + c;
 #pragma unroll
-        for (int k = 0; k < KT; ++k) if (k < K) pp[(long)k * d] = dwk[k];
+        for (int k = 0; k < KT; ++k) if (EXACT || k < K) pp[(long)k * d] = dwk[k];
         pp[(long)K * d] = dbs;
+        DW_STAMP(5);
         // gradient of the pad value: virtual frames tau in [-pad_left, -1] (first time tile only; its dy
         // window starts at frame pad_left-(K-1) <= 0):  dg[tau] = sum_k w[k] dy[tau + pad_left - k]
         if (dgpad && blockIdx.x == 0) {
@@ -347,7 +373,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
 #pragma unroll
                 for (int k = 0; k < KT; ++k) {
                     const int td = tau + pad_left - k;
-                    if (k < K && td >= 0 && td - td0 < rows) acc += wk[k] * dwin[(td - td0) * d + c];
+                    if ((EXACT || k < K) && td >= 0 && td - td0 < rows) acc += wk[k] * dwin[(td - td0) * d + c];
                 }
             atomicAdd(dgpad + c, acc);
         }
@@ -384,13 +410,14 @@ extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bi
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
     const size_t lds = (size_t)(DW_TT + K - 1) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_fwd: window does not fit LDS (d=%d)", d);
-#define DW_FWD(KT)                                                                                                           \
+#define DW_FWD(KT, EX)                                                                                                           \
     do {                                                                                                                     \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(dwconv_glu_fwd_kernel<KT>, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, gpad, T, d, \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel<KT, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((dwconv_glu_fwd_kernel<KT, EX>), dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, gpad, T, d, \
                            K, pad_left, y);                                                                                  \
     } while (0)
-    if (K <= 7) DW_FWD(7); else if (K <= 15) DW_FWD(15); else DW_FWD(31);
+    if (K == 15) DW_FWD(15, true); else if (K == 7) DW_FWD(7, true); else if (K == 31) DW_FWD(31, true);
+    else if (K < 7) DW_FWD(7, false); else if (K < 15) DW_FWD(15, false); else DW_FWD(31, false);
 #undef DW_FWD
     OE_LAUNCH_CHECK("dwconv_glu_fwd");
     return 0;
@@ -404,13 +431,14 @@ extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
     const size_t lds = (size_t)2 * (DW_TT + K - 1) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_bwd: window does not fit LDS (d=%d)", d);
-#define DW_BWD(KT)                                                                                                           \
+#define DW_BWD(KT, EX)                                                                                                           \
     do {                                                                                                                     \
-        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel<KT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(dwconv_glu_bwd_kernel<KT>, dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_bwd_kernel<KT, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((dwconv_glu_bwd_kernel<KT, EX>), dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, dy, w, gpad, T, d, \
                            K, pad_left, da, workspace, dgpad);                                                               \
     } while (0)
-    if (K <= 7) DW_BWD(7); else if (K <= 15) DW_BWD(15); else DW_BWD(31);
+    if (K == 15) DW_BWD(15, true); else if (K == 7) DW_BWD(7, true); else if (K == 31) DW_BWD(31, true);
+    else if (K < 7) DW_BWD(7, false); else if (K < 15) DW_BWD(15, false); else DW_BWD(31, false);
 #undef DW_BWD
     OE_LAUNCH_CHECK("dwconv_glu_bwd");
     hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 64), oe_cdiv(B * oe_cdiv(T, DW_TT), 16)), dim3(256), 0, (hipStream_t)stream, workspace,

@@ -309,7 +309,10 @@ def test_conv1_fwd_wgrad_and_conv2_dgrad():
     torch.testing.assert_close(db1.cpu(), b1.grad, rtol=5e-4, atol=5e-4)
 
 
-@pytest.mark.parametrize("causal,K,d,T", [(False, 15, 32, 21), (True, 15, 32, 21), (False, 7, 256, 50), (False, 31, 64, 40), (True, 7, 32, 5)])
+# K = 7 / 15 / 31 take the instantiations without a per-tap test, every other K the bounded ones (K < 7, < 15, < 31)
+@pytest.mark.parametrize("causal,K,d,T", [(False, 15, 32, 21), (True, 15, 32, 21), (False, 7, 256, 50), (False, 31, 64, 40), (True, 7, 32, 5),
+                                          (False, 3, 32, 21), (True, 5, 64, 19), (False, 9, 64, 40), (True, 13, 32, 33),
+                                          (False, 17, 32, 30), (True, 29, 64, 37), (False, 15, 256, 248)])
 def test_dwconv_glu_fwd_bwd(causal, K, d, T):
     torch.manual_seed(17)
     B = 3
