@@ -1,250 +1,380 @@
-// CTC head on device: log-sum-exp per frame, alpha/beta recursion with wave
-// shuffles, gradient w.r.t. the logits, and greedy search.
+// CTC head on device: softmax rows, alpha/beta recursion with wave shuffles,
+// gradient w.r.t. the logits, and greedy search.
 //
 // Replaces  /root/reference/openeat/modules/ctc.py:38-45  (log_softmax ->
 // torch.nn.CTCLoss(sum, zero_infinity) -> /B and its autograd) and
 // /root/reference/openeat/models/asr_model.py:318-325 (greedy).
 //
 // Pass structure (HBM-bound; B*T*V*4 bytes = the logits):
-//   k1 rowstats : read logits once           -> lse[b,t], lp[b,t,s] = logp at the 2L+1 states
+//   k1 rows     : one wave per frame holds its row in registers: read logits ONCE, write
+//                 softmax * scale ONCE (the dense part of the gradient, in place if asked),
+//                 and emit lp[b,t,s] = log2-prob at the 2L+1 states
 //   k2 alphabeta: one block per utterance, wave 0 runs alpha, wave 1 runs beta
-//                 concurrently; neighbours s-1,s-2 come from lane shuffles
-//   k3 grad     : read logits once, write dlogits once:
-//                 (softmax - sum_{s:l'_s=c} exp(alpha+beta-lp-ll)) * scale
-// Algorithmic bytes: 2*B*T*V*4 (+ 3 small state arrays); k1's read is the one
-// pass above that minimum (it disappears once the LSE is fused into the
-// producing GEMM's epilogue).
+//                 concurrently; neighbours s-1,s-2 come from lane shuffles; lp is
+//                 prefetched a whole chunk of frames ahead (registers), so a step costs the
+//                 shuffle + lse3 chain and not a global-memory round trip
+//   k3 labels   : per frame, the <= 2L+1 classes that occur in the target get
+//                 (softmax - sum_{s:l'_s=c} exp(alpha+beta-lp-ll)) * scale (states of one class are
+//                 linked once per utterance by a third wave of k2); rows of infeasible
+//                 utterances are zeroed (zero_infinity)
+// Algorithmic bytes: 2*B*T*V*4 (+ 3 small state arrays), which is what k1 moves.
 #include "oe_common.h"
 #include "../../include/openeat_hip.h"
 
 #define NEG_INF (-INFINITY)
+#define CTC_MAXQ 8          // states per lane in k1 / k3 (Sp <= 64 * 8)
 
 // ------------------------------------------------------------------ k1 ------
-__global__ __launch_bounds__(256) void ctc_rowstats_kernel(const float* __restrict__ logits, long ldv, int B, int T, int V,
-                                                            const int* __restrict__ hlens, const int* __restrict__ targets,
-                                                            int Lmax, const int* __restrict__ tlens, int Sp,
-                                                            float* __restrict__ lse_out, float* __restrict__ lp_out) {
+// NV4 > 0: the row is NV4 float4 per lane (V <= 256 * NV4; rows 16-byte aligned and padded to a multiple of four floats);
+// NV4 == 0: any V / alignment, the row is read twice (the second time from L2).
+// dlogits is not __restrict__: it may alias logits (every load of a row is issued before its first store).
+template <int NV4, bool WRITE>
+__global__ __launch_bounds__(256) void ctc_rows_kernel(const float* logits, long ldv, long rows, int T, int V,
+                                                        const int* __restrict__ hlens, const int* __restrict__ targets,
+                                                        int Lmax, const int* __restrict__ tlens, int Sp, float scale,
+                                                        const float* __restrict__ utt_weight, float* __restrict__ lp_out,
+                                                        float* dlogits) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= (long)B * T) return;
+    if (row >= rows) return;
     const int b = (int)(row / T), t = (int)(row % T);
-    if (t >= hlens[b]) return;
     const float* p = logits + row * ldv;
-    float m = NEG_INF, s = 0.f;
-    const bool vec = ((((uintptr_t)p) & 15) == 0);
-    int done = 0;
-    if (vec) {
-        const int nv = V >> 2;
-        const float4* p4 = reinterpret_cast<const float4*>(p);
-        for (int i = lane; i < nv; i += 64) {
-            float4 v = p4[i];
-            float mx = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-            float mn = fmaxf(m, mx);
-            s = s * __expf(m - mn) + __expf(v.x - mn) + __expf(v.y - mn) + __expf(v.z - mn) + __expf(v.w - mn);
-            m = mn;
+    float* g = WRITE ? dlogits + row * ldv : nullptr;
+    const int nv = (V + 3) >> 2;
+    if (t >= hlens[b]) {                      // padded frame: exact zeros, no statistics
+        if (WRITE) {
+            if (NV4 > 0) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int i = lane; i < nv; i += 64) reinterpret_cast<float4*>(g)[i] = z;
+            } else {
+                for (int i = lane; i < V; i += 64) g[i] = 0.f;
+            }
         }
-        done = nv << 2;
+        return;
     }
-    for (int i = done + lane; i < V; i += 64) {
-        float x = p[i];
-        float mn = fmaxf(m, x);
-        s = s * __expf(m - mn) + __expf(x - mn);
-        m = mn;
-    }
-    if (m == NEG_INF) s = 0.f;
-    wave_lse(m, s);
-    const float lse = m + __logf(s);
-    if (lane == 0) lse_out[row] = lse;
+    if (WRITE && utt_weight) scale *= utt_weight[b];
     const int L = min(tlens[b], Lmax);
     const int S = 2 * L + 1;
-    for (int st = lane; st < S; st += 64) {
-        const int lab = (st & 1) ? targets[(long)b * Lmax + (st >> 1)] : 0;
-        lp_out[row * Sp + st] = p[lab] - lse;
+    // logits at the states' classes, loaded together with the row
+    float lv[CTC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < CTC_MAXQ; ++q) {
+        const int st = lane + 64 * q;
+        lv[q] = 0.f;
+        if (st < S) lv[q] = p[(st & 1) ? targets[(long)b * Lmax + (st >> 1)] : 0];
+    }
+    float m, l2s;          // log-softmax in base 2 = (x - m) * log2(e) - log2(sum exp(x - m))
+    if (NV4 > 0) {
+        float4 v[NV4 > 0 ? NV4 : 1];
+        const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            const int i = lane + 64 * j;
+            v[j] = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+            if (i < nv) v[j] = p4[i];
+        }
+        m = NEG_INF;
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            const int e = (lane + 64 * j) * 4;        // columns past V (row padding) do not count
+            if (e + 1 >= V) v[j].y = NEG_INF;
+            if (e + 2 >= V) v[j].z = NEG_INF;
+            if (e + 3 >= V) v[j].w = NEG_INF;
+            m = fmaxf(m, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV4; ++j) {
+            v[j].x = __expf(v[j].x - m); v[j].y = __expf(v[j].y - m);
+            v[j].z = __expf(v[j].z - m); v[j].w = __expf(v[j].w - m);
+            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+        }
+        s = wave_sum(s);
+        l2s = __builtin_amdgcn_logf(s);
+        if (WRITE) {
+            const float f = scale / s;
+#pragma unroll
+            for (int j = 0; j < NV4; ++j) {
+                const int i = lane + 64 * j;
+                if (i < nv) reinterpret_cast<float4*>(g)[i] = make_float4(v[j].x * f, v[j].y * f, v[j].z * f, v[j].w * f);
+            }
+        }
+    } else {
+        m = NEG_INF;
+        for (int i = lane; i < V; i += 64) m = fmaxf(m, p[i]);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int i = lane; i < V; i += 64) s += __expf(p[i] - m);
+        s = wave_sum(s);
+        l2s = __builtin_amdgcn_logf(s);
+        if (WRITE) {
+            const float f = scale / s;
+            for (int i = lane; i < V; i += 64) g[i] = __expf(p[i] - m) * f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CTC_MAXQ; ++q) {
+        const int st = lane + 64 * q;
+        if (st < S) lp_out[row * Sp + st] = (lv[q] - m) * 1.4426950408889634f - l2s;
     }
 }
 
 // ------------------------------------------------------------------ k2 ------
-__device__ __forceinline__ float lse3(float a, float b, float c) {
-    float m = fmaxf(a, fmaxf(b, c));
-    if (m == NEG_INF) return NEG_INF;
-    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+// The recursion is one dependent chain per frame on a lone wave, so its cost is the chain's length.  Kept short by:
+//  * base-2 logs throughout (lp, alpha, beta, ll are log2 values in the workspace): exp / log are the bare v_exp_f32 /
+//    v_log_f32, no scaling multiplies and none of logf's denormal handling (the argument of the log is in [1, 3]);
+//  * a finite "log 0" (CTC_NEG) instead of -inf: max - max is 0 and never NaN, so there is no guard in the chain;
+//    CTC_NEG + anything the recursion adds stays CTC_NEG in fp32 (ulp(1e30) = 7.6e22);
+//  * neighbours through DPP wave shifts (one VALU move) instead of ds_bpermute round trips;
+//  * the direction is a template parameter of the recursion, not a per-step branch.
+#define CTC_NEG (-1.0e30f)
+#define CTC_LOG2E 1.4426950408889634f
+#define CTC_LN2 0.6931471805599453f
+
+__device__ __forceinline__ float ctc_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float ctc_log2(float x) { return __builtin_amdgcn_logf(x); }
+// lane i <- lane i-1 (lane 0 <- CTC_NEG) / lane i <- lane i+1 (lane 63 <- CTC_NEG)
+__device__ __forceinline__ float wave_shr1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, CTC_NEG), __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, CTC_NEG), __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+// log2(2^a + 2^b + 2^c) + add
+__device__ __forceinline__ float lse3_add(float a, float b, float c, float add) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    return ctc_log2(ctc_exp2(a - m) + ctc_exp2(b - m) + ctc_exp2(c - m)) + (m + add);
 }
 
-template <int NS>
-__global__ __launch_bounds__(128) void ctc_alphabeta_kernel(int T, const int* __restrict__ hlens, const int* __restrict__ targets,
-                                                            int Lmax, const int* __restrict__ tlens, int Sp,
-                                                            const float* __restrict__ lp, float* __restrict__ alpha,
-                                                            float* __restrict__ beta, float* __restrict__ ll_out,
-                                                            float* __restrict__ nll_out) {
-    __shared__ float fin[2];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool fwd = (threadIdx.x < 64);           // wave 0: alpha, wave 1: beta (wave-uniform)
-    const int Tb = min(hlens[b], T);
-    const int L = min(tlens[b], Lmax);
-    const int S = 2 * L + 1;
-    const int s0 = lane * NS;
-    if (threadIdx.x < 2) fin[threadIdx.x] = NEG_INF;
-
-    int lab[NS];
-    bool skip[NS];   // may take the s-2 (alpha) / s+2 (beta) transition
+// One direction of the recursion for utterance rows [base, base + Tb): NS states per lane; CH frames of lp are fetched
+// at a time, one chunk ahead.  Returns this lane's final values in a[].
+template <bool FWD, int NS, int CH, bool FULL>
+__device__ __forceinline__ void ctc_chunk(int c0, int Tb, const long (&ostr)[NS], float (&a)[NS], const float (&cap)[NS],
+                                          const float (&cur)[CH][NS], float* (&op)[NS]) {
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = s0 + j;
-        lab[j] = (s < S && (s & 1)) ? targets[(long)b * Lmax + (s >> 1)] : 0;
-    }
-#pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = s0 + j;
-        skip[j] = false;
-        if (s < S && (s & 1)) {
-            if (fwd) { if (s >= 2) skip[j] = lab[j] != targets[(long)b * Lmax + ((s - 2) >> 1)]; }
-            else { if (s + 2 < S) skip[j] = lab[j] != targets[(long)b * Lmax + ((s + 2) >> 1)]; }
-        }
-    }
-    __syncthreads();
-
-    float* out = fwd ? alpha : beta;
-    float a[NS];
-#pragma unroll
-    for (int j = 0; j < NS; ++j) a[j] = NEG_INF;
-
-    if (Tb > 0) {
-        const long base = (long)b * T;
-        // ---- first column
-        {
-            const int t = fwd ? 0 : Tb - 1;
-            const float* lpr = lp + (base + t) * Sp;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) {
-                const int s = s0 + j;
-                const bool start = fwd ? (s <= 1) : (s >= S - 2);
-                if (s < S && start) a[j] = lpr[s];
-                if (s < S) out[(base + t) * Sp + s] = a[j];
-            }
-        }
-        // ---- recursion; next row of lp is fetched one step ahead
-        float cur[NS];
-        if (Tb > 1) {
-            const int t = fwd ? 1 : Tb - 2;
-#pragma unroll
-            for (int j = 0; j < NS; ++j) cur[j] = (s0 + j < S) ? lp[(base + t) * Sp + s0 + j] : NEG_INF;
-        }
-        for (int step = 1; step < Tb; ++step) {
-            const int t = fwd ? step : Tb - 1 - step;
-            float nxt[NS];
-            if (step + 1 < Tb) {
-                const int tn = fwd ? t + 1 : t - 1;
-#pragma unroll
-                for (int j = 0; j < NS; ++j) nxt[j] = (s0 + j < S) ? lp[(base + tn) * Sp + s0 + j] : NEG_INF;
-            }
-            float p1, p2;  // neighbour lane's nearest / second nearest state
-            if (fwd) {
-                p1 = __shfl_up(a[NS - 1], 1, 64);
-                p2 = (NS >= 2) ? __shfl_up(a[NS >= 2 ? NS - 2 : 0], 1, 64) : __shfl_up(a[0], 2, 64);
-                if (lane == 0) { p1 = NEG_INF; p2 = NEG_INF; }
-                if (NS == 1 && lane == 1) p2 = NEG_INF;
-            } else {
-                p1 = __shfl_down(a[0], 1, 64);
-                p2 = (NS >= 2) ? __shfl_down(a[NS >= 2 ? 1 : 0], 1, 64) : __shfl_down(a[0], 2, 64);
-                if (lane == 63) { p1 = NEG_INF; p2 = NEG_INF; }
-                if (NS == 1 && lane == 62) p2 = NEG_INF;
-            }
+    for (int i = 0; i < CH; ++i) {
+        if (FULL || c0 + i < Tb) {       // wave-uniform; whole chunks carry no test
+            // neighbour lane's nearest / second nearest state
+            const float p1 = FWD ? wave_shr1(a[NS - 1]) : wave_shl1(a[0]);
+            const float p2 = FWD ? (NS >= 2 ? wave_shr1(a[NS >= 2 ? NS - 2 : 0]) : wave_shr1(p1))
+                                 : (NS >= 2 ? wave_shl1(a[NS >= 2 ? 1 : 0]) : wave_shl1(p1));
             float na[NS];
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 float n1, n2;
-                if (fwd) {
+                if (FWD) {
                     n1 = (j >= 1) ? a[j >= 1 ? j - 1 : 0] : p1;
                     n2 = (j >= 2) ? a[j >= 2 ? j - 2 : 0] : (j == 1 ? p1 : p2);
                 } else {
                     n1 = (j + 1 < NS) ? a[j + 1 < NS ? j + 1 : 0] : p1;
                     n2 = (j + 2 < NS) ? a[j + 2 < NS ? j + 2 : 0] : (j + 1 < NS ? p1 : p2);
                 }
-                if (!skip[j]) n2 = NEG_INF;
-                na[j] = lse3(a[j], n1, n2) + cur[j];
+                na[j] = lse3_add(a[j], n1, fminf(n2, cap[j]), cur[i][j]);
             }
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                a[j] = (s0 + j < S) ? na[j] : NEG_INF;
-                if (s0 + j < S) out[(base + t) * Sp + s0 + j] = a[j];
-                cur[j] = nxt[j];
+                a[j] = na[j];
+                op[j] += ostr[j];
+                *op[j] = a[j];
             }
         }
-        if (fwd) {
+    }
+}
+
+// One direction of the recursion for utterance rows [base, base + Tb): NS states per lane; CH frames of lp are fetched
+// at a time, one chunk ahead.  Returns this lane's final values in a[].  dump: one float any lane may scribble on.
+template <bool FWD, int NS, int CH>
+__device__ __forceinline__ void ctc_recurse(int lane, int Tb, int S, int Sp, const int* __restrict__ tg, const float* __restrict__ lp_rows,
+                                            float* __restrict__ out_rows, float* __restrict__ dump, float (&a)[NS]) {
+    const int s0 = lane * NS;
+    float cap[NS];   // upper bound on the s-2 (alpha) / s+2 (beta) term: that transition exists only between different labels
+    bool valid[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int s = s0 + j;
+        valid[j] = s < S;
+        bool skip = false;
+        if (s < S && (s & 1)) {
+            if (FWD) { if (s >= 2) skip = tg[s >> 1] != tg[(s - 2) >> 1]; }
+            else { if (s + 2 < S) skip = tg[s >> 1] != tg[(s + 2) >> 1]; }
+        }
+        cap[j] = skip ? 3.0e38f : CTC_NEG;
+    }
+    // step k of the recursion works on frame  FWD ? k : Tb-1-k
+    const long tstride = FWD ? (long)Sp : -(long)Sp;
+    const float* lp0 = lp_rows + (long)(FWD ? 0 : Tb - 1) * Sp + s0;      // frame of step 0, this lane's first state
+    // states past S store to the dump word with stride 0: the stores of a step need no predicate
+    float* op[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) op[j] = valid[j] ? out_rows + (long)(FWD ? 0 : Tb - 1) * Sp + s0 + j : dump;
+    long ostr[NS];
+#pragma unroll
+    for (int j = 0; j < NS; ++j) ostr[j] = valid[j] ? tstride : 0;
+    // ---- first column
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        const int s = s0 + j;
+        const bool start = FWD ? (s <= 1) : (s >= S - 2);
+        a[j] = CTC_NEG;
+        if (valid[j] && start) a[j] = lp0[j];
+        *op[j] = a[j];
+    }
+    // ---- recursion, steps 1 .. Tb-1 in chunks of CH.  States past S carry lp = 0: they stay CTC_NEG (beta's flow is
+    // from high s to low s, so they must), and their values go to the dump word.
+    float cur[CH][NS], nxt[CH][NS];
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            cur[i][j] = 0.f;
+            if (1 + i < Tb && valid[j]) cur[i][j] = lp0[(1 + i) * tstride + j];
+        }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+        for (int j = 0; j < NS; ++j) asm volatile("" : "+v"(cur[i][j]));
+    for (int c0 = 1; c0 < Tb; c0 += CH) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
-                if (s0 + j == S - 1) fin[0] = a[j];
-                if (S >= 2 && s0 + j == S - 2) fin[1] = a[j];
+                nxt[i][j] = 0.f;
+                if (c0 + CH + i < Tb && valid[j]) nxt[i][j] = lp0[(c0 + CH + i) * tstride + j];
             }
+        if (c0 + CH <= Tb) ctc_chunk<FWD, NS, CH, true>(c0, Tb, ostr, a, cap, cur, op);
+        else ctc_chunk<FWD, NS, CH, false>(c0, Tb, ostr, a, cap, cur, op);
+        // the next chunk becomes current HERE: pinning the values makes the compiler wait for the prefetch once per
+        // chunk.  Left to itself it waits lazily at each step's first use of a prefetched register, and with the steps'
+        // stores in between that wait is vmcnt(0): every step then sits out its own store's acknowledgement
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                cur[i][j] = nxt[i][j];
+                asm volatile("" : "+v"(cur[i][j]));
+            }
+    }
+}
+
+// One block per utterance: wave 0 runs alpha, wave 1 beta, and wave 2 meanwhile links the states that share a class (a
+// label occurring more than once in the target), once per utterance: chain[b][s] for odd s = (next state with the same
+// label, + 1; 0 = none) | (first of its label ? 1 << 16 : 0).  k3 follows these chains per frame instead of comparing
+// labels (that comparison was O(S^2) per frame).
+template <int NS, int CH>
+__global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __restrict__ hlens, const int* __restrict__ targets,
+                                                            int Lmax, const int* __restrict__ tlens, int Sp,
+                                                            const float* __restrict__ lp, float* __restrict__ alpha,
+                                                            float* __restrict__ beta, float* __restrict__ ll_out,
+                                                            float* __restrict__ nll_out, int* __restrict__ chain,
+                                                            float* __restrict__ dump) {
+    __shared__ float fin[2];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Tb = min(hlens[b], T);
+    const int S = 2 * min(tlens[b], Lmax) + 1;
+    const int* tg = targets + (long)b * Lmax;
+    const long base = (long)b * T * Sp;
+    if (threadIdx.x < 2) fin[threadIdx.x] = CTC_NEG;
+    __syncthreads();
+    if (wv == 2) {
+        for (int s = 1 + 2 * lane; s < S; s += 128) {
+            const int c = tg[s >> 1];
+            int head = 1, nx = 0;
+            for (int q = 1; q < s; q += 2) if (tg[q >> 1] == c) { head = 0; break; }
+            for (int q = s + 2; q < S; q += 2) if (tg[q >> 1] == c) { nx = q + 1; break; }
+            chain[(long)b * Sp + s] = nx | (head << 16);
+        }
+    } else if (Tb > 0) {
+        float a[NS];
+        if (wv == 0) {
+            ctc_recurse<true, NS, CH>(lane, Tb, S, Sp, tg, lp + base, alpha + base, dump, a);
+#pragma unroll
+            for (int j = 0; j < NS; ++j) {
+                if (lane * NS + j == S - 1) fin[0] = a[j];
+                if (lane * NS + j == S - 2) fin[1] = a[j];
+            }
+        } else {
+            ctc_recurse<false, NS, CH>(lane, Tb, S, Sp, tg, lp + base, beta + base, dump, a);
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        // log2-likelihood; anything that still carries the CTC_NEG scale is an infeasible alignment:
+        // zero_infinity makes it contribute 0 loss and 0 gradient
         float ll = NEG_INF;
         if (Tb > 0) {
-            float m = fmaxf(fin[0], fin[1]);
-            if (m != NEG_INF) ll = m + __logf(__expf(fin[0] - m) + __expf(fin[1] - m));
+            const float m = fmaxf(fin[0], fin[1]);
+            const float v = m + ctc_log2(ctc_exp2(fin[0] - m) + ctc_exp2(fin[1] - m));
+            if (v > 0.5f * CTC_NEG) ll = v;
         }
-        // zero_infinity: an infeasible alignment contributes 0 loss and 0 gradient
-        ll_out[b] = ll;
-        nll_out[b] = (ll == NEG_INF) ? 0.f : -ll;
+        ll_out[b] = ll;                                        // base 2, for k3
+        nll_out[b] = (ll == NEG_INF) ? 0.f : -ll * CTC_LN2;
     }
 }
 
 // ------------------------------------------------------------------ k3 ------
-__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, long ldv, int T, int V,
-                                                        const int* __restrict__ hlens, const int* __restrict__ targets,
-                                                        int Lmax, const int* __restrict__ tlens, int Sp,
-                                                        const float* __restrict__ lse, const float* __restrict__ lp,
-                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                        const float* __restrict__ ll_in, float scale,
-                                                        const float* __restrict__ utt_weight, float* dlogits) {
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // gam[S], then lab[S] (as int)
-    const long row = blockIdx.x;
-    const int b = (int)(row / T), t = (int)(row % T);
-    if (utt_weight) scale *= utt_weight[b];
-    const float* p = logits + row * ldv;
-    float* g = dlogits + row * ldv;
+// One wave per frame (four per block).  k1 has written softmax * scale everywhere; the classes of the target get their
+// occupation term here, and frames of an infeasible utterance (ll = -inf) are zeroed.  Block 0 also sums the loss.
+// Sums run in a fixed order (blank: per-lane partials + shuffle tree; a label: along its chain): deterministic.
+__global__ __launch_bounds__(256) void ctc_labels_kernel(long rows, int B, int T, int V, long ldv, const int* __restrict__ hlens,
+                                                          const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens,
+                                                          int Sp, const float* __restrict__ lp, const float* __restrict__ alpha,
+                                                          const float* __restrict__ beta, const float* __restrict__ ll_in,
+                                                          const int* __restrict__ chain, const float* __restrict__ nll,
+                                                          float scale, const float* __restrict__ utt_weight,
+                                                          float* __restrict__ dlogits, float* __restrict__ loss_sum) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // per wave: gam[Sp]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (loss_sum && blockIdx.x == 0 && wv == 0) {
+        float s = 0.f;
+        for (int i = lane; i < B; i += 64) s += utt_weight ? nll[i] * utt_weight[i] : nll[i];
+        s = wave_sum(s);
+        if (lane == 0) loss_sum[0] = s;
+    }
+    const long row = (long)blockIdx.x * 4 + wv;
+    const bool inrange = row < rows;
+    const int b = inrange ? (int)(row / T) : 0, t = inrange ? (int)(row % T) : 0;
+    const bool frame = inrange && t < hlens[b];
     const float ll = ll_in[b];
-    const bool live = (t < hlens[b]) && (ll != NEG_INF);
-    const bool vec = ((((uintptr_t)p) & 15) == 0) && ((((uintptr_t)g) & 15) == 0);
-    const int nv = vec ? (V >> 2) : 0;
-    if (!live) {
-        float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = threadIdx.x; i < nv; i += 256) reinterpret_cast<float4*>(g)[i] = z;
-        for (int i = (nv << 2) + threadIdx.x; i < V; i += 256) g[i] = 0.f;
-        return;
+    float* g = dlogits + row * ldv;
+    if (frame && ll == NEG_INF) {
+        for (int i = lane; i < V; i += 64) g[i] = 0.f;
     }
-    const float l = lse[row];
-    // dense part: softmax * scale
-    for (int i = threadIdx.x; i < nv; i += 256) {
-        float4 v = reinterpret_cast<const float4*>(p)[i];
-        v.x = __expf(v.x - l) * scale; v.y = __expf(v.y - l) * scale;
-        v.z = __expf(v.z - l) * scale; v.w = __expf(v.w - l) * scale;
-        reinterpret_cast<float4*>(g)[i] = v;
+    const bool live = frame && ll != NEG_INF;
+    if (utt_weight) scale *= utt_weight[b];
+    const int S = live ? 2 * min(tlens[b], Lmax) + 1 : 0;
+    float* gam = sh + (size_t)wv * Sp;
+    const float* lpr = lp + row * Sp;
+    float blank = 0.f, own[CTC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < CTC_MAXQ; ++q) {
+        const int s = lane + 64 * q;
+        own[q] = 0.f;
+        if (s < S) {
+            const long o = row * Sp + s;
+            own[q] = lpr[s];
+            const float gm = __builtin_amdgcn_exp2f(alpha[o] + beta[o] - own[q] - ll);
+            gam[s] = gm;
+            if (!(s & 1)) blank += gm;
+        }
     }
-    for (int i = (nv << 2) + threadIdx.x; i < V; i += 256) g[i] = __expf(p[i] - l) * scale;
-
-    const int L = min(tlens[b], Lmax);
-    const int S = 2 * L + 1;
-    float* gam = sh;
-    int* labs = reinterpret_cast<int*>(sh + S);
-    for (int s = threadIdx.x; s < S; s += 256) {
-        const float lps = lp[row * Sp + s];
-        gam[s] = __expf(alpha[row * Sp + s] + beta[row * Sp + s] - lps - ll);
-        labs[s] = (s & 1) ? targets[(long)b * Lmax + (s >> 1)] : 0;
-    }
-    __syncthreads();   // also orders the dense stores before the per-label stores below
-    for (int s = threadIdx.x; s < S; s += 256) {
-        const int c = labs[s];
-        bool first = true;
-        // blanks sit on even s, labels on odd s: only same-parity states can share a class
-        for (int q = (s & 1); q < s; q += 2) if (labs[q] == c) { first = false; break; }
-        if (!first) continue;
-        float occ = 0.f;
-        for (int q = s; q < S; q += 2) if (labs[q] == c) occ += gam[q];   // fixed order: deterministic
-        g[c] = (__expf(lp[row * Sp + s]) - occ) * scale;
+    blank = wave_sum(blank);
+    __syncthreads();
+    if (live && lane == 0) g[0] = (__builtin_amdgcn_exp2f(own[0]) - blank) * scale;
+    const int* ch = chain + (long)b * Sp;
+#pragma unroll
+    for (int q = 0; q < CTC_MAXQ; ++q) {
+        const int s = lane + 64 * q;
+        if (s < S && (s & 1)) {
+            int info = ch[s];
+            if (info >> 16) {
+                float occ = gam[s];
+                for (int nx = (info & 0xffff) - 1; nx >= 0; nx = (ch[nx] & 0xffff) - 1) occ += gam[nx];
+                g[targets[(long)b * Lmax + (s >> 1)]] = (__builtin_amdgcn_exp2f(own[q]) - occ) * scale;
+            }
+        }
     }
 }
 
@@ -257,7 +387,7 @@ __global__ void ctc_sum_kernel(const float* __restrict__ nll, const float* __res
 
 extern "C" size_t oe_ctc_workspace_floats(int B, int T, int Lmax) {
     size_t Sp = 2 * (size_t)Lmax + 1;
-    return (size_t)B * T + (size_t)B + 3 * (size_t)B * T * Sp + 16;
+    return (size_t)B + 3 * (size_t)B * T * Sp + (size_t)B * Sp + 16;
 }
 
 extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
@@ -268,30 +398,46 @@ extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, in
     OE_REQUIRE(B > 0 && T > 0 && V > 1 && Lmax >= 0 && ldv >= V, "oe_ctc_loss_fused: bad shape B=%d T=%d V=%d Lmax=%d ldv=%ld",
                B, T, V, Lmax, ldv);
     const int Sp = 2 * Lmax + 1;
-    OE_REQUIRE(Sp <= 64 * 8, "oe_ctc_loss_fused: target length %d exceeds the 255-label limit of the wave recursion", Lmax);
+    OE_REQUIRE(Sp <= 64 * CTC_MAXQ, "oe_ctc_loss_fused: target length %d exceeds the 255-label limit of the wave recursion", Lmax);
     hipStream_t st = (hipStream_t)stream;
-    float* lse = workspace;
-    float* ll = lse + (size_t)B * T;
+    float* ll = workspace;
     float* lp = ll + B;
     float* alpha = lp + (size_t)B * T * Sp;
     float* beta = alpha + (size_t)B * T * Sp;
+    int* chain = reinterpret_cast<int*>(beta + (size_t)B * T * Sp);
+    float* dump = reinterpret_cast<float*>(chain + (size_t)B * Sp);      // the 16 spare floats at the end
     const long rows = (long)B * T;
-    hipLaunchKernelGGL(ctc_rowstats_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, st, logits, ldv, B, T, V, hlens, targets,
-                       Lmax, tlens, Sp, lse, lp);
-    OE_LAUNCH_CHECK("ctc_rowstats");
-#define AB(NS) hipLaunchKernelGGL(ctc_alphabeta_kernel<NS>, dim3(B), dim3(128), 0, st, T, hlens, targets, Lmax, tlens, Sp, \
-                                  lp, alpha, beta, ll, nll)
-    if (Sp <= 64) AB(1); else if (Sp <= 128) AB(2); else if (Sp <= 256) AB(4); else AB(8);
+    // register-resident rows need 16-byte aligned rows that are padded to whole float4s
+    const bool vec = (((uintptr_t)logits & 15) == 0) && (!dlogits || ((uintptr_t)dlogits & 15) == 0) && (ldv % 4 == 0) &&
+                     (ldv >= (((long)V + 3) & ~3L)) && V <= 256 * 32;
+    const int nv4 = !vec ? 0 : V <= 256 * 4 ? 4 : V <= 256 * 8 ? 8 : V <= 256 * 16 ? 16 : 32;
+#define ROWS(NV4, WR)                                                                                                          \
+    hipLaunchKernelGGL((ctc_rows_kernel<NV4, WR>), dim3(oe_cdiv(rows, 4)), dim3(256), 0, st, logits, ldv, rows, T, V, hlens,    \
+                       targets, Lmax, tlens, Sp, grad_scale, utt_weight, lp, dlogits)
+#define ROWS_W(NV4) do { if (dlogits) ROWS(NV4, true); else ROWS(NV4, false); } while (0)
+    switch (nv4) {
+        case 4: ROWS_W(4); break;
+        case 8: ROWS_W(8); break;
+        case 16: ROWS_W(16); break;
+        case 32: ROWS_W(32); break;
+        default: ROWS_W(0); break;
+    }
+#undef ROWS_W
+#undef ROWS
+    OE_LAUNCH_CHECK("ctc_rows");
+#define AB(NS, CH) hipLaunchKernelGGL((ctc_alphabeta_kernel<NS, CH>), dim3(B), dim3(192), 0, st, T, hlens, targets, Lmax, tlens, \
+                                      Sp, lp, alpha, beta, ll, nll, chain, dump)
+    if (Sp <= 64) AB(1, 32); else if (Sp <= 128) AB(2, 16); else if (Sp <= 256) AB(4, 8); else AB(8, 4);
 #undef AB
     OE_LAUNCH_CHECK("ctc_alphabeta");
-    if (loss_sum) {
+    if (dlogits) {
+        hipLaunchKernelGGL(ctc_labels_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), (size_t)4 * Sp * sizeof(float), st, rows, B, T, V,
+                           ldv, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll, chain, nll, grad_scale, utt_weight, dlogits,
+                           loss_sum);
+        OE_LAUNCH_CHECK("ctc_labels");
+    } else if (loss_sum) {
         hipLaunchKernelGGL(ctc_sum_kernel, dim3(1), dim3(64), 0, st, nll, utt_weight, B, loss_sum);
         OE_LAUNCH_CHECK("ctc_sum");
-    }
-    if (dlogits) {
-        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)rows), dim3(256), (size_t)Sp * 8, st, logits, ldv, T, V, hlens,
-                           targets, Lmax, tlens, Sp, lse, lp, alpha, beta, ll, grad_scale, utt_weight, dlogits);
-        OE_LAUNCH_CHECK("ctc_grad");
     }
     return 0;
 }

@@ -217,7 +217,7 @@ def test_layernorm_fwd_bwd(rows, d, eps):
 
 
 # -------------------------------------------------------------------- CTC ----
-def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_weight=None):
+def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_weight=None, want_grad=True):
     B, T, V = logits.shape
     ldv = ldv or V
     buf = torch.zeros(B, T, ldv, device=DEV)
@@ -229,11 +229,13 @@ def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_we
     nll = torch.empty(B, device=DEV)
     tot = torch.empty(1, device=DEV)
     dl = buf if inplace else torch.full((B, T, ldv), float("nan"), device=DEV)
+    if not want_grad:
+        dl = None
     uw = None if utt_weight is None else cu(utt_weight.float())
     hip.check(L.oe_ctc_loss_fused(hip.ptr(buf), ldv, B, T, V, hip.ptr(hl), hip.ptr(yd), Lmax, hip.ptr(yl), scale,
                                   hip.ptr(uw), hip.ptr(nll), hip.ptr(tot), hip.ptr(dl), hip.ptr(ws), hip.stream()), "ctc")
     sync()
-    return nll.cpu(), tot.cpu(), dl[:, :, :V].cpu()
+    return nll.cpu(), tot.cpu(), (dl[:, :, :V].cpu() if want_grad else None)
 
 
 def test_ctc_golden_f07():
@@ -271,6 +273,35 @@ def test_ctc_vs_oracle(B, T, V, Lmax, ldv):
         n2, g2 = ctc_np.ctc_nll_and_grad(logits.numpy(), hl.numpy(), ys.numpy(), yl.numpy())
         np.testing.assert_allclose(nll.numpy(), n2, rtol=1e-4, atol=1e-3)
         np.testing.assert_allclose(dl.numpy(), g2, rtol=2e-3, atol=2e-5)
+
+
+# row kernel variants: rows kept in registers (4 / 8 / 16 / 32 float4 per lane) or read twice (rows that are not whole
+# aligned float4s, or wider than 8192); utterance lengths at the edges of the recursion's 32-frame prefetch chunks
+@pytest.mark.parametrize("V,ldv,inplace", [(37, 37, True), (37, 39, False), (37, 40, True), (1500, 1500, False), (3246, 3246, True),
+                                           (3246, 3248, False), (5000, 5000, True), (9000, 9000, False)])
+def test_ctc_row_variants_and_chunk_edges(V, ldv, inplace):
+    torch.manual_seed(11)
+    T, Lmax = 70, 5
+    hl = torch.tensor([70, 1, 2, 32, 33, 34, 3, 65, 64])
+    yl = torch.tensor([5, 1, 1, 5, 3, 0, 5, 4, 2])          # utterance 6: five labels in three frames -> infeasible
+    B = hl.numel()
+    ys = torch.randint(1, V, (B, Lmax))
+    ys[0, 1] = ys[0, 0]                                     # a repeat (needs the blank between)
+    logits = torch.randn(B, T, V) * 2
+    w = torch.rand(B) + 0.5
+    lg = logits.clone().requires_grad_()
+    per = F.ctc_loss(lg.transpose(0, 1).log_softmax(2), ys, hl, yl, reduction="none", zero_infinity=True)
+    (per * w).sum().backward()
+    nll0, tot0, none = run_ctc(logits, hl, ys, yl, ldv=ldv, utt_weight=w, want_grad=False)      # loss only
+    assert none is None
+    nll, tot, dl = run_ctc(logits, hl, ys, yl, ldv=ldv, scale=0.25, inplace=inplace, utt_weight=w)
+    assert torch.equal(nll, nll0) and torch.equal(tot, tot0)
+    torch.testing.assert_close(nll, per.detach(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(tot[0], (per * w).sum().detach(), rtol=1e-4, atol=1e-3)
+    torch.testing.assert_close(dl, 0.25 * lg.grad, rtol=2e-3, atol=1e-5)
+    assert float(nll[6]) == 0.0 and bool((dl[6] == 0).all())                                   # zero_infinity
+    for b in range(B):
+        assert bool((dl[b, int(hl[b]):] == 0).all())                                           # padded frames exactly 0
 
 
 def test_ctc_greedy_matches_topk_and_collapse():
