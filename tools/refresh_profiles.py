@@ -36,8 +36,10 @@ with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
         f.write(f"| `{n}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {int(r['TotalDurationNs']) / 1e6 / steps:.3f} | "
                 f"{100 * int(r['TotalDurationNs']) / tot:.2f} |\n")
 for a, b in ((f"{tag}_bench_p3.json", f"{tag}_bench_p3.json"), (f"{tag}_bench_p3.err", f"{tag}_bench_p3.log"), (f"{tag}_gemm_bench.txt", f"{tag}_gemm_bench.txt"),
-             (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p3.txt")):
-    shutil.copy(f"{src}/{a}", f"{dst}/{b}")
+             (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p3.txt"), (f"{tag}_ctc_bench.txt", f"{tag}_ctc_bench.txt"),
+             (f"{tag}_mfma_busy_northstar.md", f"{tag}_mfma_busy_northstar.md")):
+    if os.path.exists(f"{src}/{a}"):
+        shutil.copy(f"{src}/{a}", f"{dst}/{b}")
 pm = json.load(open(f"{dst}/{tag}_pmc_hbm_traffic.json"))
 print(f"bench {line['ms_per_step']:.2f} ms/step {line['value']:.0f} frames/s graph={line['config']['hip_graph']}")
 print(f"roofline live {ro['achieved']:.1f} TF/s {ro['gemm_ms_per_step']:.2f} ms {ro['avg_launch_us']:.2f} us | rocprof {1574.63445504 / (gt / 1e6 / steps):.1f} TF/s "
