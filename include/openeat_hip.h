@@ -296,6 +296,15 @@ int oe_spec_substitute(float* x, int B, int Tmax, int F, const int* subs, int ns
  * own nframes[b] frames.  Distribution parity with the reference (which uses numpy's global generator), not bit parity. */
 int oe_feature_dither(float* x, const int* nframes, int B, int Tmax, int F, float a, unsigned long long seed, void* stream);
 
+/* Speed perturbation of a padded waveform batch (audio_processor.py:20-35: sox `speed s` + `rate sr`): utterance b is
+ * read speed[b] times faster and resampled back to the same rate, out[b, i] = x_b(i * speed[b]) through a Hann-windowed
+ * sinc (cutoff 0.95 * min(1, 1/s), 16 zero crossings each side, unit DC gain); speed 1 copies.  wav (B, ld_in) with
+ * n_in[b] valid samples, out (B, ld_out) with n_out[b] valid samples (the host sets n_out[b] = floor(n_in[b] / speed[b]
+ * + 0.5)), samples past n_out[b] up to Nmax_out are zeroed.  sox itself is outside the reference tree: distribution
+ * parity, checked against a float64 restatement and scipy's polyphase resampler. */
+int oe_speed_perturb(const float* wav, long ld_in, const int* n_in, const float* speed, int B, int Nmax_out, float* out,
+                     long ld_out, const int* n_out, void* stream);
+
 /* CTC prefix beam search, HOST code (all pointers are host pointers): the per-frame recursion of
  * asr_model.py:359-396 on the top-`beam` (log-prob, token) pairs of every frame (computed on the
  * device).  Doubles and insertion-ordered stable pruning as in the reference's Python, so the

@@ -11,6 +11,7 @@ _SUBMODULES = [
     "modules", "modules.attention", "modules.cmvn", "modules.convolution", "modules.ctc", "modules.decoder",
     "modules.decoder_layer", "modules.embedding", "modules.encoder", "modules.encoder_layer",
     "modules.label_smoothing_loss", "modules.positionwise_feed_forward", "modules.subsampling", "modules.swish",
+    "dataset", "dataset.audio_processor", "dataset.dataset", "dataset.sampler",
     "utils", "utils.checkpoint", "utils.cmvn", "utils.common", "utils.executor", "utils.mask", "utils.scheduler",
 ]
 for _name in _SUBMODULES:

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "oe_spec_augment": (I, [P, P, I, I, I, P, I, P, I, F, P]),
     "oe_spec_substitute": (I, [P, I, I, I, P, I, I, P]),
     "oe_feature_dither": (I, [P, P, I, I, I, F, U64, P]),
+    "oe_speed_perturb": (I, [P, L, P, P, I, I, P, L, P, P]),
     "oe_ctc_prefix_beam_host": (I, [P, P, I, I, I, P, P, P]),
     "oe_ctc_prefix_beam_host_batch": (I, [P, P, I, I, P, I, I, P, P, P, I]),
     "oe_grad_norm_workspace_floats": (SZ, []),

@@ -1,0 +1,117 @@
+"""GPU: speed perturbation kernel against its float64 restatement, and the device collate (wav files -> speed ->
+fbank -> normalisation -> spec-substitute -> SpecAugment -> padded batch dict) against the oracle pipeline run per
+utterance in the reference's order of python-`random` draws (dataset.py:39-119, 186-240)."""
+import os
+import random
+import sys
+import wave
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pytestmark = pytest.mark.gpu
+
+from oracle import augment as OA  # noqa: E402
+from oracle import batching as OB  # noqa: E402
+from oracle import fbank as FB  # noqa: E402
+
+DEV = "cuda"
+
+
+def test_speed_perturb_kernel_matches_float64_restatement():
+    from openeat_amd.dataset.audio_processor import _speed_perturb, speed_perturb_batch
+    rng = np.random.default_rng(3)
+    lens = [5000, 4321, 3000, 777, 5000]
+    speeds = [0.9, 1.0, 1.1, 0.77, 1.3]
+    wav = np.zeros((5, 5000), dtype=np.float32)
+    for b, n in enumerate(lens):
+        wav[b, :n] = rng.uniform(-0.5, 0.5, n)
+    out, n_out = speed_perturb_batch(torch.from_numpy(wav).to(DEV), lens, speeds)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    assert out.shape[1] == max(n_out)
+    for b, (n, s) in enumerate(zip(lens, speeds)):
+        ref = OB.speed_perturb(wav[b, :n], s)
+        assert n_out[b] == len(ref)
+        np.testing.assert_allclose(out[b, :n_out[b]], ref, rtol=0, atol=2e-5)          # |x| <= 0.5, fp32 taps vs float64
+        assert np.all(out[b, n_out[b]:] == 0)                                          # batch padding zeroed
+    assert np.array_equal(out[1, :lens[1]], wav[1, :lens[1]])                          # speed 1 is a copy
+    one = _speed_perturb(torch.from_numpy(wav[:1]).to(DEV), 16000, 0.9)
+    assert one.shape == (1, n_out[0]) and torch.equal(one.cpu(), torch.from_numpy(out[:1, :n_out[0]]))
+
+
+def _write_wavs(tmp_path, lens, seed=0):
+    rng = np.random.default_rng(seed)
+    paths, sigs = [], []
+    for i, n in enumerate(lens):
+        x = (rng.uniform(-0.4, 0.4, n) * 32768).astype("<i2")
+        p = str(tmp_path / f"u{i}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+        paths.append(p)
+        sigs.append(x.astype(np.float32) / 32768.0)
+    return paths, sigs
+
+
+@pytest.mark.parametrize("speed_rate", [0.0, 1.0])
+def test_device_collate_matches_the_per_utterance_pipeline(tmp_path, speed_rate):
+    from openeat_amd.dataset.dataset import audio_collate_func
+    lens = [16000, 9000, 12345, 20000]
+    paths, sigs = _write_wavs(tmp_path, lens)
+    labels = [[3, 4, 5], [7], [8, 9], [2, 2, 2, 6]]
+    batch = [(f"k{i}", paths[i], labels[i], 1.0) for i in range(4)]
+    conf = dict(mel_bins=80, wav_dither=0.0, speed_perturb_rate=speed_rate, speeds=[0.9, 1.1, 0.1])
+    coll = audio_collate_func(spec_aug=True, spec_aug_conf=dict(num_t_mask=2, num_f_mask=2, max_t=20, max_f=10), spec_sub=True,
+                              spec_sub_conf=dict(max_t=10, num_t_sub=2), data_type="wav", feature_extraction_conf=conf, device=DEV)
+    random.seed(7)
+    keys, out = coll([batch])                       # DataLoader(batch_size=1) hands the pre-formed batch in a list
+    torch.cuda.synchronize()
+    # the same thing one utterance at a time on the CPU, python-random draws in the reference's order
+    random.seed(7)
+    feats = []
+    for i in range(4):
+        x = sigs[i]
+        speed = 1.0
+        if random.random() < speed_rate:
+            speed = OB.speed_generator(conf["speeds"])
+        if speed != 1.0:
+            x = OB.speed_perturb(x, speed).astype(np.float32)
+        feats.append(FB.utt_normalize(FB.fbank(torch.from_numpy(x))).numpy())
+    order = np.argsort([f.shape[0] for f in feats])[::-1]
+    feats = [feats[i] for i in order]
+    feats = [OA.spec_substitute(f, max_t=10, num_t_sub=2) for f in feats]
+    feats = [OA.spec_augmentation(f, num_t_mask=2, num_f_mask=2, max_t=20, max_f=10) for f in feats]
+    assert keys == [f"k{i}" for i in order]
+    assert out["features_length"].tolist() == [f.shape[0] for f in feats]
+    assert out["features"].shape == (4, feats[0].shape[0], 80) and out["features"].is_cuda
+    got = out["features"].cpu().numpy()
+    tol = dict(rtol=2e-3, atol=5e-3) if speed_rate == 0.0 else dict(rtol=5e-3, atol=2e-2)   # normalised log-mel; resampler taps fp32
+    for r, f in enumerate(feats):
+        np.testing.assert_allclose(got[r, :f.shape[0]], f, **tol)
+        assert np.all(got[r, f.shape[0]:] == 0)
+        assert np.array_equal(got[r, :f.shape[0]] == 0, f == 0)                      # the masks sit on the same cells
+    want_t = [labels[i] for i in order]
+    assert out["targets_length"].tolist() == [len(t) for t in want_t]
+    tg = out["targets"].cpu()
+    assert tg.dtype == torch.int32 and tg.shape == (4, 4)
+    for r, t in enumerate(want_t):
+        assert tg[r, :len(t)].tolist() == t and bool((tg[r, len(t):] == -1).all())
+
+
+def test_collated_batch_trains_a_step(tmp_path):
+    """model(**batch) with the collate's dict, as executor.py:47 calls it."""
+    from openeat_amd.dataset.dataset import audio_collate_func
+    from openeat_amd.models.asr_model import ASRModel
+    paths, _ = _write_wavs(tmp_path, [16000, 12000, 14000], seed=1)
+    batch = [(f"k{i}", paths[i], [3 + i, 4, 5], 1.0) for i in range(3)]
+    coll = audio_collate_func(data_type="wav", feature_extraction_conf=dict(mel_bins=80, wav_dither=0.0, speed_perturb_rate=0.0), device=DEV)
+    _, b = coll(batch)
+    torch.manual_seed(0)
+    m = ASRModel(80, 30, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+                 linear_units=64, reverse_weight=0.3, dropout_rate=0.0).to(DEV)
+    loss, acc = m(**b)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
