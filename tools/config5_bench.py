@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""BASELINE.json configs[4] on ONE MI355X: 24L Conformer d=512 (h=8, ff=2048, K=15; 192.5 M parameters), SpecAug + online
+speed perturbation, mixed-length utterances ~ U(2 s, 16 s) in padded-budget buckets (openeat_amd.dataset).  Everything
+from the padded waveform batch on is inside the timed region: speed perturb, fbank, normalisation, SpecAugment, forward,
+backward, clip, Adam (eager steps: the shapes change from batch to batch).  Prints one JSON line.
+
+  python tools/config5_bench.py [--utts 400] [--budget 48000] [--steps 40]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from openeat_amd import augment, hip  # noqa: E402
+from openeat_amd.dataset.audio_processor import speed_perturb_batch  # noqa: E402
+from openeat_amd.dataset.dataset import bucket_batches  # noqa: E402
+from openeat_amd.engine import TrainEngine  # noqa: E402
+from openeat_amd.frontend import Fbank, utt_normalize_  # noqa: E402
+from openeat_amd.models.asr_model import ASRModel  # noqa: E402
+
+V = 3246
+ap = argparse.ArgumentParser()
+ap.add_argument("--utts", type=int, default=400)
+ap.add_argument("--budget", type=int, default=48000, help="padded 10 ms frames per batch")
+ap.add_argument("--steps", type=int, default=40)
+ap.add_argument("--warmup", type=int, default=4)
+args = ap.parse_args()
+hip.GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "3"))
+dev = torch.device("cuda", 0)
+torch.manual_seed(777)
+random.seed(777)
+conf = dict(encoder_num_blocks=24, decoder_num_blocks=3, r_decoder_num_blocks=3, d_model=512, attention_heads=8, linear_units=2048,
+            dropout_rate=0.1, input_layer="conv2d", pos_enc_layer_type="rel_pos", activation_type="swish", macaron_style=True,
+            use_cnn_module=True, cnn_module_kernel=15, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3)
+model = ASRModel(80, V, **conf).to(dev).train()
+eng = TrainEngine(model, lr=1e-3, grad_clip=5.0)
+fb = Fbank(80, device=dev)
+
+# corpus: (key, path, frames AFTER the speed change, token ids, speed); ~3 tokens per second
+entries = []
+for i in range(args.utts):
+    sec = random.uniform(2.0, 16.0)
+    speed = random.choice([0.9, 1.0, 1.1])
+    entries.append((f"u{i}", sec, sec * 100 / speed, [random.randint(2, V - 2) for _ in range(max(1, int(sec * 3)))], speed))
+batches = bucket_batches(entries, max_padded_frames=args.budget, length_multiple=32)
+random.shuffle(batches)
+batches = batches[: args.steps + args.warmup] if len(batches) >= args.steps + args.warmup else batches
+print(f"[config5] {len(entries)} utterances -> {len(batches)} batches, sizes {sorted({len(b) for b in batches})}", file=sys.stderr)
+
+
+def host_batch(b):
+    """What a loader hands over: padded raw waveforms (random), their lengths, speeds, padded targets."""
+    n = [int(sec * 16000) for _, sec, _, _ in b]
+    wav = (torch.rand(len(b), max(n)) - 0.5)
+    for i, k in enumerate(n):
+        wav[i, k:] = 0
+    L = max(len(t) for _, _, t, _ in b)
+    tg = torch.full((len(b), L), -1, dtype=torch.int32)
+    for i, (_, _, t, _) in enumerate(b):
+        tg[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+    return wav.to(dev), n, [s for *_, s in b], tg.to(dev), torch.tensor([len(t) for _, _, t, _ in b], dtype=torch.int32, device=dev)
+
+
+def step(hb):
+    wav, n, speeds, tg, tl = hb
+    wav, n = speed_perturb_batch(wav, n, speeds)
+    feats, nfr = fb(wav, torch.tensor(n, dtype=torch.int32, device=dev))
+    utt_normalize_(feats, nfr)
+    nf = [fb.num_frames(k) for k in n]
+    augment.spec_augment_(feats, nf, num_t_mask=3, num_f_mask=2, max_t=50, max_f=10)     # train.yaml:51-56: 3 x 50 / 2 x 10
+    loss, _ = eng.step(dict(features=feats, features_length=nfr, targets=tg, targets_length=tl))
+    return loss, sum(nf)
+
+
+staged = [host_batch(b) for b in batches]                      # inputs resident in HBM before the clock starts
+for hb in staged[: args.warmup]:
+    step(hb)
+torch.cuda.synchronize()
+frames, t0 = 0, time.perf_counter()
+for hb in staged[args.warmup:]:
+    loss, f = step(hb)
+    frames += f
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+k = len(staged) - args.warmup
+padded = sum(len(b) * max(fb.num_frames(int(sec * 16000 / s + 0.5)) for _, sec, _, s in b) for b in batches[args.warmup:])
+print(json.dumps({"workload": "configs[4] on 1 GPU: 24L Conformer d=512 h=8 ff=2048 (192.5 M params), U(2,16) s utterances, speeds {0.9,1,1.1}, "
+                  "SpecAug 3x50/2x10, padded-budget buckets", "steps": k, "ms_per_step": dt / k * 1e3,
+                  "audio_frames_per_s": frames / dt, "true_over_padded_frames": frames / padded, "budget_padded_frames": args.budget,
+                  "loss": float(loss), "precision": hip.GEMM_PRECISION}))
