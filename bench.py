@@ -140,6 +140,7 @@ def main():
     ap.add_argument("--gemm-table", action="store_true", help="log the per-problem GEMM timing table of one step to stderr")
     ap.add_argument("--dropout", type=float, default=None, help="tuning aid: override the config's dropout 0.1 (the reported line is only valid at the default)")
     ap.add_argument("--no-decode", action="store_true", help="skip the attention-rescoring RTF measurement")
+    ap.add_argument("--serial-decoders", action="store_true", help="tuning: keep the right-to-left decoder on the main stream")
     ap.add_argument("--decode-utts", type=int, default=64)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -166,7 +167,7 @@ def main():
         conf["dropout_rate"] = args.dropout
         log(f"NOTE: dropout overridden to {args.dropout} - not the BASELINE config, tuning only")
     model = ASRModel(80, V, **conf).to(dev).train()
-    engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=not args.serial_decoders)
     fb = Fbank(80, device=dev)
     wav, tgt, tlen = synth_batch(args.batch, args.seconds, args.target_len, seed=rank, device=dev)
     T = fb.num_frames(wav.shape[1])

@@ -16,9 +16,11 @@ from openeat_amd.utils import common
 
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, grad_clip: float = 5.0, accum_grad: int = 1,
-                 n_allreduce_chunks: int = 4, static_shapes: bool = False, async_wgrad: bool = True):
+                 n_allreduce_chunks: int = 4, static_shapes: bool = False, async_wgrad: bool = True,
+                 parallel_decoders: bool = False):
         self.model = model
         ops.ASYNC_WGRAD = bool(async_wgrad)
+        ops.PARALLEL_DECODERS = bool(parallel_decoders)
         self.arena = ParamArena(model).activate()
         self.optimizer = FusedAdam(self.arena, lr=lr, max_grad_norm=grad_clip)
         self.reducer = GradAllReduce(self.arena.grad, n_allreduce_chunks)

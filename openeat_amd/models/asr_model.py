@@ -70,6 +70,16 @@ class ASRModel(torch.nn.Module):
             cb = hooks["encoder_out"]
             encoder_out.register_hook(lambda g, cb=cb: cb())      # returns None: the gradient is not modified
         encoder_out_lens = encoder_mask.squeeze(1).sum(1)
+        if ops.PARALLEL_DECODERS and encoder_out.is_cuda and self.ctc_weight < 1:
+            # the CTC head (a few chip-filling launches) on a third stream beside the decoders' latency-bound chains
+            main, side = torch.cuda.current_stream(), ops.ctc_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
+            loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length)
+            main.wait_stream(side)
+            loss_ctc.record_stream(main)
+            return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att, acc
         loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
         if self.ctc_weight < 1:
             loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length)
@@ -83,16 +93,36 @@ class ASRModel(torch.nn.Module):
         L = ys_in_pad.size(1)
         tgt_mask = (~make_pad_mask(ys_in_lens, L)).unsqueeze(1) & subsequent_mask(L, device=ys_in_pad.device).unsqueeze(0)
         dec = self.decoder
-        l_hid = dec.left_decoder.hidden(ys_in_pad, tgt_mask, encoder_out, encoder_mask)
-        lo = dec.left_decoder.output_layer
-        loss_att, n_ok, n_valid = self.criterion_att.fused_head(l_hid, lo.weight, lo.bias, ys_out_pad)
-        if self.reverse_weight > 0:
-            r_ys_pad = reverse_pad_list(ys_pad, ys_pad_lens, float(self.ignore_id))
-            r_ys_in_pad, r_ys_out_pad = add_sos_eos(r_ys_pad, self.sos, self.eos, self.ignore_id)
+
+        def left():
+            l_hid = dec.left_decoder.hidden(ys_in_pad, tgt_mask, encoder_out, encoder_mask)
+            lo = dec.left_decoder.output_layer
+            return self.criterion_att.fused_head(l_hid, lo.weight, lo.bias, ys_out_pad)
+
+        if not self.reverse_weight > 0:
+            loss_att, n_ok, n_valid = left()
+            return loss_att, torch.true_divide(n_ok, n_valid)
+        r_ys_pad = reverse_pad_list(ys_pad, ys_pad_lens, float(self.ignore_id))
+        r_ys_in_pad, r_ys_out_pad = add_sos_eos(r_ys_pad, self.sos, self.eos, self.ignore_id)
+
+        def right():
             r_hid = dec.right_decoder.hidden(r_ys_in_pad, tgt_mask, encoder_out, encoder_mask)
             ro = dec.right_decoder.output_layer
-            r_loss, _, _ = self.criterion_att.fused_head(r_hid, ro.weight, ro.bias, r_ys_out_pad)
-            loss_att = loss_att * (1 - self.reverse_weight) + r_loss * self.reverse_weight
+            return self.criterion_att.fused_head(r_hid, ro.weight, ro.bias, r_ys_out_pad)[0]
+
+        if ops.PARALLEL_DECODERS and encoder_out.is_cuda:
+            # the right decoder on its own stream beside the left one (ops.PARALLEL_DECODERS): fork here, join below
+            main, side = torch.cuda.current_stream(), ops.decoder_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                r_loss = right()
+            loss_att, n_ok, n_valid = left()
+            main.wait_stream(side)
+            r_loss.record_stream(main)
+        else:
+            loss_att, n_ok, n_valid = left()
+            r_loss = right()
+        loss_att = loss_att * (1 - self.reverse_weight) + r_loss * self.reverse_weight
         return loss_att, torch.true_divide(n_ok, n_valid)
 
     # ----------------------------------------------------------------- decode --

@@ -162,6 +162,37 @@ def side_stream():
 def join_side_stream():
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
+    if _decoder_stream is not None:
+        torch.cuda.current_stream().wait_stream(_decoder_stream)
+    if _ctc_stream is not None:
+        torch.cuda.current_stream().wait_stream(_ctc_stream)
+
+
+# ---- the right-to-left decoder beside the left-to-right one -----------------------
+# The two decoders of the bi-decoder (decoder.py:278-309) share nothing but their inputs, and their launches are small
+# (992 rows: 16 x 4 tiles of a GEMM, i.e. 64 blocks on 256 CUs, each bound by its own latency).  With this switch on,
+# ASRModel._calc_att_loss runs the right decoder and its loss head on a second stream: ONE fork after the encoder, ONE
+# join where the two losses are combined; autograd replays each node on the stream of its forward, so backward forks
+# the same way.  (The per-layer weight-gradient fork above is a different matter: hundreds of cross-queue waits.)
+PARALLEL_DECODERS = False
+_decoder_stream = None
+
+
+_ctc_stream = None
+
+
+def ctc_stream():
+    global _ctc_stream
+    if _ctc_stream is None:
+        _ctc_stream = torch.cuda.Stream()
+    return _ctc_stream
+
+
+def decoder_stream():
+    global _decoder_stream
+    if _decoder_stream is None:
+        _decoder_stream = torch.cuda.Stream()
+    return _decoder_stream
 
 
 class _Side:

@@ -45,7 +45,8 @@ def worker():
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     model = _model(dev)
-    eng = TrainEngine(model, lr=1e-2, grad_clip=5.0)
+    # as bench.py runs it at N > 1: right decoder and CTC head on their own streams, collectives started from backward hooks
+    eng = TrainEngine(model, lr=1e-2, grad_clip=5.0, parallel_decoders=True)
     assert eng.reducer.world == 2 and hasattr(model, "grad_ready_hooks") and hasattr(model.encoder, "grad_ready_hooks")
     issued = []
     orig = eng.reducer.reduce_tail

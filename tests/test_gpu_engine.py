@@ -154,6 +154,37 @@ def test_graph_replay_equals_eager_steps():
     check_updates(m2.state_dict(), m1.state_dict(), None, steps=5)
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_right_decoder_on_its_own_stream_gives_the_same_training(graph):
+    """ops.PARALLEL_DECODERS: the right-to-left decoder and its loss head run on a second stream (one fork, one join,
+    mirrored by autograd in backward).  Same losses and the same parameters after 5 steps as the single-stream engine,
+    eager and as a captured HIP graph (the fork must be part of the capture)."""
+    m1, m2 = tiny(seed=9).to(DEV).train(), tiny(seed=9).to(DEV).train()
+    b = batch_of(seed=4)
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    for _ in range(5):
+        l_seq, _ = e1.step(b)
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+    try:
+        assert ops.PARALLEL_DECODERS
+        if graph:
+            e2.capture(b, warmup=2)
+            for _ in range(3):
+                l_par, _ = e2.replay()
+        else:
+            for _ in range(5):
+                l_par, _ = e2.step(b)
+        torch.cuda.synchronize()
+    finally:
+        e2.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        ops.PARALLEL_DECODERS = False
+    torch.testing.assert_close(l_par, l_seq, rtol=1e-4, atol=1e-5)
+    check_updates(m2.state_dict(), m1.state_dict(), None, steps=5)
+
+
 def test_dropout_training_step_runs_and_is_seed_dependent():
     m = tiny(seed=9, dropout=0.1).to(DEV).train()
     b = batch_of(seed=4)
