@@ -134,7 +134,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--target-len", type=int, default=30)
     ap.add_argument("--no-graph", action="store_true", help="run the step eagerly instead of replaying a HIP graph")
-    ap.add_argument("--graph-multi", action="store_true", help="also calibrate the HIP-graph replay when N > 1 (default: eager only)")
+    ap.add_argument("--no-graph-multi", dest="graph_multi", action="store_false",
+                    help="N > 1: do not try the HIP-graph replay of forward+backward, time eager steps only")
     ap.add_argument("--force-graph", action="store_true", help="time the HIP-graph replay even if the eager step calibrated faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-table", action="store_true", help="log the per-problem GEMM timing table of one step to stderr")
@@ -220,8 +221,11 @@ def main():
         return agree((time.perf_counter() - t) / n * 1e3)
 
     use_graph = False
-    # N > 1 stays eager unless --graph-multi: a capture while RCCL's watchdog thread polls its events could not be
-    # exercised on this round's one-GPU boxes, and the eager step is the path the 2-rank tests cover
+    # N > 1: the graph holds zero-grad + forward + backward, the all-reduce of the whole arena and the optimizer follow it
+    # eagerly (exposed, ~1 ms at 8 GPUs) - against an eager step that overlaps the collectives with backward but is
+    # host-bound (~1100 launches, 23-28 ms on the boxes seen).  Both are tried and the faster is timed; the capture runs
+    # in thread-local error mode (RCCL's watchdog thread polls events meanwhile) and any capture error falls back to eager.
+    # Rehearsed with 2 ranks over gloo on one GPU (capture + replay + rank-agreed choice); RCCL itself needs > 1 GPU.
     if not args.no_graph and (world == 1 or args.graph_multi):
         n_trial = 10 if world == 1 else 5
         t_eager = trial(eager, n_trial)              # before the capture: the graph's private memory pool changes allocator state
