@@ -64,19 +64,33 @@ class ASRModel(torch.nn.Module):
         assert targets_length.dim() == 1, targets_length.shape
         assert (features.shape[0] == features_length.shape[0] == targets.shape[0] == targets_length.shape[0]), \
             (features.shape, features_length.shape, targets.shape, targets_length.shape)
+        par = ops.PARALLEL_DECODERS and features.is_cuda and self.ctc_weight < 1
+        prep = None
+        if par:
+            # the decoders' token bookkeeping (sos/eos, reversal, masks: ~60 tiny launches that depend on the targets only)
+            # runs on the decoder stream while the encoder runs here; it is joined where the decoders start
+            main, side = torch.cuda.current_stream(), ops.decoder_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                prep = self._att_inputs(targets, targets_length)
         encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        if par:
+            main.wait_stream(side)
+            for t in prep:
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
         hooks = getattr(self, "grad_ready_hooks", None)          # set by TrainEngine for multi-GPU overlap
         if hooks and encoder_out.requires_grad:
             cb = hooks["encoder_out"]
             encoder_out.register_hook(lambda g, cb=cb: cb())      # returns None: the gradient is not modified
         encoder_out_lens = encoder_mask.squeeze(1).sum(1)
-        if ops.PARALLEL_DECODERS and encoder_out.is_cuda and self.ctc_weight < 1:
+        if par:
             # the CTC head (a few chip-filling launches) on a third stream beside the decoders' latency-bound chains
             main, side = torch.cuda.current_stream(), ops.ctc_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
-            loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length)
+            loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length, prep)
             main.wait_stream(side)
             loss_ctc.record_stream(main)
             return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att, acc
@@ -86,12 +100,21 @@ class ASRModel(torch.nn.Module):
             return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att, acc
         return loss_ctc, None
 
-    def _calc_att_loss(self, encoder_out, encoder_mask, ys_pad, ys_pad_lens):
-        """asr_model.py:159-203; the output layers are fused with the loss."""
+    def _att_inputs(self, ys_pad, ys_pad_lens):
+        """asr_model.py:162-176: decoder inputs / targets of both directions and the target mask (token bookkeeping only)."""
         ys_in_pad, ys_out_pad = add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
         ys_in_lens = ys_pad_lens + 1
         L = ys_in_pad.size(1)
         tgt_mask = (~make_pad_mask(ys_in_lens, L)).unsqueeze(1) & subsequent_mask(L, device=ys_in_pad.device).unsqueeze(0)
+        r_ys_in_pad = r_ys_out_pad = None
+        if self.reverse_weight > 0:
+            r_ys_pad = reverse_pad_list(ys_pad, ys_pad_lens, float(self.ignore_id))
+            r_ys_in_pad, r_ys_out_pad = add_sos_eos(r_ys_pad, self.sos, self.eos, self.ignore_id)
+        return ys_in_pad, ys_out_pad, tgt_mask, r_ys_in_pad, r_ys_out_pad
+
+    def _calc_att_loss(self, encoder_out, encoder_mask, ys_pad, ys_pad_lens, prep=None):
+        """asr_model.py:159-203; the output layers are fused with the loss."""
+        ys_in_pad, ys_out_pad, tgt_mask, r_ys_in_pad, r_ys_out_pad = prep if prep is not None else self._att_inputs(ys_pad, ys_pad_lens)
         dec = self.decoder
 
         def left():
@@ -102,8 +125,6 @@ class ASRModel(torch.nn.Module):
         if not self.reverse_weight > 0:
             loss_att, n_ok, n_valid = left()
             return loss_att, torch.true_divide(n_ok, n_valid)
-        r_ys_pad = reverse_pad_list(ys_pad, ys_pad_lens, float(self.ignore_id))
-        r_ys_in_pad, r_ys_out_pad = add_sos_eos(r_ys_pad, self.sos, self.eos, self.ignore_id)
 
         def right():
             r_hid = dec.right_decoder.hidden(r_ys_in_pad, tgt_mask, encoder_out, encoder_mask)
