@@ -21,6 +21,7 @@ class TrainEngine:
         self.model = model
         ops.ASYNC_WGRAD = bool(async_wgrad)
         ops.PARALLEL_DECODERS = bool(parallel_decoders)
+        self.parallel = bool(parallel_decoders)
         self.arena = ParamArena(model).activate()
         self.optimizer = FusedAdam(self.arena, lr=lr, max_grad_norm=grad_clip)
         self.reducer = GradAllReduce(self.arena.grad, n_allreduce_chunks)
@@ -77,6 +78,7 @@ class TrainEngine:
     def step(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):
         """Eager step (any shapes)."""
         common.STATIC_SHAPES = self.static_shapes
+        ops.POS_PROJ_AHEAD = self.parallel and self.reducer.world == 1      # not beside the backward hooks' collectives
         if lr is not None:
             self.optimizer.set_lr(lr)
         self.arena.zero_grad()
@@ -90,6 +92,7 @@ class TrainEngine:
         with several ranks the graph holds zero-grad + forward + backward and the gradient all-reduce and
         the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph)."""
         self._split = self.reducer.world > 1
+        ops.POS_PROJ_AHEAD = self.parallel            # inside a capture the collectives all come after the graph
         common.STATIC_SHAPES = True
         self.static_shapes = True
         self._static = {k: v.clone() for k, v in example_batch.items()}

@@ -29,12 +29,18 @@ class MultiHeadedAttention(nn.Module):
         xkv = None if query is key else key
         p = self.dropout.p if self.training else 0.0
         rel = isinstance(self, RelPositionMultiHeadedAttention)
+        pp = None
+        ahead = getattr(self, "_pp_ahead", None)                  # (linear_pos(pos_emb), event) from the encoder's side stream
+        if rel and ahead is not None:
+            pp, ev = ahead
+            torch.cuda.current_stream().wait_event(ev)
+            pp.record_stream(torch.cuda.current_stream())
         return ops.attention(query, xkv, self.linear_q.weight, self.linear_q.bias, self.linear_k.weight,
                              self.linear_k.bias, self.linear_v.weight, self.linear_v.bias, self.linear_out.weight,
                              self.linear_out.bias, mask, self.h, p,
                              pos_emb if rel else None, self.linear_pos.weight if rel else None,
                              self.pos_bias_u if rel else None, self.pos_bias_v if rel else None,
-                             residual, out_dropout if self.training else 0.0)
+                             residual, out_dropout if self.training else 0.0, pp)
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, mask: Optional[torch.Tensor],
                 pos_emb: Optional[torch.Tensor] = None, residual: torch.Tensor = None,

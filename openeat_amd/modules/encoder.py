@@ -90,10 +90,30 @@ class TransformerEncoder(torch.nn.Module):
         xs, masks, pos_emb = self.embed(xs, masks)
         m8 = masks.to(torch.uint8).contiguous()
         hooks = getattr(self, "grad_ready_hooks", None)           # {layer index: callback}, set by TrainEngine (multi-GPU)
-        for i, layer in enumerate(self.encoders):
-            if hooks and i in hooks and xs.requires_grad:
-                xs.register_hook(lambda g, cb=hooks[i]: cb())     # gradient of layer i's input ready = layers >= i done
-            for _ in range(self.num_blocks_share):
-                xs, _ = layer(xs, m8, pos_emb)
+        ahead = []
+        if ops.POS_PROJ_AHEAD and xs.is_cuda:
+            # every layer's linear_pos(pos_emb) on the side stream now (ops.POS_PROJ_AHEAD); a layer waits for its own event
+            main, side = torch.cuda.current_stream(), ops.decoder_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for layer in self.encoders:
+                    att = getattr(layer, "self_attn", None)
+                    if hasattr(att, "linear_pos"):
+                        pp = ops.pos_proj(pos_emb, att.linear_pos.weight)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        att._pp_ahead = (pp, ev)
+                        ahead.append(att)
+        try:
+            for i, layer in enumerate(self.encoders):
+                if hooks and i in hooks and xs.requires_grad:
+                    xs.register_hook(lambda g, cb=hooks[i]: cb())     # gradient of layer i's input ready = layers >= i done
+                for _ in range(self.num_blocks_share):
+                    xs, _ = layer(xs, m8, pos_emb)
+        finally:
+            for att in ahead:
+                att._pp_ahead = None
+            if ahead:
+                torch.cuda.current_stream().wait_stream(ops.decoder_stream())
         xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
         return xs, masks, pos_emb

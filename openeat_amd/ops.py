@@ -567,7 +567,7 @@ class AttentionFn(torch.autograd.Function):
     optional fused `residual + dropout(.)` of the caller (encoder_layer.py:89)."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out):
+    def forward(ctx, xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out, pp_in=None):
         xq = _chk(xq, "attention query")
         self_attn = xkv is None
         B, T1, d = xq.shape
@@ -599,7 +599,7 @@ class AttentionFn(torch.autograd.Function):
         if rel:
             assert self_attn and pos_emb.shape[-2] == T2
             pe2 = _chk(pos_emb, "pos_emb").reshape(-1, d)
-            pp = gemm_nt(pe2, wpos)                              # (T, d): linear_pos has no bias
+            pp = pp_in if pp_in is not None else gemm_nt(pe2, wpos)     # (T, d): linear_pos has no bias
             kp = _new(B, T2, d, like=xq)
             keybias = _new(B, H, T2, like=xq)
             hip.call("oe_relpos_prepare", k, ks[0], ks[1], pp, d, pu, pv, B, T2, H, D, scale, kp, keybias)
@@ -619,6 +619,7 @@ class AttentionFn(torch.autograd.Function):
                               None if self_attn else kv, kp, keybias, pp, None if not rel else pe2, wpos, pu, pv, m8, att, lse)
         ctx.cfg = (self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, residual is not None, mstr)
         ctx.biases = (bq, bk, bv, bo)
+        ctx.pp_external = pp_in is not None
         return y.view(B, T1, d)
 
     @staticmethod
@@ -658,7 +659,8 @@ class AttentionFn(torch.autograd.Function):
             dpp = _new(T2, d, like=dy)
             (dpu, rpu), (dpv, rpv) = grad_sink(pu), grad_sink(pv)
             hip.call("oe_relpos_backward", dkp, dkb, k, ks[0], ks[1], pp, d, pu, pv, B, T2, H, D, scale, dk, dpp, d, dpu, dpv)
-            dwpos = wgrad(wpos, dpp, pe2)
+            if not ctx.pp_external:
+                dwpos = wgrad(wpos, dpp, pe2)
 
         def split_or_sink(parts_w, parts_b, dy_fused, x_in):
             """Weight/bias gradients of a fused projection: one GEMM / one column sum."""
@@ -694,12 +696,37 @@ class AttentionFn(torch.autograd.Function):
             dxkv, (dwk, dwv), (dbk, dbv) = split_or_sink((wk, wv), (bk, bv), dkv, xkv2)
             dxkv = dxkv.view(B, T2, d)
         return (dx, dxkv, dwq, dbq, dwk, dbk, dwv, dbv, dwo, dbo, None, None, dwpos, rpu, rpv, None, None,
-                (dy if has_res else None), None)
+                (dy if has_res else None), None, (dpp if (rel and ctx.pp_external) else None))
 
 
 def attention(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_attn=0.0, pos_emb=None, wpos=None, pu=None, pv=None,
-              residual=None, p_out=0.0):
-    return AttentionFn.apply(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out)
+              residual=None, p_out=0.0, pp=None):
+    return AttentionFn.apply(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out, pp)
+
+
+# linear_pos(pos_emb) (attention.py:185) depends on the positional table and one weight only: with POS_PROJ_AHEAD the
+# encoder computes it for every layer on the side stream when it starts, as an autograd node of its own - so the
+# projection AND its weight gradient (which autograd runs on the same stream) leave the layers' critical chain.
+# Off for eager multi-rank steps: there the backward hooks hand finished slices of the gradient arena to the collective,
+# and this node's weight gradient would run after its layer's slice had gone.
+POS_PROJ_AHEAD = False
+
+
+class PosProjFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos_emb, wpos):
+        pe2 = _chk(pos_emb, "pos_emb").reshape(-1, wpos.shape[1])
+        ctx.save_for_backward(pe2, wpos)
+        return gemm_nt(pe2, wpos)
+
+    @staticmethod
+    def backward(ctx, dpp):
+        pe2, wpos = ctx.saved_tensors
+        return None, wgrad(wpos, dpp.contiguous(), pe2)
+
+
+def pos_proj(pos_emb, wpos):
+    return PosProjFn.apply(pos_emb, wpos)
 
 
 # --------------------------------------------------------------------------- #

@@ -181,6 +181,7 @@ def test_right_decoder_on_its_own_stream_gives_the_same_training(graph):
         e2.arena.deactivate()
         ops.set_seed_device_counter(None)
         ops.PARALLEL_DECODERS = False
+        ops.POS_PROJ_AHEAD = False
     torch.testing.assert_close(l_par, l_seq, rtol=1e-4, atol=1e-5)
     check_updates(m2.state_dict(), m1.state_dict(), None, steps=5)
 
