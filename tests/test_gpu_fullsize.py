@@ -62,6 +62,43 @@ def test_ctc_full_size_properties():
     torch.testing.assert_close(g2, 2 * g1, rtol=1e-6, atol=1e-7)
 
 
+def test_ctc_north_star_shape_against_aten_on_a_sample():
+    """B=64 x 16 s (T'=398, L=48: two states per lane in the recursion, 13 float4 per lane in the row kernel): the whole
+    batch through oe_ctc_loss_fused in place; four of the utterances (full length, ragged, shortest feasible, empty
+    target) against aten's CPU ctc_loss + autograd; row sums and exact zeros on the rest."""
+    import torch.nn.functional as F
+    from openeat_amd import hip
+    torch.manual_seed(5)
+    Bn, Tn, Ln = 64, 398, 48
+    Vp = (V + 3) // 4 * 4
+    logits = torch.randn(Bn, Tn, Vp) * 1.5
+    hl = torch.randint(200, Tn + 1, (Bn,), dtype=torch.int32)
+    yl = torch.randint(20, Ln + 1, (Bn,), dtype=torch.int32)
+    ys = torch.randint(1, V, (Bn, Ln), dtype=torch.int32)
+    hl[0], yl[0] = Tn, Ln
+    ys[2, :] = 9
+    hl[2], yl[2] = 2 * Ln - 1, Ln                        # 48 identical labels need exactly 95 frames: one feasible path
+    yl[3] = 0
+    ld = logits.to(DEV)
+    ws = torch.empty(hip.lib().oe_ctc_workspace_floats(Bn, Tn, Ln), device=DEV)
+    nll, tot = torch.empty(Bn, device=DEV), torch.empty(1, device=DEV)
+    hip.call("oe_ctc_loss_fused", ld, Vp, Bn, Tn, V, hl.to(DEV), ys.to(DEV), Ln, yl.to(DEV), 1.0, None, nll, tot, ld, ws)
+    torch.cuda.synchronize()
+    g = ld[:, :, :V].cpu()
+    nll = nll.cpu()
+    sel = [0, 1, 2, 3]
+    lg = logits[sel, :, :V].clone().requires_grad_()
+    per = F.ctc_loss(lg.transpose(0, 1).log_softmax(2), ys[sel].long(), hl[sel].long(), yl[sel].long(), reduction="none", zero_infinity=True)
+    per.sum().backward()
+    torch.testing.assert_close(nll[sel], per.detach(), rtol=1e-4, atol=2e-2)
+    torch.testing.assert_close(g[sel], lg.grad, rtol=5e-3, atol=5e-5)
+    assert float(nll[2]) > 0 and torch.isfinite(nll).all() and torch.isfinite(g).all()
+    torch.testing.assert_close(tot.cpu()[0], nll.sum(), rtol=1e-5, atol=1e-2)
+    frames = torch.arange(Tn)[None, :] < hl[:, None]
+    assert bool((g[~frames] == 0).all())
+    assert float(g.sum(-1)[frames].abs().max()) < 2e-2                                 # softmax - occupancies: 1 - 1 (log-domain ulp at |ll| ~ 3000)
+
+
 @pytest.mark.parametrize("prec,tol", [(0, 2e-4), (3, 2e-4)])
 def test_gemm_full_size_linearity_and_layout_agreement(prec, tol):
     from openeat_amd import hip
