@@ -160,6 +160,7 @@ def side_stream():
 
 
 def join_side_stream():
+    flush_wgrads()
     if _side_stream is not None:
         torch.cuda.current_stream().wait_stream(_side_stream)
     if _decoder_stream is not None:
@@ -226,6 +227,47 @@ def _wgrad_ctx(to_arena: bool, *tensors):
     return _Side(*tensors) if (ASYNC_WGRAD and to_arena) else _Inline()
 
 
+# Deferred form for captured graphs: a cross-queue edge costs ~6 us at replay, so a fork per weight gradient (150 of them)
+# loses more than the overlap gives (21.5 vs 19.6 ms/step).  With WGRAD_DEFER = n > 0 the launches are collected instead
+# (the closures keep their operands alive) and every n of them go to the side stream behind ONE fork; the engine flushes
+# the rest and joins after backward.  Operands are never modified in place after a weight gradient has been requested
+# (the eager side stream relies on the same property).
+WGRAD_DEFER = 0
+_deferred = []
+
+
+def _run_wgrad(to_arena: bool, tensors, fn):
+    if WGRAD_DEFER > 0 and to_arena:
+        # the stream that produces this launch's operands: the flush must order the side stream after every one of them
+        # (the decoders' backward runs on other streams than the encoder's)
+        _deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)], torch.cuda.current_stream()))
+        if len(_deferred) >= WGRAD_DEFER:
+            flush_wgrads()
+        return
+    with _wgrad_ctx(to_arena, *tensors):
+        fn()
+
+
+def flush_wgrads():
+    global _deferred
+    if not _deferred:
+        return
+    side = side_stream()
+    origins = []
+    for _, _, st in _deferred:
+        if all(st != o for o in origins):
+            origins.append(st)
+    for st in origins:
+        side.wait_stream(st)
+    with torch.cuda.stream(side):
+        for fn, _, _ in _deferred:
+            fn()
+    for _, ts, _ in _deferred:
+        for t in ts:
+            t.record_stream(side)
+    _deferred = []
+
+
 # ---- parameter-gradient sinks ------------------------------------------------
 # With a ParamArena active the kernels accumulate into the flat gradient buffer and
 # autograd is told "no gradient" (None); otherwise a fresh tensor is returned.
@@ -233,8 +275,8 @@ def wgrad(param, dy, x, alpha=1.0, alpha_dev=None):
     tgt = _arena.grad_target(param)
     if tgt is None:
         return gemm_tn(dy, x, alpha=alpha, alpha_dev=alpha_dev).view(param.shape)
-    with _wgrad_ctx(True, dy, x, alpha_dev):
-        gemm_tn(dy, x, out=tgt.view(dy.shape[1], x.shape[1]), alpha=alpha, alpha_dev=alpha_dev)
+    _run_wgrad(True, (dy, x, alpha_dev),
+               lambda: gemm_tn(dy, x, out=tgt.view(dy.shape[1], x.shape[1]), alpha=alpha, alpha_dev=alpha_dev))
     return None
 
 
@@ -258,8 +300,8 @@ def wgrad_bias(w, b, dy, x, alpha=1.0, alpha_dev=None):
     tw, tb = _arena.grad_target(w), _arena.grad_target(b)
     ow = tw.view(N, K) if tw is not None else _new(N, K, like=dy, zero=True)
     ob = tb if tb is not None else _new(N, like=dy, zero=True)
-    with _wgrad_ctx(tw is not None and tb is not None, dy, x, alpha_dev):
-        gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob)
+    _run_wgrad(tw is not None and tb is not None, (dy, x, alpha_dev),
+               lambda: gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob))
     return (None if tw is not None else ow.view(w.shape)), (None if tb is not None else ob)
 
 
@@ -671,8 +713,8 @@ class AttentionFn(torch.autograd.Function):
                 gw = _arena.grad_target(parts_w[0])
                 gw_all = torch.as_strided(gw, (n, x_in.shape[1]), (x_in.shape[1], 1))
                 gb = _arena.grad_target(parts_b[0])
-                with _wgrad_ctx(True, dy_fused, x_in):
-                    gemm_tn(dy_fused, x_in, out=gw_all, bias_out=torch.as_strided(gb, (n,), (1,)))
+                _run_wgrad(True, (dy_fused, x_in),
+                           lambda: gemm_tn(dy_fused, x_in, out=gw_all, bias_out=torch.as_strided(gb, (n,), (1,))))
                 return dx_in, [None] * len(parts_w), [None] * len(parts_b)
             dwf, dbf = gemm_tn(dy_fused, x_in), colsum(dy_fused)
             ws, bs, o = [], [], 0
@@ -784,8 +826,7 @@ class ConvModuleFn(torch.autograd.Function):
         (db1, rb1) = grad_sink(b1)
         tw1 = _arena.grad_target(w1)
         ow1 = tw1.view(2 * d, d) if tw1 is not None else _new(2 * d, d, like=dy, zero=True)
-        with _wgrad_ctx(tw1 is not None and rb1 is None and not causal, da, xm):
-            gemm_tn(da, xm, out=ow1, bias_out=db1)
+        _run_wgrad(tw1 is not None and rb1 is None and not causal, (da, xm), lambda: gemm_tn(da, xm, out=ow1, bias_out=db1))
         dw1 = None if tw1 is not None else ow1.view(w1.shape)
         if causal:
             db1_pad = torch.empty_like(db1)
