@@ -142,6 +142,9 @@ def main():
     ap.add_argument("--dropout", type=float, default=None, help="tuning aid: override the config's dropout 0.1 (the reported line is only valid at the default)")
     ap.add_argument("--no-decode", action="store_true", help="skip the attention-rescoring RTF measurement")
     ap.add_argument("--serial-decoders", action="store_true", help="tuning: keep the right-to-left decoder on the main stream")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="profiling: every kernel on one stream (no decoder / CTC / weight-gradient streams), so that a profiler's "
+                         "per-kernel durations are those of the kernel alone, as the live roofline measurement takes them")
     ap.add_argument("--decode-utts", type=int, default=64)
     ap.add_argument("--cpu-batch", type=int, default=16)
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -168,7 +171,8 @@ def main():
         conf["dropout_rate"] = args.dropout
         log(f"NOTE: dropout overridden to {args.dropout} - not the BASELINE config, tuning only")
     model = ASRModel(80, V, **conf).to(dev).train()
-    engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=not args.serial_decoders)
+    engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True, async_wgrad=not args.single_stream,
+                         parallel_decoders=not (args.serial_decoders or args.single_stream))
     fb = Fbank(80, device=dev)
     wav, tgt, tlen = synth_batch(args.batch, args.seconds, args.target_len, seed=rank, device=dev)
     T = fb.num_frames(wav.shape[1])
@@ -269,12 +273,18 @@ def main():
     roof = None
     if rank == 0:
         hip.PROFILE = []
+    # the bracketed steps run on ONE stream: with the decoder / CTC / weight-gradient streams active, kernels of different
+    # streams share the chip and an event pair would time that sharing, not the kernel (rocprofv3 serialises them too)
+    from openeat_amd import ops as _ops
+    saved_streams = (_ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, engine.parallel)
+    _ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, engine.parallel = False, False, False
     for _ in range(2):
         # park the GPU behind a ~0.15 s spin kernel while the host enqueues the whole eager step: the launches then run
         # back to back and an event pair measures the kernel, not the host's time between record() and launch
         torch.cuda._sleep(int(3.5e8))
         engine.step(batch)                                      # eager steps on EVERY rank (they contain the collective);
     torch.cuda.synchronize()                                    # rank 0 brackets each GEMM launch with events
+    _ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, engine.parallel = saved_streams
     if rank == 0:
         recs, hip.PROFILE = hip.PROFILE, None
         recs = recs[len(recs) // 2:]                            # second step only

@@ -22,7 +22,7 @@ line = json.load(open(f"{src}/{tag}_bench_p3.json"))
 ro = line["roofline"]
 with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
     f.write("# Round 1 - rocprofv3 kernel stats, bench config 2, precision 3 (final kernels of the round)\n\n")
-    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-decode --no-graph --steps 5 --warmup 2` "
+    f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-decode --no-graph --single-stream --steps 5 --warmup 2` "
             "(10 optimizer steps in the trace: first step + 2 warm-up + 5 timed + 2 event-bracketed; the two `spin_kernel` launches that park the "
             f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p3.csv`.\n\n")
     f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
