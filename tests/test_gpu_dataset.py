@@ -115,3 +115,57 @@ def test_collated_batch_trains_a_step(tmp_path):
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_manifest_to_trained_epoch_as_train_py_wires_it(tmp_path):
+    """The reference's training wiring (bin/train.py:96-116,154-240) on the drop-in modules: manifest -> AudioDataset (dynamic
+    batches) -> sampler -> DataLoader(batch_size=1, collate_fn) -> Executor.train / cv with WarmupLR -> CTC greedy search."""
+    import logging
+    from torch.utils.data import DataLoader
+    from openeat.dataset.dataset import AudioDataset, audio_collate_func
+    from openeat.dataset.sampler import DistributedBatchSampler
+    from openeat.models.asr_model import ASRModel
+    from openeat.utils.executor import Executor
+    from openeat.utils.scheduler import WarmupLR
+    rng = np.random.default_rng(0)
+    chars = ["<blank>", "<unk>"] + [chr(0x4E00 + i) for i in range(20)] + ["<sos/eos>"]
+    char_dict = {c: i for i, c in enumerate(chars)}
+    lines = []
+    for i in range(14):
+        sec = float(rng.uniform(0.6, 1.6))
+        x = (rng.uniform(-0.3, 0.3, int(sec * 16000)) * 32768).astype("<i2")
+        p = str(tmp_path / f"w{i}.wav")
+        with wave.open(p, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes(x.tobytes())
+        text = "".join(chars[2 + int(c)] for c in rng.integers(0, 20, int(rng.integers(2, 6))))
+        lines.append(f"utt:u{i}\tfeat:{p}\tfeat_shape:{len(x) / 16000:.2f}\ttext:{text}")
+    man = tmp_path / "format.data"
+    man.write_text("\n".join(lines) + "\n", encoding="utf-8")
+    ds = AudioDataset(str(man), char_dict, batch_type="dynamic", max_frames_in_batch=450, sort=True, data_type="wav", min_length=10)
+    assert 3 <= len(ds) <= 14 and sum(len(b) for b in ds.data) == 14
+    coll = audio_collate_func(spec_aug=True, spec_aug_conf=dict(num_t_mask=1, num_f_mask=1, max_t=5, max_f=4), data_type="wav",
+                              feature_extraction_conf=dict(mel_bins=80, wav_dither=0.0, speed_perturb_rate=0.5, speeds=[0.9, 1.1, 0.1]),
+                              device=DEV)
+    sampler = DistributedBatchSampler(len(ds), 1, 0, shuffle=True, seed=3, mode="reference")
+    loader = DataLoader(ds, batch_size=1, sampler=sampler, collate_fn=coll, num_workers=0)
+    torch.manual_seed(1)
+    random.seed(1)
+    model = ASRModel(80, len(chars), encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+                     linear_units=64, reverse_weight=0.3, dropout_rate=0.1).to(DEV)
+    opt = torch.optim.Adam(model.parameters(), lr=2e-3)
+    sched = WarmupLR(opt, warmup_steps=5)
+    ex, log = Executor(), logging.getLogger("t")
+    args = dict(grad_clip=5.0, accum_grad=2, log_interval=100)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    losses = []
+    for epoch in range(4):
+        sampler.set_epoch(epoch)
+        losses.append(ex.train(log, model, opt, sched, loader, torch.device(DEV), args)[0])
+    cv_loss, cv_acc = ex.cv(log, model, loader, torch.device(DEV), args)
+    assert all(np.isfinite(l) for l in losses) and np.isfinite(cv_loss) and 0.0 <= cv_acc <= 1.0
+    assert losses[-1] < losses[0]                                                 # four epochs on 14 utterances: it learns something
+    assert ex.step == 4 * -(-len(ds) // 2) and any(not torch.equal(v, model.state_dict()[k]) for k, v in before.items())
+    model.eval()
+    keys, b = coll(ds[0])
+    hyps = model.ctc_greedy_search(b["features"], b["features_length"])
+    assert len(hyps) == len(keys) and all(isinstance(t, int) and 0 < t < len(chars) for h in hyps for t in h)
