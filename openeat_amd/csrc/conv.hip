@@ -380,15 +380,21 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const float* __rest
     }
 }
 
+// DW_PR_ROWS partial rows per block: 64 -> each thread has 16 loads in flight and an address sees B*T/16/64 adders
+// (with 16 rows per block the launch was 2048 blocks of four loads per thread and was bound by its scattered atomics)
+#define DW_PR_ROWS 64
 __global__ __launch_bounds__(256) void dwconv_param_reduce_kernel(const float* __restrict__ partial, int nblocks, int d, int K,
                                                                    float* __restrict__ dw, float* __restrict__ db) {
     __shared__ float sh[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + cx;                     // (k, c), c fastest
     const int n = (K + 1) * d;
-    const int b0 = blockIdx.y * 16, b1 = min(nblocks, b0 + 16);
+    const int b0 = blockIdx.y * DW_PR_ROWS, b1 = min(nblocks, b0 + DW_PR_ROWS);
     float s = 0.f;
-    if (idx < n) for (int b = b0 + ry; b < b1; b += 4) s += partial[(long)b * n + idx];
+    if (idx < n) {
+#pragma unroll 4
+        for (int b = b0 + ry; b < b1; b += 4) s += partial[(long)b * n + idx];
+    }
     sh[ry][cx] = s;
     __syncthreads();
     if (ry == 0 && idx < n) {
@@ -441,7 +447,7 @@ extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w
     else if (K < 7) DW_BWD(7, false); else if (K < 15) DW_BWD(15, false); else DW_BWD(31, false);
 #undef DW_BWD
     OE_LAUNCH_CHECK("dwconv_glu_bwd");
-    hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 64), oe_cdiv(B * oe_cdiv(T, DW_TT), 16)), dim3(256), 0, (hipStream_t)stream, workspace,
+    hipLaunchKernelGGL(dwconv_param_reduce_kernel, dim3(oe_cdiv((K + 1) * d, 64), oe_cdiv(B * oe_cdiv(T, DW_TT), DW_PR_ROWS)), dim3(256), 0, (hipStream_t)stream, workspace,
                        B * oe_cdiv(T, DW_TT), d, K, dw, db);
     OE_LAUNCH_CHECK("dwconv_param_reduce");
     return 0;

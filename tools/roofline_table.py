@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Per-kernel-class roofline table for config 2 from the rocprofv3 kernel stats of
+`bench.py --no-graph --single-stream` (profiles/<tag>_kernel_stats_p3.csv): algorithmic work per optimizer step (SURVEY 8d /
+DESIGN section 4 formulas) / measured kernel time per step, against the MI355X peaks (8 TB/s HBM, 2.5 PFLOP/s dense bf16).
+
+usage: roofline_table.py <kernel_stats.csv> <steps in trace> > profiles/<tag>_roofline_by_class.md"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+steps = float(sys.argv[2])
+ms = lambda pred: sum(int(r["TotalDurationNs"]) for r in rows if pred(r["Name"])) / 1e6 / steps
+B, T, T1, F1, Tp, d, H, ff, K, V, L1, C = 32, 998, 498, 39, 248, 256, 4, 1024, 15, 3246, 31, 256
+M = B * Tp                       # 7936 encoder rows
+Md = B * L1                      # 992 decoder rows
+f4 = 4
+act = M * d * f4                 # one encoder activation: 8.1 MB
+actd = Md * d * f4
+y1 = B * T1 * F1 * C * f4        # conv1 output: 636 MB
+attn_enc = 12 * (4 + 14) * B * H * Tp * Tp * (d // H)                    # fwd 4 + bwd 14 flops per (q, k, feature)
+attn_dec = 6 * (4 + 14) * B * H * (L1 * L1 + L1 * Tp) * (d // H)         # self + source attention of 2 x 3 decoder layers
+ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 block norms + conv-module norm per layer, after_norm
+classes = [
+    ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`)", "mfma", 1574.63445504e9, lambda n: "gemm_" in n and "kernel" in n,
+     "2*m*n*k of the step's 453 launches (counted live by bench.py)"),
+    ("attention (`attn_qtile`, `attn_ktile_bwd`, `attn_delta`)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
+     "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
+    ("CTC (`ctc_rows`, `ctc_alphabeta`, `ctc_labels`)", "hbm", 2 * M * V * f4 + 4 * M * (2 * 30 + 1) * f4, lambda n: "ctc_" in n and "greedy" not in n,
+     "logits read once + gradient written once + alpha/beta"),
+    ("LayerNorm forward", "hbm", (ln_enc * act + ln_dec * actd) * 2, lambda n: "layernorm_fwd" in n, "read x + write y"),
+    ("LayerNorm backward (+ parameter reduce)", "hbm", (ln_enc * act + ln_dec * actd) * 4, lambda n: "layernorm_bwd" in n or "ln_param_reduce" in n,
+     "read dy, x, residual gradient + write dx"),
+    ("depthwise conv + GLU forward", "hbm", 12 * 3 * act, lambda n: "dwconv_glu_fwd" in n, "read (B*T', 2d) + write (B*T', d)"),
+    ("depthwise conv + GLU backward (+ reduce)", "hbm", 12 * 5 * act, lambda n: "dwconv_glu_bwd" in n or "dwconv_param_reduce" in n, "read a, dy + write da"),
+    ("conv1 forward (`conv1_fwd`)", "hbm", y1 + B * T * 80 * f4, lambda n: "conv1_fwd" in n, "write the NHWC activation"),
+    ("conv1 weight gradient", "hbm", y1 + B * T * 80 * f4, lambda n: "conv1_wgrad" in n, "read dy1 + x"),
+    ("conv2 dgrad gather (`col2im_relu`)", "hbm", 9 * (B * Tp * 19 * C * f4) + 2 * y1, lambda n: "col2im" in n, "read dcol + y1, write dy1"),
+    ("fbank + per-utterance norm", "hbm", B * 160000 * f4 + 3 * B * T * 80 * f4, lambda n: "fbank_kernel" in n or "utt_norm" in n, "read wav, write/normalise features"),
+    ("label-smoothing loss rows", "hbm", 2 * 2 * Md * V * f4, lambda n: "lsm_" in n, "logits read + gradient written, two decoders"),
+    ("clip + Adam (`sumsq_partial`, `adam_kernel`)", "hbm", 31.3e6 * f4 * 8, lambda n: "adam_kernel" in n or "sumsq" in n, "g read twice; p, m, v read and written"),
+]
+peak = {"hbm": 8.0e12, "mfma": 2.5e15}
+unit = {"hbm": ("TB/s", 1e12), "mfma": ("TFLOP/s", 1e12)}
+tot = sum(int(r["TotalDurationNs"]) for r in rows if "spin_kernel" not in r["Name"]) / 1e6 / steps
+print("# Roofline by kernel class, config 2 (B=32 x 10 s), precision 3\n")
+print("Kernel time: rocprofv3 `--kernel-trace --stats` of `bench.py --no-graph --single-stream` (every kernel alone on one stream), "
+      f"per optimizer step; all kernels {tot:.2f} ms/step.  Work: algorithmic bytes / flops (DESIGN section 4).  Peaks: HBM 8 TB/s, "
+      "dense bf16 MFMA 2.5 PFLOP/s (precision 3 issues three MFMAs per algorithmic product).\n")
+print("| class | bound | algorithmic work / step | kernel ms / step | achieved | % of peak | work counted |\n|---|---|---|---|---|---|---|")
+seen = 0.0
+for name, bound, work, pred, note in classes:
+    t = ms(pred)
+    seen += t
+    u, s = unit[bound]
+    w = f"{work / 1e9:.1f} GFLOP" if bound == "mfma" else f"{work / 1e6:.0f} MB"
+    print(f"| {name} | {bound} | {w} | {t:.3f} | {work / (t * 1e-3) / s:.2f} {u} | {100 * work / (t * 1e-3) / peak[bound]:.1f} | {note} |")
+print(f"\nThese classes cover {seen:.2f} of the {tot:.2f} ms of kernel time per step; the rest is glue (dropout of gradients, relative-position "
+      "prepare/backward, embeddings, layout swaps, token bookkeeping).")
