@@ -75,6 +75,14 @@ typedef struct oe_gemm_args {
                         3: 3-term bf16 split hi*hi+hi*lo+lo*hi (fp32-grade, ~2^-17 per product) */
     int conv_k, conv_s;   /* kernel size / stride of the gathered conv; 0 = 3 / 2 (Conv2dSubsampling4/8); 5 / 3 is
                              Conv2dSubsampling6's second conv (subsampling.py:136) */
+    int conv_kh;          /* kernel HEIGHT when it differs from conv_k (= width); 0 = square.  The gathered window may be
+                             smaller than the input allows (conv_t2 <= (conv_t1 - kh) / s + 1): a sub-grid of positions */
+    /* Output row scatter (0 = off): logical row r = (b, t, f) over (sc_t2, sc_f2) is stored at row
+     * (b*sc_t1 + sc_s*t)*sc_f1 + sc_s*f of C (row stride ldc) and reads its actgrad_in row there too.  With conv_gather
+     * on a zero-padded dy this makes the transposed (stride-2) convolution an implicit GEMM per output-parity class that
+     * writes the input gradient in place (no column buffer): the (parity) base offsets go into the c / actgrad_in
+     * pointers.  Not with atomic_out / accumulate / preact_out / residual / rowmask / dropout. */
+    int out_scatter; int sc_t1, sc_f1, sc_t2, sc_f2, sc_s;
 } oe_gemm_args;
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);

@@ -206,10 +206,13 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
         X.KS = g->conv_k > 0 ? g->conv_k : 3;             // 0 = the 3x3 stride-2 conv of Conv2dSubsampling4/8
         X.S = g->conv_s > 0 ? g->conv_s : 2;
         OE_REQUIRE(X.C > 0 && X.C % 4 == 0, "oe_gemm_f32: conv gather needs C %% 4 == 0");
-        OE_REQUIRE(X.T1 >= X.KS && X.F1 >= X.KS && X.T2 == (X.T1 - X.KS) / X.S + 1 && X.F2 == (X.F1 - X.KS) / X.S + 1,
+        const int KH = g->conv_kh > 0 ? g->conv_kh : X.KS;             // kernel height; X.KS is the width
+        OE_REQUIRE(X.T1 >= KH && X.F1 >= X.KS && X.T2 >= 1 && X.F2 >= 1 && X.T2 <= (X.T1 - KH) / X.S + 1 && X.F2 <= (X.F1 - X.KS) / X.S + 1,
                    "oe_gemm_f32: conv gather dims inconsistent");
+        OE_REQUIRE(g->conv_kh <= 0 || ga, "oe_gemm_f32: conv_kh is for a gather on A");
+        OE_REQUIRE(gb ? (X.T2 == (X.T1 - KH) / X.S + 1 && X.F2 == (X.F1 - X.KS) / X.S + 1) : true, "oe_gemm_f32: conv gather dims inconsistent");
         X.vec_ok = ((uintptr_t)X.p % 16 == 0);
-        OE_REQUIRE(ga ? (!g->a_kmajor && g->k == X.KS * X.KS * X.C) : (g->b_kmajor && g->n == X.KS * X.KS * X.C),
+        OE_REQUIRE(ga ? (!g->a_kmajor && g->k == KH * X.KS * X.C) : (g->b_kmajor && g->n == X.KS * X.KS * X.C),
                    "oe_gemm_f32: conv gather layout mismatch");
     }
     EpiParams ep{};
@@ -218,6 +221,13 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     ep.drop_p = g->drop_p; ep.seed = g->seed; ep.seed_dev = g->seed_dev; ep.rowmask = g->rowmask;
     ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
     ep.accumulate = g->accumulate; ep.atomic = g->atomic_out; ep.a_colsum = g->a_colsum;
+    ep.scatter = g->out_scatter; ep.sc_t1 = g->sc_t1; ep.sc_f1 = g->sc_f1; ep.sc_t2 = g->sc_t2; ep.sc_f2 = g->sc_f2; ep.sc_s = g->sc_s;
+    if (g->out_scatter) {
+        OE_REQUIRE(!g->atomic_out && !g->accumulate && !g->preact_out && !g->residual && !g->rowmask && g->drop_p <= 0.f,
+                   "oe_gemm_f32: out_scatter supports alpha / bias / activation / act-grad epilogues only");
+        OE_REQUIRE(g->sc_t2 >= 1 && g->sc_f2 >= 1 && g->sc_s >= 1 && (long)(g->sc_t2 - 1) * g->sc_s < g->sc_t1 && (long)(g->sc_f2 - 1) * g->sc_s < g->sc_f1 &&
+                   g->m % ((long)g->sc_t2 * g->sc_f2) == 0, "oe_gemm_f32: out_scatter dims inconsistent");
+    }
     OE_REQUIRE(!g->a_colsum || (g->precision != 0 && g->a_kmajor && g->conv_gather != OE_GATHER_A), "oe_gemm_f32: a_colsum needs the bf16 path and a k-major A");
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
     OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3, "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");

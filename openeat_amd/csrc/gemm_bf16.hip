@@ -115,6 +115,27 @@ struct Stage {
             else ptr[s] = d.p + (long)(k0 + 4 * (idx & 7)) * d.ld + i0 + 4 * (((idx >> 3) & 7) + 8 * (idx >> 6));
         }
     }
+    // Fast path of a row-major im2col gather (conv forward, parity-class dgrad): one pointer per slot at its row's first
+    // input position, plus a wave-uniform offset per K-tile.  C is a multiple of the K-tile, so a tile never straddles a
+    // kernel row (addr_col is linear inside one); rows past `limit` (ragged last M-tile) re-read the last valid row - the
+    // epilogue discards them.
+    __device__ __forceinline__ void init_fast_gather(const OperandDesc& d, long i0, long limit) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            long r = i0 + (idx >> 3);
+            if (r >= limit) r = limit - 1;
+            ptr[s] = d.p + addr_row<true>(d, r) + (idx & 7) * 4;
+        }
+    }
+    __device__ __forceinline__ void load_fast_gather(const OperandDesc& d, int k0) {
+        const long co = addr_col<true>(d, k0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int idx = threadIdx.x + s * 256;
+            if (!PARTIAL || idx < NIDX) reg[s][0] = *reinterpret_cast<const float4*>(ptr[s] + co);
+        }
+    }
     __device__ __forceinline__ void load_fast(long ld) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
@@ -237,8 +258,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, Operan
     Stage<BN, B_KMAJOR, GATHER_B> sb;
     // FAST (chosen on the host): every tile interior, K-ranges multiples of the K-tile, vector loads legal
     constexpr bool fast = FAST;
+    constexpr bool fast_ga = FAST && GATHER_A && !A_KMAJOR;          // A = im2col gather through plain pointers
     if (fast) {
-        sa.init_fast(A, m0, k_begin);
+        if (fast_ga) sa.init_fast_gather(A, m0, M); else sa.init_fast(A, m0, k_begin);
         sb.init_fast(B, n0, k_begin);
     } else {
         sa.init(A, m0, M);
@@ -258,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, Operan
     const bool do_csum = A_KMAJOR && ep.a_colsum != nullptr && tile_x == 0;      // block-uniform
     if (A_KMAJOR) sa.zero_csum();
     if (nk > 0) {
-        if (fast) { sa.load_fast(A.ld); sb.load_fast(B.ld); }
+        if (fast) { if (fast_ga) sa.load_fast_gather(A, k_begin); else sa.load_fast(A.ld); sb.load_fast(B.ld); }
         else { sa.load(A, m0, M, k_begin, k_end); sb.load(B, n0, N, k_begin, k_end); }
         if (do_csum) sa.add_csum();
         sa.template store<TERMS>(a_hi(0), a_lo(0));
@@ -270,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, Operan
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) {
-            if (fast) { sa.load_fast(A.ld); sb.load_fast(B.ld); }
+            if (fast) { if (fast_ga) sa.load_fast_gather(A, k_begin + (kt + 1) * BK2); else sa.load_fast(A.ld); sb.load_fast(B.ld); }
             else { sa.load(A, m0, M, k_begin + (kt + 1) * BK2, k_end); sb.load(B, n0, N, k_begin + (kt + 1) * BK2, k_end); }
         }
         const __bf16* ah = a_hi(buf) + (wm * 32 * TM + frow) * PITCH + fk;
@@ -326,8 +348,12 @@ static int launch_bf16_(const OperandDesc& A, const OperandDesc& B, float* C, lo
     if (nz < 1) nz = 1;
     const int gx = oe_cdiv(N, BN), gy = oe_cdiv(M, BM);
     const bool fast = !GA && !GB && A.vec_ok && B.vec_ok && (M % BM == 0) && (N % BN == 0) && (K % BK2 == 0) && (kc % BK2 == 0);
+    // the im2col gather on a row-major A has a fast form too: interior N and K as above, any M (rows are clamped)
+    const bool fast_ga = GA && !GB && !AK && A.vec_ok && B.vec_ok && A.C % BK2 == 0 && (N % BN == 0) && (K % BK2 == 0) && (kc % BK2 == 0);
     if (!GA && !GB && fast)
         hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, false, false, TERMS, true>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
+    else if (GA && !GB && !AK && fast_ga)
+        hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, false, BKM, GA && !AK, false, TERMS, true>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
     else
         hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, AK, BKM, GA, GB, TERMS, false>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm (bf16 mfma)");

@@ -93,7 +93,39 @@ struct EpiParams {
     int accumulate;
     int atomic;
     float* a_colsum;   // optional: out[m] += alpha * sum_k A(m,k) for a k-major A (bias gradient fused into wgrad)
+    int scatter, sc_t1, sc_f1, sc_t2, sc_f2, sc_s;   // output row scatter (oe_gemm_args.out_scatter)
 };
+
+// physical row of logical row r = (b, t, f) over (sc_t2, sc_f2) when the output (and the act-grad source) is a strided
+// sub-grid of a (B, sc_t1, sc_f1) tensor
+__device__ __forceinline__ long scatter_row(const EpiParams& ep, long r) {
+    const int f = (int)(r % ep.sc_f2);
+    const long q = r / ep.sc_f2;
+    const int t = (int)(q % ep.sc_t2);
+    const long b = q / ep.sc_t2;
+    return (b * ep.sc_t1 + (long)ep.sc_s * t) * ep.sc_f1 + (long)ep.sc_s * f;
+}
+// the four rows row0, row0 + 8, row0 + 16, row0 + 24 of an epilogue pass: one division pair, then carries
+__device__ __forceinline__ void pass_rows(const EpiParams& ep, long row0, long (&ro)[4]) {
+    if (!ep.scatter) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) ro[p] = row0 + 8 * p;
+        return;
+    }
+    int f = (int)(row0 % ep.sc_f2);
+    long q = row0 / ep.sc_f2;
+    int t = (int)(q % ep.sc_t2);
+    long b = q / ep.sc_t2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        ro[p] = (b * ep.sc_t1 + (long)ep.sc_s * t) * ep.sc_f1 + (long)ep.sc_s * f;
+        f += 8;
+        while (f >= ep.sc_f2) {
+            f -= ep.sc_f2;
+            if (++t == ep.sc_t2) { t = 0; ++b; }
+        }
+    }
+}
 
 
 int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk,
@@ -168,7 +200,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     // Plain outputs (alpha, bias, activation, optional pre-activation copy; nothing to load, no dropout): store straight
     // from the accumulators.  Register r of a 32x32 tile is two full 128-byte row segments per wave-instruction, so the
     // LDS round trip of the general path buys nothing here.
-    if (interior && !ep.accumulate && !ep.actgrad_in && !ep.residual && !ep.rowmask && ep.drop_p <= 0.f && ep.beta == 1.f) {
+    if (interior && !ep.scatter && !ep.accumulate && !ep.actgrad_in && !ep.residual && !ep.rowmask && ep.drop_p <= 0.f && ep.beta == 1.f) {
         static_for<0, TM * TN>([&](auto tile_idx) {
             constexpr int i = decltype(tile_idx)::value / TN, j = decltype(tile_idx)::value % TN;
             const long col = n0 + wn * (32 * TN) + j * 32 + lrow;
@@ -219,8 +251,10 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
 #pragma unroll
             for (int p = 0; p < 4; ++p) { aux[p] = make_float4(0.f, 0.f, 0.f, 0.f); res[p] = aux[p]; dead[p] = false; }
             if (ep.actgrad_in) {
+                long ro[4];
+                pass_rows(ep, row0, ro);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) aux[p] = *reinterpret_cast<const float4*>(ep.actgrad_in + (row0 + 8 * p) * ep.ld_aux + col);
+                for (int p = 0; p < 4; ++p) aux[p] = *reinterpret_cast<const float4*>(ep.actgrad_in + ro[p] * ep.ld_aux + col);
             }
             if (ep.residual) {
 #pragma unroll
@@ -332,8 +366,15 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                     for (int p = 0; p < 4; ++p)
                         x[p] = make_float4(res[p].x + ep.beta * x[p].x, res[p].y + ep.beta * x[p].y, res[p].z + ep.beta * x[p].z, res[p].w + ep.beta * x[p].w);
                 }
+                if (ep.scatter) {
+                    long ro[4];
+                    pass_rows(ep, row0, ro);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(cdst + 8 * p * ldc) = x[p];
+                    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(C + ro[p] * ldc + col) = x[p];
+                } else {
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(cdst + 8 * p * ldc) = x[p];
+                }
                 if (i == 0 && j == 0) OE_STAMP(7);
             }
         });
@@ -363,8 +404,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 float v[4] = {t4.x, t4.y, t4.z, t4.w};
                 const bool full = (ncol == 4);
                 float aux[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
+                const long orow = ep.scatter ? scatter_row(ep, row) : row;      // where this row lives in C / the act-grad source
                 if (ep.actgrad_in) {
-                    const float* ap = ep.actgrad_in + row * ep.ld_aux + col;
+                    const float* ap = ep.actgrad_in + orow * ep.ld_aux + col;
                     if (full && aux_vec) { float4 a4 = *reinterpret_cast<const float4*>(ap); aux[0] = a4.x; aux[1] = a4.y; aux[2] = a4.z; aux[3] = a4.w; }
                     else for (int e = 0; e < ncol; ++e) aux[e] = ap[e];
                 }
@@ -388,7 +430,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                     if (full && aux_vec) *reinterpret_cast<float4*>(pp) = make_float4(pre[0], pre[1], pre[2], pre[3]);
                     else for (int e = 0; e < ncol; ++e) pp[e] = pre[e];
                 }
-                float* dst = C + row * ldc + col;
+                float* dst = C + orow * ldc + col;
                 if (full && c_vec) {
                     float4 o = make_float4(v[0], v[1], v[2], v[3]);
                     if (ep.accumulate) { const float4 c4 = *reinterpret_cast<const float4*>(dst); o.x += c4.x; o.y += c4.y; o.z += c4.z; o.w += c4.w; }

@@ -50,6 +50,8 @@ class GemmArgs(C.Structure):
         ("a_colsum", c_fp),
         ("precision", C.c_int),
         ("conv_k", C.c_int), ("conv_s", C.c_int),
+        ("conv_kh", C.c_int),
+        ("out_scatter", C.c_int), ("sc_t1", C.c_int), ("sc_f1", C.c_int), ("sc_t2", C.c_int), ("sc_f2", C.c_int), ("sc_s", C.c_int),
     ]
 
 
@@ -173,7 +175,8 @@ def _dev_f32(t: torch.Tensor, name: str):
 # --------------------------------------------------------------------------- #
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
          bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, seed_dev=None, rowmask=None,
-         residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None, a_colsum=None):
+         residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None, a_colsum=None,
+         conv_kh=0, scatter=None):
     g = GemmArgs()
     g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
     g.b, g.ldb, g.b_kmajor = b.data_ptr(), ldb, int(b_kmajor)
@@ -195,6 +198,10 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.conv_gather = conv_gather
     g.precision = GEMM_PRECISION if precision is None else precision
     g.a_colsum = None if (a_colsum is None or g.precision == 0) else a_colsum.data_ptr()
+    g.conv_kh = conv_kh
+    if scatter is not None:                      # (T1, F1, T2, F2, S): output rows (b, t, f) -> (b*T1 + S*t)*F1 + S*f
+        g.out_scatter = 1
+        g.sc_t1, g.sc_f1, g.sc_t2, g.sc_f2, g.sc_s = scatter
     if conv is not None:                         # (T1, F1, T2, F2, C) or (T1, F1, T2, F2, C, kernel size, stride)
         g.conv_t1, g.conv_f1, g.conv_t2, g.conv_f2, g.conv_c = conv[:5]
         g.conv_k, g.conv_s = (conv[5], conv[6]) if len(conv) > 5 else (0, 0)

@@ -309,6 +309,33 @@ def test_conv1_fwd_wgrad_and_conv2_dgrad():
     torch.testing.assert_close(db1.cpu(), b1.grad, rtol=5e-4, atol=5e-4)
 
 
+@pytest.mark.parametrize("prec,tol", [(0, 2e-4), (3, 2e-4)])
+@pytest.mark.parametrize("B,Ti,Fi,C", [(3, 21, 11, 32), (2, 22, 12, 64), (2, 498, 39, 64), (5, 7, 5, 32)])
+def test_conv2_input_gradient_as_four_parity_gemms(prec, tol, B, Ti, Fi, C):
+    """ops._conv_dgrad_k3s2 (gather from the zero-padded dy, row scatter + ReLU mask in the epilogue) against autograd of
+    F.conv2d(stride 2): odd and even input sizes (an even size leaves its last row / column without any tap), the
+    config-2 geometry 498 x 39, and a size smaller than one GEMM tile."""
+    from openeat_amd import ops
+    torch.manual_seed(3)
+    To, Fo = (Ti - 3) // 2 + 1, (Fi - 3) // 2 + 1
+    w = torch.randn(C, C, 3, 3) * 0.1
+    x = torch.randn(B, C, Ti, Fi, requires_grad=True)
+    dy = torch.randn(B, C, To, Fo)
+    F.conv2d(x, w, stride=2).backward(dy)
+    yin = torch.randn(B, Ti, Fi, C)                                   # the stage's input activation: only its sign matters
+    want = x.grad.permute(0, 2, 3, 1) * (yin > 0)
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = prec
+    try:
+        got = ops._conv_dgrad_k3s2(cu(dy.permute(0, 2, 3, 1).contiguous().view(-1, C)), cu(w), cu(yin), B, Ti, Fi, To, Fo, C)
+        sync()
+    finally:
+        hip.GEMM_PRECISION = old
+    scale = float(want.abs().max())
+    torch.testing.assert_close(got.cpu(), want, rtol=tol, atol=tol * scale)
+    assert bool((got.cpu()[yin <= 0] == 0).all())                     # masked positions exactly zero
+
+
 # K = 7 / 15 / 31 take the instantiations without a per-tap test, every other K the bounded ones (K < 7, < 15, < 31)
 @pytest.mark.parametrize("causal,K,d,T", [(False, 15, 32, 21), (True, 15, 32, 21), (False, 7, 256, 50), (False, 31, 64, 40), (True, 7, 32, 5),
                                           (False, 3, 32, 21), (True, 5, 64, 19), (False, 9, 64, 40), (True, 13, 32, 33),
