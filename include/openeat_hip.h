@@ -112,6 +112,16 @@ size_t oe_layernorm_bwd_workspace_floats(int rows, int d);
 int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, int act,
                      const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
                      float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+/* The same split in two: oe_layernorm_bwd_dx writes dx and the per-block partial sums of the parameter gradients into
+ * `workspace`; oe_layernorm_param_reduce_table reduces the partials of n such calls with ONE launch.  table (device
+ * memory) holds 5 int64 words per call: { workspace pointer, rows, d, dgamma pointer, dbeta pointer } (a null workspace
+ * pointer skips the entry); max_rows / max_d bound the entries' rows / d.  dgamma / dbeta are accumulated atomically.
+ * Every workspace must stay untouched until the reduction has run.  (A captured graph can hold the launch while the
+ * host fills the table after the capture: 93 reductions of 4.6 us each become one launch at config 2.) */
+int oe_layernorm_bwd_dx(const float* dy, const float* x, const float* gamma, const float* beta, int act, const float* stats,
+                        int rows, int d, const unsigned char* rowmask, const float* add, float* dx, float* workspace,
+                        void* stream);
+int oe_layernorm_param_reduce_table(const long long* table, int n, int max_rows, int max_d, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * CTC head: log_softmax + CTCLoss(reduction='sum', zero_infinity=True) and

@@ -65,6 +65,7 @@ class TrainEngine:
         loss = loss / self.accum_grad if self.accum_grad != 1 else loss
         loss.backward()
         ops.join_side_stream()                 # weight-gradient GEMMs running beside the backward chain
+        ops.ln_table_flush()                   # captured graph: every LayerNorm's parameter-gradient partials in one launch
         return loss.detach(), None if acc is None else acc.detach()
 
     def _finish(self):
@@ -124,11 +125,15 @@ class TrainEngine:
                 # with a process group alive, another thread (the collective backend's watchdog) may touch the device
                 # while we capture: only this thread's calls belong to the capture
                 mode = "thread_local" if self.reducer.world > 1 else "global"
-                with torch.cuda.graph(g, capture_error_mode=mode):
-                    self.arena.grad.zero_()
-                    self._out = self._fwd_bwd(self._static)
-                    if not self._split:
-                        self._finish()
+                ops.ln_table_begin(self.arena.flat.device)
+                try:
+                    with torch.cuda.graph(g, capture_error_mode=mode):
+                        self.arena.grad.zero_()
+                        self._out = self._fwd_bwd(self._static)
+                        if not self._split:
+                            self._finish()
+                finally:
+                    self._ln_table = ops.ln_table_end()        # the graph's launch reads this tensor: keep it alive
             finally:
                 self._capturing = False
         finally:
@@ -141,6 +146,7 @@ class TrainEngine:
         self._graph = None
         self._out = None
         self._static = {}
+        self._ln_table = None
         torch.cuda.empty_cache()
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):

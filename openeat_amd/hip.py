@@ -103,6 +103,8 @@ _SIGNATURES = {
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
     "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P, P]),
+    "oe_layernorm_bwd_dx": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P]),
+    "oe_layernorm_param_reduce_table": (I, [P, I, I, I, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),

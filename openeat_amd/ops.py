@@ -348,6 +348,55 @@ def _ln_ws(like, rows, d):
     return _new(hip.lib().oe_layernorm_bwd_workspace_floats(rows, d), like=like)
 
 
+# While a training step is being captured into a HIP graph, LayerNorm backward leaves the reduction of its per-block
+# parameter-gradient partials to ONE table-driven launch at the end of backward (ln_table_flush) instead of one small
+# launch per call.  The table is a device tensor allocated before the capture; the host fills it after the capture (the
+# workspaces' addresses inside the graph's memory pool are the same at every replay).
+LN_TABLE = None
+LN_TABLE_CAPACITY = 512
+
+
+def ln_table_begin(device):
+    global LN_TABLE
+    LN_TABLE = {"dev": torch.zeros(LN_TABLE_CAPACITY, 5, dtype=torch.int64, device=device), "entries": [], "keep": [],
+                "max_rows": 1, "max_d": 4, "launched": 0}
+    return LN_TABLE
+
+
+def ln_table_flush():
+    """Enqueue the reduction of everything recorded since the last flush (current stream; call after the side streams
+    have been joined)."""
+    t = LN_TABLE
+    if t is None or len(t["entries"]) == t["launched"]:
+        return
+    first, n = t["launched"], len(t["entries"]) - t["launched"]
+    assert len(t["entries"]) <= LN_TABLE_CAPACITY, "LN_TABLE_CAPACITY exceeded"
+    hip.call("oe_layernorm_param_reduce_table", t["dev"][first:], n, t["max_rows"], t["max_d"])
+    t["launched"] = len(t["entries"])
+    t["keep"] = []                      # later allocations may reuse the workspaces: they come after this launch in stream order
+
+
+def ln_table_end():
+    """After the capture: upload the table (host -> device copy, not capturable) and leave table mode."""
+    global LN_TABLE
+    t, LN_TABLE = LN_TABLE, None
+    if t is not None and t["entries"]:
+        t["dev"][: len(t["entries"])].copy_(torch.tensor(t["entries"], dtype=torch.int64))
+    return t
+
+
+def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, to_arena):
+    ws = _ln_ws(x, rows, d)
+    t = LN_TABLE
+    if t is None or not to_arena:
+        hip.call("oe_layernorm_bwd", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, ws)
+        return
+    hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, ws)
+    t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
+    t["keep"].append(ws)
+    t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, rowmask, act):
@@ -369,7 +418,7 @@ class LayerNormFn(torch.autograd.Function):
         rows = x.numel() // d
         dx = torch.empty_like(x)
         (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
-        hip.call("oe_layernorm_bwd", dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db, _ln_ws(x, rows, d))
+        _ln_bwd(dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db, rg is None and rb is None)
         return dx, rg, rb, None, None, None
 
 
@@ -403,8 +452,7 @@ class PreNormFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
         add = None if dres is None else dres.contiguous()
-        hip.call("oe_layernorm_bwd", dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db,
-                 _ln_ws(x, rows, d))
+        _ln_bwd(dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db, rg is None and rb is None)
         return dx, rg, rb, None, None
 
 
@@ -818,7 +866,7 @@ class ConvModuleFn(torch.autograd.Function):
         dz = gemm_nn(gq, w2m)
         dyc = torch.empty_like(yc)
         (dg, rg), (dbeta, rbeta) = grad_sink(g), grad_sink(b)
-        hip.call("oe_layernorm_bwd", dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta, _ln_ws(dz, B * T, d))
+        _ln_bwd(dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta, rg is None and rbeta is None)
         da = torch.empty_like(a)
         (dwd, rwd), (dbd, rbd) = grad_sink(wd), grad_sink(bd)
         dgpad = torch.zeros(d, device=dy.device) if causal else None
