@@ -121,7 +121,17 @@ int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const 
 int oe_layernorm_bwd_dx(const float* dy, const float* x, const float* gamma, const float* beta, int act, const float* stats,
                         int rows, int d, const unsigned char* rowmask, const float* add, float* dx, float* workspace,
                         void* stream);
+int oe_layernorm_param_reduce(const float* workspace, int rows, int d, float* dgamma, float* dbeta, void* stream);   /* one call's partials */
 int oe_layernorm_param_reduce_table(const long long* table, int n, int max_rows, int max_d, void* stream);
+/* oe_layernorm_bwd_dx with a second output gout = g_alpha * keep(g_seed, element)/(1 - g_p) * dx, rows with
+ * g_rowmask[row] == 0 zeroed: oe_dropout_scale applied to dx (same mask definition, d % 8 == 0).  dx of a pre-norm
+ * block's LayerNorm is the gradient of the PREVIOUS block's output `residual + out_scale * dropout(f(.))`
+ * (encoder_layer.py:83,89,95,106), whose backward starts by applying exactly that mask and scale. */
+int oe_layernorm_bwd_dx_drop(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                             const float* stats, int rows, int d, const unsigned char* rowmask, const float* add, float* dx,
+                             float* gout, float g_alpha, float g_p, unsigned long long g_seed,
+                             const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
+                             void* stream);
 
 /* ------------------------------------------------------------------------- *
  * CTC head: log_softmax + CTCLoss(reduction='sum', zero_infinity=True) and

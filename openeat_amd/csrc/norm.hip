@@ -67,8 +67,16 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              const float* __restrict__ stats,
                                                              int rows, int d, const unsigned char* __restrict__ rowmask,
                                                              const float* add, float* dx,
-                                                             float* __restrict__ partial) {
+                                                             float* __restrict__ partial, float* __restrict__ gout, float g_alpha,
+                                                             float g_p, unsigned long long g_seed,
+                                                             const unsigned long long* __restrict__ g_seed_dev,
+                                                             const unsigned char* __restrict__ g_rowmask) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][d]
+    // optional second output gout = g_alpha * dropout_mask(g_seed) * dx (oe_dropout_scale's definition: element idx belongs
+    // to Philox call idx >> 3): the gradient the PREVIOUS block's backward starts from, i.e. its `residual + dropout(.)`
+    // output dropout applied to this kernel's dx - saves that block a separate elementwise launch
+    const DropParams g_dpar = drop_params(g_p);
+    const unsigned long long g_seed_eff = g_seed + (g_seed_dev ? *g_seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nv = d >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
@@ -145,6 +153,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                             o.w += rstd[k] * (g[j].w - c1 - xh[j].w * c2);
                         }
                         dxr[i] = o;
+                        if (gout) {
+                            const long grow = w0 + rb + k;
+                            const unsigned long long e0 = (unsigned long long)grow * d + 4 * i;
+                            float4 gq = make_float4(o.x * g_alpha, o.y * g_alpha, o.z * g_alpha, o.w * g_alpha);
+                            if (g_p > 0.f) {
+                                const uint4 r = philox4(g_seed_eff, e0 >> 3);
+                                const bool hi = (e0 >> 2) & 1;                 // second half of the call's eight fields
+                                const unsigned wa = hi ? r.z : r.x, wb = hi ? r.w : r.y;
+                                gq.x *= drop_field(wa, 0, g_dpar); gq.y *= drop_field(wa, 1, g_dpar);
+                                gq.z *= drop_field(wb, 0, g_dpar); gq.w *= drop_field(wb, 1, g_dpar);
+                            }
+                            if (g_rowmask && !g_rowmask[grow]) gq = make_float4(0.f, 0.f, 0.f, 0.f);
+                            reinterpret_cast<float4*>(gout + grow * d)[i] = gq;
+                        }
                     }
                 }
             }
@@ -199,18 +221,38 @@ extern "C" size_t oe_layernorm_bwd_workspace_floats(int rows, int d) { return (s
 // dx and the per-block partial sums of the parameter gradients (into the workspace).  oe_layernorm_bwd = this + the
 // reduction of those partials; a caller that keeps the workspaces of many calls alive can reduce them all with ONE launch
 // of oe_layernorm_param_reduce_table instead (93 reductions of 4.6 us each per step at config 2).
-extern "C" int oe_layernorm_bwd_dx(const float* dy, const float* x, const float* gamma, const float* beta, int act,
-                                   const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
-                                   float* dx, float* workspace, void* stream) {
+extern "C" int oe_layernorm_bwd_dx_drop(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                                        const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
+                                        float* dx, float* gout, float g_alpha, float g_p, unsigned long long g_seed,
+                                        const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
+                                        void* stream) {
     OE_REQUIRE(dy && x && gamma && stats && dx && (beta || !act), "oe_layernorm_bwd: null pointer");
+    OE_REQUIRE(!gout || (d % 8 == 0 && g_p >= 0.f && g_p < 1.f && gout != dx), "oe_layernorm_bwd_dx_drop: the dropped output needs d %% 8 == 0, 0 <= p < 1");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     OE_REQUIRE(workspace, "oe_layernorm_bwd: null workspace");
     const int nb = oe_cdiv(rows, LNB_ROWS);
 #define LN_BWD(NVV, RBB) hipLaunchKernelGGL((layernorm_bwd_kernel<NVV, RBB>), dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
-                                            dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace)
+                                            dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace, gout, g_alpha, g_p,  \
+                                            g_seed, g_seed_dev, g_rowmask)
     if (d <= 256) LN_BWD(1, 4); else if (d <= 512) LN_BWD(2, 2); else if (d <= 1024) LN_BWD(4, 1); else LN_BWD(8, 1);
 #undef LN_BWD
     OE_LAUNCH_CHECK("layernorm_bwd");
+    return 0;
+}
+
+extern "C" int oe_layernorm_bwd_dx(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                                   const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
+                                   float* dx, float* workspace, void* stream) {
+    return oe_layernorm_bwd_dx_drop(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, nullptr, 1.f, 0.f, 0ull, nullptr,
+                                    nullptr, workspace, stream);
+}
+
+extern "C" int oe_layernorm_param_reduce(const float* workspace, int rows, int d, float* dgamma, float* dbeta, void* stream) {
+    OE_REQUIRE(workspace && dgamma && dbeta && rows > 0 && d > 0, "oe_layernorm_param_reduce: bad arguments");
+    const int nb = oe_cdiv(rows, LNB_ROWS);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 64), oe_cdiv(nb, PR_ROWS)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,
+                       dgamma, dbeta);
+    OE_LAUNCH_CHECK("ln_param_reduce");
     return 0;
 }
 
@@ -219,12 +261,7 @@ extern "C" int oe_layernorm_bwd(const float* dy, const float* x, const float* ga
                                 float* dx, float* dgamma, float* dbeta, float* workspace, void* stream) {
     OE_REQUIRE(dgamma && dbeta, "oe_layernorm_bwd: null pointer");
     const int rc = oe_layernorm_bwd_dx(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace, stream);
-    if (rc) return rc;
-    const int nb = oe_cdiv(rows, LNB_ROWS);
-    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(oe_cdiv(2 * d, 64), oe_cdiv(nb, PR_ROWS)), dim3(256), 0, (hipStream_t)stream, workspace, nb, d,
-                       dgamma, dbeta);
-    OE_LAUNCH_CHECK("ln_param_reduce");
-    return 0;
+    return rc ? rc : oe_layernorm_param_reduce(workspace, rows, d, dgamma, dbeta, stream);
 }
 
 // Table-driven reduction of the partials of `n` LayerNorm backward calls: entry e = 5 int64 words

@@ -61,6 +61,7 @@ class TrainEngine:
 
     # one micro-step: loss (already divided by accum_grad) and its backward
     def _fwd_bwd(self, batch):
+        ops.predrop_clear()
         loss, acc = self.model(**batch)
         loss = loss / self.accum_grad if self.accum_grad != 1 else loss
         loss.backward()

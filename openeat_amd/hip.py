@@ -104,7 +104,9 @@ _SIGNATURES = {
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
     "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P, P]),
     "oe_layernorm_bwd_dx": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P]),
+    "oe_layernorm_param_reduce": (I, [P, I, I, P, P, P]),
     "oe_layernorm_param_reduce_table": (I, [P, I, I, I, P]),
+    "oe_layernorm_bwd_dx_drop": (I, [P, P, P, P, I, P, I, I, P, P, P, P, F, F, U64, P, P, P, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),

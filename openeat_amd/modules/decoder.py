@@ -66,7 +66,7 @@ class TransformerDecoder(torch.nn.Module):
         for layer in self.decoders:
             for _ in range(self.num_blocks_share):
                 x = layer(x, tm, memory, mm)
-        return ops.layer_norm(x, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+        return ops.layer_norm(x, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps, sole_consumer=True)
 
     def forward(self, tgt, tgt_mask, memory, memory_mask) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """decoder.py:167-194 -> (logits (B,L,V), olens, pre_logits)."""

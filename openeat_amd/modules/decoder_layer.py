@@ -28,7 +28,8 @@ class DecoderLayer(nn.Module):
     def forward(self, tgt: torch.Tensor, tgt_mask: torch.Tensor, memory: torch.Tensor, memory_mask: torch.Tensor,
                 cache: Optional[torch.Tensor] = None):
         p = self.dropout.p
-        fork = lambda norm, t: ops.pre_norm(t, norm.weight, norm.bias, norm.eps)    # (residual, LN(t)) from one op
+        # (residual, LN(t)) from one op; sole: t feeds nothing else (false where the adapter also reads it)
+        fork = lambda norm, t, sole=True: ops.pre_norm(t, norm.weight, norm.bias, norm.eps, sole_consumer=sole)
         if cache is None:
             residual, y = fork(self.norm1, tgt)
             x = self.self_attn(y, y, y, tgt_mask, residual=residual, out_dropout=p)
@@ -41,7 +42,7 @@ class DecoderLayer(nn.Module):
         r, y = fork(self.norm2, x)
         x = self.src_attn(y, memory, memory, memory_mask, residual=r, out_dropout=p)
         adapt_x = self.adapter(x) if self.adapter is not None else None      # decoder_layer.py:98-101
-        r, y = fork(self.norm3, x)
+        r, y = fork(self.norm3, x, adapt_x is None)
         x = self.feed_forward(y, residual=r, out_scale=1.0, out_dropout=p)
         if adapt_x is not None:
             x = ops.add(x, adapt_x)                                           # decoder_layer.py:106

@@ -52,7 +52,7 @@ class Encoder(torch.nn.Module):
         for layer in self.encoders:
             for _ in range(self.num_blocks_share):
                 xs, _ = layer(xs, m8, pos_emb)
-        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps, sole_consumer=True)
         return xs, masks, pos_emb
 
 
@@ -115,5 +115,5 @@ class TransformerEncoder(torch.nn.Module):
                 att._pp_ahead = None
             if ahead:
                 torch.cuda.current_stream().wait_stream(ops.decoder_stream())
-        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps)
+        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps, sole_consumer=True)
         return xs, masks, pos_emb

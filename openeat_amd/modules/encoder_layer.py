@@ -33,13 +33,14 @@ class EncoderLayer(nn.Module):
             self.norm_final = nn.LayerNorm(size, eps=1e-12)
 
     @staticmethod
-    def _ln(norm: nn.LayerNorm, x, rowmask=None):
-        return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, rowmask)
+    def _ln(norm: nn.LayerNorm, x, rowmask=None, sole=True):
+        return ops.layer_norm(x, norm.weight, norm.bias, norm.eps, rowmask, sole_consumer=sole)
 
     @staticmethod
-    def _fork(norm: nn.LayerNorm, x, rowmask=None):
-        """(residual, LN(x)): the two branches of a pre-norm block from one op (their gradients meet in one kernel)."""
-        return ops.pre_norm(x, norm.weight, norm.bias, norm.eps, rowmask)
+    def _fork(norm: nn.LayerNorm, x, rowmask=None, sole=True):
+        """(residual, LN(x)): the two branches of a pre-norm block from one op (their gradients meet in one kernel).
+        sole: x feeds nothing but this fork (true everywhere in this layer except where the adapter also reads x)."""
+        return ops.pre_norm(x, norm.weight, norm.bias, norm.eps, rowmask, sole_consumer=sole)
 
     def forward(self, x: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor):
         p = self.dropout.p
@@ -56,7 +57,7 @@ class EncoderLayer(nn.Module):
             r, y = self._fork(self.norm_conv, x, rowmask)
             x = self.conv_module(y, m8, residual=r, out_dropout=p, input_masked=True)
         adapt_x = self.adapter(x) if self.adapter is not None else None      # encoder_layer.py:97-100
-        r, y = self._fork(self.norm_ff, x)
+        r, y = self._fork(self.norm_ff, x, sole=adapt_x is None)
         x = self.feed_forward(y, residual=r, out_scale=self.ff_scale, out_dropout=p)
         if adapt_x is not None:
             x = ops.add(x, adapt_x)                                           # encoder_layer.py:108

@@ -385,13 +385,53 @@ def ln_table_end():
     return t
 
 
-def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, to_arena):
+# A block's output is `residual + out_scale * dropout(f(LN(x)))`, and the LayerNorm that consumes it belongs to the NEXT block:
+# in backward that LayerNorm's dx is exactly the gradient the block starts from, which it first multiplies by its output
+# dropout mask and scale.  The block tags its output (FUSE_OUT_DROP); the next LayerNorm backward then writes that product
+# as a second output of its kernel (oe_layernorm_bwd_dx_drop) and the block's backward picks it up by the address of the
+# gradient it receives - one elementwise launch per block (66 per step at config 2) less.  Anything in between (an adapter's
+# add, a gradient autograd had to accumulate) changes the address and the block falls back to oe_dropout_scale.
+FUSE_OUT_DROP = os.environ.get("OE_FUSE_OUT_DROP", "1") == "1"
+_PREDROP = {}
+
+
+def predrop_clear():
+    _PREDROP.clear()
+
+
+def _tag_out_drop(out, out_scale, p_out, s_out, rowmask=None):
+    if FUSE_OUT_DROP and (p_out > 0 or out_scale != 1.0 or rowmask is not None):
+        out._oe_outdrop = (float(out_scale), float(p_out), int(s_out), rowmask)
+    return out
+
+
+def _out_drop_grad(dy2, out_scale, p_out, s_out, rowmask=None):
+    """dropout_scale(dy2, out_scale, p_out, s_out, rowmask) - or the copy the producing LayerNorm backward already made."""
+    hit = _PREDROP.pop(dy2.data_ptr(), None)
+    if hit is not None:
+        g, spec = hit
+        same_mask = (spec[3] is None and rowmask is None) or (spec[3] is not None and rowmask is not None and
+                                                               spec[3].data_ptr() == rowmask.data_ptr())
+        if spec[:3] == (float(out_scale), float(p_out), int(s_out)) and same_mask and g.numel() == dy2.numel():
+            return g.view(dy2.shape)
+    return dropout_scale(dy2, out_scale, p_out, s_out, rowmask)
+
+
+def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, to_arena, prev_drop=None):
     ws = _ln_ws(x, rows, d)
+    g = None
+    if prev_drop is not None and FUSE_OUT_DROP and d % 8 == 0:
+        g = torch.empty_like(dx)
+        alpha, p, seed, gmask = prev_drop
+        hip.call("oe_layernorm_bwd_dx_drop", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, g, alpha, p, seed, _seed_dev,
+                 gmask, ws)
+        _PREDROP[dx.data_ptr()] = (g, prev_drop)
+    else:
+        hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, ws)
     t = LN_TABLE
     if t is None or not to_arena:
-        hip.call("oe_layernorm_bwd", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, ws)
+        hip.call("oe_layernorm_param_reduce", ws, rows, d, dg, db)
         return
-    hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, ws)
     t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
     t["keep"].append(ws)
     t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
@@ -399,7 +439,7 @@ def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, t
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rowmask, act):
+    def forward(ctx, x, gamma, beta, eps, rowmask, act, sole_consumer=False):
         x = _chk(x, "layer_norm")
         d = x.shape[-1]
         rows = x.numel() // d
@@ -408,6 +448,9 @@ class LayerNormFn(torch.autograd.Function):
         hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, act, y, stats)
         ctx.save_for_backward(x, gamma, beta, stats, rowmask)
         ctx.act = act
+        # only when the caller vouches that x feeds nothing else: with a second consumer autograd SUMS the gradients of x
+        # (possibly in place, keeping the address), and the fused copy would hold this branch's share only
+        ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
         return y
 
     @staticmethod
@@ -418,12 +461,13 @@ class LayerNormFn(torch.autograd.Function):
         rows = x.numel() // d
         dx = torch.empty_like(x)
         (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
-        _ln_bwd(dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db, rg is None and rb is None)
-        return dx, rg, rb, None, None, None
+        _ln_bwd(dy, x, gamma, beta, ctx.act, stats, rows, d, rowmask, None, dx, dg, db, rg is None and rb is None, ctx.prev_drop)
+        return dx, rg, rb, None, None, None, None
 
 
-def layer_norm(x, gamma, beta, eps, rowmask=None, act=ACT_NONE):
-    return LayerNormFn.apply(x, gamma, beta, eps, rowmask, act)
+def layer_norm(x, gamma, beta, eps, rowmask=None, act=ACT_NONE, sole_consumer=False):
+    """sole_consumer: x is used by nothing but this norm (lets backward hand the previous block its output-dropout gradient)."""
+    return LayerNormFn.apply(x, gamma, beta, eps, rowmask, act, sole_consumer)
 
 
 class PreNormFn(torch.autograd.Function):
@@ -432,7 +476,7 @@ class PreNormFn(torch.autograd.Function):
     backward kernel itself (its `add` input) instead of a separate elementwise add by autograd."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rowmask):
+    def forward(ctx, x, gamma, beta, eps, rowmask, sole_consumer=False):
         x = _chk(x, "pre_norm")
         d = x.shape[-1]
         rows = x.numel() // d
@@ -440,25 +484,27 @@ class PreNormFn(torch.autograd.Function):
         stats = _new(rows, 2, like=x)
         hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
         ctx.save_for_backward(x, gamma, beta, stats, rowmask)
+        ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
         return x.view_as(x), y
 
     @staticmethod
     def backward(ctx, dres, dy):
         x, gamma, beta, stats, rowmask = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None, None
+            return dres, None, None, None, None, None
         d = x.shape[-1]
         rows = x.numel() // d
         dx = torch.empty_like(x)
         (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
         add = None if dres is None else dres.contiguous()
-        _ln_bwd(dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db, rg is None and rb is None)
-        return dx, rg, rb, None, None
+        _ln_bwd(dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db, rg is None and rb is None,
+                ctx.prev_drop)
+        return dx, rg, rb, None, None, None
 
 
-def pre_norm(x, gamma, beta, eps, rowmask=None):
-    """-> (residual, normed): use `residual` for the skip connection of the block."""
-    return PreNormFn.apply(x, gamma, beta, eps, rowmask)
+def pre_norm(x, gamma, beta, eps, rowmask=None, sole_consumer=False):
+    """-> (residual, normed): use `residual` for the skip connection of the block.  sole_consumer: see layer_norm."""
+    return PreNormFn.apply(x, gamma, beta, eps, rowmask, sole_consumer)
 
 
 # --------------------------------------------------------------------------- #
@@ -613,7 +659,7 @@ class FeedForwardFn(torch.autograd.Function):
         ctx.save_for_backward(x2, w1, w2, pre, a)
         ctx.biases = (b1, b2)
         ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
-        return y.view(*x.shape[:-1], w2.shape[0])
+        return _tag_out_drop(y.view(*x.shape[:-1], w2.shape[0]), out_scale, p_out, s_out)
 
     @staticmethod
     def backward(ctx, dy):
@@ -621,7 +667,7 @@ class FeedForwardFn(torch.autograd.Function):
         act, p_in, s_in, out_scale, p_out, s_out, has_res, in_shape = ctx.cfg
         dy = dy.contiguous()
         dy2 = dy.view(-1, w2.shape[0])
-        g2 = dy2 if (p_out == 0 and out_scale == 1.0) else dropout_scale(dy2, out_scale, p_out, s_out)
+        g2 = dy2 if (p_out == 0 and out_scale == 1.0) else _out_drop_grad(dy2, out_scale, p_out, s_out)
         b1, b2 = ctx.biases
         dw2, db2 = wgrad_bias(w2, b2, g2, a)
         if act in GEMM_FUSED_ACTS:
@@ -711,7 +757,7 @@ class AttentionFn(torch.autograd.Function):
         ctx.cfg = (self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, residual is not None, mstr)
         ctx.biases = (bq, bk, bv, bo)
         ctx.pp_external = pp_in is not None
-        return y.view(B, T1, d)
+        return _tag_out_drop(y.view(B, T1, d), 1.0, p_out, s_out)
 
     @staticmethod
     def backward(ctx, dy):
@@ -719,7 +765,7 @@ class AttentionFn(torch.autograd.Function):
         self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, has_res, mstr = ctx.cfg
         dy = dy.contiguous()
         dy2 = dy.view(-1, d)
-        g = dy2 if p_out == 0 else dropout_scale(dy2, 1.0, p_out, s_out)
+        g = dy2 if p_out == 0 else _out_drop_grad(dy2, 1.0, p_out, s_out)
         att2 = att.view(-1, d)
         bq, bk, bv, bo = ctx.biases
         dwo, dbo = wgrad_bias(wo, bo, g, att2)
@@ -851,7 +897,7 @@ class ConvModuleFn(torch.autograd.Function):
         ctx.save_for_backward(xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z, gpad)
         ctx.biases = (b1, bd, b2)
         ctx.cfg = (B, T, d, K, causal, act, p_out, s_out, residual is not None)
-        return y.view(B, T, d)
+        return _tag_out_drop(y.view(B, T, d), 1.0, p_out, s_out, rowmask)
 
     @staticmethod
     def backward(ctx, dy):
@@ -861,7 +907,7 @@ class ConvModuleFn(torch.autograd.Function):
         dy = dy.contiguous()
         dy2 = dy.view(-1, d)
         w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
-        gq = dy2 if (p_out == 0 and rowmask is None) else dropout_scale(dy2, 1.0, p_out, s_out, rowmask)
+        gq = dy2 if (p_out == 0 and rowmask is None) else _out_drop_grad(dy2, 1.0, p_out, s_out, rowmask)
         dw2, db2 = wgrad_bias(w2, b2, gq, z)
         dz = gemm_nn(gq, w2m)
         dyc = torch.empty_like(yc)

@@ -216,6 +216,34 @@ def test_layernorm_fwd_bwd(rows, d, eps):
     torch.testing.assert_close(db.cpu(), b.grad, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("rows,d,p,alpha,masked", [(50, 256, 0.1, 0.5, False), (37, 64, 0.25, 1.0, True), (16, 512, 0.0, 0.5, False),
+                                                    (7936, 256, 0.1, 1.0, True)])
+def test_layernorm_backward_second_output_is_dropout_scale_of_dx(rows, d, p, alpha, masked):
+    """oe_layernorm_bwd_dx_drop: dx identical to oe_layernorm_bwd_dx, and gout BIT-identical to oe_dropout_scale(dx, alpha, p,
+    seed, rowmask) - the mask a block's forward applied in its GEMM epilogue is the one its backward gets back."""
+    torch.manual_seed(21)
+    L = hip.lib()
+    x, dy, add = (torch.randn(rows, d, device=DEV) for _ in range(3))
+    gamma, beta = torch.randn(d, device=DEV), torch.randn(d, device=DEV)
+    y, stats = torch.empty_like(x), torch.empty(rows, 2, device=DEV)
+    hip.call("oe_layernorm_fwd", x, gamma, beta, 1e-5, rows, d, None, 0, y, stats)
+    rm = (torch.rand(rows, device=DEV) > 0.3).to(torch.uint8) if masked else None
+    ws = torch.empty(L.oe_layernorm_bwd_workspace_floats(rows, d), device=DEV)
+    dx0, dx1, g1 = (torch.full((rows, d), float("nan"), device=DEV) for _ in range(3))
+    hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, 0, stats, rows, d, None, add, dx0, ws)
+    seed = 0x1234567
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)                  # device step counter mixed into the seed
+    hip.call("oe_layernorm_bwd_dx_drop", dy, x, gamma, beta, 0, stats, rows, d, None, add, dx1, g1, alpha, p, seed, ctr, rm, ws)
+    want = torch.empty_like(dx0)
+    hip.call("oe_dropout_scale", dx0, dx0.numel(), d, alpha, p, seed, ctr, rm, want)
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1)
+    assert torch.equal(g1, want)
+    if p > 0:
+        kept = (g1 != 0).float().mean().item() / (0.7 if masked else 1.0)
+        assert abs(kept - (1 - p)) < 0.05
+
+
 # -------------------------------------------------------------------- CTC ----
 def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_weight=None, want_grad=True):
     B, T, V = logits.shape
