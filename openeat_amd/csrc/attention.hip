@@ -230,12 +230,19 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
     float qf[TERMS == 0 ? DPAD / 2 : 1];
     float dof[(TERMS == 0 && MODE == 1) ? DPAD / 2 : 1];
     BFrag<TERMS == 0 ? 1 : TERMS> qfr[TERMS == 0 ? 1 : KS], dofr[(TERMS != 0 && MODE == 1) ? KS : 1];
+    // dQ pass: delta_i = sum_d dO[i,d] * O[i,d] is formed here from the dO values this lane loads anyway (the two lanes of a
+    // query hold complementary halves of the features) and published for the dK/dV kernel that follows on the stream
+    float dpart = 0.f;
+    const long orow = (long)b * p.o_bs + (long)qi * p.o_rs + h * p.D;
     if constexpr (TERMS == 0) {
 #pragma unroll
         for (int s = 0; s < DPAD / 2; ++s) {
             const int d = 2 * s + lk;
             qf[s] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
-            if (MODE == 1) dof[s] = (q_ok && d < p.D) ? p.d_o[(long)b * p.o_bs + (long)qi * p.o_rs + h * p.D + d] : 0.f;
+            if (MODE == 1) {
+                dof[s] = (q_ok && d < p.D) ? p.d_o[orow + d] : 0.f;
+                dpart += (q_ok && d < p.D) ? dof[s] * p.o_in[orow + d] : 0.f;
+            }
         }
     } else {
 #pragma unroll
@@ -245,7 +252,10 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
             for (int e = 0; e < 8; ++e) {
                 const int d = 16 * s + 8 * lk + e;
                 x[e] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
-                if (MODE == 1) y[e] = (q_ok && d < p.D) ? p.d_o[(long)b * p.o_bs + (long)qi * p.o_rs + h * p.D + d] : 0.f;
+                if (MODE == 1) {
+                    y[e] = (q_ok && d < p.D) ? p.d_o[orow + d] : 0.f;
+                    dpart += (q_ok && d < p.D) ? y[e] * p.o_in[orow + d] : 0.f;
+                }
             }
             bsplit<TERMS>(x, qfr[s]);
             if (MODE == 1) bsplit<TERMS>(y, dofr[s]);
@@ -253,7 +263,13 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
     }
     float m_run = NEG_INF, l_run = 0.f;
     float lse_i = 0.f, delta_i = 0.f;
-    if (MODE == 1 && q_ok) { lse_i = p.lse[bh * p.T1 + qi]; delta_i = p.delta[bh * p.T1 + qi]; }
+    if (MODE == 1) {
+        delta_i = dpart + __shfl_xor(dpart, 32, 64);
+        if (q_ok) {
+            lse_i = p.lse[bh * p.T1 + qi];
+            if (lk == 0) p.delta[bh * p.T1 + qi] = delta_i;
+        }
+    }
     f32x16 oacc[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t)
@@ -694,30 +710,6 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
         }
 }
 
-// delta[b,h,i] = sum_d dO[b,i,h,d] * O[b,i,h,d]
-// thread per (b,i,h) with float4 loads (adjacent threads = adjacent heads = contiguous memory)
-__global__ void attn_delta_kernel(AttnParams p) {
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)p.B * p.T1 * p.H;
-    if (idx >= total) return;
-    const int h = (int)(idx % p.H);
-    const long bi = idx / p.H;
-    const int i = (int)(bi % p.T1);
-    const int b = (int)(bi / p.T1);
-    const float* a = p.d_o + (long)b * p.o_bs + (long)i * p.o_rs + h * p.D;
-    const float* o = p.o_in + (long)b * p.o_bs + (long)i * p.o_rs + h * p.D;
-    float s = 0.f;
-    if ((p.D & 3) == 0 && (((uintptr_t)a | (uintptr_t)o) & 15) == 0) {
-        for (int d = 0; d < p.D; d += 4) {
-            const float4 x = *reinterpret_cast<const float4*>(a + d), y = *reinterpret_cast<const float4*>(o + d);
-            s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
-        }
-    } else {
-        for (int d = 0; d < p.D; ++d) s += a[d] * o[d];
-    }
-    p.delta[((long)b * p.H + h) * p.T1 + i] = s;
-}
-
 static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {
     if (!(a && a->q && a->k && a->v)) { oe_set_error("%s: null q/k/v", who); return -1; }
     if (!(a->B > 0 && a->H > 0 && a->T1 > 0 && a->T2 > 0 && a->D > 0 && a->D <= 64)) {
@@ -761,9 +753,7 @@ extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
     if (int rc = fill_params(p, a, "oe_attention_bwd")) return rc;
     OE_REQUIRE(a->out && a->lse && a->d_out && a->dq && a->dk && a->dv && a->delta, "oe_attention_bwd: null pointer");
     hipStream_t st = (hipStream_t)stream;
-    const long rows = (long)p.B * p.H * p.T1;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(oe_cdiv(rows, 256)), dim3(256), 0, st, p);
-    OE_LAUNCH_CHECK("attn_delta");
+    // (delta = rowsum(dO * O) is computed by the dQ kernel and read by the dK/dV kernel: no separate launch)
     dim3 gq(oe_cdiv(p.T1, 32 * ATT_WAVES), p.H, p.B), gk(oe_cdiv(p.T2, 32 * ATT_WAVES), p.H, p.B);
 #define ATT_BWD(TT)                                                                                       \
     do {                                                                                                  \
