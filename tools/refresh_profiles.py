@@ -27,7 +27,7 @@ with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
             f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p3.csv`.\n\n")
     f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
             f"**GEMM class (`gemm_dma_kernel` + `gemm_bf16_kernel`, the kernels behind `oe_gemm_f32`): {gc / steps:.0f} launches/step, "
-            f"{gt / 1e6 / steps:.2f} ms/step, average launch {gt / gc / 1e3:.2f} us = {1574.63445504 / (gt / 1e6 / steps):.1f} TFLOP/s algorithmic** - "
+            f"{gt / 1e6 / steps:.2f} ms/step, average launch {gt / gc / 1e3:.2f} us = {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TFLOP/s algorithmic** - "
             f"bench.py's live HIP-event figure (event-pair overhead calibrated out) is {ro['gemm_ms_per_step']:.2f} ms/step, "
             f"{ro['avg_launch_us']:.2f} us average, {ro['achieved']:.1f} TFLOP/s.\n\n")
     f.write("| kernel | calls/step | avg us | ms/step | % |\n|---|---|---|---|---|\n")
@@ -42,7 +42,7 @@ for a, b in ((f"{tag}_bench_p3.json", f"{tag}_bench_p3.json"), (f"{tag}_bench_p3
         shutil.copy(f"{src}/{a}", f"{dst}/{b}")
 pm = json.load(open(f"{dst}/{tag}_pmc_hbm_traffic.json"))
 print(f"bench {line['ms_per_step']:.2f} ms/step {line['value']:.0f} frames/s graph={line['config']['hip_graph']}")
-print(f"roofline live {ro['achieved']:.1f} TF/s {ro['gemm_ms_per_step']:.2f} ms {ro['avg_launch_us']:.2f} us | rocprof {1574.63445504 / (gt / 1e6 / steps):.1f} TF/s "
+print(f"roofline live {ro['achieved']:.1f} TF/s {ro['gemm_ms_per_step']:.2f} ms {ro['avg_launch_us']:.2f} us | rocprof {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TF/s "
       f"{gt / 1e6 / steps:.2f} ms {gt / gc / 1e3:.2f} us | all kernels {tot / 1e6 / steps:.2f} ms")
 print(f"cpu {line['cpu_baseline']['value']:.0f} | decode rtf {line['decode']['rtf']:.6f} wall {line['decode']['wall_s'] * 1e3:.0f} ms")
 print(f"pmc gemm {pm['gemm']['hbm_bytes_per_step'] / 1e9:.2f} GB/step {pm['gemm']['hbm_bytes_per_launch'] / 1e6:.1f} MB/launch all {pm['all_kernels']['hbm_bytes_per_step'] / 1e9:.2f} GB/step")

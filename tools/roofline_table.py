@@ -9,6 +9,11 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
+import json
+import os
+_bench = json.load(open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), os.path.basename(sys.argv[1]).split("_")[0] + "_bench_p3.json")))
+GEMM_FLOP = _bench["roofline"]["algorithmic_gflop_per_step"] * 1e9
+GEMM_LAUNCHES = _bench["roofline"]["launches_per_step"]
 ms = lambda pred: sum(int(r["TotalDurationNs"]) for r in rows if pred(r["Name"])) / 1e6 / steps
 B, T, T1, F1, Tp, d, H, ff, K, V, L1, C = 32, 998, 498, 39, 248, 256, 4, 1024, 15, 3246, 31, 256
 M = B * Tp                       # 7936 encoder rows
@@ -21,8 +26,8 @@ attn_enc = 12 * (4 + 14) * B * H * Tp * Tp * (d // H)                    # fwd 4
 attn_dec = 6 * (4 + 14) * B * H * (L1 * L1 + L1 * Tp) * (d // H)         # self + source attention of 2 x 3 decoder layers
 ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 block norms + conv-module norm per layer, after_norm
 classes = [
-    ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`)", "mfma", 1574.63445504e9, lambda n: "gemm_" in n and "kernel" in n,
-     "2*m*n*k of the step's 453 launches (counted live by bench.py)"),
+    ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`)", "mfma", GEMM_FLOP, lambda n: "gemm_" in n and "kernel" in n,
+     f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
     ("attention (`attn_qtile`, `attn_ktile_bwd`, `attn_delta`)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
     ("CTC (`ctc_rows`, `ctc_alphabeta`, `ctc_labels`)", "hbm", 2 * M * V * f4 + 4 * M * (2 * 30 + 1) * f4, lambda n: "ctc_" in n and "greedy" not in n,
@@ -34,7 +39,6 @@ classes = [
     ("depthwise conv + GLU backward (+ reduce)", "hbm", 12 * 5 * act, lambda n: "dwconv_glu_bwd" in n or "dwconv_param_reduce" in n, "read a, dy + write da"),
     ("conv1 forward (`conv1_fwd`)", "hbm", y1 + B * T * 80 * f4, lambda n: "conv1_fwd" in n, "write the NHWC activation"),
     ("conv1 weight gradient", "hbm", y1 + B * T * 80 * f4, lambda n: "conv1_wgrad" in n, "read dy1 + x"),
-    ("conv2 dgrad gather (`col2im_relu`)", "hbm", 9 * (B * Tp * 19 * C * f4) + 2 * y1, lambda n: "col2im" in n, "read dcol + y1, write dy1"),
     ("fbank + per-utterance norm", "hbm", B * 160000 * f4 + 3 * B * T * 80 * f4, lambda n: "fbank_kernel" in n or "utt_norm" in n, "read wav, write/normalise features"),
     ("label-smoothing loss rows", "hbm", 2 * 2 * Md * V * f4, lambda n: "lsm_" in n, "logits read + gradient written, two decoders"),
     ("clip + Adam (`sumsq_partial`, `adam_kernel`)", "hbm", 31.3e6 * f4 * 8, lambda n: "adam_kernel" in n or "sumsq" in n, "g read twice; p, m, v read and written"),
@@ -50,6 +54,8 @@ print("| class | bound | algorithmic work / step | kernel ms / step | achieved |
 seen = 0.0
 for name, bound, work, pred, note in classes:
     t = ms(pred)
+    if t <= 0:
+        continue
     seen += t
     u, s = unit[bound]
     w = f"{work / 1e9:.1f} GFLOP" if bound == "mfma" else f"{work / 1e6:.0f} MB"
