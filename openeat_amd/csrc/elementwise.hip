@@ -70,14 +70,26 @@ __global__ void relpos_backward_kernel(const float* __restrict__ dkp, const floa
     const int t = (int)(idx / ((long)D * H));
     const float uu = u[h * D + d], vv = v[h * D + d], pv = p[(long)t * p_rs + h * D + d];
     float dps = 0.f, dus = 0.f, dvs = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float g = dkp[((long)b * T + t) * H * D + h * D + d];
-        const float gb = dkeybias[((long)b * H + h) * T + t] * scale;
-        const long ko = (long)b * k_bs + (long)t * k_rs + h * D + d;
-        dus += gb * k[ko];
-        dk[ko] = g + gb * uu;
-        dps += g + gb * vv;
-        dvs += gb * pv;
+    // eight utterances at a time: all their loads are issued before the first store (one utterance at a time the 32
+    // iterations were 32 dependent round trips, 21 us per call)
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float g[8], gb[8], kv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int b = min(b0 + i, B - 1);
+            g[i] = dkp[((long)b * T + t) * H * D + h * D + d];
+            gb[i] = dkeybias[((long)b * H + h) * T + t] * scale;
+            kv[i] = k[(long)b * k_bs + (long)t * k_rs + h * D + d];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (b0 + i < B) {
+                dus += gb[i] * kv[i];
+                dk[(long)(b0 + i) * k_bs + (long)t * k_rs + h * D + d] = g[i] + gb[i] * uu;
+                dps += g[i] + gb[i] * vv;
+                dvs += gb[i] * pv;
+            }
+        }
     }
     dp[(long)t * dp_rs + h * D + d] = dps;
     atomicAdd(du + h * D + d, dus);
