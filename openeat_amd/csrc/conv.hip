@@ -63,10 +63,12 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
         for (int k = 0; k < 10; ++k) acc[e][k] = 0.f;
     const long npos = (long)B * T1 * F1;
     const long p0 = (long)blockIdx.x * pos_per_block;
-    for (long pos = p0 + grp; pos < min(npos, p0 + pos_per_block); pos += ngrp) {
-        const int f = (int)(pos % F1);
-        const int t = (int)((pos / F1) % T1);
-        const long b = pos / ((long)F1 * T1);
+    // (f, t, b) of this group's position advance by carries: two 64-bit divisions per position cost as much as its 40 FMAs
+    const long pstart = p0 + grp, pend = min(npos, p0 + pos_per_block);
+    int f = (int)(pstart % F1), t = (int)((pstart / F1) % T1);
+    long b = pstart / ((long)F1 * T1);
+#pragma unroll 2
+    for (long pos = pstart; pos < pend; pos += ngrp) {
         const float* xp = x + (b * T + 2 * t) * F + 2 * f;
         float xv[9];
 #pragma unroll
@@ -81,6 +83,8 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
             for (int k = 0; k < 9; ++k) acc[e][k] += g[e] * xv[k];
             acc[e][9] += g[e];
         }
+        f += ngrp;
+        while (f >= F1) { f -= F1; if (++t == T1) { t = 0; ++b; } }
     }
     // reduce the position slots of this block through LDS, then one atomic per output per block
     extern __shared__ float sh[];                  // [ngrp][C][10]
