@@ -140,6 +140,7 @@ class TrainEngine:
         finally:
             ops.ASYNC_WGRAD = async_wgrad
             ops.WGRAD_DEFER = 0
+            ops.drop_deferred()                # a capture that failed midway must not leave launches behind for an eager step
         self._graph = g
 
     def drop_graph(self):

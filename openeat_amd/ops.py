@@ -249,6 +249,12 @@ def _run_wgrad(to_arena: bool, tensors, fn):
         fn()
 
 
+def drop_deferred():
+    """Forget deferred launches without running them (after a failed capture)."""
+    global _deferred
+    _deferred = []
+
+
 def flush_wgrads():
     global _deferred
     if not _deferred:
