@@ -186,6 +186,45 @@ def test_right_decoder_on_its_own_stream_gives_the_same_training(graph):
     check_updates(m2.state_dict(), m1.state_dict(), None, steps=5)
 
 
+def test_failed_capture_leaves_the_engine_usable(monkeypatch):
+    """bench.py falls back to eager steps when a capture raises: after a capture that fails midway (here: at the end of
+    backward, with weight gradients still deferred) an eager step of the same engine must equal a fresh engine's step."""
+    m1, m2 = tiny(seed=13).to(DEV).train(), tiny(seed=13).to(DEV).train()
+    b = batch_of(seed=8)
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+    l_ref, _ = e1.step(b)
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+    try:
+        real_flush = ops.ln_table_flush
+
+        def boom():
+            if e2._capturing:                                       # only inside the capture itself, not in its warm-up step
+                raise RuntimeError("injected failure inside the capture")
+            return real_flush()
+        monkeypatch.setattr(ops, "ln_table_flush", boom)
+        with pytest.raises(RuntimeError):                           # the injected error, or the runtime's complaint at capture end
+            e2.capture(b, warmup=1)                                 # (the warm-up step is one real optimizer step)
+        monkeypatch.undo()
+        torch.cuda.synchronize()
+        assert e2._graph is None and ops.WGRAD_DEFER == 0 and ops.LN_TABLE is None and not ops._deferred
+        assert not e2._capturing
+        l_eager, _ = e2.step(b)
+        torch.cuda.synchronize()
+    finally:
+        e2.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        ops.PARALLEL_DECODERS = False
+        ops.POS_PROJ_AHEAD = False
+    e1.arena.activate()
+    l_ref2, _ = e1.step(b)                                          # the reference engine's second step
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    torch.testing.assert_close(l_eager, l_ref2, rtol=1e-4, atol=1e-5)
+    check_updates(m2.state_dict(), m1.state_dict(), None, steps=2)
+
+
 def test_dropout_training_step_runs_and_is_seed_dependent():
     m = tiny(seed=9, dropout=0.1).to(DEV).train()
     b = batch_of(seed=4)
