@@ -95,6 +95,8 @@ class TrainEngine:
         with several ranks the graph holds zero-grad + forward + backward and the gradient all-reduce and
         the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph)."""
         self._split = self.reducer.world > 1
+        warmup = max(1, int(warmup))                  # at least one eager step first: streams, events and lazily initialised
+                                                      # state must exist before the capture (a cold capture ended "unjoined")
         ops.POS_PROJ_AHEAD = self.parallel            # inside a capture the collectives all come after the graph
         common.STATIC_SHAPES = True
         self.static_shapes = True
