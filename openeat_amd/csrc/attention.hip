@@ -245,17 +245,34 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
             }
         }
     } else {
+        // eight consecutive features per step: two float4 loads when rows are 16-byte aligned and D is a multiple of 8
+        const bool vq = (p.D % 8 == 0) && (p.q_rs % 4 == 0) && ((((uintptr_t)qb) & 15) == 0);
+        const bool vo = (p.D % 8 == 0) && (p.o_rs % 4 == 0) && (p.o_bs % 4 == 0) &&
+                        (MODE != 1 || (((((uintptr_t)p.d_o) | ((uintptr_t)p.o_in)) & 15) == 0));
+        auto load8 = [&](const float* row, int d0, bool vec, float (&out)[8]) {
+            if (vec && q_ok && d0 + 8 <= p.D) {
+                const float4 a = *reinterpret_cast<const float4*>(row + d0), c = *reinterpret_cast<const float4*>(row + d0 + 4);
+                out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = c.x; out[5] = c.y; out[6] = c.z; out[7] = c.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (q_ok && d0 + e < p.D) ? row[d0 + e] : 0.f;
+            }
+        };
+        const float* qrow = qb + (long)(q_ok ? qi : 0) * p.q_rs;
+        const long orow_c = q_ok ? orow : (long)b * p.o_bs + h * p.D;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
+            const int d0 = 16 * s + 8 * lk;
             float x[8], y[8];
+            load8(qrow, d0, vq, x);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = 16 * s + 8 * lk + e;
-                x[e] = (q_ok && d < p.D) ? qb[(long)qi * p.q_rs + d] * p.scale : 0.f;
-                if (MODE == 1) {
-                    y[e] = (q_ok && d < p.D) ? p.d_o[orow + d] : 0.f;
-                    dpart += (q_ok && d < p.D) ? y[e] * p.o_in[orow + d] : 0.f;
-                }
+            for (int e = 0; e < 8; ++e) x[e] *= p.scale;
+            if (MODE == 1) {
+                float ov[8];
+                load8(p.d_o + orow_c, d0, vo, y);
+                load8(p.o_in + orow_c, d0, vo, ov);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dpart += y[e] * ov[e];
             }
             bsplit<TERMS>(x, qfr[s]);
             if (MODE == 1) bsplit<TERMS>(y, dofr[s]);
