@@ -554,16 +554,27 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
             vf[s] = ok ? p.v[(long)b * p.v_bs + (long)kj * p.v_rs + h * p.D + d] : 0.f;
         }
     } else {
+        // eight consecutive features per step: two float4 loads when the rows are 16-byte aligned and D is a multiple of 8
+        const float* krow = p.k + (long)b * p.k_bs + (long)(k_ok ? kj : 0) * p.k_rs + h * p.D;
+        const float* vrow = p.v + (long)b * p.v_bs + (long)(k_ok ? kj : 0) * p.v_rs + h * p.D;
+        const bool vk = (p.D % 8 == 0) && (p.k_rs % 4 == 0) && (p.k_bs % 4 == 0) && ((((uintptr_t)p.k) & 15) == 0);
+        const bool vv = (p.D % 8 == 0) && (p.v_rs % 4 == 0) && (p.v_bs % 4 == 0) && ((((uintptr_t)p.v) & 15) == 0);
+        auto load8 = [&](const float* row, int d0, bool vec, float (&out)[8]) {
+            if (vec && k_ok && d0 + 8 <= p.D) {
+                const float4 a = *reinterpret_cast<const float4*>(row + d0), c = *reinterpret_cast<const float4*>(row + d0 + 4);
+                out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w; out[4] = c.x; out[5] = c.y; out[6] = c.z; out[7] = c.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) out[e] = (k_ok && d0 + e < p.D) ? row[d0 + e] : 0.f;
+            }
+        };
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float x[8], y[8];
+            load8(krow, 16 * s + 8 * lk, vk, x);
+            load8(vrow, 16 * s + 8 * lk, vv, y);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int d = 16 * s + 8 * lk + e;
-                const bool ok = k_ok && d < p.D;
-                x[e] = ok ? p.k[(long)b * p.k_bs + (long)kj * p.k_rs + h * p.D + d] * p.scale : 0.f;
-                y[e] = ok ? p.v[(long)b * p.v_bs + (long)kj * p.v_rs + h * p.D + d] : 0.f;
-            }
+            for (int e = 0; e < 8; ++e) x[e] *= p.scale;
             bsplit<TERMS>(x, kfr[s]);
             bsplit<TERMS>(y, vfr[s]);
         }
