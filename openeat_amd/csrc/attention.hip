@@ -78,8 +78,13 @@ template <int TERMS, int LD>
 __device__ __forceinline__ void row_frag(const float* tile, int row, int s, int g, BFrag<TERMS>& f) {
     float x[8];
     const float* p = tile + row * LD + 16 * s + 8 * g;
+    if constexpr (LD % 4 == 0) {
+        const float4 a = *reinterpret_cast<const float4*>(p), c = *reinterpret_cast<const float4*>(p + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = c.x; x[5] = c.y; x[6] = c.z; x[7] = c.w;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = p[e];
+        for (int e = 0; e < 8; ++e) x[e] = p[e];
+    }
     bsplit<TERMS>(x, f);
 }
 // A[acc_row(8s + e, g)][col] of an LDS tile: the rows this lane's accumulator registers 8s..8s+7 stand for
@@ -187,7 +192,8 @@ __device__ __forceinline__ void tile_store(const TileRegs<DPAD>& t, float* dst) 
         const int e = (threadIdx.x % ATT_GROUP) + i * ATT_GROUP;
         const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
         float* d = dst + row * LD + c4;
-        d[0] = t.v[i].x; d[1] = t.v[i].y; d[2] = t.v[i].z; d[3] = t.v[i].w;
+        if constexpr (LD % 4 == 0) *reinterpret_cast<float4*>(d) = t.v[i];
+        else { d[0] = t.v[i].x; d[1] = t.v[i].y; d[2] = t.v[i].z; d[3] = t.v[i].w; }
     }
 }
 
@@ -206,10 +212,10 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs
 // of its four-wave blocks per CU to have all 512 blocks of config 2 resident at once)
 template <int DPAD, int MODE, int TERMS, int SPLIT>
 __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(AttnParams p) {
-    constexpr int LD = DPAD + 1;
+    constexpr int LD = DPAD + 4;             // pitch: rows stay 16-byte aligned (b128 LDS accesses) and 4 banks apart
     constexpr int DT = DPAD / 32;
     constexpr int KS = DPAD / 16;            // bf16 k-steps over the features
-    __shared__ float KVs[SPLIT][2][32 * LD];         // [group][K | V] tiles; reused as the merge buffer at the end
+    __shared__ __attribute__((aligned(16))) float KVs[SPLIT][2][32 * LD];         // [group][K | V] tiles; reused as the merge buffer at the end
     __shared__ float kbs[SPLIT][32];                 // per-key bias of the tile; -inf marks a key masked for every query
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % ATT_WAVES, grp = threadIdx.x / ATT_GROUP;
     const int gtid = threadIdx.x % ATT_GROUP;
@@ -524,10 +530,10 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
 // ------------------------------------------------------------- dK / dV -------
 template <int DPAD, int TERMS, int SPLIT>
 __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnParams p) {
-    constexpr int LD = DPAD + 1;
+    constexpr int LD = DPAD + 4;             // pitch: rows stay 16-byte aligned (b128 LDS accesses) and 4 banks apart
     constexpr int DT = DPAD / 32;
     constexpr int KS = DPAD / 16;
-    __shared__ float QOs[SPLIT][2][32 * LD];         // [group][Q | dO] tiles; reused as the merge buffer at the end
+    __shared__ __attribute__((aligned(16))) float QOs[SPLIT][2][32 * LD];         // [group][Q | dO] tiles; reused as the merge buffer at the end
     __shared__ float lds_s[SPLIT][2][32];            // [group][lse | delta]
     const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) % ATT_WAVES, grp = threadIdx.x / ATT_GROUP;
     const int gtid = threadIdx.x % ATT_GROUP;
