@@ -37,7 +37,8 @@ KERNEL_NAMES = {0: "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)",
                 3: "gemm_dma_kernel + gemm_bf16_kernel <terms=3> (the kernels behind oe_gemm_f32 precision 3: "
                    "hi*hi+hi*lo+lo*hi, v_mfma_f32_32x32x16_bf16)"}
 DTYPE_NAMES = {0: "f32", 1: "bf16 (MFMA inputs; fp32 storage, accumulate, softmax, norms, losses, optimizer)",
-               3: "bf16x3 (3-term bf16 split on the matrix cores, fp32-grade; fp32 everywhere else)"}
+               3: "bf16x3 (matrix products as hi*hi+hi*lo+lo*hi on bf16 MFMA: ~2^-17 relative error per product, fp32 accumulate - "
+                  "narrower than the reference's fp32 products, wider than bf16; fp32 storage and fp32 everywhere else)"}
 
 
 def synth_batch(B, seconds, L, seed, device):
@@ -69,7 +70,8 @@ def cpu_baseline(B, seconds, L, steps):
     wav, tgt, tlen = synth_batch(B, seconds, L, 0, "cpu")
     frames = 0
     times = []
-    for it in range(steps + 1):
+    warm = 2                                                     # 2 warm-up + 5 timed steps, median
+    for it in range(steps + warm):
         t0 = time.perf_counter()
         feats = torch.stack([FB.utt_normalize(FB.fbank(w)) for w in wav])
         flen = torch.full((B,), feats.shape[1], dtype=torch.int32)
@@ -80,11 +82,12 @@ def cpu_baseline(B, seconds, L, steps):
         opt.step()
         dt = time.perf_counter() - t0
         log(f"  cpu step {it}: {dt:.1f} s")
-        if it > 0:                                              # first iteration = warm-up
+        if it >= warm:
             times.append(dt)
-            frames += B * feats.shape[1]
-    return {"value": frames / sum(times), "unit": "audio-frames/s", "cores": cores, "kind": "port",
-            "sample": f"B={B} x {seconds:g} s utterances, {steps} timed fwd+bwd+clip+Adam steps after 1 warm-up, dropout 0.1"}
+    med = sorted(times)[len(times) // 2]
+    return {"value": B * feats.shape[1] / med, "unit": "audio-frames/s", "cores": cores, "kind": "port",
+            "sample": f"B={B} x {seconds:g} s utterances (the GPU run's batch), fbank+fwd+bwd+clip+Adam, dropout 0.1: {warm} warm-up + {steps} "
+                      f"timed steps, median step {med:.2f} s (BASELINE.md section 3 protocol); threads = this box's CPU share, capped at 16"}
 
 
 def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3, lm=None, lm_weight=0.0):
@@ -146,8 +149,9 @@ def main():
                     help="profiling: every kernel on one stream (no decoder / CTC / weight-gradient streams), so that a profiler's "
                          "per-kernel durations are those of the kernel alone, as the live roofline measurement takes them")
     ap.add_argument("--decode-utts", type=int, default=64)
-    ap.add_argument("--cpu-batch", type=int, default=16)
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--no-other-modes", action="store_true", help="skip the extra ms/step measurements in arithmetic modes 0 (fp32) and 1 (bf16)")
     args = ap.parse_args()
 
     from openeat_amd import ddp, hip
@@ -314,19 +318,53 @@ def main():
         prec = hip.GEMM_PRECISION
         peak = PEAK_FP32_MFMA_TFLOPS if prec == 0 else PEAK_BF16_MFMA_TFLOPS
         mfma_flops = flops * (3 if prec == 3 else 1)            # the 3-term split issues 3 MFMAs per algorithmic product
-        traffic = None                                           # HBM bytes per launch from the committed PMC passes
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")) as f:
-                pmc = json.load(f)
-            if pmc.get("precision") == prec:
-                traffic = pmc["gemm"]["hbm_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+        # HBM bytes per launch: PMC counters cannot be read from inside this process - the figure is the one of the
+        # committed rocprofv3 --pmc passes of this same command (tools/final_profiles.sh), and the line says so
+        traffic, traffic_src = None, None
+        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    pmc = json.load(f)
+                if pmc.get("precision") == prec:
+                    traffic = pmc["gemm"]["hbm_bytes_per_launch"]
+                    traffic_src = f"profiles/{name} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections applied; not measured in this run)"
+                    break
+            except (OSError, KeyError, ValueError):
+                pass
         roof = {"kernel": KERNEL_NAMES[prec], "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                "frac": ach / peak, "traffic": traffic, "launches_per_step": len(recs),
+                "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(recs),
                 "avg_launch_us": secs / max(len(recs), 1) * 1e6, "gemm_ms_per_step": secs * 1e3,
                 "algorithmic_gflop_per_step": flops / 1e9, "mfma_issue_tflops": mfma_flops / secs / 1e12,
                 "event_pair_overhead_us": pair_ms * 1e3}
+
+    # ---- the same step in the other arithmetic modes (one GPU only): mode 0 = exact-fp32 matrix products, the arithmetic
+    # that equals the reference's; mode 1 = plain bf16 MFMA inputs.  A fresh HIP graph per mode, 2 + 5 replays.
+    other = {}
+    if world == 1 and not args.no_other_modes and not args.no_graph:
+        main_prec = hip.GEMM_PRECISION
+        for mode, key in ((0, "dtype_reference_equal"), (1, "dtype_bf16")):
+            if mode == main_prec:
+                continue
+            try:
+                engine.drop_graph()
+                hip.GEMM_PRECISION = mode
+                engine.capture(batch, warmup=1)
+                for _ in range(2):
+                    engine.replay()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(5):
+                    o2 = engine.replay()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - t) / 5 * 1e3
+                other[key] = {"dtype": DTYPE_NAMES[mode].split(" ")[0], "precision_mode": mode, "ms_per_step": ms,
+                              "value": args.batch * T / (ms * 1e-3), "steps": 5, "loss": float(o2[0])}
+                log(f"mode {mode}: {ms:.2f} ms/step")
+            except Exception as e:
+                other[key] = {"precision_mode": mode, "error": f"{type(e).__name__}: {e}"}
+            finally:
+                hip.GEMM_PRECISION = main_prec
+        engine.drop_graph()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -356,7 +394,7 @@ def main():
                                        "CTC+attention joint loss, fbank+fwd+bwd+clip+Adam, dropout 0.1",
                            "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph},
                 **({"invalid": f"dropout overridden to {args.dropout}"} if args.dropout is not None else {}),
-                "loss": loss, "roofline": roof, "cpu_baseline": cpu, "decode": dec}
+                "loss": loss, "roofline": roof, "cpu_baseline": cpu, **other, "decode": dec}
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -245,6 +245,18 @@ int oe_act_grad(const float* dy, const float* pre, long n, int act, float* out, 
 /* log_softmax over the last dim (ctc.py:56-64; asr_model.py:484-488). */
 int oe_log_softmax(const float* x, long rows, int V, float* out, void* stream);
 
+/* Masked softmax (+ dropout) over the last dim of a MATERIALISED score tensor: the module-API method
+ * MultiHeadedAttention.forward_attention (attention.py:65-97) - the training / decoding path never builds this tensor
+ * (oe_attention_fwd).  scores (B,H,T1,T2) dense; mask bytes (b,i,j) at mask + b*mask_bstride + i*mask_rstride + j
+ * (mask_rstride = 0: a (B,1,T2) key mask; NULL: no mask), 0 = masked: -inf before the softmax, 0 after it
+ * (attention.py:85-88).  y = the softmax (kept for backward), out = y * dropout(drop_p, element index) (out may alias y
+ * when drop_p == 0).  backward: dscores = y * (g - sum_j g_j y_j), g = dout * the same dropout mask; rows = B*H*T1. */
+int oe_masked_softmax_fwd(const float* scores, const unsigned char* mask, long mask_bstride, long mask_rstride, int B, int H,
+                          int T1, int T2, float drop_p, unsigned long long seed, const unsigned long long* seed_dev, float* y,
+                          float* out, void* stream);
+int oe_masked_softmax_bwd(const float* y, const float* dout, long rows, int T2, float drop_p, unsigned long long seed,
+                          const unsigned long long* seed_dev, float* dscores, void* stream);
+
 /* GlobalCMVN (modules/cmvn.py:43-45): y = (x - mean[f]) * istd[f]. */
 int oe_global_cmvn(const float* x, const float* mean, const float* istd, long n, int F, float* y, void* stream);
 

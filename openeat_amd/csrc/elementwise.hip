@@ -328,6 +328,83 @@ extern "C" int oe_log_softmax(const float* x, long rows, int V, float* out, void
     return 0;
 }
 
+// masked softmax over the last dim of a materialised score tensor (attention.py:83-90, the module-API method
+// forward_attention; the hot path never builds this tensor - it runs the fused kernels of attention.hip).
+// One wave per row (b, h, i).  y = softmax with mask==0 positions at -inf, then 0-filled (rows without a valid key: all 0);
+// out = y * dropout mask (element index row * T2 + j).
+__global__ __launch_bounds__(256) void masked_softmax_fwd_kernel(const float* __restrict__ s, const unsigned char* __restrict__ mask,
+                                                                 long m_bs, long m_rs, int H, int T1, int T2, long rows, float p,
+                                                                 unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                                 float* __restrict__ y, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int i = (int)(row % T1);
+    const long b = row / ((long)T1 * H);
+    const unsigned char* mrow = mask ? mask + b * m_bs + (long)i * m_rs : nullptr;
+    const float* sp = s + row * T2;
+    float m = -INFINITY, z = 0.f;
+    for (int j = lane; j < T2; j += 64) {
+        if (mrow && !mrow[j]) continue;
+        const float v = sp[j];
+        const float mn = fmaxf(m, v);
+        z = z * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    }
+    if (m == -INFINITY) z = 0.f;
+    wave_lse(m, z);
+    const float inv = z > 0.f ? 1.f / z : 0.f;
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+    const DropParams dp = drop_params(p);
+    for (int j = lane; j < T2; j += 64) {
+        const bool dead = (mrow && !mrow[j]) || m == -INFINITY;
+        const float v = dead ? 0.f : __expf(sp[j] - m) * inv;
+        y[row * T2 + j] = v;
+        if (out != y) out[row * T2 + j] = p > 0.f ? v * drop_elem(seed, (unsigned long long)(row * T2 + j), dp) : v;
+    }
+}
+// ds = y * (g - sum_j g_j y_j), g = dout * dropout mask
+__global__ __launch_bounds__(256) void masked_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dout, int T2, long rows,
+                                                                 float p, unsigned long long seed, const unsigned long long* __restrict__ seed_dev,
+                                                                 float* __restrict__ ds) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    if (seed_dev) seed += *seed_dev * 0x9E3779B97F4A7C15ull;
+    const DropParams dp = drop_params(p);
+    float acc = 0.f;
+    for (int j = lane; j < T2; j += 64) {
+        const long e = row * T2 + j;
+        const float g = p > 0.f ? dout[e] * drop_elem(seed, (unsigned long long)e, dp) : dout[e];
+        acc += g * y[e];
+    }
+    acc = wave_sum(acc);
+    for (int j = lane; j < T2; j += 64) {
+        const long e = row * T2 + j;
+        const float g = p > 0.f ? dout[e] * drop_elem(seed, (unsigned long long)e, dp) : dout[e];
+        ds[e] = y[e] * (g - acc);
+    }
+}
+extern "C" int oe_masked_softmax_fwd(const float* scores, const unsigned char* mask, long mask_bstride, long mask_rstride, int B, int H,
+                                     int T1, int T2, float drop_p, unsigned long long seed, const unsigned long long* seed_dev,
+                                     float* y, float* out, void* stream) {
+    OE_REQUIRE(scores && y && out && B > 0 && H > 0 && T1 > 0 && T2 > 0 && drop_p >= 0.f && drop_p < 1.f, "oe_masked_softmax_fwd: bad arguments");
+    OE_REQUIRE(drop_p == 0.f || out != y, "oe_masked_softmax_fwd: dropout needs a separate output buffer");
+    const long rows = (long)B * H * T1;
+    hipLaunchKernelGGL(masked_softmax_fwd_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, scores, mask, mask_bstride,
+                       mask_rstride, H, T1, T2, rows, drop_p, seed, seed_dev, y, out);
+    OE_LAUNCH_CHECK("masked_softmax_fwd");
+    return 0;
+}
+extern "C" int oe_masked_softmax_bwd(const float* y, const float* dout, long rows, int T2, float drop_p, unsigned long long seed,
+                                     const unsigned long long* seed_dev, float* dscores, void* stream) {
+    OE_REQUIRE(y && dout && dscores && rows > 0 && T2 > 0 && drop_p >= 0.f && drop_p < 1.f, "oe_masked_softmax_bwd: bad arguments");
+    hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y, dout, T2, rows, drop_p, seed,
+                       seed_dev, dscores);
+    OE_LAUNCH_CHECK("masked_softmax_bwd");
+    return 0;
+}
+
 // y = act(x) (stand-alone activation module, swish.py:15-17)
 __global__ void act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

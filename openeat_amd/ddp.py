@@ -45,6 +45,7 @@ class GradAllReduce:
         self.chunks = [flat_grad[i:min(n, i + step)] for i in range(0, n, step)]
         self._done_from = n            # floats [_done_from, n) have already been handed to the collective this step
         self._works = []
+        self.overlap_enabled = True    # False on the non-boundary micro-steps of gradient accumulation (DDP's no_sync)
         self._avg = (hasattr(dist.ReduceOp, "AVG") and flat_grad.is_cuda and dist.is_initialized()
                      and dist.get_backend(process_group) == "nccl")
 
@@ -60,7 +61,7 @@ class GradAllReduce:
     def reduce_tail(self, start: int):
         """Gradients of floats [start, end of what is still pending) are final: start their all-reduce now (async; the
         collective is ordered after everything already enqueued on the current stream)."""
-        if self.world == 1 or start >= self._done_from:
+        if self.world == 1 or not self.overlap_enabled or start >= self._done_from:
             return
         if start > 0:
             start = (start + 1023) // 1024 * 1024      # 4 KiB aligned slices; the few floats skipped go with the next tail
@@ -68,6 +69,14 @@ class GradAllReduce:
                 return
         self._issue(self.grad[start:self._done_from])
         self._done_from = start
+
+    def agree_min(self, value: int) -> int:
+        """MIN over the ranks of a small integer (the loop's "do we all have a batch" handshake)."""
+        if self.world == 1:
+            return value
+        t = torch.tensor([value], dtype=torch.int32, device=self.grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return int(t.item())
 
     def __call__(self):
         """After backward: reduce what no hook has sent yet, wait for everything, average."""

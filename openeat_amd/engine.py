@@ -28,7 +28,8 @@ class TrainEngine:
         self.reducer.broadcast_parameters(self.arena.flat)
         if self.reducer.world > 1:
             self._install_overlap_hooks()
-        self.accum_grad = accum_grad
+        self.accum_grad = max(1, int(accum_grad))
+        self._micro = 0                          # micro-steps accumulated since the last optimizer step
         self.static_shapes = static_shapes
         dev = self.arena.flat.device
         self.seed_counter = torch.zeros(1, dtype=torch.int64, device=dev)      # advanced once per step on device
@@ -71,29 +72,51 @@ class TrainEngine:
 
     def _finish(self):
         self.reducer()
-        self.optimizer.step(lr_from_device=self._graph is not None or self._capturing)
+        # inside a capture the learning rate is whatever replay() puts into lr_dev; everywhere else (eager steps, also
+        # those taken beside a captured graph) it is the optimizer's current param_groups value
+        self.optimizer.step(lr_from_device=self._capturing or self._replaying)
         self.seed_counter.add_(1)
 
     _capturing = False
+    _replaying = False
     _hooks_off = False          # capture()'s warm-up steps: same launch structure as the capture (whole arena reduced after backward)
     _split = False
 
     def step(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None):
-        """Eager step (any shapes)."""
+        """Eager (micro-)step, any shapes.  With accum_grad = k the gradient arena is zeroed before the first of k
+        calls, every call adds the gradient of loss / k, and only the k-th call exchanges gradients (the backward-overlap
+        hooks and the final all-reduce), clips, runs Adam - /root/reference/openeat/utils/executor.py:42-63 (no_sync on
+        the micro-steps in between, one optimizer step per k batches).  Returns (loss / k, acc) of this call."""
         common.STATIC_SHAPES = self.static_shapes
         ops.POS_PROJ_AHEAD = self.parallel and self.reducer.world == 1      # not beside the backward hooks' collectives
         if lr is not None:
             self.optimizer.set_lr(lr)
-        self.arena.zero_grad()
-        out = self._fwd_bwd(batch)
-        self._finish()
+        if self._micro == 0:
+            self.arena.zero_grad()
+        boundary = self._micro + 1 >= self.accum_grad
+        hooks_off, self._hooks_off = self._hooks_off, self._hooks_off or not boundary     # no collective before the last micro-step
+        try:
+            out = self._fwd_bwd(batch)
+        finally:
+            self._hooks_off = hooks_off
+        if boundary:
+            self._finish()
+            self._micro = 0
+        else:
+            self._micro += 1
+            self.seed_counter.add_(1)          # fresh dropout masks for the next micro-step
         return out
 
     # ---- HIP-graph path: fixed shapes, no host sync inside the step -----------------------------
     def capture(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
         """Capture the step as a HIP graph.  With one rank the whole step (incl. clip + Adam) is one graph;
         with several ranks the graph holds zero-grad + forward + backward and the gradient all-reduce and
-        the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph)."""
+        the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph).
+        The `warmup` steps that precede the capture are REAL optimizer steps on `example_batch` (parameters, Adam
+        moments, step count and dropout counter advance; a scheduler should count them); the capture itself executes
+        nothing.  Gradient accumulation (accum_grad > 1) is an eager-step feature: refused here."""
+        if self.accum_grad != 1:
+            raise NotImplementedError("TrainEngine.capture: accum_grad > 1 is only supported by eager steps")
         self._split = self.reducer.world > 1
         warmup = max(1, int(warmup))                  # at least one eager step first: streams, events and lazily initialised
                                                       # state must exist before the capture (a cold capture ended "unjoined")
@@ -160,8 +183,12 @@ class TrainEngine:
                 self._static[k].copy_(v)
         if lr is not None:
             self.optimizer.set_lr(lr)
-            self.optimizer.lr_dev.fill_(lr)
+        self.optimizer.lr_dev.fill_(float(self.optimizer.param_groups[0]["lr"]))     # the graph's Adam reads lr_dev
         self._graph.replay()
         if self._split:
-            self._finish()
+            self._replaying = True
+            try:
+                self._finish()
+            finally:
+                self._replaying = False
         return self._out

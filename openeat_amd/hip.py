@@ -124,6 +124,8 @@ _SIGNATURES = {
     "oe_act_fwd": (I, [P, L, I, P, P]),
     "oe_act_grad": (I, [P, P, L, I, P, P]),
     "oe_log_softmax": (I, [P, L, I, P, P]),
+    "oe_masked_softmax_fwd": (I, [P, P, L, L, I, I, I, I, F, U64, P, P, P, P]),
+    "oe_masked_softmax_bwd": (I, [P, P, L, I, F, U64, P, P, P]),
     "oe_global_cmvn": (I, [P, P, P, L, I, P, P]),
     "oe_conv1_fwd": (I, [P, P, P, I, I, I, I, P, P]),
     "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),

@@ -64,6 +64,7 @@ class ASRModel(torch.nn.Module):
         assert targets_length.dim() == 1, targets_length.shape
         assert (features.shape[0] == features_length.shape[0] == targets.shape[0] == targets_length.shape[0]), \
             (features.shape, features_length.shape, targets.shape, targets_length.shape)
+        ops.predrop_clear()                     # a new tape starts: nothing of the previous backward may be picked up
         par = ops.PARALLEL_DECODERS and features.is_cuda and self.ctc_weight < 1
         prep = None
         if par:

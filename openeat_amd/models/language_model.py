@@ -70,6 +70,7 @@ class LanguageModel(torch.nn.Module):
         """language_model.py:69-107."""
         assert targets_length.dim() == 1, targets_length.shape
         assert input_targets.shape[0] == targets_length.shape[0], (input_targets.shape, targets_length.shape)
+        ops.predrop_clear()
         if self.autoregressive:
             ys_in, ys_out = add_sos_eos(input_targets, self.sos, self.eos, self.ignore_id)
             in_lens = targets_length + 1

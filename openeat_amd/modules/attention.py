@@ -1,7 +1,7 @@
 """Multi-head attention layers (/root/reference/openeat/modules/attention.py).
 Projections, scores, mask, softmax, dropout and the context product run as
 fused HIP kernels; the (B,H,T1,T2) score tensor is never materialised."""
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
 from torch import nn
@@ -42,6 +42,20 @@ class MultiHeadedAttention(nn.Module):
                              self.pos_bias_u if rel else None, self.pos_bias_v if rel else None,
                              residual, out_dropout if self.training else 0.0, pp)
 
+    def forward_qkv(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor
+                    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """attention.py:36-63: the three projections as (B, h, T, d_k) views (head axis transposed forward, as the
+        reference returns them).  Module-API surface; forward() runs the fused projection + attention kernels."""
+        B = query.size(0)
+        lin = lambda m, x: ops.linear(x, m.weight, m.bias).view(B, -1, self.h, self.d_k).transpose(1, 2)
+        return lin(self.linear_q, query), lin(self.linear_k, key), lin(self.linear_v, value)
+
+    def forward_attention(self, value: torch.Tensor, scores: torch.Tensor, mask: Optional[torch.Tensor]) -> torch.Tensor:
+        """attention.py:65-97 on a materialised (B, h, T1, T2) score tensor: masked softmax, 0-fill, dropout, @ value,
+        merge heads, linear_out.  value (B, h, T2, d_k); mask (B,1,T2) or (B,T1,T2) or None."""
+        x = ops.scores_attention(value, scores, mask, self.dropout.p if self.training else 0.0)
+        return ops.linear(x, self.linear_out.weight, self.linear_out.bias)
+
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, mask: Optional[torch.Tensor],
                 pos_emb: Optional[torch.Tensor] = None, residual: torch.Tensor = None,
                 out_dropout: float = 0.0) -> torch.Tensor:
@@ -60,6 +74,18 @@ class RelPositionMultiHeadedAttention(MultiHeadedAttention):
         self.pos_bias_v = nn.Parameter(torch.Tensor(self.h, self.d_k))
         torch.nn.init.xavier_uniform_(self.pos_bias_u)
         torch.nn.init.xavier_uniform_(self.pos_bias_v)
+
+    def rel_shift(self, x: torch.Tensor, zero_triu: bool = False) -> torch.Tensor:
+        """attention.py:140-164 (unused by forward there, :202-204, and here): row i of the (T1, T2) score matrix moves
+        T1 - 1 - i places to the left through the flattened matrix.  Pure re-indexing, no arithmetic: one zero column in
+        front, the buffer re-read with the two trailing sizes swapped, first row dropped."""
+        b, h, t1, t2 = x.shape
+        padded = torch.nn.functional.pad(x, (1, 0))                       # (b, h, t1, t2 + 1)
+        x = padded.reshape(b, h, t2 + 1, t1)[:, :, 1:].reshape(b, h, t1, t2)
+        if zero_triu:
+            keep = torch.ones(t1, t2, device=x.device, dtype=x.dtype).tril(t2 - t1)
+            x = x * keep
+        return x
 
     def forward(self, query: torch.Tensor, key: torch.Tensor, value: torch.Tensor, mask: Optional[torch.Tensor],
                 pos_emb: torch.Tensor, residual: torch.Tensor = None, out_dropout: float = 0.0):

@@ -25,10 +25,12 @@ class ConvolutionModule(nn.Module):
         self.kernel_size = kernel_size
         self._act = act_id_of(activation)
 
-    def forward(self, x: torch.Tensor, mask_pad: Optional[torch.Tensor] = None, cache=None,
-                residual: torch.Tensor = None, out_dropout: float = 0.0, input_masked: bool = False) -> torch.Tensor:
-        """x (B,T,C); mask_pad (B,1,T) non-zero = real frame.  (The streaming ``cache`` of the causal
-        variant is not part of the training/offline path and is not supported.)"""
+    def forward(self, x: torch.Tensor, mask_pad: torch.Tensor = torch.ones((0, 0, 0), dtype=torch.bool),
+                cache: torch.Tensor = torch.zeros((0, 0, 0)), residual: torch.Tensor = None, out_dropout: float = 0.0,
+                input_masked: bool = False) -> torch.Tensor:
+        """x (B,T,C); mask_pad (B,1,T) non-zero = real frame, empty (the reference's default, convolution.py:75) = no
+        mask.  (The streaming ``cache`` of the causal variant is not part of the training/offline path: a non-empty one
+        is refused.)"""
         if cache is not None and cache.numel() > 0:
             raise NotImplementedError("streaming cache is outside the accelerated path")
         rowmask = None

@@ -38,6 +38,21 @@ class Decoder(torch.nn.Module):
                 x = layer(x, tgt_mask, memory, memory_mask)
         return x
 
+    def forward_one_step(self, tgt, tgt_mask, memory, memory_mask, cache: Optional[List[torch.Tensor]] = None
+                         ) -> Tuple[torch.Tensor, List[torch.Tensor]]:
+        """decoder.py:76-108: one decoding step of the embedding-free stack; cache = each block application's previous
+        output (B, L-1, d); returns (x (B, L, d), new_cache)."""
+        x = tgt
+        tm = tgt_mask.to(torch.uint8).contiguous() if tgt_mask.dtype != torch.uint8 else tgt_mask
+        mm = memory_mask.to(torch.uint8).contiguous() if memory_mask.dtype != torch.uint8 else memory_mask
+        new_cache = []
+        for i, layer in enumerate(self.decoders):
+            for j in range(self.num_blocks_share):
+                c = None if cache is None else cache[i * self.num_blocks_share + j]
+                x = layer(x, tm, memory, mm, cache=c)
+                new_cache.append(x)
+        return x, new_cache
+
 
 class TransformerDecoder(torch.nn.Module):
     def __init__(self, vocab_size: int, d_model: int, dropout_rate: float = 0.1, attention_heads: int = 4,

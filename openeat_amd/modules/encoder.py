@@ -71,6 +71,9 @@ class TransformerEncoder(torch.nn.Module):
         if input_layer not in sub:
             raise ValueError("unknown input_layer: " + input_layer)
         pos = {"abs_pos": PositionalEncoding, "rel_pos": RelPositionalEncoding}
+        if pos_enc_layer_type == "no_pos":
+            # the reference selects a class it neither defines nor imports (encoder.py:165-166): same failure, same type
+            raise NameError("name 'NoPositionalEncoding' is not defined")
         if pos_enc_layer_type not in pos:
             raise ValueError("unknown pos_enc_layer: " + pos_enc_layer_type)
         self.global_cmvn = global_cmvn

@@ -14,6 +14,11 @@ class BaseSubsampling(torch.nn.Module):
         self.right_context = 0
         self.subsampling_rate = 1
 
+    def position_encoding(self, offset: int, size: int) -> torch.Tensor:
+        """subsampling.py:19-20: forwarded to the positional-encoding object (whose class defines no such method in
+        the reference, embedding.py:14-88: calling it there is an AttributeError, and so it is here)."""
+        return self.pos_enc.position_encoding(offset, size)
+
 
 class Conv2dSubsampling4(BaseSubsampling):
     """subsampling.py:65-116.  Parameters keep the reference's names/shapes:

@@ -397,6 +397,9 @@ def ln_table_end():
 # as a second output of its kernel (oe_layernorm_bwd_dx_drop) and the block's backward picks it up by the address of the
 # gradient it receives - one elementwise launch per block (66 per step at config 2) less.  Anything in between (an adapter's
 # add, a gradient autograd had to accumulate) changes the address and the block falls back to oe_dropout_scale.
+# Entries live from the LayerNorm backward that makes them to the block backward that consumes them; whatever is left
+# (a block that was never differentiated) is dropped when the next forward pass starts (ASRModel.forward /
+# LanguageModel.forward / TrainEngine call predrop_clear).
 FUSE_OUT_DROP = os.environ.get("OE_FUSE_OUT_DROP", "1") == "1"
 _PREDROP = {}
 
@@ -415,7 +418,11 @@ def _out_drop_grad(dy2, out_scale, p_out, s_out, rowmask=None):
     """dropout_scale(dy2, out_scale, p_out, s_out, rowmask) - or the copy the producing LayerNorm backward already made."""
     hit = _PREDROP.pop(dy2.data_ptr(), None)
     if hit is not None:
-        g, spec = hit
+        # the entry keeps the producing dx alive, so no other tensor can have been given this address meanwhile; an
+        # in-place change of dx since (autograd summing a second consumer's gradient into it) shows in its version
+        g, spec, dx, version = hit
+        if dx._version != version or dx.numel() != dy2.numel():
+            return dropout_scale(dy2, out_scale, p_out, s_out, rowmask)
         same_mask = (spec[3] is None and rowmask is None) or (spec[3] is not None and rowmask is not None and
                                                                spec[3].data_ptr() == rowmask.data_ptr())
         if spec[:3] == (float(out_scale), float(p_out), int(s_out)) and same_mask and g.numel() == dy2.numel():
@@ -431,7 +438,7 @@ def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, t
         alpha, p, seed, gmask = prev_drop
         hip.call("oe_layernorm_bwd_dx_drop", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, g, alpha, p, seed, _seed_dev,
                  gmask, ws)
-        _PREDROP[dx.data_ptr()] = (g, prev_drop)
+        _PREDROP[dx.data_ptr()] = (g, prev_drop, dx, dx._version)
     else:
         hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, ws)
     t = LN_TABLE
@@ -845,6 +852,59 @@ class AttentionFn(torch.autograd.Function):
 def attention(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, H, p_attn=0.0, pos_emb=None, wpos=None, pu=None, pv=None,
               residual=None, p_out=0.0, pp=None):
     return AttentionFn.apply(xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out, pp)
+
+
+class ScoresAttentionFn(torch.autograd.Function):
+    """attention.py:65-97 up to (not including) linear_out, on MATERIALISED scores: masked softmax -> 0-fill -> dropout ->
+    attn @ value -> heads merged.  Module-API surface only (MultiHeadedAttention.forward_attention); forward() uses
+    AttentionFn, which never builds the (B,H,T1,T2) tensor.  value (B,H,T2,dk) in any strides with a contiguous last
+    dim (forward_qkv returns transposed views); returns (B,T1,H*dk)."""
+
+    @staticmethod
+    def forward(ctx, value, scores, mask, p):
+        scores = _chk(scores, "scores")
+        if not value.is_cuda or value.dtype != torch.float32:
+            raise TypeError("value: openeat_amd ops need float32 CUDA tensors; there is no CPU fallback")
+        if value.stride(-1) != 1:
+            value = value.contiguous()
+        B, H, T1, T2 = scores.shape
+        dk = value.shape[-1]
+        m8, mstr = _mask_u8(mask)
+        seed = next_seed() if p > 0 else 0
+        y = torch.empty_like(scores)
+        att = torch.empty_like(scores) if p > 0 else y
+        hip.call("oe_masked_softmax_fwd", scores, m8, mstr[0], mstr[1], B, H, T1, T2, float(p), seed, _seed_dev, y, att)
+        out = _new(B, T1, H, dk, like=scores)
+        for b in range(B):
+            for h in range(H):
+                v = value[b, h]
+                hip.gemm(att[b, h], v, out[b, :, h], T1, dk, T2, lda=T2, ldb=v.stride(0), ldc=H * dk, b_kmajor=True)
+        ctx.save_for_backward(value, y, att)
+        ctx.cfg = (p, seed)
+        return out.view(B, T1, H * dk)
+
+    @staticmethod
+    def backward(ctx, dout):
+        value, y, att = ctx.saved_tensors
+        p, seed = ctx.cfg
+        B, H, T1, T2 = y.shape
+        dk = value.shape[-1]
+        dout = dout.contiguous().view(B, T1, H, dk)
+        datt = torch.empty_like(y)
+        dv = torch.zeros(B, H, T2, dk, device=y.device, dtype=torch.float32)
+        for b in range(B):
+            for h in range(H):
+                g, v = dout[b, :, h], value[b, h]
+                hip.gemm(g, v, datt[b, h], T1, T2, dk, lda=H * dk, ldb=v.stride(0), ldc=T2)                       # dO @ V^T
+                hip.gemm(att[b, h], g, dv[b, h], T2, dk, T1, lda=T2, ldb=H * dk, ldc=dk, a_kmajor=True, b_kmajor=True,
+                         atomic_out=True)                                                                         # P^T @ dO
+        ds = torch.empty_like(y)
+        hip.call("oe_masked_softmax_bwd", y, datt, B * H * T1, T2, float(p), seed, _seed_dev, ds)
+        return dv, ds, None, None
+
+
+def scores_attention(value, scores, mask, p=0.0):
+    return ScoresAttentionFn.apply(value, scores, mask, p)
 
 
 # linear_pos(pos_emb) (attention.py:185) depends on the positional table and one weight only: with POS_PROJ_AHEAD the

@@ -26,11 +26,32 @@ class Executor:
         logger.info("using accumulate grad, new batch size is {} times larger than before".format(accum_grad))
         num_seen_utts, total_loss, total_acc = 0, 0.0, 0.0
         n_batches = len(data_loader)
-        for batch_idx, (keys, batch) in enumerate(data_loader):
+        multi = reducer is not None and reducer.world > 1
+        it = iter(data_loader)
+        batch_idx = -1
+        while True:
+            # The reference wraps the loop in DistributedDataParallel.join() (executor.py:24-29) so that ranks may see
+            # different numbers of batches, and skips empty batches per rank (:37-38).  Here the gradient exchange is an
+            # explicit collective, so the ranks first agree on what this iteration is: 2 = everyone has a batch, 1 = some
+            # rank's batch came back empty (all skip it: equal collective counts, same accumulation phase everywhere),
+            # 0 = some rank's loader is exhausted (all stop: the surplus batches of the others are dropped).
+            try:
+                keys, batch = next(it)
+                state = 2 if len(keys) > 0 else 1
+            except StopIteration:
+                keys, batch, state = (), None, 0
+            if multi:
+                state = reducer.agree_min(state)
+            if state == 0:
+                break
+            batch_idx += 1
+            if state == 1:
+                continue
             batch = map_to_device(batch, device)
             num_utts = len(keys)
-            if num_utts == 0:
-                continue
+            boundary = batch_idx % accum_grad == 0
+            if reducer is not None:
+                reducer.overlap_enabled = boundary           # model.no_sync on the micro-steps in between (executor.py:42-45)
             loss, acc = model(**batch)
             loss = torch.mean(loss) / accum_grad
             acc = None if acc is None else torch.mean(acc)
@@ -40,7 +61,7 @@ class Executor:
                 if acc is not None:
                     total_acc += acc.item() * num_utts
             loss.backward()
-            if batch_idx % accum_grad == 0:
+            if boundary:
                 if reducer is not None:
                     reducer()
                 if fused:

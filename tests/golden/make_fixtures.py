@@ -407,10 +407,15 @@ def f10_helpers():
     print("f10_helpers.json")
 
 
-def _e2e(name, kwargs, lens, tlens, V, seed, beam=4, store_sd=True):
+def _e2e(name, kwargs, lens, tlens, V, seed, beam=4, store_sd=True, force_token=None):
     torch.manual_seed(777)   # the reference's own seed, bin/train.py:47
     model = ASRModel(80, V, **kwargs)
     randomize(model, seed, scale=0.5)
+    if force_token is not None:
+        # a left decoder that always answers `force_token`, and targets that hold it at every other position:
+        # th_accuracy (utils/common.py:135-157) then is a known non-trivial fraction instead of the 0.0 of random weights
+        with torch.no_grad():
+            model.decoder.left_decoder.output_layer.bias[force_token] += 40.0
     model.eval()
     B, T = len(lens), max(lens)
     g = torch.Generator().manual_seed(seed)
@@ -420,6 +425,8 @@ def _e2e(name, kwargs, lens, tlens, V, seed, beam=4, store_sd=True):
     tgt = torch.full((B, Lm), -1, dtype=torch.int32)
     for b in range(B):
         tgt[b, : tlens[b]] = torch.randint(2, V - 1, (tlens[b],), generator=g, dtype=torch.int32)
+        if force_token is not None:
+            tgt[b, 0: tlens[b]: 2] = force_token
         feats[b, lens[b]:] = 0.0
     tlen = torch.tensor(tlens, dtype=torch.int32)
     loss, acc = model(feats, flen, tgt, tlen)
@@ -486,6 +493,48 @@ def f20_e2e_adapters():
          lens=[95, 70, 43], tlens=[7, 5, 3], V=40, seed=20)
 
 
+def f23_e2e_nonzero_accuracy():
+    """Tiny Conformer end to end with an attention-decoder accuracy that is neither 0 nor 1."""
+    _e2e("f23_tiny_conformer_acc",
+         dict(encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+              linear_units=64, dropout_rate=0.0, activation_type="swish", macaron_style=True, use_cnn_module=True,
+              cnn_module_kernel=15, pos_enc_layer_type="rel_pos", ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3),
+         lens=[95, 70, 43, 88], tlens=[7, 5, 3, 6], V=40, seed=23, force_token=5)
+
+
+def f22_api_signatures():
+    """Public surface of the reference's hot-path classes: for every class the methods it defines (own or inherited from
+    another reference class) and their parameter names / defaults, as inspect.signature reports them.  Data only."""
+    import inspect
+    from openeat.modules.encoder import Encoder
+    from openeat.modules.decoder import Decoder, TransformerDecoder
+    from openeat.modules.encoder_layer import EncoderLayer
+    from openeat.modules.decoder_layer import DecoderLayer
+    from openeat.modules.positionwise_feed_forward import PositionwiseFeedForward
+    from openeat.modules.subsampling import Conv2dSubsampling6, Conv2dSubsampling8, LinearNoSubsampling
+    classes = [ASRModel, TransformerEncoder, Encoder, BiTransformerDecoder, TransformerDecoder, Decoder, MultiHeadedAttention,
+               RelPositionMultiHeadedAttention, EncoderLayer, DecoderLayer, ConvolutionModule, PositionwiseFeedForward, CTC,
+               LabelSmoothingLoss, Conv2dSubsampling4, Conv2dSubsampling6, Conv2dSubsampling8, LinearNoSubsampling,
+               PositionalEncoding, RelPositionalEncoding, GlobalCMVN, Swish]
+    out = {}
+    for c in classes:
+        methods = {}
+        for name, fn in inspect.getmembers(c, predicate=inspect.isfunction):
+            if not fn.__module__.startswith("openeat."):
+                continue                                   # torch.nn.Module's own methods
+            if name.startswith("_") and name != "__init__":
+                continue
+            params = []
+            for pn, pv in inspect.signature(fn).parameters.items():
+                d = pv.default
+                params.append([pn, None if d is inspect.Parameter.empty else repr(d)])
+            methods[name] = params
+        out[c.__module__ + "." + c.__name__] = methods
+    with open(os.path.join(HERE, "f22_api_signatures.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("f22_api_signatures:", sum(len(m) for m in out.values()), "methods of", len(out), "classes")
+
+
 def f13_misc():
     p = torch.nn.Parameter(torch.zeros(1))
     opt = torch.optim.Adam([p], lr=1e-3)
@@ -514,3 +563,4 @@ if __name__ == "__main__":
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
         f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations(); f20_e2e_adapters(); f21_encoder_conv2d6()
+        f22_api_signatures(); f23_e2e_nonzero_accuracy()

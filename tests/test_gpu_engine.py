@@ -324,3 +324,72 @@ def test_feature_dither_on_device_distribution():
         assert abs(float(v.mean())) < a * 0.01 and abs(float(v.var()) - a * a / 12) < a * a / 12 * 0.03
         assert bool((y[b, n:] == 0).all())
     assert not torch.equal(y[0, :333], y[2, :333])
+
+
+def test_gradient_accumulation_matches_reference_loop():
+    """TrainEngine(accum_grad=2): two micro-steps, ONE optimizer step whose gradient is the sum of the two micro-batch
+    gradients of loss / 2 (executor.py:42-63) - checked against the CPU oracle doing exactly that with torch Adam; then a
+    second accumulated step.  Between the boundaries nothing is exchanged, clipped or applied."""
+    model = tiny(seed=21).to(DEV).train()
+    sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batches = [batch_of(seed=30 + i) for i in range(4)]
+    eng = TrainEngine(model, lr=1e-3, grad_clip=5.0, accum_grad=2)
+    try:
+        before = eng.arena.flat.clone()
+        l0, _ = eng.step(batches[0])
+        assert torch.equal(eng.arena.flat, before), "a non-boundary micro-step must not move the parameters"
+        assert float(eng.optimizer.step_state[0]) == 0.0
+        l1, _ = eng.step(batches[1])
+        assert float(eng.optimizer.step_state[0]) == 1.0 and not torch.equal(eng.arena.flat, before)
+        l2, _ = eng.step(batches[2])
+        l3, _ = eng.step(batches[3])
+        torch.cuda.synchronize()
+        assert float(eng.optimizer.step_state[0]) == 2.0
+        with pytest.raises(NotImplementedError):
+            eng.capture(batches[0])
+    finally:
+        eng.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    cfg = O.Config(input_size=80, vocab_size=40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1,
+                   d_model=32, attention_heads=4, linear_units=64, dropout_rate=0.0, ctc_weight=0.3, lsm_weight=0.1,
+                   reverse_weight=0.3)
+    sd = {k: v.clone().requires_grad_() for k, v in sd0.items()}
+    opt = torch.optim.Adam(list(sd.values()), lr=1e-3)
+    ref = []
+    for i, b in enumerate(batches):
+        cb = {k: v.cpu() for k, v in b.items()}
+        if i % 2 == 0:
+            opt.zero_grad()
+        l, _ = O.forward(sd, cfg, cb["features"], cb["features_length"], cb["targets"], cb["targets_length"])
+        (l / 2).backward()
+        ref.append(float(l) / 2)
+        if i % 2 == 1:
+            torch.nn.utils.clip_grad_norm_(list(sd.values()), 5.0)
+            opt.step()
+    for got, want in zip((l0, l1, l2, l3), ref):
+        assert abs(float(got) - want) < 5e-4 * abs(want), (float(got), want)
+    check_updates(model.state_dict(), sd, sd0, steps=2)
+
+
+def test_eager_step_beside_a_captured_graph_uses_the_current_learning_rate():
+    """After capture(), an eager step with a new lr must apply that lr (not the one the last replay left on the device),
+    and a replay without an lr argument must apply the optimizer's current one."""
+    m = tiny(seed=23).to(DEV).train()
+    b = batch_of(seed=5)
+    e = TrainEngine(m, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    try:
+        e.capture(b, warmup=1)
+        e.replay(lr=1e-3)
+        p0 = e.arena.flat.clone()
+        e.step(b, lr=0.0)                                   # eager, lr 0: parameters must stay put
+        torch.cuda.synchronize()
+        assert torch.equal(e.arena.flat, p0)
+        e.replay()                                          # lr is still 0 in param_groups
+        torch.cuda.synchronize()
+        assert torch.equal(e.arena.flat, p0)
+        e.replay(lr=1e-3)
+        torch.cuda.synchronize()
+        assert not torch.equal(e.arena.flat, p0)
+    finally:
+        e.arena.deactivate()
+        ops.set_seed_device_counter(None)

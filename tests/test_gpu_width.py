@@ -1,0 +1,96 @@
+"""GPU: the WHOLE model at the benchmarked width against the CPU oracle - BASELINE.json configs[1]'s 12-layer Conformer
+(d=256, h=4, ff=1024, K=15, 12+3+3, V=3246), dropout 0, on bench.py's synthetic batch (uniform-noise wav through the
+device fbank) with ragged utterance lengths, ragged target lengths and one short utterance.  At this width the GEMMs run
+the interior 128x128 / 64x64 straight-line tiles, the LDS-DMA ring and the split-K paths that bench.py times - the d=32
+goldens only reach the bounds-checked edge tiles.
+
+Run in both arithmetic modes: precision 0 (exact-fp32 matrix products) and precision 3 (bf16x3 on the matrix cores, the
+mode bench.py reports).  Tolerances: loss rtol 2e-4; every parameter-gradient norm within 3e-3
+relative (floor 1e-6 absolute: Adam-irrelevant parameters such as the key bias have true gradient ~0); CTC-greedy token
+ids identical to the oracle's on every utterance.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from openeat_amd.frontend import Fbank, utt_normalize_  # noqa: E402
+from openeat_amd.models.asr_model import ASRModel  # noqa: E402
+from oracle import asr as O  # noqa: E402
+
+DEV = "cuda"
+V = 3246
+CONF = dict(encoder_num_blocks=12, decoder_num_blocks=3, r_decoder_num_blocks=3, d_model=256, attention_heads=4,
+            linear_units=1024, dropout_rate=0.0, input_layer="conv2d", pos_enc_layer_type="rel_pos", activation_type="swish",
+            macaron_style=True, use_cnn_module=True, cnn_module_kernel=15, causal=False, ctc_weight=0.3, lsm_weight=0.1,
+            reverse_weight=0.3, length_normalized_loss=False)
+SECONDS = [10.0, 9.4, 8.7, 7.5, 6.2, 5.6, 10.0, 1.5]            # ragged; the last one is the short utterance
+TLENS = [30, 27, 25, 22, 18, 16, 30, 4]
+
+_CACHE = {}
+
+
+def _setup():
+    if _CACHE:
+        return _CACHE
+    torch.manual_seed(777)
+    model = ASRModel(80, V, **CONF)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    B = len(SECONDS)
+    ns = torch.tensor([int(16000 * s) for s in SECONDS])
+    wav = torch.rand(B, int(ns.max()), generator=g) - 0.5       # bench.py::synth_batch
+    tgt = torch.full((B, max(TLENS)), -1, dtype=torch.int32)
+    for b in range(B):
+        wav[b, int(ns[b]):] = 0.0
+        tgt[b, : TLENS[b]] = torch.randint(2, V - 1, (TLENS[b],), generator=g, dtype=torch.int32)
+    tlen = torch.tensor(TLENS, dtype=torch.int32)
+    feats, nfr = Fbank(80, device=DEV)(wav.to(DEV), ns.to(DEV))
+    utt_normalize_(feats, nfr)
+    torch.cuda.synchronize()
+    assert nfr.tolist()[0] == 998 and nfr.tolist()[-1] == 148
+    # the oracle on the same features (CPU, a few seconds)
+    cfg = O.Config(input_size=80, vocab_size=V, **CONF)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    loss, acc = O.forward(osd, cfg, feats.cpu(), nfr.cpu(), tgt, tlen)
+    loss.backward()
+    greedy = O.ctc_greedy_search({k: v.detach() for k, v in osd.items()}, cfg, feats.cpu(), nfr.cpu())
+    _CACHE.update(sd=sd, feats=feats, nfr=nfr, tgt=tgt, tlen=tlen, loss=float(loss), acc=float(acc), greedy=greedy,
+                  gnorm={k: float(v.grad.norm()) for k, v in osd.items() if v.grad is not None},
+                  gctc=osd["ctc.ctc_lo.weight"].grad.clone(), gemb=osd["encoder.embed.conv.0.weight"].grad.clone())
+    return _CACHE
+
+
+@pytest.mark.parametrize("prec", [0, 3], ids=["fp32-mfma", "bf16x3-mfma"])
+def test_config2_width_model_matches_oracle(prec):
+    from openeat_amd import hip
+    c = _setup()
+    model = ASRModel(80, V, **CONF)
+    model.load_state_dict(c["sd"])
+    model = model.to(DEV).eval()
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = prec
+    try:
+        loss, acc = model(c["feats"], c["nfr"], c["tgt"].to(DEV), c["tlen"].to(DEV))
+        loss.backward()
+        with torch.no_grad():
+            greedy = model.ctc_greedy_search(c["feats"], c["nfr"])
+        torch.cuda.synchronize()
+    finally:
+        hip.GEMM_PRECISION = old
+    assert abs(float(loss) - c["loss"]) <= 2e-4 * abs(c["loss"]), (float(loss), c["loss"])
+    assert abs(float(acc) - c["acc"]) <= 1e-6
+    bad = []
+    for k, p in model.named_parameters():
+        want = c["gnorm"][k]
+        got = float(p.grad.norm())
+        if abs(got - want) > 3e-3 * abs(want) + 1e-6:
+            bad.append((k, got, want))
+    assert not bad, bad[:10]
+    # element-wise on the two ends of the network: the last layer's weight gradient and the first conv's
+    for key, ref in (("ctc.ctc_lo.weight", c["gctc"]), ("encoder.embed.conv.0.weight", c["gemb"])):
+        got = dict(model.named_parameters())[key].grad.cpu()
+        assert float((got - ref).abs().max()) <= 3e-3 * float(ref.abs().max()), key
+    assert greedy == c["greedy"]                                   # bit-exact CTC-greedy ids on all 8 utterances
+    assert sum(len(h) for h in greedy) > 0

@@ -172,3 +172,45 @@ def test_native_prefix_beam_search_batch_matches_per_utterance_and_oracle():
         for (_, a), (_, w) in zip(got[b], want):
             assert abs(a - w) <= 1e-12 * max(1.0, abs(w))
     assert max(len(p) for p, _ in got[0]) > 20
+
+
+def test_public_method_surface_matches_reference_f22():
+    """Every public method of the reference's hot-path classes (tests/golden/f22_api_signatures.json, written by
+    make_fixtures.py from inspect.signature of the reference) exists here under the same import path, takes the
+    reference's parameters in the reference's order with the reference's defaults; parameters added here (fused
+    residual / dropout hooks) come after them and are optional."""
+    import importlib
+    import inspect
+    ref = load_golden_json("f22_api_signatures")
+    assert len(ref) >= 20
+    problems = []
+    for qual, methods in ref.items():
+        mod, cls = qual.rsplit(".", 1)
+        ours = getattr(importlib.import_module(mod), cls)                  # `openeat.*` is the alias package of the boundary
+        for name, params in methods.items():
+            fn = getattr(ours, name, None)
+            if fn is None:
+                problems.append(f"{qual}.{name}: missing")
+                continue
+            mine = list(inspect.signature(fn).parameters.items())
+            if any(p.kind is inspect.Parameter.VAR_POSITIONAL or p.kind is inspect.Parameter.VAR_KEYWORD for _, p in mine):
+                continue                                                   # **kwargs pass-through keeps the call contract
+            for i, (pn, default) in enumerate(params):
+                if i >= len(mine) or mine[i][0] != pn:
+                    problems.append(f"{qual}.{name}: parameter {i} is {mine[i][0] if i < len(mine) else None!r}, reference has {pn!r}")
+                    break
+                d = mine[i][1].default
+                got = None if d is inspect.Parameter.empty else repr(d)
+                if got != default:
+                    problems.append(f"{qual}.{name}({pn}): default {got}, reference {default}")
+            for pn, p in mine[len(params):]:
+                if p.default is inspect.Parameter.empty:
+                    problems.append(f"{qual}.{name}: extra required parameter {pn!r}")
+    assert not problems, "\n".join(problems)
+
+
+def test_no_pos_fails_like_the_reference():
+    """encoder.py:165-166 selects NoPositionalEncoding, a name the reference never defines: NameError there and here."""
+    from openeat_amd.modules.encoder import TransformerEncoder
+    with pytest.raises(NameError):
+        TransformerEncoder(80, pos_enc_layer_type="no_pos", d_model=16, attention_heads=4, linear_units=32, num_blocks=1)
