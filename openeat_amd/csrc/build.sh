@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function -ff
 pids=()
 for f in *.hip; do
   o=obj/${f%.hip}.o
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ oe_common.h -nt "$o" ] || [ gemm_common.h -nt "$o" ] || [ ../../include/openeat_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ oe_common.h -nt "$o" ] || [ gemm_common.h -nt "$o" ] || [ attn_common.h -nt "$o" ] || [ ../../include/openeat_hip.h -nt "$o" ]; then
     echo "hipcc $f"
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)

@@ -45,6 +45,15 @@ def ref_attention(q, k, v, mask, keybias, scale):
     (3, 4, 9, 9, 16, "full", False),
     (1, 4, 130, 130, 64, "none", False),
     (2, 4, 40, 40, 36, "key", True),
+    # the LDS-plane kernels (attention_bf16.hip: resident axis > 64 rows, precision 1 / 3): several 64-row chunks, ragged last
+    # chunk and tile, waves without rows, a short streamed axis against a long resident one and vice versa, D < 64 padded
+    (2, 4, 248, 248, 64, "key", True),
+    (1, 2, 398, 398, 64, "key", True),
+    (2, 2, 200, 31, 64, "key", False),
+    (2, 2, 31, 200, 64, "key", True),
+    (1, 2, 97, 97, 8, "full", False),
+    (2, 2, 129, 70, 32, "key", True),
+    (1, 2, 150, 150, 40, "none", False),
 ])
 @pytest.mark.parametrize("prec", [0, 3, 1])
 def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias, prec):
@@ -124,7 +133,8 @@ def test_attention_fully_masked_rows_give_zeros():
     assert torch.all(out[1] == 0) and torch.isfinite(out[0]).all()
 
 
-@pytest.mark.parametrize("T1,T2,prec", [(32, 32, 0), (70, 40, 3), (33, 96, 3), (20, 13, 0), (45, 45, 3)])
+@pytest.mark.parametrize("T1,T2,prec", [(32, 32, 0), (70, 40, 3), (33, 96, 3), (20, 13, 0), (45, 45, 3),
+                                        (136, 136, 3), (100, 75, 3), (40, 160, 3), (130, 96, 1)])
 def test_attention_dropout_consistency(T1, T2, prec):
     """Dropout in the attention weights.  The kernel's own mask is recovered from a V = identity probe; then
     forward == (mask/keep * softmax) V and the three backward kernels agree with autograd through that mask.

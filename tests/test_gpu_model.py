@@ -46,6 +46,12 @@ def load_into(module, sd, prefix):
 
 
 def close(a, b, rtol=1e-4, atol=5e-5, msg=""):
+    """precision 0: as given.  precision 3: a sum of K bf16x3 products carries ~2^-17 x sum|a_k||b_k|, i.e. an error
+    relative to the magnitudes that went INTO the sum, not to a (possibly cancelled) result: the absolute floor is tied to
+    the tensor's scale, 2e-5 x max|reference| (conv outputs of magnitude ~100 are off by up to ~1e-3 there)."""
+    from openeat_amd import hip
+    if hip.GEMM_PRECISION == 3 and b.numel() > 0 and b.is_floating_point():
+        atol = max(atol, 2e-5 * float(b.abs().max()))
     torch.testing.assert_close(a.detach().cpu(), b, rtol=rtol, atol=atol, msg=lambda m: f"{msg}: {m}")
 
 
@@ -349,8 +355,12 @@ def test_batched_rescoring_equals_per_utterance_rescoring():
 
 
 def test_batched_rescoring_on_ragged_batch_equals_per_utterance_rescoring():
-    """The real config-4/5 case: utterances of different lengths in one padded batch (padded frames, ragged encoder
-    masks, ragged n-best lengths) - every utterance's pick equals the one-utterance API on its own unpadded frames."""
+    """The real config-4/5 case: utterances of different lengths in one padded batch (zero-padded frames, ragged encoder
+    masks, ragged n-best lengths).  The batch's own length arithmetic - the mask subsampling of subsampling.py:116 - counts
+    c_b encoder frames for an utterance of n_b input frames, usually one more than the ((n_b-1)//2-1)//2 the utterance alone
+    would produce: the extra frame's conv window hangs over into the zero padding.  The one-utterance API (the reference's
+    B == 1 algorithm, itself pinned by the F11/F12 goldens) therefore gets each utterance zero-padded to the 4 c_b + 3
+    frames that yield exactly those c_b encoder frames - then the picks must be identical."""
     g = load_golden("f12_tiny_conformer")
     meta = load_golden_json("f12_tiny_conformer")
     model = ASRModel(80, meta["V"], **meta["kwargs"])
@@ -363,10 +373,18 @@ def test_batched_rescoring_on_ragged_batch_equals_per_utterance_rescoring():
         feats[b, n:] = 0.0
     flen = torch.tensor(lens, dtype=torch.int32, device=DEV)
     tok2chr = {t: str(t) for t in range(meta["V"])}
+    from openeat_amd.utils.mask import make_pad_mask
+    enc_frames = (~make_pad_mask(flen.cpu(), max(lens))).unsqueeze(1)[:, :, :-2:2][:, :, :-2:2].sum(-1).view(-1).tolist()
+    assert enc_frames != [((n - 1) // 2 - 1) // 2 for n in lens]              # the over-count is really exercised
     with torch.no_grad():
         batch = model.attention_rescoring_batch(feats, flen, 4, ctc_weight=0.5, reverse_weight=0.3)
-        single = [list(model.attention_rescoring(feats[b:b + 1, :n].contiguous(), flen[b:b + 1], 4, ctc_weight=0.5,
-                                                 reverse_weight=0.3, token2char=tok2chr)[0]) for b, n in enumerate(lens)]
+        single = []
+        for b, (n, c) in enumerate(zip(lens, enc_frames)):
+            m = 4 * c + 3
+            x = torch.zeros(1, m, 80, device=DEV)
+            x[0, : min(n, m)] = feats[b, : min(n, m)]
+            ml = torch.tensor([m], dtype=torch.int32, device=DEV)
+            single.append(list(model.attention_rescoring(x, ml, 4, ctc_weight=0.5, reverse_weight=0.3, token2char=tok2chr)[0]))
     assert batch == single
     assert len({len(h) for h in single}) > 1
 
