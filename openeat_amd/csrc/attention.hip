@@ -241,8 +241,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[t][r] = 0.f;
     const DropParams dpar = drop_params(p.drop_p);
-    const bool drop_aligned = (p.T2 % 8) == 0;
-    const unsigned long long drop_rowbase = ((unsigned long long)(bh * p.T1 + (q_ok ? qi : 0))) * p.T2;
+    const unsigned long long drop_row = (unsigned long long)(bh * p.T1 + (q_ok ? qi : 0));        // attn_common.h: mask definition
     const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
     // a (B,1,T2) key mask is the same for every query: fold it into the staged per-key bias;
     // only a full (B,T1,T2) mask (decoder self-attention) is read per (query, key)
@@ -330,7 +329,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
                 for (int r = 0; r < 16; ++r) oacc[t][r] *= corr;
             if (p.drop_p > 0.f) {
                 float dm[16];
-                drop_tile_qlane(seed_eff, drop_rowbase, j0, lk, drop_aligned, dpar, dm);
+                attn_drop_qlane(seed_eff, drop_row, j0, lk, dpar, dm);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) pr[r] *= dm[r];
             }
@@ -380,7 +379,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(At
             float dmask[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dmask[r] = 1.f;
-            if (p.drop_p > 0.f) drop_tile_qlane(seed_eff, drop_rowbase, j0, lk, drop_aligned, dpar, dmask);
+            if (p.drop_p > 0.f) attn_drop_qlane(seed_eff, drop_row, j0, lk, dpar, dmask);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = (pr[r] == NEG_INF) ? 0.f : __expf(pr[r] - lse_i);
@@ -535,7 +534,6 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
         for (int r = 0; r < 16; ++r) { dkacc[t][r] = 0.f; dvacc[t][r] = 0.f; }
     float dbias = 0.f;
     const DropParams dpar = drop_params(p.drop_p);
-    const bool drop_aligned = (p.T2 % 8) == 0;
     const unsigned long long seed_eff = eff_seed(p.seed, p.seed_dev);
 
     // this group's share of the query tiles; tiles past T1 contribute nothing (ok = false for every element)
@@ -582,28 +580,7 @@ __global__ __launch_bounds__(ATT_GROUP * SPLIT) void attn_ktile_bwd_kernel(AttnP
         float pd[16], ds[16], dsc[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dsc[r] = 1.f;
-        if (p.drop_p > 0.f) {
-            if (drop_aligned) {
-                // the 8 lanes of a key block share 16 calls (one per query row of the tile): lane c computes rows c, c + 8
-                const int c = lj & 7;
-                const unsigned long long kblk = (unsigned long long)(k0 + (lj & ~7));
-                const unsigned long long rowa = (unsigned long long)(bh * p.T1 + min(i0 + acc_row(c, lk), p.T1 - 1)) * p.T2;
-                const unsigned long long rowb = (unsigned long long)(bh * p.T1 + min(i0 + acc_row(c + 8, lk), p.T1 - 1)) * p.T2;
-                const uint4 wa = philox4(seed_eff, (rowa + kblk) >> 3), wb = philox4(seed_eff, (rowb + kblk) >> 3);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int src = (lane & ~7) | (r & 7);
-                    const uint4 ws = (r < 8) ? wa : wb;
-                    const unsigned x0 = __shfl(ws.x, src, 64), x1 = __shfl(ws.y, src, 64), x2 = __shfl(ws.z, src, 64), x3 = __shfl(ws.w, src, 64);
-                    const unsigned w = (c >> 1) == 0 ? x0 : (c >> 1) == 1 ? x1 : (c >> 1) == 2 ? x2 : x3;
-                    dsc[r] = drop_field(w, c & 1, dpar);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    dsc[r] = drop_elem(seed_eff, ((unsigned long long)(bh * p.T1 + min(i0 + acc_row(r, lk), p.T1 - 1))) * p.T2 + min(kj, p.T2 - 1), dpar);
-            }
-        }
+        if (p.drop_p > 0.f) attn_drop_klane(seed_eff, (unsigned long long)(bh * p.T1), i0, kj, lk, dpar, dsc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int qr = acc_row(r, lk);

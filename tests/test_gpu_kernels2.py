@@ -98,7 +98,10 @@ def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias, prec):
                       o_strides=(T1 * d, d), mask=md, mask_strides=mstr, keybias=kbd, precision=prec)
     hip.attention_fwd(a)
     sync()
-    torch.testing.assert_close(out.cpu(), out_ref.detach(), **(TOL if prec != 1 else dict(rtol=3e-2, atol=3e-2)))
+    # precision 3: ~2^-17 per product on sums of T2 terms of magnitude |p||v| - the floor grows with the values summed, not
+    # with the (cancelled) result: 4e-5 covers T2 = 398 at |v| ~ 4
+    tol_fwd = TOL if prec == 0 else dict(rtol=2e-4, atol=4e-5) if prec == 3 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(out.cpu(), out_ref.detach(), **tol_fwd)
 
     wd = cu(w)
     dkb = torch.empty(B, H, T2, device=DEV) if bias else None
@@ -108,7 +111,8 @@ def test_attention_fwd_bwd(B, H, T1, T2, D, mask_kind, bias, prec):
                        dkeybias=dkb, delta=delta, precision=prec)
     hip.attention_bwd(a2)
     sync()
-    g = dict(rtol=5e-4, atol=5e-5) if prec != 1 else dict(rtol=5e-2, atol=8e-2)
+    # (precision 3: sums over up to 398 queries / keys of ~2^-17-accurate products: absolute floor 1e-4, see tol_fwd)
+    g = dict(rtol=5e-4, atol=5e-5) if prec == 0 else dict(rtol=5e-4, atol=1e-4) if prec == 3 else dict(rtol=5e-2, atol=8e-2)
     torch.testing.assert_close(dqd.cpu().reshape(B, T1, H, D), q.grad, **g)
     torch.testing.assert_close(dkd.cpu().reshape(B, T2, H, D), k.grad, **g)
     torch.testing.assert_close(dvd.cpu().reshape(B, T2, H, D), v.grad, **g)
@@ -138,8 +142,9 @@ def test_attention_fully_masked_rows_give_zeros():
 def test_attention_dropout_consistency(T1, T2, prec):
     """Dropout in the attention weights.  The kernel's own mask is recovered from a V = identity probe; then
     forward == (mask/keep * softmax) V and the three backward kernels agree with autograd through that mask.
-    T2 % 8 == 0 takes the path where lanes share Philox calls (forward/dQ: pairs, dK/dV: groups of eight), any other
-    T2 the per-element path; both must describe the same mask in all three kernels."""
+    The mask is a hash of (row, key quad) (attn_common.h): forward / dQ draw it per lane, dK/dV shares it across the four
+    lanes of a key quad by DPP broadcasts; both kernel families (attention.hip for short resident axes, attention_bf16.hip
+    for long ones - some cases here mix them) must describe the same mask in all three kernels."""
     torch.manual_seed(13)
     B, H, D = 2, 2, 32
     p_drop = 0.25
@@ -181,7 +186,7 @@ def test_attention_dropout_consistency(T1, T2, prec):
     hip.attention_fwd(a)
     hip.attention_bwd(a)
     sync()
-    g = dict(rtol=1e-3, atol=1e-4)
+    g = dict(rtol=1e-3, atol=1e-4) if prec != 1 else dict(rtol=5e-2, atol=8e-2)
     torch.testing.assert_close(out.cpu(), ref.detach(), **g)
     torch.testing.assert_close(dv.cpu(), v.grad, **g)
     torch.testing.assert_close(dq.cpu(), q.grad, **g)

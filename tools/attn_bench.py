@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Attention forward / backward kernels alone at the config-2 encoder shape (B=32, H=4, T=248, D=64, dropout 0.1, key mask,
 key bias) and at the north-star shape (B=64, T=398): median HIP-event time per launch, for the LDS-plane kernels
-(attention_bf16.hip) and the first-generation kernels (attention.hip, OE_ATTN_PLANES=0) in ONE process, interleaved.
+(attention_bf16.hip) and the first-generation kernels (attention.hip, OE_ATTN_PLANES=0), one child process per arm
+(the dispatch switch is read once per process).  OE_BENCH_DROP overrides the dropout rate 0.1.
 
     python tools/attn_bench.py [precision] [B T]
 Run under rocprofv3 --kernel-trace for the per-kernel split."""
@@ -26,7 +27,7 @@ def run(prec, B, T, H=4, D=64):
     mask[:, :, T - 18:] = 0
     kbias, dkb = torch.randn(B, H, T, device=dev), torch.empty(B, H, T, device=dev)
     st = (T * H * D, H * D)
-    kw = dict(q_strides=st, k_strides=st, v_strides=st, o_strides=st, mask=mask, mask_strides=(T, 0), keybias=kbias, drop_p=0.1, seed=1,
+    kw = dict(q_strides=st, k_strides=st, v_strides=st, o_strides=st, mask=mask, mask_strides=(T, 0), keybias=kbias, drop_p=float(os.environ.get("OE_BENCH_DROP", "0.1")), seed=1,
               precision=prec)
     af = hip.attn_args(q, k, v, out, lse, B, H, T, T, D, 1 / math.sqrt(D), **kw)
     ab = hip.attn_args(q, k, v, out, lse, B, H, T, T, D, 1 / math.sqrt(D), d_out=do, dq=dq, dk=dk, dv=dv, dkeybias=dkb, delta=delta, **kw)

@@ -22,9 +22,22 @@ lse = torch.empty(B, H, T, device="cuda")
 st = (T * H * D, H * D)
 a = hip.attn_args(q, k, v, out, lse, B, H, T, T, D, 1 / math.sqrt(D), q_strides=st, k_strides=st, v_strides=st, o_strides=st,
                   drop_p=0.1, seed=1, precision=prec)
+planes = hasattr(lib, "oe_debug_set_attn_planes_stamp_buffer") and os.environ.get("OE_ATTN_PLANES", "1") != "0"
+if planes:
+    buf2 = torch.zeros(32 * 4 * 12, dtype=torch.int64, device="cuda")
+    assert lib.oe_debug_set_attn_planes_stamp_buffer(C.c_void_p(buf2.data_ptr())) == 0
 for _ in range(3):
     hip.attention_fwd(a)
 torch.cuda.synchronize()
+if planes:
+    s2 = buf2.view(128, 12).cpu().double()
+    names2 = ["Q fragments + first prefetch issue", "first chunk lands + written + barrier", "prefetch issue", "K row frags + S MFMA issue",
+              "softmax (+ S wait) + O rescale", "dropout", "P split + V col frags + PV MFMA issue", "MFMA drain", "commit next chunk",
+              "barrier", "total"]
+    med2 = s2.median(0).values
+    for n, m in zip(names2, med2):
+        print(f"{n:40s} {m:9.0f} cycles ({100 * m / med2[10]:5.1f} %)")
+    sys.exit(0)
 s = buf.view(128, 8).cpu().double()
 names = ["prologue", "wait barrier 1", "tile store + barrier 2", "prefetch issue", "S frags + MFMA issue", "softmax (+S wait)",
          "dropout + PV issue + loop tail", "total"]
