@@ -51,19 +51,8 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 // epilogues costs 40 quarter-rate 32-bit multiplies for eight).  One hash serves the four consecutive keys a lane of the
 // forward / dQ kernels holds per accumulator group; in dK/dV (lane = key, registers = queries) the four lanes of a key
 // quad compute four of the sixteen query rows each and pass the words round with DPP quad broadcasts.
-__device__ __forceinline__ unsigned rotl32(unsigned x, int k) { return (x << k) | (x >> (32 - k)); }
 __device__ __forceinline__ uint2 attn_drop_hash(unsigned long long seed, unsigned long long row, unsigned quad) {
-    unsigned a = (unsigned)row ^ (unsigned)seed;
-    unsigned b = quad ^ (unsigned)(seed >> 32);
-    unsigned c = (unsigned)(row >> 32) + 0xdeadbeefu + (unsigned)seed;
-    c ^= b; c -= rotl32(b, 14);
-    a ^= c; a -= rotl32(c, 11);
-    b ^= a; b -= rotl32(a, 25);
-    c ^= b; c -= rotl32(b, 16);
-    a ^= c; a -= rotl32(c, 4);
-    b ^= a; b -= rotl32(a, 14);
-    c ^= b; c -= rotl32(b, 24);
-    return make_uint2(b, c);                     // fields 0, 1 = low / high half of .x; fields 2, 3 = of .y
+    return drop_hash4(seed ^ ((unsigned long long)quad << 32), row);          // oe_common.h: the lookup3 final() mix
 }
 __device__ __forceinline__ float attn_drop_scale(const uint2& h, int field, const DropParams& d) {
     const unsigned w = (field & 2) ? h.y : h.x;

@@ -335,7 +335,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                         // calls of passes 0 and 2, the odd lane those of passes 1 and 3, and they swap the other half
                         const int odd = lane & 1;
                         const unsigned long long b0 = (e0 - 4 * odd) + (unsigned long long)(8 * odd) * N;     // block of pass `odd`
-                        const uint4 ca = philox4(seed, b0 >> 3), cb = philox4(seed, (b0 + (unsigned long long)16 * N) >> 3);
+                        const uint4 ca = drop_words8(seed, b0 >> 3), cb = drop_words8(seed, (b0 + (unsigned long long)16 * N) >> 3);
                         const unsigned r0 = __shfl_xor(odd ? ca.x : ca.z, 1, 64), r1 = __shfl_xor(odd ? ca.y : ca.w, 1, 64);
                         const unsigned r2 = __shfl_xor(odd ? cb.x : cb.z, 1, 64), r3 = __shfl_xor(odd ? cb.y : cb.w, 1, 64);
                         unsigned w[4][2];                                   // [pass][word of this lane's half]

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                             const unsigned long long e0 = (unsigned long long)grow * d + 4 * i;
                             float4 gq = make_float4(o.x * g_alpha, o.y * g_alpha, o.z * g_alpha, o.w * g_alpha);
                             if (g_p > 0.f) {
-                                const uint4 r = philox4(g_seed_eff, e0 >> 3);
+                                const uint4 r = drop_words8(g_seed_eff, e0 >> 3);
                                 const bool hi = (e0 >> 2) & 1;                 // second half of the call's eight fields
                                 const unsigned wa = hi ? r.z : r.x, wb = hi ? r.w : r.y;
                                 gq.x *= drop_field(wa, 0, g_dpar); gq.y *= drop_field(wa, 1, g_dpar);

@@ -57,9 +57,8 @@ __device__ __forceinline__ void wave_lse(float& m, float& s) {
     }
 }
 
-// ---- counter-based RNG for dropout (Philox-4x32-10) -------------------------
-// One call yields 4 uniform 32-bit words for (seed, counter); masks are
-// regenerated in backward from the same (seed, element index), never stored.
+// ---- counter-based RNG (Philox-4x32-10): feature-dither noise (augment.hip) ----
+// One call yields 4 uniform 32-bit words for (seed, counter).
 __device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
     uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
     uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0x9E3779B9u, c3 = 0xBB67AE85u;
@@ -76,11 +75,33 @@ __device__ __forceinline__ uint4 philox4(uint64_t seed, uint64_t ctr) {
     }
     return make_uint4(c0, c1, c2, c3);
 }
-// Dropout masks.  Element idx of the tensor a mask applies to belongs to Philox call idx >> 3, which yields eight
-// 16-bit fields for the eight consecutive elements of its block; the element is kept iff field (idx & 7) >= thr with
-// thr = round(p * 65536), and kept values are scaled by 65536 / (65536 - thr) - the exact inverse of the realised
-// keep probability (p = 0.1 -> 0.100006).  One call serves eight elements: consumers that hold fewer (a float4 per
-// lane in the GEMM epilogue, four keys per lane in attention) share calls between neighbouring lanes.
+// Dropout masks.  Element idx of the tensor a mask applies to takes the 16-bit field (idx & 3) of the 64-bit hash of
+// (seed, idx >> 2); it is kept iff field >= thr with thr = round(p * 65536), and kept values are scaled by
+// 65536 / (65536 - thr) - the exact inverse of the realised keep probability (p = 0.1 -> 0.100006).  The hash is the
+// final() mix of Bob Jenkins' lookup3 (public domain): add / xor / rotate only, 21 full-rate instructions for four
+// elements.  (The first version drew Philox-4x32-10: 40 quarter-rate 32-bit multiplies per call - in-kernel stamps put
+// the generator at 20 % of the attention forward and ~5 us of every GEMM with a dropout epilogue.  Philox stays for the
+// feature-dither noise, augment.hip.)  Masks are regenerated in backward from the same (seed, element index), never
+// stored.  drop_words8(seed, i) packs the two hashes of the aligned block of eight elements 8i..8i+7 as
+// {fields 0,1 | 2,3 | 4,5 | 6,7} for consumers that share an eight-element block between neighbouring lanes.
+__device__ __forceinline__ unsigned oe_rotl32(unsigned x, int k) { return (x << k) | (x >> (32 - k)); }
+__device__ __forceinline__ uint2 drop_hash4(uint64_t seed, uint64_t quad) {
+    unsigned a = (unsigned)quad ^ (unsigned)seed;
+    unsigned b = (unsigned)(quad >> 32) ^ (unsigned)(seed >> 32);
+    unsigned c = 0xdeadbeefu + (unsigned)seed;
+    c ^= b; c -= oe_rotl32(b, 14);
+    a ^= c; a -= oe_rotl32(c, 11);
+    b ^= a; b -= oe_rotl32(a, 25);
+    c ^= b; c -= oe_rotl32(b, 16);
+    a ^= c; a -= oe_rotl32(c, 4);
+    b ^= a; b -= oe_rotl32(a, 14);
+    c ^= b; c -= oe_rotl32(b, 24);
+    return make_uint2(b, c);                     // fields 0, 1 = low / high half of .x; fields 2, 3 = of .y
+}
+__device__ __forceinline__ uint4 drop_words8(uint64_t seed, uint64_t idx8) {
+    const uint2 h0 = drop_hash4(seed, 2 * idx8), h1 = drop_hash4(seed, 2 * idx8 + 1);
+    return make_uint4(h0.x, h0.y, h1.x, h1.y);
+}
 struct DropParams { unsigned thr; float inv_keep; };
 __device__ __forceinline__ DropParams drop_params(float p) {
     DropParams d;
@@ -91,16 +112,14 @@ __device__ __forceinline__ DropParams drop_params(float p) {
 __device__ __forceinline__ float drop_field(unsigned w, int half, const DropParams& d) {
     return ((w >> (16 * half)) & 0xFFFFu) >= d.thr ? d.inv_keep : 0.f;
 }
-// one element on its own (ragged edges / unaligned rows): a whole call for one field
+// one element on its own (ragged edges / unaligned rows): a whole hash for one field
 __device__ __forceinline__ float drop_elem(unsigned long long seed, unsigned long long idx, const DropParams& d) {
-    const uint4 r = philox4(seed, idx >> 3);
-    const int f = (int)(idx & 7);
-    const unsigned w = (f >> 1) == 0 ? r.x : (f >> 1) == 1 ? r.y : (f >> 1) == 2 ? r.z : r.w;
-    return drop_field(w, f & 1, d);
+    const uint2 h = drop_hash4(seed, idx >> 2);
+    return drop_field((idx & 2) ? h.y : h.x, (int)(idx & 1), d);
 }
-// the eight elements of block idx8 from one call
+// the eight elements of the aligned block idx8
 __device__ __forceinline__ void drop_block8(unsigned long long seed, unsigned long long idx8, const DropParams& d, float (&m)[8]) {
-    const uint4 r = philox4(seed, idx8);
+    const uint4 r = drop_words8(seed, idx8);
     m[0] = drop_field(r.x, 0, d); m[1] = drop_field(r.x, 1, d); m[2] = drop_field(r.y, 0, d); m[3] = drop_field(r.y, 1, d);
     m[4] = drop_field(r.z, 0, d); m[5] = drop_field(r.z, 1, d); m[6] = drop_field(r.w, 0, d); m[7] = drop_field(r.w, 1, d);
 }
