@@ -87,6 +87,37 @@ typedef struct oe_gemm_args {
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);
 
+/* ------------------------------------------------------------------------- *
+ * Position-wise feed forward as one kernel (positionwise_feed_forward.py:36-43 with the caller's residual / dropout of
+ * encoder_layer.py:81-83,104-106, decoder_layer.py:104-106):
+ *     y = residual + beta * drop_out( W2 . drop_in( act( W1 x + b1 ) ) + b2 )
+ * on the bf16 matrix cores (precision 1 or 3, as oe_gemm_args.precision); the (rows, ff) intermediate stays in
+ * registers.  The weights are consumed pre-split and in MFMA-fragment order: oe_ffn_pack_weights writes W1 (ff, d) and
+ * W2 (d, ff) into w1p / w2p (oe_ffn_packed_bytes each) and must be re-run whenever the weights change.
+ * oe_ffn_supported: d in {128, 256}, ff a multiple of 128, act 0 / 1 / 2 (none, relu, swish), precision 1 / 3 - anything
+ * else is the caller's two oe_gemm_f32 launches.  pre_out / act_out (optional, (rows, ff) dense): the pre-activation
+ * W1 x + b1 and the dropped activation, for the backward GEMMs; act_out needs pre_out.  Dropout masks are those of
+ * oe_gemm_f32's epilogue on the same tensors (element index row * ff + col with seed_in, row * d + col with seed_out,
+ * seed_dev mixed in the same way), so oe_gemm_f32 / oe_dropout_scale regenerate them in backward.
+ * All pointers 16-byte aligned, ldx / ldr / ldy multiples of 4.
+ * ------------------------------------------------------------------------- */
+typedef struct oe_ffn_args {
+    const float* x; long ldx;                  /* (rows, d) */
+    const void* w1p; const float* b1;          /* packed W1, bias (ff) or NULL */
+    const void* w2p; const float* b2;          /* packed W2, bias (d) or NULL */
+    int rows, d, ff, act, precision;
+    float drop_in; unsigned long long seed_in;
+    float drop_out; unsigned long long seed_out;
+    const unsigned long long* seed_dev;
+    float* pre_out; float* act_out;
+    const float* residual; long ldr; float beta;
+    float* y; long ldy;
+} oe_ffn_args;
+size_t oe_ffn_packed_bytes(int d, int ff, int precision);
+int oe_ffn_supported(int d, int ff, int precision, int act);
+int oe_ffn_pack_weights(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, void* stream);
+int oe_ffn_fwd(const oe_ffn_args* args, void* stream);
+
 /* column sums: out[n] (+)= alpha * sum_m x[m,n]  - bias gradients of every
  * Linear (autograd of aten::addmm).  alpha_dev optional device scalar. */
 int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const float* alpha_dev,

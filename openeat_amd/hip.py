@@ -72,6 +72,19 @@ class AttnArgs(C.Structure):
     ]
 
 
+class FfnArgs(C.Structure):
+    _fields_ = [
+        ("x", c_fp), ("ldx", C.c_long),
+        ("w1p", c_fp), ("b1", c_fp), ("w2p", c_fp), ("b2", c_fp),
+        ("rows", C.c_int), ("d", C.c_int), ("ff", C.c_int), ("act", C.c_int), ("precision", C.c_int),
+        ("drop_in", C.c_float), ("seed_in", C.c_ulonglong), ("drop_out", C.c_float), ("seed_out", C.c_ulonglong),
+        ("seed_dev", c_fp),
+        ("pre_out", c_fp), ("act_out", c_fp),
+        ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
+        ("y", c_fp), ("ldy", C.c_long),
+    ]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -99,6 +112,10 @@ _SIGNATURES = {
     "oe_last_error": (C.c_char_p, []),
     "oe_abi_version": (I, []),
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
+    "oe_ffn_packed_bytes": (SZ, [I, I, I]),
+    "oe_ffn_supported": (I, [I, I, I, I]),
+    "oe_ffn_pack_weights": (I, [P, P, I, I, I, P, P, P]),
+    "oe_ffn_fwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
@@ -219,6 +236,20 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
         PROFILE.append((e0, e1, 2.0 * m * n * k, (m, n, k, int(a_kmajor), int(b_kmajor), int(conv_gather), int(split_k))))
         return
     check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
+
+
+def ffn_fwd(x2, w1p, b1, w2p, b2, rows, d, ff, act, *, drop_in=0.0, seed_in=0, drop_out=0.0, seed_out=0, seed_dev=None, pre_out=None,
+            act_out=None, residual=None, ldr=0, beta=1.0, y=None, precision=None):
+    a = FfnArgs()
+    dp = lambda t: None if t is None else t.data_ptr()
+    a.x, a.ldx = x2.data_ptr(), x2.stride(0)
+    a.w1p, a.b1, a.w2p, a.b2 = w1p.data_ptr(), dp(b1), w2p.data_ptr(), dp(b2)
+    a.rows, a.d, a.ff, a.act = rows, d, ff, act
+    a.precision = GEMM_PRECISION if precision is None else precision
+    a.drop_in, a.seed_in, a.drop_out, a.seed_out, a.seed_dev = drop_in, seed_in, drop_out, seed_out, dp(seed_dev)
+    a.pre_out, a.act_out, a.residual, a.ldr, a.beta = dp(pre_out), dp(act_out), dp(residual), ldr, beta
+    a.y, a.ldy = y.data_ptr(), y.stride(0)
+    check(lib().oe_ffn_fwd(C.byref(a), stream()), "oe_ffn_fwd")
 
 
 def call(name, *args):

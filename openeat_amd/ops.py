@@ -646,6 +646,30 @@ def global_cmvn(x, mean, istd):
 # --------------------------------------------------------------------------- #
 # Position-wise feed forward (+ optional fused residual / outer dropout)
 # --------------------------------------------------------------------------- #
+# The fused feed-forward kernel (csrc/ffn.hip) consumes the weights pre-split to bf16 planes in MFMA-fragment order.  They
+# are re-packed on every call (~3 us for the two 1 MB matrices): the optimizer moves the weights every step through a raw
+# kernel, which no tensor version counter sees, so a cache could only be trusted for frozen models.
+FUSED_FFN = os.environ.get("OE_FUSED_FFN", "1") == "1"
+
+
+def _ffn_fused_ok(x2, w1, w2, act, res2):
+    d, ff = w1.shape[1], w1.shape[0]
+    if hip.GEMM_PRECISION == 0 or not hip.lib().oe_ffn_supported(d, ff, hip.GEMM_PRECISION, act):
+        return False
+    ok = lambda t: t is None or (t.data_ptr() % 16 == 0 and t.stride(-1) == 1)
+    return (w1.is_contiguous() and w2.is_contiguous() and ok(x2) and ok(res2) and x2.stride(0) % 4 == 0 and
+            (res2 is None or res2.stride(0) % 4 == 0) and w1.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0)
+
+
+def _ffn_packed(w1, w2, d, ff):
+    prec = hip.GEMM_PRECISION
+    nbytes = hip.lib().oe_ffn_packed_bytes(d, ff, prec)
+    w1p = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    w2p = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+    hip.call("oe_ffn_pack_weights", w1, w2, d, ff, prec, w1p, w2p)
+    return w1p, w2p
+
+
 class FeedForwardFn(torch.autograd.Function):
     """y = [residual + out_scale * drop_out(] w_2(drop_in(act(w_1 x + b_1))) + b_2 [)]
     positionwise_feed_forward.py:36-43 and encoder_layer.py:81-83,104-106 / decoder_layer.py:104-106."""
@@ -657,6 +681,22 @@ class FeedForwardFn(torch.autograd.Function):
         x2 = x.reshape(-1, d)
         M, ff = x2.shape[0], w1.shape[0]
         s_in, s_out = (next_seed() if p_in > 0 else 0), (next_seed() if p_out > 0 else 0)
+        res2 = None if residual is None else _chk(residual, "residual").reshape(-1, w2.shape[0])
+        if FUSED_FFN and _ffn_fused_ok(x2, w1, w2, act, res2):
+            # one kernel (csrc/ffn.hip): the (M, ff) intermediate stays in registers; pre / a are written only when a
+            # backward will read them
+            need = any(ctx.needs_input_grad)
+            pre = _new(M, ff, like=x) if need else None
+            a = _new(M, ff, like=x) if need else None
+            w1p, w2p = _ffn_packed(w1, w2, d, ff)
+            y = _new(M, d, like=x)
+            hip.ffn_fwd(x2, w1p, b1, w2p, b2, M, d, ff, act, drop_in=p_in, seed_in=s_in, drop_out=p_out, seed_out=s_out,
+                        seed_dev=_seed_dev, pre_out=pre, act_out=a, residual=res2, ldr=0 if res2 is None else res2.stride(0),
+                        beta=out_scale, y=y)
+            ctx.save_for_backward(x2, w1, w2, pre, a)
+            ctx.biases = (b1, b2)
+            ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
+            return _tag_out_drop(y.view(*x.shape[:-1], w2.shape[0]), out_scale, p_out, s_out)
         pre = _new(M, ff, like=x)
         if act in GEMM_FUSED_ACTS:
             a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
@@ -666,7 +706,6 @@ class FeedForwardFn(torch.autograd.Function):
             hip.call("oe_act_fwd", pre, pre.numel(), act, a)
             if p_in > 0:
                 a = dropout_scale(a, 1.0, p_in, s_in)
-        res2 = None if residual is None else _chk(residual, "residual").reshape(-1, w2.shape[0])
         y = gemm_nt(a, w2, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, residual=res2,
                     ldr=0 if res2 is None else res2.stride(0), beta=out_scale)
         ctx.save_for_backward(x2, w1, w2, pre, a)

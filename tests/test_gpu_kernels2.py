@@ -444,3 +444,54 @@ def test_grad_norm_and_adam_match_torch():
     hip.call("oe_adam_step", p, bad, m, v, n, lr_dev, 0.0, 0.9, 0.999, 1e-8, 5.0, norm, state)
     sync()
     assert torch.equal(p, before) and torch.equal(state, step_before)
+
+
+# ------------------------------------------------------ fused feed forward -----
+@pytest.mark.parametrize("rows,d,ff,act,prec,p_in,p_out,nout", [
+    (7936, 256, 1024, 2, 3, 0.0, 0.0, 2),          # config 2, swish
+    (1000, 256, 1024, 2, 3, 0.1, 0.1, 2),          # ragged last block (1000 = 31 * 32 + 8), both dropouts
+    (77, 256, 512, 1, 3, 0.0, 0.0, 0),             # relu, no saved intermediates, ff = 4 tiles per wave
+    (992, 256, 1024, 2, 1, 0.0, 0.0, 1),           # plain bf16 products, pre-activation only
+    (333, 128, 512, 1, 3, 0.0, 0.25, 2),           # d = 128 (configs[0] width)
+    (64, 128, 128, 0, 1, 0.0, 0.0, 2),             # one ff tile per wave, no activation
+])
+def test_fused_feed_forward_kernel(rows, d, ff, act, prec, p_in, p_out, nout):
+    """oe_ffn_fwd (csrc/ffn.hip) against float64: y = residual + beta * drop(W2 drop(act(W1 x + b1)) + b2), the saved
+    pre-activation and activation, and - with dropout - bit-identical masks to oe_gemm_f32's epilogue on the same tensors
+    (the unfused backward regenerates them from the same seeds)."""
+    torch.manual_seed(60)
+    x = torch.randn(rows, d)
+    w1, b1 = torch.randn(ff, d) / math.sqrt(d), torch.randn(ff) * 0.1
+    w2, b2 = torch.randn(d, ff) / math.sqrt(ff), torch.randn(d) * 0.1
+    res = torch.randn(rows, d)
+    beta, s_in, s_out = 0.5, 0x1111, 0x2222
+    L = hip.lib()
+    assert L.oe_ffn_supported(d, ff, prec, act)
+    nb = L.oe_ffn_packed_bytes(d, ff, prec)
+    w1p, w2p = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    xd, w1d, w2d, b1d, b2d, resd = cu(x), cu(w1), cu(w2), cu(b1), cu(b2), cu(res)
+    hip.call("oe_ffn_pack_weights", w1d, w2d, d, ff, prec, w1p, w2p)
+    pre = torch.full((rows, ff), float("nan"), device=DEV) if nout >= 1 else None
+    aout = torch.full((rows, ff), float("nan"), device=DEV) if nout == 2 else None
+    y = torch.full((rows, d), float("nan"), device=DEV)
+    ctr = torch.tensor([3], dtype=torch.int64, device=DEV)
+    hip.ffn_fwd(xd, w1p, b1d, w2p, b2d, rows, d, ff, act, drop_in=p_in, seed_in=s_in, drop_out=p_out, seed_out=s_out, seed_dev=ctr,
+                pre_out=pre, act_out=aout, residual=resd, ldr=d, beta=beta, y=y, precision=prec)
+    sync()
+    # the masks the unfused path would draw: dropout_scale of ones with the same (seed, counter, element index)
+    ones_in, ones_out = torch.ones(rows, ff, device=DEV), torch.ones(rows, d, device=DEV)
+    m_in, m_out = torch.empty_like(ones_in), torch.empty_like(ones_out)
+    hip.call("oe_dropout_scale", ones_in, ones_in.numel(), ff, 1.0, p_in, s_in, ctr, None, m_in)
+    hip.call("oe_dropout_scale", ones_out, ones_out.numel(), d, 1.0, p_out, s_out, ctr, None, m_out)
+    sync()
+    h = x.double() @ w1.double().t() + b1.double()
+    a = (h * torch.sigmoid(h) if act == 2 else h.clamp(min=0) if act == 1 else h) * m_in.cpu().double()
+    want = res.double() + beta * ((a @ w2.double().t() + b2.double()) * m_out.cpu().double())
+    tol = dict(rtol=2e-4, atol=3e-5 * float(want.abs().max())) if prec == 3 else dict(rtol=3e-2, atol=2e-2 * float(want.abs().max()))
+    torch.testing.assert_close(y.cpu().double(), want, **tol)
+    if nout >= 1:
+        torch.testing.assert_close(pre.cpu().double(), h, **(dict(rtol=2e-4, atol=3e-5 * float(h.abs().max())) if prec == 3 else dict(rtol=3e-2, atol=3e-2)))
+    if nout == 2:
+        torch.testing.assert_close(aout.cpu().double(), a, **(dict(rtol=2e-4, atol=3e-5 * float(h.abs().max())) if prec == 3 else dict(rtol=3e-2, atol=3e-2)))
+        if p_in > 0:
+            assert torch.equal(aout == 0, m_in == 0) or float(((aout == 0) != (m_in == 0)).float().mean()) < 1e-4      # (a itself can be exactly 0)
