@@ -26,17 +26,13 @@
 //
 // Supported: d in {128, 256}, ff a multiple of 128, activation relu / swish; anything else stays on the two-GEMM path.
 #include <stdlib.h>
-#include "oe_common.h"
+#include "gemm_common.h"          // f32x16, static_for
 #include "../../include/openeat_hip.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define FFN_THREADS 256
 #define FFN_ROWS 32
-#define FFN_SLOTS 4                    // ring slots per wave
-#define FFN_STAGE_PIECES 8             // 1 KiB pieces per stage
-#define FFN_STAGE_BYTES (FFN_STAGE_PIECES * 1024)
 
 __device__ __forceinline__ int ffn_acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
 
@@ -92,14 +88,6 @@ struct FfnParams {
     const unsigned long long* seed_dev;
 };
 
-// one LDS-DMA piece: 64 lanes x 16 B, lane-linear on both sides (ffn_pack_kernel wrote the source in that order)
-__device__ __forceinline__ void ffn_dma16(const void* src, unsigned dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-}
-template <int N> __device__ __forceinline__ void ffn_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
-
 template <int TERMS> struct WFrag { bf16x8 hi, lo; };
 template <int TERMS>
 __device__ __forceinline__ f32x16 ffn_mma(const WFrag<TERMS>& a, const WFrag<TERMS>& b, f32x16 c) {
@@ -118,23 +106,24 @@ __device__ __forceinline__ void ffn_split(const float (&x)[8], WFrag<TERMS>& f) 
     }
 }
 
-// D = model width (128 / 256); NOUT = number of (rows, ff) outputs written per ff tile (0, 1 or 2): their store instructions
-// count in vmcnt, so the counted waits depend on it.
+// D = model width (128 / 256); NOUT = number of (rows, ff) outputs written per ff tile (0, 1 or 2).
+//
+// Weight fragments go L2 -> REGISTERS directly: the packed layout makes every fragment one fully coalesced 1 KiB
+// wave-load (global_load_dwordx4), four register sets rotate (three stages = 24 KiB per wave in flight ahead of the MFMAs)
+// and hipcc counts the waits itself.  The first version streamed the pieces through a wave-private LDS-DMA ring: alone the
+// stream ran at ~57 GB/s per CU (35 us for the 2 MiB), the MFMAs alone take 12 us, together 67 us - DMA issue, LDS-DMA
+// writes, fragment reads and MFMAs of one wave serialise on a SIMD that holds nothing else (tools/ffn_bench.py).
 template <int D, int TERMS, int NOUT>
 __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
     constexpr int PL = TERMS == 3 ? 2 : 1;
     constexpr int KS = D / 16, DT = D / 32;
-    constexpr int KS_PER_STAGE = FFN_STAGE_PIECES / PL;              // GEMM1 k-steps per stage
-    constexpr int FR_PER_STAGE = FFN_STAGE_PIECES / PL;              // GEMM2 (dt, s) fragments per stage
-    constexpr int NS1 = KS / KS_PER_STAGE, NS2 = (DT * 2) / FR_PER_STAGE;
+    constexpr int FR = 4;                                            // fragments per stage (GEMM1: k-steps, GEMM2: (dt, s) pairs)
+    constexpr int NS1 = KS / FR, NS2 = (DT * 2) / FR;
     constexpr int NSTG = NS1 + NS2;                                  // stages per ff tile
-    constexpr int STORES = NOUT * 4;                                 // float4 store instructions per lane and ff tile
-    constexpr int RING_BYTES = FFN_SLOTS * FFN_STAGE_BYTES;          // per wave
-    constexpr int PART_PITCH = D;                                    // one wave's partial y, [m][(c + 4 m) mod D]: the rotation keeps
-    constexpr int PART_BYTES = FFN_ROWS * PART_PITCH * 4;            // float4 groups whole and spreads a column over the banks
-    static_assert(4 * RING_BYTES >= 4 * PART_BYTES, "the partial sums overlay the rings");
-    static_assert(NS1 >= 1 && NS2 >= 1 && KS % KS_PER_STAGE == 0 && (DT * 2) % FR_PER_STAGE == 0, "stage split");
-    __shared__ __attribute__((aligned(1024))) char ring_raw[4 * RING_BYTES];
+    constexpr int STAGE_BYTES = FR * PL * 1024;
+    constexpr int NSET = 4;                                          // register sets; NSET - 1 stages in flight
+    static_assert(NS1 >= 1 && NS2 >= 1 && KS % FR == 0 && (DT * 2) % FR == 0 && NSTG % NSET == 0, "stage split");
+    __shared__ __attribute__((aligned(16))) float part_s[4][FFN_ROWS * D];     // partial y of each wave, [m][(c + 4 m) mod D]
     __shared__ __attribute__((aligned(16))) float patch_s[4][32 * 36];
     extern __shared__ __attribute__((aligned(16))) float b1_s[];     // ff floats
 
@@ -146,6 +135,9 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
     const int FT = p.ff / 32;
     const int my_tiles = (FT - wave + 3) / 4;                        // ff tiles wave, wave + 4, ...
     const int total = my_tiles * NSTG;                               // stages of this wave's stream
+    // every block streams the SAME weights: block b starts its walk b tiles further on, so that the blocks of an XCD do not
+    // all ask the same L2 channels for the same lines at the same time
+    const int rot = blockIdx.x % my_tiles;
 
     for (int i = threadIdx.x; i < p.ff; i += FFN_THREADS) b1_s[i] = p.b1 ? p.b1[i] : 0.f;
 
@@ -160,29 +152,28 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
             ffn_split<TERMS>(v, xf[ks]);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the counted waits below start from an empty queue
     __syncthreads();                                                 // b1_s
 
-    const unsigned ring = (unsigned)(uintptr_t)ring_raw + (unsigned)wave * RING_BYTES;
-    const char* ring_p = ring_raw + wave * RING_BYTES;
-    const char* w1b = reinterpret_cast<const char*>(p.w1p);
-    const char* w2b = reinterpret_cast<const char*>(p.w2p);
+    const char* w1b = reinterpret_cast<const char*>(p.w1p) + lane * 16;
+    const char* w2b = reinterpret_cast<const char*>(p.w2p) + lane * 16;
     const long w1_tile_bytes = (long)KS * PL * 1024, w2_tile_bytes = (long)DT * 2 * PL * 1024;
-    // stage n of the wave's stream -> source address (lane's 16 bytes of piece 0)
-    auto issue = [&](int n) {
-        const int ti = n / NSTG, within = n % NSTG;
-        const int ft = wave + 4 * ti;
-        const char* src = within < NS1 ? w1b + ft * w1_tile_bytes + (long)within * FFN_STAGE_BYTES
-                                       : w2b + ft * w2_tile_bytes + (long)(within - NS1) * FFN_STAGE_BYTES;
-        src += lane * 16;
-        const unsigned dst = ring + (unsigned)(n % FFN_SLOTS) * FFN_STAGE_BYTES;
+    // stage m of the wave's stream: tile (m / NSTG), GEMM1 stages first
+    auto load_stage = [&](int m, WFrag<TERMS> (&f)[FR]) {
+        const int ti = m / NSTG, within = m % NSTG;
+        const int ft = wave + 4 * ((ti + rot) % my_tiles);
+        const char* src = within < NS1 ? w1b + ft * w1_tile_bytes + (long)within * STAGE_BYTES
+                                       : w2b + ft * w2_tile_bytes + (long)(within - NS1) * STAGE_BYTES;
 #pragma unroll
-        for (int j = 0; j < FFN_STAGE_PIECES; ++j) ffn_dma16(src + j * 1024, dst + j * 1024u);
+        for (int j = 0; j < FR; ++j) {
+            f[j].hi = *reinterpret_cast<const bf16x8*>(src + (j * PL) * 1024);
+            if (TERMS == 3) f[j].lo = *reinterpret_cast<const bf16x8*>(src + (j * PL + 1) * 1024);
+        }
     };
-    int issued = 0;
-#pragma unroll
-    for (int n = 0; n < FFN_SLOTS - 1; ++n)
-        if (n < total) { issue(n); ++issued; }
+    WFrag<TERMS> fr[NSET][FR];
+    static_for<0, NSET - 1>([&](auto k_c) {
+        constexpr int k = decltype(k_c)::value;
+        if (k < total) load_stage(k, fr[k]);
+    });
 
     f32x16 yacc[DT];
 #pragma unroll
@@ -194,41 +185,21 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
     const DropParams dp_in = drop_params(p.p_in), dp_out = drop_params(p.p_out);
     float* patch = patch_s[wave];
 
-    int n = 0;                                                       // next stage to consume
-    int waits_since_stores = FFN_SLOTS;                              // stage waits since an ff tile's output stores were issued
-    // Consuming stage n (vmcnt counts LDS-DMA pieces AND stores, in issue order): up to two younger stages' pieces may stay
-    // in flight, plus the tile's output stores while they are younger than the awaited pieces, i.e. for the FFN_SLOTS - 1
-    // stages that were already in flight when the stores were issued.  The tail of the stream has fewer younger pieces.
-    // Then stage n + 3 is issued into the slot stage n - 1 left (its fragments went into MFMAs issued before this point).
-    auto wait_stage = [&]() {
-        const int younger = min(issued - n - 1, FFN_SLOTS - 2);     // stages
-        const bool st = STORES > 0 && waits_since_stores < FFN_SLOTS - 1;
-        ++waits_since_stores;
-        if (younger >= 2) { if (st) ffn_wait_vm<2 * FFN_STAGE_PIECES + STORES>(); else ffn_wait_vm<2 * FFN_STAGE_PIECES>(); }
-        else if (younger == 1) { if (st) ffn_wait_vm<FFN_STAGE_PIECES + STORES>(); else ffn_wait_vm<FFN_STAGE_PIECES>(); }
-        else ffn_wait_vm<0>();
-        if (issued < total) { issue(issued); ++issued; }
-    };
-
+    int n = 0;                                                       // stage whose MFMAs come next; n % NSET == its set (NSTG % NSET == 0)
     for (int ti = 0; ti < my_tiles; ++ti) {
-        const int ft = wave + 4 * ti;
+        const int ft = wave + 4 * ((ti + rot) % my_tiles);
         // ---- h^T tile = W1[ft] . x^T
         f32x16 hacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+        static_for<0, NS1>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int cu = st % NSET, pf = (st + NSET - 1) % NSET;
+            if (n + NSET - 1 < total) load_stage(n + NSET - 1, fr[pf]);     // into the set of stage n - 1
 #pragma unroll
-        for (int st = 0; st < NS1; ++st) {
-            wait_stage();
-            const char* sp = ring_p + (n % FFN_SLOTS) * FFN_STAGE_BYTES + lane * 16;
-#pragma unroll
-            for (int j = 0; j < KS_PER_STAGE; ++j) {
-                WFrag<TERMS> a;
-                a.hi = *reinterpret_cast<const bf16x8*>(sp + (j * PL) * 1024);
-                if (TERMS == 3) a.lo = *reinterpret_cast<const bf16x8*>(sp + (j * PL + 1) * 1024);
-                hacc = ffn_mma<TERMS>(a, xf[st * KS_PER_STAGE + j], hacc);
-            }
+            for (int j = 0; j < FR; ++j) hacc = ffn_mma<TERMS>(fr[cu][j], xf[st * FR + j], hacc);
             ++n;
-        }
+        });
         // ---- epilogue 1 (in place, fc on the accumulator rows): + b1, [pre ->], activation, dropout, [act ->], split
         float hv[16];
 #pragma unroll
@@ -247,14 +218,8 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
 #pragma unroll
             for (int ps = 0; ps < 4; ++ps) {
                 const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
-                const float4 v = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
-                // rows past the end: the store still ISSUES (the counted waits assume STORES instructions per tile) to row rows-1,
-                // whose owner lane writes the same clamped row's value only if it is the real one - so send those to a real row's
-                // own address with its own data instead: clamp the row and re-read that row of the patch
-                const long gr = min(m0 + row, (long)p.rows - 1);
-                const int prow = (int)(gr - m0);
-                const float4 vv = (m0 + row < p.rows) ? v : *reinterpret_cast<const float4*>(&patch[prow * 36 + c4]);
-                *reinterpret_cast<float4*>(out + gr * p.ff + ft * 32 + c4) = vv;
+                if (m0 + row < p.rows)
+                    *reinterpret_cast<float4*>(out + (m0 + row) * p.ff + ft * 32 + c4) = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
             }
         };
         if (NOUT >= 1 && p.pre) store_tile(p.pre);
@@ -275,7 +240,6 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
             }
         }
         if (NOUT == 2 && p.act_out) store_tile(p.act_out);
-        if (STORES > 0) waits_since_stores = 0;
         WFrag<TERMS> af[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -285,27 +249,24 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
             ffn_split<TERMS>(v, af[s]);
         }
         // ---- y^T += W2[:, ft] . a^T
+        static_for<0, NS2>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int cu = (NS1 + st) % NSET, pf = (NS1 + st + NSET - 1) % NSET;
+            if (n + NSET - 1 < total) load_stage(n + NSET - 1, fr[pf]);
 #pragma unroll
-        for (int st = 0; st < NS2; ++st) {
-            wait_stage();
-            const char* sp = ring_p + (n % FFN_SLOTS) * FFN_STAGE_BYTES + lane * 16;
-#pragma unroll
-            for (int j = 0; j < FR_PER_STAGE; ++j) {
-                const int fr = st * FR_PER_STAGE + j;                // (dt, s) = (fr >> 1, fr & 1)
-                WFrag<TERMS> a;
-                a.hi = *reinterpret_cast<const bf16x8*>(sp + (j * PL) * 1024);
-                if (TERMS == 3) a.lo = *reinterpret_cast<const bf16x8*>(sp + (j * PL + 1) * 1024);
-                yacc[fr >> 1] = ffn_mma<TERMS>(a, af[fr & 1], yacc[fr >> 1]);
+            for (int j = 0; j < FR; ++j) {
+                constexpr int dummy = 0; (void)dummy;
+                const int frx = st * FR + j;                          // (dt, s) = (frx >> 1, frx & 1)
+                yacc[frx >> 1] = ffn_mma<TERMS>(fr[cu][j], af[frx & 1], yacc[frx >> 1]);
             }
             ++n;
-        }
+        });
     }
-    // ---- sum the four partial y^T through LDS (the rings are dead once every wave is here), epilogue 2, store rows
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    float* part = reinterpret_cast<float*>(ring_raw);
+    // ---- sum the four partial y^T through LDS, epilogue 2, store rows
+    constexpr int PART_PITCH = D;
+    float* part = &part_s[0][0];
     {
-        float* mine = part + wave * (FFN_ROWS * PART_PITCH);
+        float* mine = part_s[wave];
 #pragma unroll
         for (int t = 0; t < DT; ++t)
 #pragma unroll

@@ -650,11 +650,15 @@ def global_cmvn(x, mean, istd):
 # are re-packed on every call (~3 us for the two 1 MB matrices): the optimizer moves the weights every step through a raw
 # kernel, which no tensor version counter sees, so a cache could only be trusted for frozen models.
 FUSED_FFN = os.environ.get("OE_FUSED_FFN", "1") == "1"
+# One block of the fused kernel owns 32 rows and streams ALL of W1 and W2: it pays once there are enough rows to fill the
+# chip (config 2: 7936 rows = 248 blocks, 71 us incl. the weight packing against 79 us for the two GEMMs); the decoders'
+# 992 rows are 31 blocks that each still take the full ~56 us, against 41 us for their two small GEMMs.
+FUSED_FFN_MIN_ROWS = int(os.environ.get("OE_FUSED_FFN_MIN_ROWS", "4096"))
 
 
 def _ffn_fused_ok(x2, w1, w2, act, res2):
     d, ff = w1.shape[1], w1.shape[0]
-    if hip.GEMM_PRECISION == 0 or not hip.lib().oe_ffn_supported(d, ff, hip.GEMM_PRECISION, act):
+    if hip.GEMM_PRECISION == 0 or x2.shape[0] < FUSED_FFN_MIN_ROWS or not hip.lib().oe_ffn_supported(d, ff, hip.GEMM_PRECISION, act):
         return False
     ok = lambda t: t is None or (t.data_ptr() % 16 == 0 and t.stride(-1) == 1)
     return (w1.is_contiguous() and w2.is_contiguous() and ok(x2) and ok(res2) and x2.stride(0) % 4 == 0 and

@@ -62,10 +62,13 @@ def _setup():
     return _CACHE
 
 
-@pytest.mark.parametrize("prec", [0, 3], ids=["fp32-mfma", "bf16x3-mfma"])
-def test_config2_width_model_matches_oracle(prec):
-    from openeat_amd import hip
+@pytest.mark.parametrize("prec,fused_ffn", [(0, False), (3, False), (3, True)], ids=["fp32-mfma", "bf16x3-mfma", "bf16x3-mfma-fused-ffn"])
+def test_config2_width_model_matches_oracle(prec, fused_ffn):
+    """fused_ffn: the one-kernel feed forward (csrc/ffn.hip) forced on at this batch's 1984 rows (by default it takes over from
+    4096 rows on, i.e. at bench.py's batch) - the same tolerances end to end."""
+    from openeat_amd import hip, ops
     c = _setup()
+    old_min, ops.FUSED_FFN_MIN_ROWS = ops.FUSED_FFN_MIN_ROWS, (0 if fused_ffn else 1 << 30)
     model = ASRModel(80, V, **CONF)
     model.load_state_dict(c["sd"])
     model = model.to(DEV).eval()
@@ -79,6 +82,7 @@ def test_config2_width_model_matches_oracle(prec):
         torch.cuda.synchronize()
     finally:
         hip.GEMM_PRECISION = old
+        ops.FUSED_FFN_MIN_ROWS = old_min
     assert abs(float(loss) - c["loss"]) <= 2e-4 * abs(c["loss"]), (float(loss), c["loss"])
     assert abs(float(acc) - c["acc"]) <= 1e-6
     bad = []
