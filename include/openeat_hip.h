@@ -31,6 +31,12 @@ extern "C" {
 const char* oe_last_error(void);
 int oe_abi_version(void);
 
+/* Capture hygiene (host only): while `origin` is capturing, how many of the `n_sides` streams hold captured work of the same
+ * capture that the origin's next launch would NOT be ordered after (forks that have not been led back).  Returns that
+ * count (0 = every fork rejoined; *unjoined_index = first offender), or -1 on error.  No reference counterpart: the
+ * reference's step is not captured. */
+int oe_capture_unjoined_streams(void* origin, void* const* sides, int n_sides, int* unjoined_index);
+
 /* ------------------------------------------------------------------------- *
  * GEMM with fused epilogue.  C[m,n] = epi( alpha * sum_k A(m,k) B(n,k) )
  * Replaces aten::addmm/mm/bmm behind every torch.nn.Linear and 1x1 Conv1d of
@@ -275,6 +281,10 @@ int oe_act_grad(const float* dy, const float* pre, long n, int act, float* out, 
 
 /* log_softmax over the last dim (ctc.py:56-64; asr_model.py:484-488). */
 int oe_log_softmax(const float* x, long rows, int V, float* out, void* stream);
+/* Per-row top-k, sorted descending, of x (rows, V) or - log_softmax != 0 - of its row-wise log-softmax, fused
+ * (asr_model.py:251, 358 `log_softmax(...).topk(beam_size)`; :258 `scores.topk`).  vals (rows, k) f32, idx (rows, k) i64;
+ * ties go to the lowest index.  k <= V <= 40000. */
+int oe_topk_rows(const float* x, long rows, int V, int k, int log_softmax, float* vals, long long* idx, void* stream);
 
 /* Masked softmax (+ dropout) over the last dim of a MATERIALISED score tensor: the module-API method
  * MultiHeadedAttention.forward_attention (attention.py:65-97) - the training / decoding path never builds this tensor
@@ -350,6 +360,13 @@ int oe_fbank(const float* wav, const int* nsamples, int B, long wav_stride, int 
              float scale, float preemph, const float* window, const float* twiddle, const int* mel_start,
              const int* mel_off, const float* mel_w, float floor_eps, const float* cmvn_mean,
              const float* cmvn_istd, float* out, void* stream);
+/* The same with kaldi's waveform dither (dataset.py:98, `dither=wav_dither`): N(0, dither^2) noise on every sample of every
+ * frame's window (after the x 2^15), drawn from a counter-based generator keyed by (seed, frame, sample).  Distribution
+ * parity with the reference (torch's global generator there), not bit parity.  dither = 0 is oe_fbank. */
+int oe_fbank_dither(const float* wav, const int* nsamples, int B, long wav_stride, int Tmax, int win, int hop, int n_mel,
+                    float scale, float preemph, const float* window, const float* twiddle, const int* mel_start,
+                    const int* mel_off, const float* mel_w, float floor_eps, const float* cmvn_mean,
+                    const float* cmvn_istd, float dither, unsigned long long seed, float* out, void* stream);
 /* Per-utterance (x - mean_t)/std_t over each utterance's own nframes[b] frames, in place
  * (feature_processor.py:5-8: population std, no epsilon). */
 int oe_utt_normalize(float* x, const int* nframes, int B, int Tmax, int F, void* stream);

@@ -405,6 +405,73 @@ extern "C" int oe_masked_softmax_bwd(const float* y, const float* dout, long row
     return 0;
 }
 
+// Per-row top-k, optionally of the row's log-softmax (asr_model.py:251, 358: `logp.topk(beam_size)` after log_softmax; :258
+// `scores.topk`).  One wave per row: the row is staged in LDS while the online log-sum-exp runs (the same arithmetic as
+// log_softmax_kernel, so the values equal log_softmax -> topk bit for bit), every lane remembers the best of its own strided
+// elements, and k rounds pick the wave-wide best (ties: lowest index), strike it out and rescan only the winning lane.
+// Sorted descending like torch.topk.  HBM-bound: one read of the row, k values + k int64 indices written.
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long rows, int V, int k, int log_softmax,
+                                                        float* __restrict__ vals, long long* __restrict__ idx) {
+    extern __shared__ float topk_rows_s[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long row = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (row >= rows) return;                                     // wave-uniform; no block barrier below
+    float* r = topk_rows_s + (size_t)wave * V;
+    const float* p = x + row * V;
+    float m = -INFINITY, s = 0.f, bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < V; i += 64) {
+        const float v = p[i];
+        r[i] = v;
+        const float mn = fmaxf(m, v);
+        s = s * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+        if (v == v && (v > bv || bi == 0x7fffffff)) { bv = v; bi = i; }
+    }
+    if (m == -INFINITY) s = 0.f;
+    wave_lse(m, s);
+    const float lse = log_softmax ? m + __logf(s) : 0.f;
+    for (int j = 0; j < k; ++j) {
+        const float mv = wave_max(bv);
+        int cand = (bv == mv) ? bi : 0x7fffffff;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) {
+            vals[row * k + j] = mv - lse;
+            idx[row * k + j] = cand == 0x7fffffff ? 0 : cand;
+        }
+        if (bi == cand && cand != 0x7fffffff) {                  // the winner strikes its element out and rescans its own stride
+            r[bi] = __builtin_nanf("");                          // struck: never compares (so -inf entries stay selectable)
+            bv = -INFINITY;
+            bi = 0x7fffffff;
+            for (int i = lane; i < V; i += 64) {
+                const float v = r[i];
+                if (v == v && (v > bv || bi == 0x7fffffff)) { bv = v; bi = i; }
+            }
+        }
+    }
+}
+extern "C" int oe_topk_rows(const float* x, long rows, int V, int k, int log_softmax, float* vals, long long* idx, void* stream) {
+    OE_REQUIRE(x && vals && idx && rows > 0 && V > 0 && k > 0 && k <= V, "oe_topk_rows: bad arguments (rows=%ld V=%d k=%d)", rows, V, k);
+    OE_REQUIRE(V <= 40000, "oe_topk_rows: a row of %d floats does not fit in LDS", V);
+    const int waves = V <= 10000 ? 4 : V <= 20000 ? 2 : 1;
+    const size_t lds = (size_t)waves * V * sizeof(float);
+    if (lds > 64 * 1024) {
+        static bool raised = false;                               // once per process: opt in to more than 64 KB of dynamic LDS
+        if (!raised) {
+            if (hipFuncSetAttribute((const void*)topk_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                oe_set_error("oe_topk_rows: cannot raise the dynamic LDS limit");
+                return -1;
+            }
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(oe_cdiv(rows, waves)), dim3(64 * waves), lds, (hipStream_t)stream, x, rows, V, k, log_softmax,
+                       vals, idx);
+    OE_LAUNCH_CHECK("topk_rows");
+    return 0;
+}
+
 // y = act(x) (stand-alone activation module, swish.py:15-17)
 __global__ void act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -27,7 +27,8 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank_kernel(const float* __res
                                                               const float* __restrict__ twiddle, const int* __restrict__ mel_start,
                                                               const int* __restrict__ mel_off, const float* __restrict__ mel_w,
                                                               float floor_eps, const float* __restrict__ cmvn_mean,
-                                                              const float* __restrict__ cmvn_istd, float* __restrict__ out) {
+                                                              const float* __restrict__ cmvn_istd, float* __restrict__ out,
+                                                              float dither, unsigned long long dither_seed) {
     __shared__ float2 bufA[FB_WAVES][FB_NFFT];
     __shared__ float2 bufB[FB_WAVES][FB_NFFT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -45,7 +46,16 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank_kernel(const float* __res
     const float* src = wav + (long)b * wav_stride + (long)t * hop;
     for (int i = lane; i < FB_NFFT; i += 64) {
         float v = 0.f;
-        if (live && i < win) v = src[i] * scale;
+        if (live && i < win) {
+            v = src[i] * scale;
+            if (dither != 0.f) {
+                // kaldi's waveform dither (dataset.py:98: dither=wav_dither): independent N(0, dither^2) noise on every sample
+                // of every frame's window, after scaling.  Box-Muller on two hashed uniforms of (frame, sample).
+                const uint2 h = drop_hash4(dither_seed, (unsigned long long)frame * FB_NFFT + i);
+                const float u1 = ((float)(h.x >> 8) + 0.5f) * (1.f / 16777216.f), u2 = (float)(h.y >> 8) * (1.f / 16777216.f);
+                v += dither * sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+            }
+        }
         A[i].x = v;
         part += v;
     }
@@ -105,6 +115,14 @@ extern "C" int oe_fbank(const float* wav, const int* nsamples, int B, long wav_s
                         float scale, float preemph, const float* window, const float* twiddle, const int* mel_start,
                         const int* mel_off, const float* mel_w, float floor_eps, const float* cmvn_mean,
                         const float* cmvn_istd, float* out, void* stream) {
+    return oe_fbank_dither(wav, nsamples, B, wav_stride, Tmax, win, hop, n_mel, scale, preemph, window, twiddle, mel_start, mel_off,
+                           mel_w, floor_eps, cmvn_mean, cmvn_istd, 0.f, 0ull, out, stream);
+}
+
+extern "C" int oe_fbank_dither(const float* wav, const int* nsamples, int B, long wav_stride, int Tmax, int win, int hop, int n_mel,
+                               float scale, float preemph, const float* window, const float* twiddle, const int* mel_start,
+                               const int* mel_off, const float* mel_w, float floor_eps, const float* cmvn_mean,
+                               const float* cmvn_istd, float dither, unsigned long long seed, float* out, void* stream) {
     OE_REQUIRE(wav && window && twiddle && mel_start && mel_off && mel_w && out, "oe_fbank: null pointer");
     OE_REQUIRE(B > 0 && Tmax > 0 && win > 0 && win <= FB_NFFT && hop > 0 && n_mel > 0, "oe_fbank: bad shape (window must be <= %d samples)", FB_NFFT);
     OE_REQUIRE(nsamples || wav_stride >= (long)(Tmax - 1) * hop + win, "oe_fbank: Tmax frames do not fit in wav_stride samples");
@@ -112,7 +130,7 @@ extern "C" int oe_fbank(const float* wav, const int* nsamples, int B, long wav_s
     const long frames = (long)B * Tmax;
     hipLaunchKernelGGL(fbank_kernel, dim3(oe_cdiv(frames, FB_WAVES)), dim3(64 * FB_WAVES), 0, (hipStream_t)stream, wav, nsamples,
                        B, wav_stride, Tmax, win, hop, n_mel, scale, preemph, window, twiddle, mel_start, mel_off, mel_w, floor_eps,
-                       cmvn_mean, cmvn_istd, out);
+                       cmvn_mean, cmvn_istd, out, dither, seed);
     OE_LAUNCH_CHECK("fbank");
     return 0;
 }

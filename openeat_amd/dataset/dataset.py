@@ -202,13 +202,16 @@ class audio_collate_func(object):
                 w, sr = self.wav_reader(value[0])
                 if len(value) == 3:
                     w = w[int(float(value[1]) * sr):int(float(value[2]) * sr)]
-                if 'resample_rate' in conf and conf['resample_rate'] != sr:
-                    raise NotImplementedError("resample_rate != file rate is out of scope")
-                assert sample_rate in (None, sr), "one sample rate per batch"
-                sample_rate = sr
                 speed = x[3]
                 if random.random() < rate:
                     speed = _speed_generator(speeds)
+                if 'resample_rate' in conf and conf['resample_rate'] != sr:
+                    # dataset.py:81-84 resamples (torchaudio Resample) after the speed perturbation; both are one pass of
+                    # the same windowed-sinc interpolator here: read sr / resample_rate times faster, times the speed.
+                    speed = float(speed) * sr / conf['resample_rate']
+                    sr = conf['resample_rate']
+                assert sample_rate in (None, sr), "one sample rate per batch"
+                sample_rate = sr
                 keys.append(x[0]); wavs.append(w); labels.append(np.array(x[2])); spd.append(float(speed))
             except NotImplementedError:
                 raise
@@ -223,14 +226,14 @@ class audio_collate_func(object):
         wav = host.to(self.device)
         if any(s != 1.0 for s in spd):
             wav, n = speed_perturb_batch(wav, n, spd)
-        if conf.get('wav_dither', 0.0) != 0.0:
-            raise NotImplementedError("wav_dither != 0 (kaldi.fbank's waveform dither) is not built; the recipe uses 0.0")
         if self._fbank is None or self._fbank_rate != sample_rate:
             self._fbank = Fbank(num_mel_bins=conf.get('mel_bins', 80), sample_rate=float(sample_rate), device=self.device)
             self._fbank_rate = sample_rate
         fb = self._fbank
         nfr = [fb.num_frames(k) for k in n]
-        feats, _ = fb(wav, torch.tensor(n, dtype=torch.int32, device=self.device))
+        dither = float(conf.get('wav_dither', 0.0))                    # dataset.py:98; the noise is keyed by a host-drawn seed
+        feats, _ = fb(wav, torch.tensor(n, dtype=torch.int32, device=self.device), dither=dither,
+                      seed=random.getrandbits(63) if dither != 0.0 else 0)
         order = np.argsort(nfr)[::-1]                                   # :115
         idx = torch.as_tensor(order.copy(), device=self.device)
         return [keys[i] for i in order], feats.index_select(0, idx), [nfr[i] for i in order], [labels[i] for i in order]

@@ -3,6 +3,7 @@ optionally replayed as one HIP graph (the step of the reference's
 Executor.train, /root/reference/openeat/utils/executor.py:36-63)."""
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Dict, Optional
 
 import torch
@@ -37,6 +38,11 @@ class TrainEngine:
         self._graph: Optional[torch.cuda.CUDAGraph] = None
         self._static: Dict[str, torch.Tensor] = {}
         self._out = None
+        self._ln_table = None
+        # step_cached(): one captured graph per batch shape, least recently used dropped first, all in ONE memory pool
+        self._cache: "OrderedDict[tuple, Optional[tuple]]" = OrderedDict()
+        self._pool = None
+        self.cache_hits = self.cache_misses = 0
 
     def _install_overlap_hooks(self):
         """Start the gradient all-reduce of the arena tail whose gradients are final while backward is still running:
@@ -108,7 +114,7 @@ class TrainEngine:
         return out
 
     # ---- HIP-graph path: fixed shapes, no host sync inside the step -----------------------------
-    def capture(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2):
+    def capture(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2, pool=None, _warm: bool = False):
         """Capture the step as a HIP graph.  With one rank the whole step (incl. clip + Adam) is one graph;
         with several ranks the graph holds zero-grad + forward + backward and the gradient all-reduce and
         the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph).
@@ -118,8 +124,10 @@ class TrainEngine:
         if self.accum_grad != 1:
             raise NotImplementedError("TrainEngine.capture: accum_grad > 1 is only supported by eager steps")
         self._split = self.reducer.world > 1
-        warmup = max(1, int(warmup))                  # at least one eager step first: streams, events and lazily initialised
-                                                      # state must exist before the capture (a cold capture ended "unjoined")
+        unjoined = 0
+        # at least one eager step first: streams, events and lazily initialised state must exist before the capture (a
+        # cold capture ended "unjoined"); step_cached() has just made that step itself (_warm)
+        warmup = 0 if _warm else max(1, int(warmup))
         ops.POS_PROJ_AHEAD = self.parallel            # inside a capture the collectives all come after the graph
         common.STATIC_SHAPES = True
         self.static_shapes = True
@@ -153,11 +161,14 @@ class TrainEngine:
                 mode = "thread_local" if self.reducer.world > 1 else "global"
                 ops.ln_table_begin(self.arena.flat.device)
                 try:
-                    with torch.cuda.graph(g, capture_error_mode=mode):
-                        self.arena.grad.zero_()
-                        self._out = self._fwd_bwd(self._static)
-                        if not self._split:
-                            self._finish()
+                    with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                        try:
+                            self.arena.grad.zero_()
+                            self._out = self._fwd_bwd(self._static)
+                            if not self._split:
+                                self._finish()
+                        finally:
+                            unjoined = self._lead_forks_back()      # also when the step raised: capture_end comes next
                 finally:
                     self._ln_table = ops.ln_table_end()        # the graph's launch reads this tensor: keep it alive
             finally:
@@ -166,15 +177,84 @@ class TrainEngine:
             ops.ASYNC_WGRAD = async_wgrad
             ops.WGRAD_DEFER = 0
             ops.drop_deferred()                # a capture that failed midway must not leave launches behind for an eager step
+        if unjoined:
+            raise RuntimeError(f"TrainEngine.capture: {unjoined} forked stream(s) had not rejoined the capturing stream at the end "
+                               "of the step (a fork without its join); they were joined to close the capture, the graph is dropped")
         self._graph = g
 
+    @staticmethod
+    def _lead_forks_back() -> int:
+        """Last thing inside a capture: every stream the step forked onto must be an ancestor of the capturing stream's
+        next launch (ending a capture with unjoined work is an error - and has ended in SIGSEGV inside capture_end on
+        this stack).  Offenders are joined so that the capture can be closed; the caller raises."""
+        from openeat_amd import hip
+        origin = torch.cuda.current_stream()
+        bad = 0
+        while True:
+            n, first = hip.capture_unjoined_streams(origin, ops.forked_streams())
+            if n == 0:
+                return bad
+            bad += 1
+            origin.wait_stream(first)
+
     def drop_graph(self):
-        """Forget the captured graph (and give its memory pool back): subsequent steps are eager again."""
+        """Forget the captured graph(s) (and give their memory pool back): subsequent steps are eager again."""
         self._graph = None
         self._out = None
         self._static = {}
         self._ln_table = None
+        self._cache.clear()
+        self._pool = None
         torch.cuda.empty_cache()
+
+    # ---- ragged training: one graph per batch shape ------------------------------------------------
+    def step_cached(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, max_graphs: int = 64):
+        """A training step on a batch of any shape, replayed from a captured graph when this shape has been seen before
+        (/root/reference/openeat/dataset/dataset.py:337-364 forms length buckets: a handful of (B, T) shapes recur all
+        epoch).  First sight of a shape: the step runs eagerly - a real step - and is then captured for the next time
+        (the capture executes nothing).  At most `max_graphs` graphs are kept, least recently used dropped first; all of
+        them allocate from one memory pool, so the activation memory held is that of the largest shape, not the sum.
+        Callers bound the number of distinct shapes by padding to multiples (frames: the bucket's length_multiple;
+        targets: pad_targets below)."""
+        if self.accum_grad != 1:
+            return self.step(batch, lr)
+        key = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items()))
+        rec = self._cache.get(key, False)
+        if rec is False:
+            self.cache_misses += 1
+            self.static_shapes = True
+            out = self.step(batch, lr)
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            try:
+                self.capture(batch, pool=self._pool, _warm=True)
+                rec = (self._graph, self._static, self._out, self._ln_table)
+            except RuntimeError:
+                rec = None                       # this shape does not capture: it keeps running eagerly
+            self._graph, self._static, self._out, self._ln_table = None, {}, None, None
+            self._cache[key] = rec
+            while len(self._cache) > max(1, max_graphs):
+                self._cache.popitem(last=False)
+            return out
+        self._cache.move_to_end(key)
+        if rec is None:
+            return self.step(batch, lr)
+        self.cache_hits += 1
+        self._graph, self._static, self._out, self._ln_table = rec
+        try:
+            return self.replay(batch, lr)
+        finally:
+            self._graph, self._static, self._out, self._ln_table = None, {}, None, None
+
+
+def pad_targets(targets: torch.Tensor, multiple: int = 16, ignore_id: int = -1) -> torch.Tensor:
+    """Pad the label matrix (B, L) with ignore_id to the next multiple of `multiple` columns: fewer distinct batch shapes
+    for step_cached (padding labels are ignored exactly as the collate's own padding is, dataset.py:219)."""
+    L = targets.shape[1]
+    Lp = -(-L // multiple) * multiple
+    if Lp == L:
+        return targets
+    return torch.nn.functional.pad(targets, (0, Lp - L), value=ignore_id)
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
         assert self._graph is not None

@@ -53,7 +53,9 @@ class Fbank:
     def num_frames(self, n: int) -> int:
         return 0 if n < self.win else 1 + (n - self.win) // self.hop
 
-    def __call__(self, wav: torch.Tensor, nsamples: torch.Tensor = None, cmvn=None, out: torch.Tensor = None):
+    def __call__(self, wav: torch.Tensor, nsamples: torch.Tensor = None, cmvn=None, out: torch.Tensor = None,
+                 dither: float = 0.0, seed: int = 0):
+        """dither: kaldi.fbank's waveform dither (dataset.py:98), N(0, dither^2) per window sample, keyed by `seed`."""
         assert wav.is_cuda and wav.dtype == torch.float32 and wav.dim() == 2, "fbank needs a float32 CUDA (B,N) tensor"
         wav = wav.contiguous()
         B, N = wav.shape
@@ -62,8 +64,12 @@ class Fbank:
             out = torch.empty(B, T, self.n_mel, device=wav.device)
         ns = None if nsamples is None else nsamples.to(torch.int32).contiguous()
         mean, istd = (None, None) if cmvn is None else cmvn
-        hip.call("oe_fbank", wav, ns, B, N, T, self.win, self.hop, self.n_mel, self.scale, self.preemph, self.window,
-                 self.twiddle, self.mel_start, self.mel_off, self.mel_w, FLT_EPS, mean, istd, out)
+        if dither != 0.0:
+            hip.call("oe_fbank_dither", wav, ns, B, N, T, self.win, self.hop, self.n_mel, self.scale, self.preemph, self.window,
+                     self.twiddle, self.mel_start, self.mel_off, self.mel_w, FLT_EPS, mean, istd, float(dither), int(seed), out)
+        else:
+            hip.call("oe_fbank", wav, ns, B, N, T, self.win, self.hop, self.n_mel, self.scale, self.preemph, self.window,
+                     self.twiddle, self.mel_start, self.mel_off, self.mel_w, FLT_EPS, mean, istd, out)
         if ns is None:
             nframes = torch.full((B,), T, dtype=torch.int32, device=wav.device)
         else:

@@ -111,6 +111,7 @@ I, L, F, P, U64, SZ = C.c_int, C.c_long, C.c_float, c_fp, C.c_ulonglong, C.c_siz
 _SIGNATURES = {
     "oe_last_error": (C.c_char_p, []),
     "oe_abi_version": (I, []),
+    "oe_capture_unjoined_streams": (I, [P, C.POINTER(C.c_void_p), I, C.POINTER(I)]),
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
     "oe_ffn_packed_bytes": (SZ, [I, I, I]),
     "oe_ffn_supported": (I, [I, I, I, I]),
@@ -141,6 +142,7 @@ _SIGNATURES = {
     "oe_act_fwd": (I, [P, L, I, P, P]),
     "oe_act_grad": (I, [P, P, L, I, P, P]),
     "oe_log_softmax": (I, [P, L, I, P, P]),
+    "oe_topk_rows": (I, [P, L, I, I, I, P, P, P]),
     "oe_masked_softmax_fwd": (I, [P, P, L, L, I, I, I, I, F, U64, P, P, P, P]),
     "oe_masked_softmax_bwd": (I, [P, P, L, I, F, U64, P, P, P]),
     "oe_global_cmvn": (I, [P, P, P, L, I, P, P]),
@@ -154,6 +156,7 @@ _SIGNATURES = {
     "oe_lsm_workspace_bytes": (SZ, [L]),
     "oe_lsm_loss_fused": (I, [P, L, L, I, P, I, F, I, F, F, I, P, P, P]),
     "oe_fbank": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, P, P]),
+    "oe_fbank_dither": (I, [P, P, I, L, I, I, I, I, F, F, P, P, P, P, P, F, P, P, F, U64, P, P]),
     "oe_utt_normalize": (I, [P, P, I, I, I, P]),
     "oe_spec_augment": (I, [P, P, I, I, I, P, I, P, I, F, P]),
     "oe_spec_substitute": (I, [P, I, I, I, P, I, I, P]),
@@ -178,6 +181,17 @@ def check(rc: int, what: str):
     if rc != 0:
         msg = lib().oe_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def capture_unjoined_streams(origin: "torch.cuda.Stream", sides):
+    """Streams among `sides` whose captured work the capturing stream `origin` is not yet ordered after."""
+    sides = [s for s in sides if s is not None]
+    arr = (C.c_void_p * max(len(sides), 1))(*[s.cuda_stream for s in sides])
+    first = I(-1)
+    n = lib().oe_capture_unjoined_streams(C.c_void_p(origin.cuda_stream), arr, len(sides), C.byref(first))
+    if n < 0:
+        check(n, "oe_capture_unjoined_streams")
+    return n, (sides[first.value] if n > 0 else None)
 
 
 def ptr(t: Optional[torch.Tensor]):

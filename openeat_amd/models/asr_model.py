@@ -165,8 +165,7 @@ class ASRModel(torch.nn.Module):
         assert features.shape[0] == features_length.shape[0]
         assert features.shape[0] == 1
         encoder_out, _, _ = self._encode(features, features_length)
-        ctc_probs = self.ctc.log_softmax(encoder_out).squeeze(0)
-        top_p, top_i = ctc_probs.topk(beam_size, dim=1)
+        top_p, top_i = ops.topk_rows(self.ctc.logits(encoder_out).squeeze(0), beam_size, log_softmax=True)
         from openeat_amd import hip
         return hip.ctc_prefix_beam_host(top_p.cpu(), top_i.cpu(), beam_size), encoder_out
 
@@ -239,7 +238,7 @@ class ASRModel(torch.nn.Module):
         B = features.shape[0]
         encoder_out, encoder_mask, _ = self._encode(features, features_length)
         lens = encoder_mask.squeeze(1).sum(1)
-        top_p, top_i = self.ctc.log_softmax(encoder_out).topk(beam_size, dim=2)
+        top_p, top_i = ops.topk_rows(self.ctc.logits(encoder_out), beam_size, log_softmax=True)
         top_p, top_i, lens_h = top_p.cpu(), top_i.cpu(), lens.cpu().tolist()
         nbest = hip.ctc_prefix_beam_host_batch(top_p, top_i, lens_h, beam_size)
         for b in range(B):                                     # a very short utterance can yield fewer than `beam` prefixes
@@ -306,12 +305,11 @@ class ASRModel(torch.nn.Module):
                 break
             hyps_mask = subsequent_mask(i, device=device).unsqueeze(0).repeat(R, 1, 1)
             p, cache, _ = self.decoder.forward_one_step(hyps, hyps_mask, encoder_out, encoder_mask, cache=cache)
-            logp = ops.log_softmax_rows(p)
-            top_k_logp, top_k_index = logp.topk(beam_size)
+            top_k_logp, top_k_index = ops.topk_rows(p, beam_size, log_softmax=True)
             top_k_logp = mask_finished_scores(top_k_logp, end_flag)
             top_k_index = mask_finished_preds(top_k_index, end_flag, self.eos)
             scores = (scores + top_k_logp).view(B, beam_size * beam_size)
-            scores, offset_k_index = scores.topk(k=beam_size)
+            scores, offset_k_index = ops.topk_rows(scores, beam_size)
             scores = scores.view(-1, 1)
             base = torch.arange(B, device=device).view(-1, 1).repeat(1, beam_size) * beam_size * beam_size
             best_k_index = base.view(-1) + offset_k_index.view(-1)

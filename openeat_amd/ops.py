@@ -160,6 +160,14 @@ def side_stream():
     return _side_stream
 
 
+def forked_streams():
+    """Every stream the step may fork work onto (the engine checks that a capture has led them all back)."""
+    return [s for s in (_side_stream, _decoder_stream, _ctc_stream) if s is not None] + list(_extra_streams)
+
+
+_extra_streams = []          # streams registered by callers that fork on their own (tests; experiments)
+
+
 def join_side_stream():
     flush_wgrads()
     if _side_stream is not None:
@@ -1350,6 +1358,18 @@ def ctc_greedy(logits, ldv, B, T, V, hlens, eos):
     hl = hlens.to(torch.int32).contiguous()
     hip.call("oe_ctc_greedy", logits, ldv, B, T, V, hl, eos, fb, ot, ol)
     return ot, ol
+
+
+def topk_rows(x, k: int, log_softmax: bool = False):
+    """`x.topk(k)` over the last dim - of log_softmax(x) when asked - in one kernel (asr_model.py:251, 258, 358).
+    Returns (values float32, indices int64), sorted descending; ties go to the lowest index."""
+    x = _chk(x, "topk_rows")
+    V = x.shape[-1]
+    rows = x.numel() // V
+    vals = torch.empty(*x.shape[:-1], k, dtype=torch.float32, device=x.device)
+    idx = torch.empty(*x.shape[:-1], k, dtype=torch.int64, device=x.device)
+    hip.call("oe_topk_rows", x, rows, V, int(k), int(bool(log_softmax)), vals, idx)
+    return vals, idx
 
 
 def log_softmax_rows(x):

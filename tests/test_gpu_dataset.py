@@ -169,3 +169,60 @@ def test_manifest_to_trained_epoch_as_train_py_wires_it(tmp_path):
     keys, b = coll(ds[0])
     hyps = model.ctc_greedy_search(b["features"], b["features_length"])
     assert len(hyps) == len(keys) and all(isinstance(t, int) and 0 < t < len(chars) for h in hyps for t in h)
+
+
+def test_fbank_waveform_dither():
+    """kaldi.fbank(dither=wav_dither) (dataset.py:98): dither 0 is the plain kernel bit for bit; the noise is a function of the
+    seed; on silence the log-mel statistics are those of white noise of that standard deviation through the oracle."""
+    from openeat_amd.frontend import Fbank
+    fb = Fbank(num_mel_bins=80, sample_rate=16000.0, device=DEV)
+    rng = np.random.default_rng(5)
+    wav = torch.from_numpy(rng.uniform(-0.3, 0.3, (3, 16000)).astype(np.float32)).to(DEV)
+    ns = torch.tensor([16000, 12000, 8000], dtype=torch.int32, device=DEV)
+    plain, _ = fb(wav, ns)
+    zero, _ = fb(wav, ns, dither=0.0, seed=9)
+    assert torch.equal(plain, zero)
+    a, _ = fb(wav, ns, dither=1.0, seed=9)
+    b, _ = fb(wav, ns, dither=1.0, seed=9)
+    c, _ = fb(wav, ns, dither=1.0, seed=10)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert float((a - plain).abs().max()) < 0.05            # one LSB of noise under a 0.3 full-scale signal barely moves the log-mels
+    assert torch.equal(a[1, fb.num_frames(12000):], torch.zeros_like(a[1, fb.num_frames(12000):]))
+    # silence + dither d  ==  white noise of sigma d / 32768 (stationary, so independent per-frame draws have the same law)
+    d = 2.0
+    sil = torch.zeros(4, 160000, device=DEV)
+    got, _ = fb(sil, None, dither=d, seed=123)
+    ref = FB.fbank(torch.from_numpy(rng.normal(0, d / 32768.0, 640000).astype(np.float32)))
+    gm, rm = got.reshape(-1, 80).double().mean(0).cpu(), ref.double().mean(0)
+    gs, rs = got.reshape(-1, 80).double().std(0).cpu(), ref.double().std(0)
+    assert float((gm - rm).abs().max()) < 0.03, float((gm - rm).abs().max())     # ~4000 frames: standard error of a bin mean ~0.01
+    assert float((gs / rs - 1).abs().max()) < 0.1
+
+
+def test_collate_resamples_to_resample_rate(tmp_path):
+    """dataset.py:81-84: a file whose rate differs from resample_rate is resampled before the features.  A band-limited signal
+    decimated by two and written at 8 kHz comes back to the 16 kHz original."""
+    from openeat_amd.dataset.audio_processor import speed_perturb_batch
+    from openeat_amd.dataset.dataset import audio_collate_func
+    rng = np.random.default_rng(11)
+    n = 32000
+    spec = np.fft.rfft(rng.normal(0, 1, n))
+    spec[int(3000 / 8000 * (n // 2)):] = 0                   # nothing above 3 kHz
+    x16 = np.fft.irfft(spec, n)
+    x16 = (0.3 * x16 / np.abs(x16).max()).astype(np.float32)
+    x8 = np.ascontiguousarray(x16[::2])
+    up, n_up = speed_perturb_batch(torch.from_numpy(x8[None]).to(DEV), [n // 2], [0.5])
+    assert n_up == [n]
+    err = (up[0].cpu().numpy() - x16)[200:-200]
+    assert np.abs(err).max() < 2e-3, np.abs(err).max()
+    p = str(tmp_path / "u8k.wav")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000); w.writeframes((x8 * 32768).astype("<i2").tobytes())
+    conf = dict(mel_bins=80, wav_dither=0.0, speed_perturb_rate=0.0, resample_rate=16000)
+    coll = audio_collate_func(data_type="wav", feature_extraction_conf=conf, device=DEV)
+    keys, out = coll([("k0", p, [3, 4], 1.0)])
+    want = FB.utt_normalize(FB.fbank(torch.from_numpy(x16))).numpy()
+    assert out["features_length"].tolist() == [want.shape[0]]
+    got = out["features"][0].cpu().numpy()
+    lo = slice(0, 50)                                        # mel bins below ~2.6 kHz, where the signal lives
+    assert np.abs(got[5:-5, lo] - want[5:-5, lo]).max() < 0.1, np.abs(got[5:-5, lo] - want[5:-5, lo]).max()

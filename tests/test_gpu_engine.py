@@ -225,6 +225,103 @@ def test_failed_capture_leaves_the_engine_usable(monkeypatch):
     check_updates(m2.state_dict(), m1.state_dict(), None, steps=2)
 
 
+def test_capture_refuses_a_fork_that_never_rejoined(monkeypatch):
+    """TrainEngine.capture checks, before it ends the capture, that every stream the step forked onto has been led back
+    (oe_capture_unjoined_streams walks the graph under construction).  The regular multi-stream configuration (side
+    weight-gradient stream + right decoder + CTC head on their own streams) passes; a launch left on a fourth stream with no
+    join is reported as an error instead of reaching capture_end unjoined, and the engine stays usable."""
+    from openeat_amd import hip
+    m1, m2 = tiny(seed=21).to(DEV).train(), tiny(seed=21).to(DEV).train()
+    b = batch_of(seed=5)
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+    calls = []
+    real = hip.capture_unjoined_streams
+    monkeypatch.setattr(hip, "capture_unjoined_streams", lambda o, s: calls.append((len(s), real(o, s))) or calls[-1][1])
+    stray = torch.cuda.Stream()
+    try:
+        e1.capture(b, warmup=1)
+        assert calls and calls[-1][0] >= 2 and calls[-1][1][0] == 0          # >= 2 forked streams known, none unjoined
+        e1.replay()
+        torch.cuda.synchronize()
+        e1.drop_graph()
+        e1.arena.deactivate()
+        # the same engine configuration with one launch left behind on a stream nobody joins
+        e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+        ops._extra_streams.append(stray)
+        real_flush = ops.ln_table_flush
+        scratch = torch.zeros(64, device=DEV)
+
+        def flush_and_stray():
+            if e2._capturing:
+                stray.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(stray):
+                    scratch.add_(1.0)
+            return real_flush()
+        monkeypatch.setattr(ops, "ln_table_flush", flush_and_stray)
+        with pytest.raises(RuntimeError, match="had not rejoined"):
+            e2.capture(b, warmup=1)
+        monkeypatch.setattr(ops, "ln_table_flush", real_flush)
+        torch.cuda.synchronize()
+        assert e2._graph is None and not e2._capturing
+        l2, _ = e2.step(b)                                                    # still a working engine
+        torch.cuda.synchronize()
+        assert torch.isfinite(l2)
+    finally:
+        ops._extra_streams.clear()
+        for e in (e1, locals().get("e2")):
+            if e is not None:
+                e.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        ops.PARALLEL_DECODERS = False
+        ops.POS_PROJ_AHEAD = False
+
+
+def test_step_cached_replays_one_graph_per_batch_shape():
+    """TrainEngine.step_cached (ragged training, dataset.py:337-364 buckets): the first batch of a shape runs eagerly and is
+    captured, later batches of that shape replay the graph; the parameter trajectory equals the eager engine's on the same
+    batch sequence; the cache is LRU-bounded; label padding by pad_targets changes nothing."""
+    from openeat_amd.engine import pad_targets
+    shapes = [dict(B=3, T=95, L=7), dict(B=2, T=131, L=9), dict(B=4, T=67, L=5)]
+    seq = [0, 1, 0, 2, 1, 0, 2, 2, 1, 0]
+    batches = []
+    for i, k in enumerate(seq):
+        b = batch_of(seed=40 + i, **shapes[k])
+        b["features_length"] = b["features_length"] - torch.arange(b["features"].shape[0], dtype=torch.int32, device=DEV) * 4   # ragged
+        b["targets_length"][-1] -= 2
+        b["targets"][-1, -2:] = -1
+        batches.append(b)
+    m1, m2, m3 = (tiny(seed=31).to(DEV).train() for _ in range(3))
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    ref = [float(e1.step(b)[0]) for b in batches]
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0)
+    try:
+        got = [float(e2.step_cached(dict(b, targets=pad_targets(b["targets"], 4)))[0]) for b in batches]
+        torch.cuda.synchronize()
+        assert (e2.cache_misses, e2.cache_hits) == (3, 7) and len(e2._cache) == 3
+        assert all(r is not None for r in e2._cache.values())            # every shape captured
+    finally:
+        e2.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    for g, r in zip(got, ref):
+        assert abs(g - r) < 2e-4 * abs(r) + 1e-4, (got, ref)
+    check_updates(m2.state_dict(), m1.state_dict(), None, steps=len(seq))
+    e3 = TrainEngine(m3, lr=1e-3, grad_clip=5.0)
+    try:
+        got3 = [float(e3.step_cached(b, max_graphs=1)[0]) for b in batches]
+        torch.cuda.synchronize()
+        assert len(e3._cache) == 1 and e3.cache_hits == 1                # only "2, 2" repeats back to back
+        e3.drop_graph()
+        assert not e3._cache
+    finally:
+        e3.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    for g, r in zip(got3, ref):
+        assert abs(g - r) < 2e-4 * abs(r) + 1e-4
+    check_updates(m3.state_dict(), m1.state_dict(), None, steps=len(seq))
+
+
 def test_dropout_training_step_runs_and_is_seed_dependent():
     m = tiny(seed=9, dropout=0.1).to(DEV).train()
     b = batch_of(seed=4)

@@ -495,3 +495,33 @@ def test_fused_feed_forward_kernel(rows, d, ff, act, prec, p_in, p_out, nout):
         torch.testing.assert_close(aout.cpu().double(), a, **(dict(rtol=2e-4, atol=3e-5 * float(h.abs().max())) if prec == 3 else dict(rtol=3e-2, atol=3e-2)))
         if p_in > 0:
             assert torch.equal(aout == 0, m_in == 0) or float(((aout == 0) != (m_in == 0)).float().mean()) < 1e-4      # (a itself can be exactly 0)
+
+
+@pytest.mark.parametrize("rows,V,k", [(37, 3246, 10), (5, 100, 10), (3, 11000, 16), (2, 25000, 4), (9, 7, 7), (130, 65, 1)])
+def test_topk_rows_kernel(rows, V, k):
+    """oe_topk_rows against log_softmax_rows -> torch.topk (asr_model.py:251, 258, 358): values bit-equal, indices equal."""
+    from openeat_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(rows * 1000 + V)
+    x = (torch.randn(rows, V, generator=g) * 3).cuda()
+    for lsm in (False, True):
+        ref = ops.log_softmax_rows(x) if lsm else x
+        rv, ri = ref.topk(k, dim=-1)
+        gv, gi = ops.topk_rows(x, k, log_softmax=lsm)
+        assert gi.dtype == torch.int64 and gv.shape == (rows, k)
+        assert torch.equal(gv, rv)
+        assert torch.equal(gi, ri)                           # randn values: no ties
+    # the beam-search score matrix (asr_model.py:258): -inf entries and exact ties -> lowest index first, all indices distinct
+    s = torch.full((4, 100), -float("inf"), device="cuda")
+    s[0, [5, 17, 60]] = torch.tensor([1.0, 3.0, 2.0], device="cuda")
+    s[1, :] = 0.5
+    s[2, 40:] = torch.arange(60, device="cuda").float()
+    gv, gi = ops.topk_rows(s, 10)
+    assert gi[0, :3].tolist() == [17, 60, 5] and gv[0, :3].tolist() == [3.0, 2.0, 1.0] and bool(torch.isinf(gv[0, 3:]).all())
+    assert len(set(gi[0].tolist())) == 10
+    assert gi[1].tolist() == list(range(10)) and gi[2].tolist() == list(range(99, 89, -1))
+    assert len(set(gi[3].tolist())) == 10
+    # 3-D input, as the batched rescoring calls it
+    x3 = torch.randn(3, 7, 50, device="cuda")
+    gv, gi = ops.topk_rows(x3, 5, log_softmax=True)
+    rv, ri = ops.log_softmax_rows(x3).topk(5, dim=-1)
+    assert torch.equal(gv, rv) and torch.equal(gi, ri)
