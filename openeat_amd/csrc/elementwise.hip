@@ -407,7 +407,7 @@ extern "C" int oe_masked_softmax_bwd(const float* y, const float* dout, long row
 
 // Per-row top-k, optionally of the row's log-softmax (asr_model.py:251, 358: `logp.topk(beam_size)` after log_softmax; :258
 // `scores.topk`).  One wave per row: the row is staged in LDS while the online log-sum-exp runs (the same arithmetic as
-// log_softmax_kernel, so the values equal log_softmax -> topk bit for bit), every lane remembers the best of its own strided
+// log_softmax_kernel; the values equal log_softmax -> topk to the last bit or two), every lane remembers the best of its own strided
 // elements, and k rounds pick the wave-wide best (ties: lowest index), strike it out and rescan only the winning lane.
 // Sorted descending like torch.topk.  HBM-bound: one read of the row, k values + k int64 indices written.
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long rows, int V, int k, int log_softmax,

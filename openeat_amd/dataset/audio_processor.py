@@ -51,7 +51,8 @@ def speed_perturb_batch(wav: torch.Tensor, nsamples: Sequence[int], speeds: Sequ
     ni = torch.tensor([int(n) for n in nsamples], dtype=torch.int32).to(dev)
     no = torch.tensor(n_out, dtype=torch.int32).to(dev)
     sp = torch.tensor([float(s) for s in speeds], dtype=torch.float32).to(dev)
-    hip.call("oe_speed_perturb", wav, wav.stride(0), ni, sp, B, out.shape[1], out, out.stride(0), no)
+    ld_in = wav.stride(0) if B > 1 else max(wav.shape[1], 1)      # a lone row may carry any (even zero) batch stride
+    hip.call("oe_speed_perturb", wav, ld_in, ni, sp, B, out.shape[1], out, out.stride(0), no)
     return out, n_out
 
 

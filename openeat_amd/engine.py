@@ -247,15 +247,6 @@ class TrainEngine:
             self._graph, self._static, self._out, self._ln_table = None, {}, None, None
 
 
-def pad_targets(targets: torch.Tensor, multiple: int = 16, ignore_id: int = -1) -> torch.Tensor:
-    """Pad the label matrix (B, L) with ignore_id to the next multiple of `multiple` columns: fewer distinct batch shapes
-    for step_cached (padding labels are ignored exactly as the collate's own padding is, dataset.py:219)."""
-    L = targets.shape[1]
-    Lp = -(-L // multiple) * multiple
-    if Lp == L:
-        return targets
-    return torch.nn.functional.pad(targets, (0, Lp - L), value=ignore_id)
-
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
         assert self._graph is not None
         if batch is not None:
@@ -272,3 +263,13 @@ def pad_targets(targets: torch.Tensor, multiple: int = 16, ignore_id: int = -1) 
             finally:
                 self._replaying = False
         return self._out
+
+
+def pad_targets(targets: torch.Tensor, multiple: int = 16, ignore_id: int = -1) -> torch.Tensor:
+    """Pad the label matrix (B, L) with ignore_id to the next multiple of `multiple` columns: fewer distinct batch shapes
+    for step_cached (padding labels are ignored exactly as the collate's own padding is, dataset.py:219)."""
+    L = targets.shape[1]
+    Lp = -(-L // multiple) * multiple
+    if Lp == L:
+        return targets
+    return torch.nn.functional.pad(targets, (0, Lp - L), value=ignore_id)

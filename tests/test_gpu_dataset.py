@@ -195,7 +195,10 @@ def test_fbank_waveform_dither():
     ref = FB.fbank(torch.from_numpy(rng.normal(0, d / 32768.0, 640000).astype(np.float32)))
     gm, rm = got.reshape(-1, 80).double().mean(0).cpu(), ref.double().mean(0)
     gs, rs = got.reshape(-1, 80).double().std(0).cpu(), ref.double().std(0)
-    assert float((gm - rm).abs().max()) < 0.03, float((gm - rm).abs().max())     # ~4000 frames: standard error of a bin mean ~0.01
+    # per-bin standard error of the difference of the two means: ours has ~4000 independent frames, the oracle's 4000 frames
+    # overlap by 60 % (counted as 1600); the narrow low mel bins have a log-energy spread of ~1, the wide high ones ~0.1
+    se = rs * (1.0 / got.reshape(-1, 80).shape[0] + 1.0 / 1600) ** 0.5
+    assert bool(((gm - rm).abs() < 4.5 * se + 0.003).all()), ((gm - rm).abs() / se).max()
     assert float((gs / rs - 1).abs().max()) < 0.1
 
 
