@@ -33,8 +33,9 @@ MODEL_CONF = dict(encoder_num_blocks=12, decoder_num_blocks=3, r_decoder_num_blo
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 KERNEL_NAMES = {0: "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)",
-                1: "gemm_dma_kernel + gemm_bf16_kernel <terms=1> (the kernels behind oe_gemm_f32 precision 1, v_mfma_f32_32x32x16_bf16)",
-                3: "gemm_dma_kernel + gemm_bf16_kernel <terms=3> (the kernels behind oe_gemm_f32 precision 3: "
+                1: "gemm_dma_kernel + gemm_bf16_kernel + ffn_fwd_kernel <terms=1> (the kernels behind oe_gemm_f32 / oe_ffn_fwd precision 1, "
+                   "v_mfma_f32_32x32x16_bf16)",
+                3: "gemm_dma_kernel + gemm_bf16_kernel + ffn_fwd_kernel <terms=3> (the kernels behind oe_gemm_f32 / oe_ffn_fwd precision 3: "
                    "hi*hi+hi*lo+lo*hi, v_mfma_f32_32x32x16_bf16)"}
 DTYPE_NAMES = {0: "f32", 1: "bf16 (MFMA inputs; fp32 storage, accumulate, softmax, norms, losses, optimizer)",
                3: "bf16x3 (matrix products as hi*hi+hi*lo+lo*hi on bf16 MFMA: ~2^-17 relative error per product, fp32 accumulate - "

@@ -34,6 +34,8 @@ ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--mode", default="cached", choices=["cached", "eager"])
 ap.add_argument("--max-graphs", type=int, default=64)
+ap.add_argument("--model", default="24L512", choices=["24L512", "12L256"],
+                help="12L256: the configs[1] model on the same ragged data (launch-bound when run eagerly)")
 args = ap.parse_args()
 hip.GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "3"))
 dev = torch.device("cuda", 0)
@@ -42,6 +44,8 @@ random.seed(777)
 conf = dict(encoder_num_blocks=24, decoder_num_blocks=3, r_decoder_num_blocks=3, d_model=512, attention_heads=8, linear_units=2048,
             dropout_rate=0.1, input_layer="conv2d", pos_enc_layer_type="rel_pos", activation_type="swish", macaron_style=True,
             use_cnn_module=True, cnn_module_kernel=15, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3)
+if args.model == "12L256":
+    conf.update(encoder_num_blocks=12, d_model=256, attention_heads=4)
 model = ASRModel(80, V, **conf).to(dev).train()
 eng = TrainEngine(model, lr=1e-3, grad_clip=5.0)
 fb = Fbank(80, device=dev)
@@ -109,13 +113,43 @@ for hb in staged[args.warmup:]:
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 k = len(staged) - args.warmup
+# GEMM class of one (the largest) batch, eager and on one stream: every oe_gemm_f32 / oe_ffn_fwd launch bracketed by HIP events
+# with the GPU parked behind a spin kernel while the host enqueues (bench.py's method), flops counted per launch
+from openeat_amd import ops as _ops  # noqa: E402
+big = max(staged, key=lambda hb: hb[0].numel())
+saved = (_ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, eng.parallel)
+_ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, eng.parallel = False, False, False
+mode, args.mode = args.mode, "eager"
+hip.PROFILE = []
+for _ in range(2):
+    torch.cuda._sleep(int(1.2e9))
+    step(big)
+torch.cuda.synchronize()
+recs, hip.PROFILE = hip.PROFILE, None
+args.mode = mode
+_ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, eng.parallel = saved
+recs = recs[len(recs) // 2:]
+torch.cuda._sleep(int(1.0e8))
+pairs = []
+for _ in range(200):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    pairs.append((e0, e1))
+torch.cuda.synchronize()
+pair_ms = sorted(a.elapsed_time(b) for a, b in pairs)[100]
+g_secs = sum(max(r[0].elapsed_time(r[1]) - pair_ms, 0.0) for r in recs) * 1e-3
+g_flops = sum(r[2] for r in recs)
+gemm_roof = {"batch": f"B={big[0].shape[0]} x {big[0].shape[1]} samples", "launches": len(recs), "gemm_ms": g_secs * 1e3,
+             "algorithmic_gflop": g_flops / 1e9, "achieved_tflops": g_flops / g_secs / 1e12, "peak_tflops_dense_bf16": 2500.0,
+             "frac": g_flops / g_secs / 1e12 / 2500.0, "mfma_issue_tflops": g_flops * (3 if hip.GEMM_PRECISION == 3 else 1) / g_secs / 1e12}
 padded = sum(len(b) * max(fb.num_frames(int(sec * 16000 / s + 0.5)) for _, sec, _, s in b) for b in batches[args.warmup:])
-print(json.dumps({"workload": "configs[4] on 1 GPU: 24L Conformer d=512 h=8 ff=2048 (192.5 M params), U(2,16) s utterances, speeds {0.9,1,1.1}, "
-                  "SpecAug 3x50/2x10, padded-budget buckets", "steps": k, "ms_per_step": dt / k * 1e3,
+what = ("configs[4] on 1 GPU: 24L Conformer d=512 h=8 ff=2048 (192.5 M params)" if args.model == "24L512" else
+        "configs[4]'s ragged data through configs[1]'s model: 12L Conformer d=256 h=4 ff=2048")
+print(json.dumps({"workload": what + ", U(2,16) s utterances, speeds {0.9,1,1.1}, SpecAug 3x50/2x10, padded-budget buckets", "steps": k, "ms_per_step": dt / k * 1e3,
                   "audio_frames_per_s": frames / dt, "true_over_padded_frames": frames / padded, "budget_padded_frames": args.budget,
                   "loss": float(loss), "precision": hip.GEMM_PRECISION, "mode": args.mode,
                   "first_pass_ms_per_step_incl_captures": first_pass,
                   "graph_cache": None if args.mode != "cached" else {
                       "shapes_captured": sum(r is not None for r in eng._cache.values()), "shapes_eager_only": sum(r is None for r in eng._cache.values()),
                       "timed_pass_hits": eng.cache_hits - h0, "timed_pass_misses": eng.cache_misses - m0, "max_graphs": args.max_graphs},
-                  "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2**30}))
+                  "peak_memory_GiB": torch.cuda.max_memory_allocated() / 2**30, "gemm_class_roofline": gemm_roof}))

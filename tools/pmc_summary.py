@@ -31,7 +31,7 @@ def load(counter):
 
 
 fetch, write = load("FETCH_SIZE"), load("WRITE_SIZE")
-is_gemm = lambda n: "gemm_" in n and "kernel" in n
+is_gemm = lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n
 rows = []
 for name in sorted(set(fetch) | set(write)):
     n = max(fetch[name][0], write[name][0]) / steps

@@ -16,7 +16,7 @@ shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_p3
 rows = [r for r in csv.DictReader(open(f"{src}/trace/{tag}_kernel_stats.csv")) if "spin_kernel" not in r["Name"]]
 steps = 10.0
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
-gem = [r for r in rows if "gemm_" in r["Name"]]
+gem = [r for r in rows if "gemm_" in r["Name"] or "ffn_fwd_kernel" in r["Name"]]
 gt, gc = sum(int(r["TotalDurationNs"]) for r in gem), sum(int(r["Calls"]) for r in gem)
 line = json.load(open(f"{src}/{tag}_bench_p3.json"))
 ro = line["roofline"]
@@ -26,7 +26,7 @@ with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
             "(10 optimizer steps in the trace: first step + 2 warm-up + 5 timed + 2 event-bracketed; the two `spin_kernel` launches that park the "
             f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p3.csv`.\n\n")
     f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
-            f"**GEMM class (`gemm_dma_kernel` + `gemm_bf16_kernel`, the kernels behind `oe_gemm_f32`): {gc / steps:.0f} launches/step, "
+            f"**GEMM class (`gemm_dma_kernel` + `gemm_bf16_kernel` + `ffn_fwd_kernel`, the kernels behind `oe_gemm_f32` / `oe_ffn_fwd`): {gc / steps:.0f} launches/step, "
             f"{gt / 1e6 / steps:.2f} ms/step, average launch {gt / gc / 1e3:.2f} us = {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TFLOP/s algorithmic** - "
             f"bench.py's live HIP-event figure (event-pair overhead calibrated out) is {ro['gemm_ms_per_step']:.2f} ms/step, "
             f"{ro['avg_launch_us']:.2f} us average, {ro['achieved']:.1f} TFLOP/s.\n\n")
