@@ -372,6 +372,10 @@ int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, 
     int tile = (b22 >= (wg ? 200 : 400) && M >= 128 && N >= 128) ? 22 : (b12 >= 400 && N >= 128) ? 12 : 11;
     static const int forced_tile = getenv("OE_GEMM_TILE") ? atoi(getenv("OE_GEMM_TILE")) : 0;   // tuning aid (tools/gemm_bench.py)
     if (forced_tile) tile = forced_tile;
+    if (wg && !ga && !gb) {   // weight gradients: bf16 planes in LDS, two K-groups of waves per block (gemm_tn.hip)
+        const int r = oe_gemm_tn_planes_try(A, B, C, ldc, M, N, K, sk, ep, terms, st);
+        if (r != 1) return r;
+    }
     if (!ga) {   // interior, aligned problems: the LDS-DMA ring kernel
         const int r = oe_gemm_dma_try(A, B, C, ldc, M, N, K, sk, ep, a_kmajor, b_kmajor, gb, terms, tile, st);
         if (r != 1) return r;

@@ -132,6 +132,8 @@ int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, 
                           const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, int terms, hipStream_t st);
 
 // LDS-DMA variant (gemm_dma.hip): returns 1 when the problem does not qualify, else the launch status
+int oe_gemm_tn_planes_try(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep,
+                          int terms, hipStream_t st);
 int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep,
                     bool a_kmajor, bool b_kmajor, bool gather_b, int terms, int tile, hipStream_t st);
 

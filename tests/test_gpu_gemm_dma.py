@@ -124,3 +124,35 @@ if __name__ == "__main__":
             check_case(prec, rel, M, N, K)
         test_conv2_weight_gradient_gather_ring(prec, rel, 128, 2, 65, 17, 2)      # 128x128 tiles when OE_GEMM_TILE=22
     print("dma-ring cases ok")
+
+
+TN_CASES = [  # (rows of dW, cols of dW, reduction length, split asked by the caller, atomic, with bias gradient)
+    (1024, 256, 7936, 16, True, True), (256, 1024, 7936, 16, True, False), (256, 256, 7936, 24, True, True),
+    (768, 256, 1984, 21, True, True), (200, 132, 1100, 3, True, True), (128, 128, 1024, 1, False, False),
+    (260, 388, 1500, 1, False, True), (128, 4864, 1024, 1, True, False)]
+
+
+@pytest.mark.parametrize("prec,rel", PRECS)
+@pytest.mark.parametrize("m,n,k,sk,atomic,bias", TN_CASES)
+def test_weight_gradient_planes_kernel(prec, rel, m, n, k, sk, atomic, bias):
+    """gemm_tn.hip (both operands k-major, bf16 planes in LDS, two K-groups per block): dW = alpha dY^T X against float64,
+    accumulating on top of what the destination holds (atomic split-K) or overwriting / accumulating in place (one split),
+    the bias gradient fused, ragged output edges (multiples of 4), a ragged last K-chunk, a device-side alpha."""
+    from openeat_amd import hip
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    dy, x = torch.randn(k, m, generator=g), torch.randn(k, n, generator=g)
+    start = torch.randn(m, n, generator=g)
+    dyd, xd = dy.to(DEV), x.to(DEV)
+    alpha_dev = torch.tensor([0.5], device=DEV)
+    for accumulate in ((True,) if atomic else (False, True)):
+        dw = start.to(DEV).clone()
+        db = torch.full((m,), 2.0, device=DEV)
+        hip.gemm(dyd, xd, dw, m, n, k, lda=m, ldb=n, ldc=n, a_kmajor=True, b_kmajor=True, split_k=sk, atomic_out=atomic,
+                 accumulate=accumulate and not atomic, alpha=3.0, alpha_dev=alpha_dev, a_colsum=db if bias else None, precision=prec)
+        torch.cuda.synchronize()
+        ref = 1.5 * (dy.double().t() @ x.double()) + (start.double() if (atomic or accumulate) else 0.0)
+        err = float((dw.cpu().double() - ref).abs().max()) / math.sqrt(k)
+        assert err < 1.5 * rel * 2.0, (accumulate, err)        # alpha = 1.5; the maximum over up to 6e5 outputs of a K = 7936 sum
+        if bias:
+            refb = 2.0 + 1.5 * dy.double().sum(0)
+            assert float((db.cpu().double() - refb).abs().max()) < 2e-3 * math.sqrt(k)

@@ -45,6 +45,9 @@ for name, kind, (m, n, k) in SHAPES:
     live = s[:, 4] > 0
     s = s[live].double()
     nb = int(live.sum())
+    if nb == 0:
+        print(f"{name:14s} not on the LDS-DMA kernel (no stamps)")
+        continue
     t0 = s[:, 0].min()
     seg = [(s[:, i + 1] - s[:, i]).median().item() for i in range(4)]
     e = [(s[:, b] - s[:, a]).median().item() for a, b in ((3, 5), (5, 6), (6, 7), (7, 4))]
