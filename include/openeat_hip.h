@@ -271,6 +271,13 @@ int oe_embed_bwd(const long long* tokens, const float* dout, long rows, int d, i
  * between the checkpoint layout (subsampling.py:79 OIHW, :113 channel-major
  * flatten) and the NHWC kernels. */
 int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out, int accumulate, void* stream);
+/* Helpers of the input gradient of a stride-2 3x3 NHWC convolution done as four stride-1 implicit GEMMs, one per parity
+ * class of the input position (the backward of subsampling.py:110-116's second Conv2d):
+ * oe_pad1_nhwc: dy (B, To, Fo, C) -> out (B, To+2, Fo+2, C) with a border of zeros (C % 4 == 0, 16-byte aligned);
+ * oe_conv_dgrad_k3s2_weights: OIHW weight w[C][C][3][3] -> the four classes' B operands [ci][(window row, window col, co)]
+ * back to back in out (9 C^2 floats; class (t1%2, f1%2) at offsets 0, 4C^2, 6C^2, 8C^2). */
+int oe_pad1_nhwc(const float* dy, int B, int To, int Fo, int C, float* out, void* stream);
+int oe_conv_dgrad_k3s2_weights(const float* w, int C, float* out, void* stream);
 
 /* out = a*(*a_dev)*x + b*y (y, a_dev may be NULL). */
 int oe_axpby(const float* x, const float* y, long n, float a, float b, const float* a_dev, float* out, void* stream);

@@ -456,3 +456,62 @@ extern "C" int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w
     OE_LAUNCH_CHECK("dwconv_param_reduce");
     return 0;
 }
+
+
+// ---- helpers of the stride-2 3x3 input gradient (ops._conv_dgrad_k3s2) --------------------------------------------------
+// (1) dy (B, To, Fo, C) -> dyp (B, To + 2, Fo + 2, C) with a border of zeros, one pass (was torch.zeros + a strided copy:
+//     two passes over 170 MB at config 2).  C % 4 == 0.
+__global__ __launch_bounds__(256) void pad1_nhwc_kernel(const float4* __restrict__ dy, int B, int To, int Fo, int C4, float4* __restrict__ out) {
+    const long n = (long)B * (To + 2) * (Fo + 2) * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long q = i / C4;
+        const int f = (int)(q % (Fo + 2)) - 1;
+        q /= (Fo + 2);
+        const int t = (int)(q % (To + 2)) - 1;
+        const long b = q / (To + 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < To && f >= 0 && f < Fo) v = dy[((b * To + t) * Fo + f) * C4 + c];
+        out[i] = v;
+    }
+}
+extern "C" int oe_pad1_nhwc(const float* dy, int B, int To, int Fo, int C, float* out, void* stream) {
+    OE_REQUIRE(dy && out && B > 0 && To > 0 && Fo > 0 && C > 0 && C % 4 == 0, "oe_pad1_nhwc: bad arguments (C must be a multiple of 4)");
+    OE_REQUIRE((((uintptr_t)dy | (uintptr_t)out) & 15) == 0, "oe_pad1_nhwc: pointers must be 16-byte aligned");
+    const long n = (long)B * (To + 2) * (Fo + 2) * (C / 4);
+    hipLaunchKernelGGL(pad1_nhwc_kernel, dim3((unsigned)min((long)oe_cdiv(n, 256), 65536L)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, B, To, Fo, C / 4, (float4*)out);
+    OE_LAUNCH_CHECK("pad1_nhwc");
+    return 0;
+}
+// (2) the B operands of the four parity classes (t1 % 2, f1 % 2) from the OIHW weight w[co][ci][3][3], back to back:
+//     class (pt, pf) uses taps khs = {2, 0} (pt = 0) or {1} (pt = 1), kws likewise; its operand is [ci][(window row, window
+//     col, co)].  Offsets (floats): (0,0) 0, (0,1) 4 C^2, (1,0) 6 C^2, (1,1) 8 C^2; 9 C^2 in all.  (Was 10 stacks + 4 copies.)
+__global__ __launch_bounds__(256) void conv_dgrad_k3s2_weights_kernel(const float* __restrict__ w, int C, float* __restrict__ out) {
+    const long n = 9L * C * C;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long cc = (long)C * C;
+    int cls, KH, KW;
+    long base;
+    if (i < 4 * cc) { cls = 0; KH = 2; KW = 2; base = 0; }
+    else if (i < 6 * cc) { cls = 1; KH = 2; KW = 1; base = 4 * cc; }
+    else if (i < 8 * cc) { cls = 2; KH = 1; KW = 2; base = 6 * cc; }
+    else { cls = 3; KH = 1; KW = 1; base = 8 * cc; }
+    const long r = i - base;                       // [ci][khi][kwi][co]
+    const int co = (int)(r % C);
+    long q = r / C;
+    const int kwi = (int)(q % KW);
+    q /= KW;
+    const int khi = (int)(q % KH);
+    const int ci = (int)(q / KH);
+    const int kh = (cls >> 1) ? 1 : (khi == 0 ? 2 : 0);      // pt = cls >> 1, pf = cls & 1
+    const int kw = (cls & 1) ? 1 : (kwi == 0 ? 2 : 0);
+    out[i] = w[(((long)co * C + ci) * 3 + kh) * 3 + kw];
+}
+extern "C" int oe_conv_dgrad_k3s2_weights(const float* w, int C, float* out, void* stream) {
+    OE_REQUIRE(w && out && C > 0, "oe_conv_dgrad_k3s2_weights: bad arguments");
+    hipLaunchKernelGGL(conv_dgrad_k3s2_weights_kernel, dim3(oe_cdiv(9L * C * C, 256)), dim3(256), 0, (hipStream_t)stream, w, C, out);
+    OE_LAUNCH_CHECK("conv_dgrad_k3s2_weights");
+    return 0;
+}

@@ -138,6 +138,8 @@ _SIGNATURES = {
     "oe_embed_fwd": (I, [P, P, P, L, I, I, I, F, P, P]),
     "oe_embed_bwd": (I, [P, P, L, I, I, F, P, P]),
     "oe_swap_last2": (I, [P, L, I, I, P, I, P]),
+    "oe_pad1_nhwc": (I, [P, I, I, I, I, P, P]),
+    "oe_conv_dgrad_k3s2_weights": (I, [P, I, P, P]),
     "oe_axpby": (I, [P, P, L, F, F, P, P, P]),
     "oe_act_fwd": (I, [P, L, I, P, P]),
     "oe_act_grad": (I, [P, P, L, I, P, P]),

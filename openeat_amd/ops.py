@@ -1066,21 +1066,21 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
     bounds and the gather needs no predicate) and whose epilogue scatters the rows to dx[:, t1 % 2 :: 2, f1 % 2 :: 2]
     and applies the mask.  The same 2*M*N*K flops as the column-buffer form, 1.4 GB less written and 2.7 GB less gathered
     at config 2."""
-    dyp = torch.zeros(B, To + 2, Fo + 2, C, device=dy.device, dtype=torch.float32)
-    dyp[:, 1:To + 1, 1:Fo + 1] = dy.view(B, To, Fo, C)
+    dyp = _new(B, To + 2, Fo + 2, C, like=dy)
+    hip.call("oe_pad1_nhwc", dy, B, To, Fo, C, dyp)
+    wcls = _new(9 * C * C, like=dy)                    # the four classes' B operands [ci][(window row, window col, co)], one launch
+    hip.call("oe_conv_dgrad_k3s2_weights", wk, C, wcls)
     dyin = torch.empty_like(yin)
     flat_in, flat_out, flat_y = dyp.view(-1), dyin.view(-1), yin.reshape(-1)
+    w_off = 0
     for pt in (0, 1):
-        khs = [2, 0] if pt == 0 else [1]               # window row 0 is dy row i - 1 (tap 2), row 1 is dy row i (tap 0); odd t1: tap 1
+        KH = 2 if pt == 0 else 1                       # window row 0 is dy row i - 1 (tap 2), row 1 is dy row i (tap 0); odd t1: tap 1
         ni = (Ti + 1 - pt) // 2
         for pf in (0, 1):
-            kws = [2, 0] if pf == 0 else [1]
+            KW = 2 if pf == 0 else 1
             nj = (Fi + 1 - pf) // 2
-            KH, KW = len(khs), len(kws)
-            # B operand [ci][(window row, window col, co)]
-            # (plain slices and stacks: indexing with a list would build an index tensor on the host, which a graph capture forbids)
-            wsel = torch.stack([torch.stack([wk[:, :, kh, kw] for kw in kws], dim=-1) for kh in khs], dim=-2)    # (co, ci, KH, KW)
-            wsel = wsel.permute(1, 2, 3, 0).contiguous().view(C, KH * KW * C)
+            wsel = wcls[w_off:w_off + KH * KW * C * C].view(C, KH * KW * C)
+            w_off += KH * KW * C * C
             a_off = (pt * (Fo + 2) + pf) * C           # odd classes start one padded row / column further
             o_off = (pt * Fi + pf) * C
             hip.gemm(flat_in[a_off:], wsel, flat_out[o_off:], B * ni * nj, C, KH * KW * C, lda=0, ldb=KH * KW * C, ldc=C,
