@@ -56,6 +56,12 @@ class GradAllReduce:
 
     def _issue(self, t: torch.Tensor):
         op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        if not self._avg and t.is_cuda:
+            # a host-staged backend (gloo rehearsals on one GPU): its device-to-host copy behind a HIP-graph launch that has
+            # not finished took SECONDS per call on this stack (tools/n2_probe.py: graphs alone 35 ms, arena all-reduce
+            # alone 32 ms, back to back 6-12 s); behind a finished stream it takes its 32 ms.  RCCL's collectives are
+            # kernels ordered by stream events and never come here.
+            torch.cuda.current_stream().synchronize()
         self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
 
     def reduce_tail(self, start: int):

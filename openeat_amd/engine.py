@@ -18,7 +18,7 @@ from openeat_amd.utils import common
 class TrainEngine:
     def __init__(self, model: torch.nn.Module, lr: float = 1e-3, grad_clip: float = 5.0, accum_grad: int = 1,
                  n_allreduce_chunks: int = 4, static_shapes: bool = False, async_wgrad: bool = True,
-                 parallel_decoders: bool = False):
+                 parallel_decoders: bool = False, segmented: Optional[bool] = None):
         self.model = model
         ops.ASYNC_WGRAD = bool(async_wgrad)
         ops.PARALLEL_DECODERS = bool(parallel_decoders)
@@ -27,7 +27,13 @@ class TrainEngine:
         self.optimizer = FusedAdam(self.arena, lr=lr, max_grad_norm=grad_clip)
         self.reducer = GradAllReduce(self.arena.grad, n_allreduce_chunks)
         self.reducer.broadcast_parameters(self.arena.flat)
-        if self.reducer.world > 1:
+        # capture() with several ranks records the step as a chain of graphs cut where the eager step's backward hooks sit,
+        # so that the gradient all-reduces start between the replays (None: exactly when world > 1; True on one rank
+        # exercises the same path with no-op collectives)
+        import os
+        self.segmented = (self.reducer.world > 1 and os.environ.get("OE_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
+        self._segments = None
+        if self.reducer.world > 1 or self.segmented:
             self._install_overlap_hooks()
         self.accum_grad = max(1, int(accum_grad))
         self._micro = 0                          # micro-steps accumulated since the last optimizer step
@@ -85,6 +91,7 @@ class TrainEngine:
 
     _capturing = False
     _replaying = False
+    _seg_keep = None
     _hooks_off = False          # capture()'s warm-up steps: same launch structure as the capture (whole arena reduced after backward)
     _split = False
 
@@ -161,14 +168,17 @@ class TrainEngine:
                 mode = "thread_local" if self.reducer.world > 1 else "global"
                 ops.ln_table_begin(self.arena.flat.device)
                 try:
-                    with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-                        try:
-                            self.arena.grad.zero_()
-                            self._out = self._fwd_bwd(self._static)
-                            if not self._split:
-                                self._finish()
-                        finally:
-                            unjoined = self._lead_forks_back()      # also when the step raised: capture_end comes next
+                    if self.segmented:
+                        g, unjoined = self._capture_segments(pool, mode)
+                    else:
+                        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                            try:
+                                self.arena.grad.zero_()
+                                self._out = self._fwd_bwd(self._static)
+                                if not self._split:
+                                    self._finish()
+                            finally:
+                                unjoined = self._lead_forks_back()      # also when the step raised: capture_end comes next
                 finally:
                     self._ln_table = ops.ln_table_end()        # the graph's launch reads this tensor: keep it alive
             finally:
@@ -178,9 +188,53 @@ class TrainEngine:
             ops.WGRAD_DEFER = 0
             ops.drop_deferred()                # a capture that failed midway must not leave launches behind for an eager step
         if unjoined:
+            self._segments = None
             raise RuntimeError(f"TrainEngine.capture: {unjoined} forked stream(s) had not rejoined the capturing stream at the end "
                                "of the step (a fork without its join); they were joined to close the capture, the graph is dropped")
         self._graph = g
+
+    def _capture_segments(self, pool, mode):
+        """The step as a chain of HIP graphs in one memory pool (DistributedDataParallel's backward/all-reduce overlap,
+        /root/reference/openeat/bin/train_ddp.py:212-219, without giving the graphs up): graph 0 = zero-grad + forward +
+        backward of the heads down to the encoder output; then one graph per stretch of encoder layers between the cut
+        points (ops.cut: where the eager step's hooks sit), the last one ending in the input layer.  After graph k the
+        gradients of everything downstream of its cut are final: replay() hands that tail of the arena to the collective
+        and goes straight on to graph k + 1.  Returns (first graph, unjoined-stream count)."""
+        pool = pool if pool is not None else torch.cuda.graph_pool_handle()
+        self._split = True                        # clip + Adam follow the last all-reduce, outside the graphs
+        us = self.arena.unit_start
+        segs, unjoined = [], 0
+        ops.CUTS = []
+        try:
+            g0 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g0, pool=pool, capture_error_mode=mode):
+                try:
+                    self.arena.grad.zero_()
+                    self._out = self._fwd_bwd(self._static)
+                finally:
+                    unjoined += self._lead_forks_back()
+            cuts = list(reversed(ops.CUTS))       # backward order: the encoder output first, then the layer cuts from the top
+            ops.CUTS = None
+            pending = g0
+            for name, upstream, leaf in cuts:
+                if leaf.grad is None:
+                    raise RuntimeError(f"segmented capture: no gradient reached the cut '{name}'")
+                segs.append((pending, us[name]))  # after `pending`: floats [us[name], ...) of the gradient arena are final
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                    try:
+                        torch.autograd.backward([upstream], [leaf.grad])
+                        ops.join_side_stream()
+                        ops.ln_table_flush()
+                    finally:
+                        unjoined += self._lead_forks_back()
+                pending = g
+            segs.append((pending, None))          # the rest of the arena goes with _finish()
+        finally:
+            ops.CUTS = None
+        self._segments = segs
+        self._seg_keep = cuts                     # the tapes' tensors live in the graphs' pool: keep the python objects too
+        return g0, unjoined
 
     @staticmethod
     def _lead_forks_back() -> int:
@@ -200,6 +254,8 @@ class TrainEngine:
     def drop_graph(self):
         """Forget the captured graph(s) (and give their memory pool back): subsequent steps are eager again."""
         self._graph = None
+        self._segments = None
+        self._seg_keep = None
         self._out = None
         self._static = {}
         self._ln_table = None
@@ -228,10 +284,10 @@ class TrainEngine:
                 self._pool = torch.cuda.graph_pool_handle()
             try:
                 self.capture(batch, pool=self._pool, _warm=True)
-                rec = (self._graph, self._static, self._out, self._ln_table)
+                rec = (self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep)
             except RuntimeError:
                 rec = None                       # this shape does not capture: it keeps running eagerly
-            self._graph, self._static, self._out, self._ln_table = None, {}, None, None
+            self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
             self._cache[key] = rec
             while len(self._cache) > max(1, max_graphs):
                 self._cache.popitem(last=False)
@@ -240,11 +296,11 @@ class TrainEngine:
         if rec is None:
             return self.step(batch, lr)
         self.cache_hits += 1
-        self._graph, self._static, self._out, self._ln_table = rec
+        self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = rec
         try:
             return self.replay(batch, lr)
         finally:
-            self._graph, self._static, self._out, self._ln_table = None, {}, None, None
+            self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
 
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
@@ -255,7 +311,13 @@ class TrainEngine:
         if lr is not None:
             self.optimizer.set_lr(lr)
         self.optimizer.lr_dev.fill_(float(self.optimizer.param_groups[0]["lr"]))     # the graph's Adam reads lr_dev
-        self._graph.replay()
+        if self._segments:
+            for g, final_from in self._segments:
+                g.replay()
+                if final_from is not None:
+                    self.reducer.reduce_tail(final_from)      # async: the next graph runs beside the collective
+        else:
+            self._graph.replay()
         if self._split:
             self._replaying = True
             try:

@@ -84,6 +84,7 @@ class ASRModel(torch.nn.Module):
         if hooks and encoder_out.requires_grad:
             cb = hooks["encoder_out"]
             encoder_out.register_hook(lambda g, cb=cb: cb())      # returns None: the gradient is not modified
+            encoder_out = ops.cut(encoder_out, "heads")           # segmented capture: the tape ends here (identity otherwise)
         encoder_out_lens = encoder_mask.squeeze(1).sum(1)
         if par:
             # the CTC head (a few chip-filling launches) on a third stream beside the decoders' latency-bound chains

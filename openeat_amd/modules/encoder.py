@@ -111,6 +111,7 @@ class TransformerEncoder(torch.nn.Module):
             for i, layer in enumerate(self.encoders):
                 if hooks and i in hooks and xs.requires_grad:
                     xs.register_hook(lambda g, cb=hooks[i]: cb())     # gradient of layer i's input ready = layers >= i done
+                    xs = ops.cut(xs, f"enc{i}")                       # segmented capture: the tape ends here (identity otherwise)
                 for _ in range(self.num_blocks_share):
                     xs, _ = layer(xs, m8, pos_emb)
         finally:

@@ -160,6 +160,21 @@ def side_stream():
     return _side_stream
 
 
+# ---- cut points for a step captured in segments (TrainEngine.capture with several ranks) ---------------------------------
+# At a cut the forward value passes through unchanged, but the autograd tape is severed: the engine first differentiates
+# from the loss down to the last cut (its gradient lands in `leaf.grad`), then resumes from each cut's upstream side
+# with that gradient - one HIP graph per piece, a gradient all-reduce issued between the replays.
+CUTS = None          # None: cut() is the identity.  A list: (name, upstream tensor, leaf) per cut, in forward order.
+
+
+def cut(x: torch.Tensor, name: str) -> torch.Tensor:
+    if CUTS is None or not x.requires_grad:
+        return x
+    leaf = x.detach().requires_grad_(True)
+    CUTS.append((name, x, leaf))
+    return leaf
+
+
 def forked_streams():
     """Every stream the step may fork work onto (the engine checks that a capture has led them all back)."""
     return [s for s in (_side_stream, _decoder_stream, _ctc_stream) if s is not None] + list(_extra_streams)

@@ -106,5 +106,70 @@ def test_two_rank_step_matches_gradient_averaging(tmp_path):
     assert float(bad.float().mean()) < 2e-3, float(bad.float().mean())
 
 
+def worker_segmented():
+    """Both ranks: three eager steps (hooks start the all-reduces inside backward) on one copy of the model, and
+    warm-up + two replays of the segmented capture (all-reduces between the graphs) on another; same batch every step."""
+    sys.path.insert(0, ROOT)
+    from openeat_amd import ddp, ops
+    from openeat_amd.engine import TrainEngine
+    rank, _, world = ddp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    batch = _batch(200 + rank, dev)
+    out = {}
+    for tag in ("eager", "segmented"):
+        model = _model(dev)
+        eng = TrainEngine(model, lr=1e-2, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+        assert eng.segmented and eng.reducer.world == 2
+        issued = []
+        orig = eng.reducer.reduce_tail
+        eng.reducer.reduce_tail = lambda start, orig=orig, issued=issued: (issued.append(start), orig(start))[1]
+        if tag == "eager":
+            for _ in range(3):
+                loss, _ = eng.step(batch)
+        else:
+            eng.capture(batch, warmup=1)                     # one real step, then the capture
+            assert len(eng._segments) == 5
+            n0 = len(issued)
+            for _ in range(2):
+                loss, _ = eng.replay()
+            assert len(issued) - n0 == 8, issued             # four tails per replay, started between the graphs
+        torch.cuda.synchronize()
+        out[tag] = (eng.arena.flat.detach().cpu(), float(loss))
+        eng.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    torch.save(out, os.environ["OE_TEST_OUT"] + f".{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_segmented_capture_matches_eager_steps(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "seg_out")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2",
+                   OE_TEST_OUT=out, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker_segmented"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-4000:]
+    got = [torch.load(out + f".{r}") for r in range(2)]
+    for tag in ("eager", "segmented"):
+        assert torch.equal(got[0][tag][0], got[1][tag][0])                   # both ranks hold the same parameters
+    a, b = got[0]["eager"][0], got[0]["segmented"][0]
+    lr, steps = 1e-2, 3
+    diff = (a - b).abs()
+    assert float(diff.max()) <= 2.05 * lr * steps
+    assert float((diff > 0.1 * lr * steps + 1e-3 * a.abs()).float().mean()) < 0.02
+    assert abs(got[0]["eager"][1] - got[0]["segmented"][1]) < 1e-3 * abs(got[0]["eager"][1])
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker":
     worker()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker_segmented":
+    worker_segmented()

@@ -322,6 +322,44 @@ def test_step_cached_replays_one_graph_per_batch_shape():
     check_updates(m3.state_dict(), m1.state_dict(), None, steps=len(seq))
 
 
+@pytest.mark.parametrize("parallel", [False, True])
+def test_segmented_capture_equals_eager_steps(parallel):
+    """TrainEngine(segmented=True): the step captured as a chain of graphs cut at the encoder output and at the quarter
+    points of the encoder stack (the multi-rank capture; on one rank the collectives between the graphs are no-ops).  Same
+    losses and parameters as eager steps; the cuts are where the arena's units start."""
+    from openeat_amd.models.asr_model import ASRModel
+
+    def four_layers():
+        torch.manual_seed(17)
+        return ASRModel(80, 40, encoder_num_blocks=4, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+                        linear_units=64, dropout_rate=0.0, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3).to(DEV).train()
+    m1, m2 = four_layers(), four_layers()
+    b = batch_of(seed=6)
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    for _ in range(4):
+        l_eager, _ = e1.step(b)
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=parallel, segmented=True)
+    try:
+        sent = []
+        e2.reducer.reduce_tail = lambda start: sent.append(start)
+        e2.capture(b, warmup=1)
+        us = e2.arena.unit_start
+        assert [f for _, f in e2._segments] == [us["heads"], us["enc3"], us["enc2"], us["enc1"], None]
+        for _ in range(3):
+            l_graph, _ = e2.replay()
+        torch.cuda.synchronize()
+        assert sent == [us["heads"], us["enc3"], us["enc2"], us["enc1"]] * 3
+    finally:
+        e2.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        ops.PARALLEL_DECODERS = False
+        ops.POS_PROJ_AHEAD = False
+    torch.testing.assert_close(l_graph, l_eager, rtol=1e-4, atol=1e-5)
+    check_updates(m2.state_dict(), m1.state_dict(), None, steps=4)
+
+
 def test_dropout_training_step_runs_and_is_seed_dependent():
     m = tiny(seed=9, dropout=0.1).to(DEV).train()
     b = batch_of(seed=4)
