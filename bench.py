@@ -230,11 +230,13 @@ def main():
         return agree((time.perf_counter() - t) / n * 1e3)
 
     use_graph = False
-    # N > 1: the graph holds zero-grad + forward + backward, the all-reduce of the whole arena and the optimizer follow it
-    # eagerly (exposed, ~1 ms at 8 GPUs) - against an eager step that overlaps the collectives with backward but is
-    # host-bound (~1100 launches, 23-28 ms on the boxes seen).  Both are tried and the faster is timed; the capture runs
-    # in thread-local error mode (RCCL's watchdog thread polls events meanwhile) and any capture error falls back to eager.
-    # Rehearsed with 2 ranks over gloo on one GPU (capture + replay + rank-agreed choice); RCCL itself needs > 1 GPU.
+    # N > 1: the step is captured as a chain of five graphs cut at the encoder output and the quarter points of the encoder
+    # stack (TrainEngine._capture_segments); the all-reduce of the arena tail that a graph has finished is issued right
+    # after its replay and runs beside the next graph, clip + Adam follow the last collective - against an eager step that
+    # overlaps the same way from autograd hooks but is host-bound (~1100 launches, 23-28 ms on the boxes seen).  Both are
+    # tried and the faster is timed; the capture runs in thread-local error mode (RCCL's watchdog thread polls events
+    # meanwhile) and any capture error falls back to eager.  Rehearsed with 2 ranks over gloo on one GPU
+    # (profiles/r02_multi_gpu_rehearsal.md); RCCL itself needs > 1 GPU.
     if not args.no_graph and (world == 1 or args.graph_multi):
         n_trial = 10 if world == 1 else 5
         t_eager = trial(eager, n_trial)              # before the capture: the graph's private memory pool changes allocator state
