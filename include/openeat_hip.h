@@ -400,6 +400,15 @@ int oe_feature_dither(float* x, const int* nframes, int B, int Tmax, int F, floa
 int oe_speed_perturb(const float* wav, long ld_in, const int* n_in, const float* speed, int B, int Nmax_out, float* out,
                      long ld_out, const int* n_out, void* stream);
 
+/* CTC prefix beam search on the device, one wavefront per utterance (asr_model.py:359-396; the host functions below are
+ * the same algorithm on the CPU and serve as its checker).  topk_logp (B, Tmax, beam) f32 and topk_idx (B, Tmax, beam) i64
+ * as oe_topk_rows writes them; lens (B) i32 valid frames per utterance or NULL; beam <= 16.  workspace:
+ * oe_ctc_prefix_beam_workspace_bytes(B, Tmax, beam) bytes of device memory whose LAST 4-byte word the caller zeroes and
+ * reads back after the stream has drained (non-zero: a prefix exceeded max_len).  Outputs, device memory: out_prefix
+ * (B, beam, max_len) i32, out_len (B, beam) i32 (-1: fewer than `beam` prefixes exist), out_score (B, beam) f64. */
+size_t oe_ctc_prefix_beam_workspace_bytes(int B, int Tmax, int beam);
+int oe_ctc_prefix_beam(const float* topk_logp, const long long* topk_idx, int B, int Tmax, const int* lens, int beam, int max_len,
+                       void* workspace, int* out_prefix, int* out_len, double* out_score, void* stream);
 /* CTC prefix beam search, HOST code (all pointers are host pointers): the per-frame recursion of
  * asr_model.py:359-396 on the top-`beam` (log-prob, token) pairs of every frame (computed on the
  * device).  Doubles and insertion-ordered stable pruning as in the reference's Python, so the

@@ -164,6 +164,8 @@ _SIGNATURES = {
     "oe_spec_substitute": (I, [P, I, I, I, P, I, I, P]),
     "oe_feature_dither": (I, [P, P, I, I, I, F, U64, P]),
     "oe_speed_perturb": (I, [P, L, P, P, I, I, P, L, P, P]),
+    "oe_ctc_prefix_beam_workspace_bytes": (SZ, [I, I, I]),
+    "oe_ctc_prefix_beam": (I, [P, P, I, I, P, I, I, P, P, P, P, P]),
     "oe_ctc_prefix_beam_host": (I, [P, P, I, I, I, P, P, P]),
     "oe_ctc_prefix_beam_host_batch": (I, [P, P, I, I, P, I, I, P, P, P, I]),
     "oe_grad_norm_workspace_floats": (SZ, []),
@@ -314,6 +316,33 @@ def attention_bwd(a: AttnArgs):
     check(lib().oe_attention_bwd(C.byref(a), stream()), "oe_attention_bwd")
 
 
+def ctc_prefix_beam_device(top_logp: torch.Tensor, top_idx: torch.Tensor, lens: Optional[torch.Tensor], beam: int, raw: bool = False):
+    """top_logp (B, T, beam) float32 / top_idx (B, T, beam) int64 CUDA tensors (ops.topk_rows), lens (B) int32 CUDA or None ->
+    per utterance [(prefix tuple, score)], as ctc_prefix_beam_host_batch returns them.  One kernel, one wave per
+    utterance; one device-to-host copy of the n-best lists.  raw=True: no copy at all - the device tensors
+    (prefixes (B, beam, T) int32, lengths (B, beam) int32 with -1 for missing entries, scores (B, beam) float64) and a
+    status word tensor the caller checks after its own synchronisation."""
+    if not (top_logp.is_cuda and top_idx.is_cuda and top_logp.dtype == torch.float32 and top_idx.dtype == torch.int64):
+        raise TypeError("ctc_prefix_beam_device: float32 / int64 CUDA tensors required")
+    top_logp, top_idx = top_logp.contiguous(), top_idx.contiguous()
+    B, T = top_logp.shape[0], top_logp.shape[1]
+    ml = max(T, 1)
+    dev = top_logp.device
+    ws = torch.empty(lib().oe_ctc_prefix_beam_workspace_bytes(B, T, beam) // 4, dtype=torch.int32, device=dev)
+    ws[-1:].zero_()
+    prefixes = torch.zeros(B, beam, ml, dtype=torch.int32, device=dev)
+    plen = torch.empty(B, beam, dtype=torch.int32, device=dev)
+    scores = torch.empty(B, beam, dtype=torch.float64, device=dev)
+    call("oe_ctc_prefix_beam", top_logp, top_idx, B, T, lens, beam, ml, ws, prefixes, plen, scores)
+    if raw:
+        return prefixes, plen, scores, ws[-1:]
+    prefixes, plen, scores, bad = prefixes.cpu().numpy(), plen.cpu().numpy(), scores.cpu().numpy(), int(ws[-1])
+    if bad:
+        raise RuntimeError("oe_ctc_prefix_beam: a prefix exceeded max_len")
+    return [[(tuple(prefixes[b, i, : plen[b, i]].tolist()), float(scores[b, i])) for i in range(beam) if plen[b, i] >= 0]
+            for b in range(B)]
+
+
 def ctc_prefix_beam_host_batch(top_logp: torch.Tensor, top_idx: torch.Tensor, lens, beam: int, n_threads: int = 0):
     """top_logp (B, T, beam) float32 / top_idx (B, T, beam) int64 CPU tensors, lens[b] valid frames ->
     per utterance [(prefix tuple, score)] (native host code, utterances spread over host threads)."""
@@ -329,7 +358,7 @@ def ctc_prefix_beam_host_batch(top_logp: torch.Tensor, top_idx: torch.Tensor, le
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     check(lib().oe_ctc_prefix_beam_host_batch(vp(lp), vp(ix), B, T, vp(ln), beam, ml, vp(prefixes), vp(plen), vp(scores), n_threads),
           "oe_ctc_prefix_beam_host_batch")
-    return [[(tuple(int(v) for v in prefixes[b, i, : plen[b, i]]), float(scores[b, i])) for i in range(beam) if plen[b, i] >= 0]
+    return [[(tuple(prefixes[b, i, : plen[b, i]].tolist()), float(scores[b, i])) for i in range(beam) if plen[b, i] >= 0]
             for b in range(B)]
 
 
@@ -346,4 +375,4 @@ def ctc_prefix_beam_host(top_logp: torch.Tensor, top_idx: torch.Tensor, beam: in
                                        prefixes.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
                                        scores.ctypes.data_as(C.c_void_p))
     check(rc, "oe_ctc_prefix_beam_host")
-    return [(tuple(int(v) for v in prefixes[i, : lens[i]]), float(scores[i])) for i in range(beam) if lens[i] >= 0]
+    return [(tuple(prefixes[i, : lens[i]].tolist()), float(scores[i])) for i in range(beam) if lens[i] >= 0]

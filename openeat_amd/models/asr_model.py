@@ -4,6 +4,7 @@
 targets_length) -> (loss, acc)``, the four decoding entry points, and the same
 flat state-dict keys.  All tensor arithmetic runs in the gfx950 kernels."""
 from collections import defaultdict
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -17,6 +18,11 @@ from openeat_amd.modules.label_smoothing_loss import LabelSmoothingLoss
 from openeat_amd.utils.cmvn import load_cmvn
 from openeat_amd.utils.common import (IGNORE_ID, add_sos_eos, log_add, remove_duplicates_and_blank, reverse_pad_list)
 from openeat_amd.utils.mask import make_pad_mask, mask_finished_preds, mask_finished_scores, subsequent_mask
+
+
+# The CTC prefix recursion on the device (beam.hip, one wave per utterance); 0: the native host implementation
+# (beam_host.cpp, same algorithm, the device kernel's checker).
+DEVICE_BEAM = os.environ.get("OE_DEVICE_BEAM", "1") != "0"
 
 
 class ASRModel(torch.nn.Module):
@@ -168,6 +174,8 @@ class ASRModel(torch.nn.Module):
         encoder_out, _, _ = self._encode(features, features_length)
         top_p, top_i = ops.topk_rows(self.ctc.logits(encoder_out).squeeze(0), beam_size, log_softmax=True)
         from openeat_amd import hip
+        if DEVICE_BEAM and beam_size <= 16:
+            return hip.ctc_prefix_beam_device(top_p.unsqueeze(0), top_i.unsqueeze(0), None, beam_size)[0], encoder_out
         return hip.ctc_prefix_beam_host(top_p.cpu(), top_i.cpu(), beam_size), encoder_out
 
     def ctc_prefix_beam_search(self, features, features_length, beam_size: int) -> List[int]:
@@ -240,21 +248,39 @@ class ASRModel(torch.nn.Module):
         encoder_out, encoder_mask, _ = self._encode(features, features_length)
         lens = encoder_mask.squeeze(1).sum(1)
         top_p, top_i = ops.topk_rows(self.ctc.logits(encoder_out), beam_size, log_softmax=True)
-        top_p, top_i, lens_h = top_p.cpu(), top_i.cpu(), lens.cpu().tolist()
-        nbest = hip.ctc_prefix_beam_host_batch(top_p, top_i, lens_h, beam_size)
-        for b in range(B):                                     # a very short utterance can yield fewer than `beam` prefixes
-            while len(nbest[b]) < beam_size:
-                nbest[b].append((nbest[b][-1][0], -float("inf")))
-        flat = [h for nb in nbest for h in nb]
-        self.last_nbest_mean_len = sum(len(h[0]) for h in flat) / max(len(flat), 1)
         R = B * beam_size
-        hl = torch.tensor([len(h[0]) for h in flat], dtype=torch.long)
-        Lm = max(int(hl.max()), 1)
-        ori = torch.full((R, Lm), self.ignore_id, dtype=torch.long)
-        for i, h in enumerate(flat):
-            if h[0]:
-                ori[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long)
-        ori, hl = ori.to(device), hl.to(device)
+        on_device = DEVICE_BEAM and beam_size <= 16
+        if on_device:
+            # the n-best lists never leave the device: prefixes (B, beam, T') int32, lengths (-1: fewer than `beam` prefixes
+            # exist - such a slot scores -inf below), CTC scores float64
+            pre, plen, ctc_scores, bad = hip.ctc_prefix_beam_device(top_p, top_i, lens.to(torch.int32), beam_size, raw=True)
+            plen = plen.view(R)
+            missing = plen < 0
+            hl = plen.clamp(min=0).long()
+            Lm = max(int(hl.max()), 1)                           # the one host sync of the n-best stage
+            if int(bad):
+                raise RuntimeError("oe_ctc_prefix_beam: a prefix exceeded max_len")
+            ori = pre.view(R, -1)[:, :Lm].long()
+            ori = ori.masked_fill(torch.arange(Lm, device=device).unsqueeze(0) >= hl.unsqueeze(1), self.ignore_id)
+            ctc_scores = ctc_scores.view(R).masked_fill(missing, -float("inf"))
+            self.last_nbest_mean_len = float(hl.float().mean())
+            nbest = None
+        else:
+            nbest = hip.ctc_prefix_beam_host_batch(top_p.cpu(), top_i.cpu(), lens.cpu().tolist(), beam_size)
+            for b in range(B):                                     # a very short utterance can yield fewer than `beam` prefixes
+                while len(nbest[b]) < beam_size:
+                    nbest[b].append((nbest[b][-1][0], -float("inf")))
+            flat = [h for nb in nbest for h in nb]
+            self.last_nbest_mean_len = sum(len(h[0]) for h in flat) / max(len(flat), 1)
+            hl = torch.tensor([len(h[0]) for h in flat], dtype=torch.long)
+            Lm = max(int(hl.max()), 1)
+            ori = torch.full((R, Lm), self.ignore_id, dtype=torch.long)
+            for i, h in enumerate(flat):
+                if h[0]:
+                    ori[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long)
+            ori, hl = ori.to(device), hl.to(device)
+            ctc_scores = torch.tensor([h[1] for h in flat], dtype=torch.float64, device=device)
+            missing = torch.isinf(ctc_scores)
         hyps_pad, _ = add_sos_eos(ori, self.sos, self.eos, self.ignore_id)
         L = hyps_pad.size(1)
         hyps_mask = (~make_pad_mask(hl + 1, L)).unsqueeze(1) & subsequent_mask(L, device=device).unsqueeze(0)
@@ -279,12 +305,18 @@ class ASRModel(torch.nn.Module):
             r_tok = torch.cat([reverse_pad_list(ori, hl, self.ignore_id).long(),
                                ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)
             score = score * (1 - reverse_weight) + seq_score(r_x, r_tok) * reverse_weight
-        score = score + torch.tensor([h[1] for h in flat], dtype=torch.float64, device=device) * ctc_weight
+        score = score + ctc_scores * ctc_weight
         if lm is not None and lm_weight > 0:                                      # neural-LM shallow fusion (asr_model.py:490-527)
             lm_lp = lm.log_probs(hyps_pad, hl + 1)
             lm_tok = lm_lp.gather(2, tok.unsqueeze(2)).squeeze(2)
             score = score + (lm_tok * valid).sum(1).double() * lm_weight
-        best = score.view(B, beam_size).argmax(1).cpu().tolist()
+        score = score.masked_fill(missing, -float("inf"))         # (0 * -inf above would be nan: the slot is out whatever the weights)
+        best = score.view(B, beam_size).argmax(1)
+        if nbest is None:
+            pick = best + torch.arange(B, device=device) * beam_size
+            toks, n = ori.index_select(0, pick).cpu(), hl.index_select(0, pick).cpu().tolist()
+            return [toks[b, : n[b]].tolist() for b in range(B)]
+        best = best.cpu().tolist()
         return [list(nbest[b][best[b]][0]) for b in range(B)]
 
     def recognize(self, features: torch.Tensor, features_length: torch.Tensor, beam_size: int = 10) -> torch.Tensor:

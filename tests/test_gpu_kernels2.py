@@ -529,3 +529,30 @@ def test_topk_rows_kernel(rows, V, k):
     rv, ri = ops.log_softmax_rows(x3).topk(5, dim=-1)
     torch.testing.assert_close(gv, rv, rtol=0, atol=2e-6)
     assert torch.equal(gi, ri)
+
+
+@pytest.mark.parametrize("B,T,V,beam,sharp", [(5, 60, 50, 10, 1.0), (8, 40, 6, 4, 0.3), (3, 120, 12, 10, 3.0), (4, 33, 40, 1, 1.0),
+                                                (2, 50, 300, 16, 2.0), (6, 25, 5, 5, 0.0)])
+def test_device_prefix_beam_equals_the_host_recursion(B, T, V, beam, sharp):
+    """oe_ctc_prefix_beam (one wave per utterance) against oe_ctc_prefix_beam_host_batch, the bit-exact restatement of
+    asr_model.py:359-396 that tests/test_oracle_golden pins: same n-best prefixes in the same order, scores equal to
+    1e-9 (device exp/log), on small vocabularies where prefixes merge all the time, with exact ties (sharp = 0: every
+    frame uniform), ragged lengths, beam 1 and 16."""
+    from openeat_amd import hip, ops
+    g = torch.Generator().manual_seed(B * 100 + T + V)
+    logits = torch.randn(B, T, V, generator=g) * sharp
+    logits[:, :, 0] += 1.0                                     # blanks are common, as in a CTC posterior
+    lens = torch.randint(max(1, T // 2), T + 1, (B,), generator=g, dtype=torch.int32)
+    lens[0] = T
+    top_p, top_i = ops.topk_rows(logits.cuda(), beam, log_softmax=True)
+    want = hip.ctc_prefix_beam_host_batch(top_p.cpu(), top_i.cpu(), lens.tolist(), beam)
+    got = hip.ctc_prefix_beam_device(top_p, top_i, lens.cuda(), beam)
+    assert len(got) == B
+    for b in range(B):
+        assert [p for p, _ in got[b]] == [p for p, _ in want[b]], (b, got[b][:3], want[b][:3])
+        for (_, s1), (_, s2) in zip(got[b], want[b]):
+            assert s1 == s2 or abs(s1 - s2) < 1e-9 * max(1.0, abs(s2)), (b, s1, s2)
+    # no lengths given: every utterance uses all T frames
+    want_all = hip.ctc_prefix_beam_host_batch(top_p.cpu(), top_i.cpu(), [T] * B, beam)
+    got_all = hip.ctc_prefix_beam_device(top_p, top_i, None, beam)
+    assert [[p for p, _ in u] for u in got_all] == [[p for p, _ in u] for u in want_all]
