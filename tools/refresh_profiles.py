@@ -15,15 +15,18 @@ subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.
 shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_p3.csv")
 rows = [r for r in csv.DictReader(open(f"{src}/trace/{tag}_kernel_stats.csv")) if "spin_kernel" not in r["Name"]]
 steps = 10.0
+adam = [int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"]]
+if adam:
+    steps = float(adam[0])                       # the Adam kernel runs once per optimizer step
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 gem = [r for r in rows if "gemm_" in r["Name"] or "ffn_fwd_kernel" in r["Name"]]
 gt, gc = sum(int(r["TotalDurationNs"]) for r in gem), sum(int(r["Calls"]) for r in gem)
 line = json.load(open(f"{src}/{tag}_bench_p3.json"))
 ro = line["roofline"]
 with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
-    f.write("# Round 1 - rocprofv3 kernel stats, bench config 2, precision 3 (final kernels of the round)\n\n")
+    f.write(f"# Round {int(tag[1:])} - rocprofv3 kernel stats, bench config 2, precision 3 (final kernels of the round)\n\n")
     f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-decode --no-graph --single-stream --steps 5 --warmup 2` "
-            "(10 optimizer steps in the trace: first step + 2 warm-up + 5 timed + 2 event-bracketed; the two `spin_kernel` launches that park the "
+            f"({steps:g} optimizer steps in the trace, counted by the Adam kernel's launches: first step + warm-up + timed + 2 event-bracketed; the `spin_kernel` launches that park the "
             f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p3.csv`.\n\n")
     f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
             f"**GEMM class (`gemm_dma_kernel` + `gemm_bf16_kernel` + `ffn_fwd_kernel`, the kernels behind `oe_gemm_f32` / `oe_ffn_fwd`): {gc / steps:.0f} launches/step, "
@@ -37,9 +40,17 @@ with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
                 f"{100 * int(r['TotalDurationNs']) / tot:.2f} |\n")
 for a, b in ((f"{tag}_bench_p3.json", f"{tag}_bench_p3.json"), (f"{tag}_bench_p3.err", f"{tag}_bench_p3.log"), (f"{tag}_gemm_bench.txt", f"{tag}_gemm_bench.txt"),
              (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p3.txt"), (f"{tag}_ctc_bench.txt", f"{tag}_ctc_bench.txt"),
-             (f"{tag}_mfma_busy_northstar.md", f"{tag}_mfma_busy_northstar.md")):
+             (f"{tag}_mfma_busy_northstar.md", f"{tag}_mfma_busy_northstar.md"), (f"{tag}_attn_bench.txt", f"{tag}_attn_bench.txt"),
+             (f"{tag}_tn_bench.txt", f"{tag}_tn_bench.txt"), (f"{tag}_bench_northstar_shape.json", f"{tag}_bench_northstar_shape.json"),
+             (f"{tag}_decode_breakdown.txt", f"{tag}_decode_breakdown.txt")):
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"{dst}/{b}")
+if os.path.exists(f"{src}/c5_cached.json"):
+    c5 = {k: json.loads(open(f"{src}/{k}.json").read().strip().splitlines()[-1]) for k in ("c5_cached", "c5_eager", "c5s_cached", "c5s_eager")
+          if os.path.exists(f"{src}/{k}.json")}
+    json.dump({"configs[4] model, per-shape graph cache": c5.get("c5_cached"), "configs[4] model, eager steps": c5.get("c5_eager"),
+               "12L d=256 model on the same ragged data, per-shape graph cache": c5.get("c5s_cached"),
+               "12L d=256 model on the same ragged data, eager steps": c5.get("c5s_eager")}, open(f"{dst}/{tag}_config5_1gpu.json", "w"), indent=1)
 pm = json.load(open(f"{dst}/{tag}_pmc_hbm_traffic.json"))
 print(f"bench {line['ms_per_step']:.2f} ms/step {line['value']:.0f} frames/s graph={line['config']['hip_graph']}")
 print(f"roofline live {ro['achieved']:.1f} TF/s {ro['gemm_ms_per_step']:.2f} ms {ro['avg_launch_us']:.2f} us | rocprof {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TF/s "

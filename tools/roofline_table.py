@@ -9,6 +9,9 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = float(sys.argv[2])
+_adam = [int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"]]
+if _adam:
+    steps = float(_adam[0])                      # optimizer steps in the trace = launches of the Adam kernel
 import json
 import os
 _bench = json.load(open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), os.path.basename(sys.argv[1]).split("_")[0] + "_bench_p3.json")))

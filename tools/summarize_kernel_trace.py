@@ -9,6 +9,9 @@ with open(path) as f:
         d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
         name = re.sub(r"\(.*", "", name)[:110]
         agg[name][0] += 1; agg[name][1] += d
+adam = [v[0] for k, v in agg.items() if "adam_kernel" in k]
+if adam:
+    steps = float(adam[0])                 # optimizer steps in the trace = launches of the Adam kernel
 tot = sum(v[1] for v in agg.values())
 print(f"total kernel time {tot/1e3:.2f} ms over trace; per step {tot/1e3/steps:.2f} ms")
 for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
