@@ -109,7 +109,7 @@ __device__ __forceinline__ void tn_store(const TnRegs& t, __bf16* img, int k0, i
 
 template <int TERMS>
 __global__ __launch_bounds__(TN_THREADS) void gemm_tn_planes_kernel(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
-                                                                   float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk,
+                                                                   float* __restrict__ C, long ldc, int M, int N, int Mr, int Nr, int K, int k_chunk,
                                                                    int gx, int gy, EpiParams ep) {
     constexpr int NPL = TERMS == 3 ? 2 : 1;
     constexpr int OP_ELEMS = NPL * TN_PLANE;                // one operand's image
@@ -136,11 +136,11 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_planes_kernel(const float*
     const int k_end = min(K, k_begin + k_chunk);
     const int nchunks = (k_end - k_begin + TN_KROWS - 1) / TN_KROWS;
 
-    // this thread's column of the staging loads (clamped at the matrix edge: whole float4s, M and N are multiples of 4;
+    // this thread's column of the staging loads (clamped at the matrix edge: whole float4s;
     // what the clamp duplicates lands in accumulator columns the bounds-checked epilogue never stores)
     const int c4 = 4 * (threadIdx.x & 31);
-    const float* a_src = Ap + min(m0 + c4, (long)M - 4);
-    const float* b_src = Bp + min(n0 + c4, (long)N - 4);
+    const float* a_src = Ap + min(m0 + c4, (long)Mr - 4);          // Mr, Nr: M, N rounded up to whole float4s (<= lda, ldb)
+    const float* b_src = Bp + min(n0 + c4, (long)Nr - 4);
     const bool do_csum = ep.a_colsum != nullptr && tile_x == 0;          // block-uniform
     float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -280,7 +280,11 @@ int oe_gemm_tn_planes_try(const OperandDesc& A, const OperandDesc& B, float* C, 
     // OE_GEMM_TN_PLANES: 0 = never, 1 = where it measured faster (default), 2 = wherever the problem qualifies (tuning)
     static const int mode = getenv("OE_GEMM_TN_PLANES") ? atoi(getenv("OE_GEMM_TN_PLANES")) : 1;
     if (!mode) return 1;
-    if (!A.vec_ok || !B.vec_ok || M % 4 || N % 4 || M < 4 || N < 4 || K < 1) return 1;
+    // staging loads are whole float4s: a row length that is not a multiple of 4 is fine when the leading dimension has
+    // the room (the CTC head's vocabulary, 3246 columns in rows of 3248): the last float4 then reads the row's own padding,
+    // and what it yields only reaches accumulator rows the bounds-checked output never stores
+    const int Mr = (M + 3) / 4 * 4, Nr = (N + 3) / 4 * 4;
+    if (!A.vec_ok || !B.vec_ok || A.ld < Mr || B.ld < Nr || M < 4 || N < 4 || K < 1) return 1;
     if (ep.bias || ep.act || ep.preact_out || ep.actgrad_in || ep.residual || ep.rowmask || ep.drop_p > 0.f || ep.beta != 1.f || ep.scatter) return 1;
     if (sk > 1 && !ep.atomic) return 1;
     const int gx = oe_cdiv(N, TN_COLS), gy = oe_cdiv(M, TN_COLS);
@@ -291,16 +295,17 @@ int oe_gemm_tn_planes_try(const OperandDesc& A, const OperandDesc& B, float* C, 
     // own split of the reduction: about one block per CU, chunks of at least 128 k-rows; never more splits than the
     // caller allowed when it asked for none (no atomics without permission)
     int nz = 1;
+    static const int blocks_target = getenv("OE_TN_BLOCKS") ? atoi(getenv("OE_TN_BLOCKS")) : 256;      // tuning
     if (ep.atomic) {
-        nz = max(1, 256 / (gx * gy));
+        nz = max(1, blocks_target / (gx * gy));
         nz = min(nz, max(1, K / 128));
     }
     int kc = oe_cdiv(oe_cdiv(K, nz), TN_KROWS) * TN_KROWS;
     nz = oe_cdiv(K, kc);
     if (terms == 3)
-        hipLaunchKernelGGL((gemm_tn_planes_kernel<3>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, K, kc, gx, gy, ep);
+        hipLaunchKernelGGL((gemm_tn_planes_kernel<3>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, Mr, Nr, K, kc, gx, gy, ep);
     else
-        hipLaunchKernelGGL((gemm_tn_planes_kernel<1>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, K, kc, gx, gy, ep);
+        hipLaunchKernelGGL((gemm_tn_planes_kernel<1>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, Mr, Nr, K, kc, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm (bf16 mfma, k-major planes)");
     return 0;
 }

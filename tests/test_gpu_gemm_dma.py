@@ -129,7 +129,7 @@ if __name__ == "__main__":
 TN_CASES = [  # (rows of dW, cols of dW, reduction length, split asked by the caller, atomic, with bias gradient)
     (1024, 256, 7936, 16, True, True), (256, 1024, 7936, 16, True, False), (256, 256, 7936, 24, True, True),
     (768, 256, 1984, 21, True, True), (200, 132, 1100, 3, True, True), (128, 128, 1024, 1, False, False),
-    (260, 388, 1500, 1, False, True), (128, 4864, 1024, 1, True, False)]
+    (260, 388, 1500, 1, False, True), (128, 4864, 1024, 1, True, False), (3246, 256, 2100, 4, True, True), (254, 130, 2050, 2, True, True)]
 
 
 @pytest.mark.parametrize("prec,rel", PRECS)
@@ -142,17 +142,21 @@ def test_weight_gradient_planes_kernel(prec, rel, m, n, k, sk, atomic, bias):
     g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
     dy, x = torch.randn(k, m, generator=g), torch.randn(k, n, generator=g)
     start = torch.randn(m, n, generator=g)
-    dyd, xd = dy.to(DEV), x.to(DEV)
+    # rows padded to whole float4s (filled with NaN: nothing of the padding may reach the result), as the CTC head's
+    # logits-gradient buffer is (3246 columns in rows of 3248)
+    mp, npad = (m + 3) // 4 * 4, (n + 3) // 4 * 4
+    dyd, xd = torch.full((k, mp), float("nan"), device=DEV), torch.full((k, npad), float("nan"), device=DEV)
+    dyd[:, :m], xd[:, :n] = dy.to(DEV), x.to(DEV)
     alpha_dev = torch.tensor([0.5], device=DEV)
     for accumulate in ((True,) if atomic else (False, True)):
         dw = start.to(DEV).clone()
         db = torch.full((m,), 2.0, device=DEV)
-        hip.gemm(dyd, xd, dw, m, n, k, lda=m, ldb=n, ldc=n, a_kmajor=True, b_kmajor=True, split_k=sk, atomic_out=atomic,
+        hip.gemm(dyd, xd, dw, m, n, k, lda=mp, ldb=npad, ldc=n, a_kmajor=True, b_kmajor=True, split_k=sk, atomic_out=atomic,
                  accumulate=accumulate and not atomic, alpha=3.0, alpha_dev=alpha_dev, a_colsum=db if bias else None, precision=prec)
         torch.cuda.synchronize()
         ref = 1.5 * (dy.double().t() @ x.double()) + (start.double() if (atomic or accumulate) else 0.0)
         err = float((dw.cpu().double() - ref).abs().max()) / math.sqrt(k)
-        assert err < 1.5 * rel * 2.0, (accumulate, err)        # alpha = 1.5; the maximum over up to 6e5 outputs of a K = 7936 sum
+        assert err < 1.5 * rel * 2.5, (accumulate, err)        # alpha = 1.5; the maximum over up to 8e5 outputs of a long sum
         if bias:
             refb = 2.0 + 1.5 * dy.double().sum(0)
             assert float((db.cpu().double() - refb).abs().max()) < 2e-3 * math.sqrt(k)
