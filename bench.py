@@ -99,6 +99,11 @@ def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3, lm=None, 
     model.eval()
     if lm is not None:
         lm.eval()
+    # the training engine's stream forks (right decoder / CTC head / positional projections beside the main chain) pay for
+    # 992-row launches; the decode batch is 640 hypotheses x 200+ tokens of chip-filling launches: one stream
+    from openeat_amd import ops as _ops
+    forks = (_ops.PARALLEL_DECODERS, _ops.POS_PROJ_AHEAD)
+    _ops.PARALLEL_DECODERS = _ops.POS_PROJ_AHEAD = False
     g = torch.Generator().manual_seed(123)
     wav = (torch.rand(n_utt, int(16000 * seconds), generator=g) - 0.5).to(dev)
     times = []
@@ -108,11 +113,13 @@ def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3, lm=None, 
         t0 = time.perf_counter()
         feats, nfr = fb(wav)
         utt_norm(feats, nfr)
-        hyps = model.attention_rescoring_batch(feats, nfr, beam, ctc_weight=0.5, reverse_weight=0.3, lm=lm, lm_weight=lm_weight)
+        hyps = model.attention_rescoring_batch(feats, nfr, beam, ctc_weight=0.5, reverse_weight=0.3, lm=lm, lm_weight=lm_weight,
+                                               use_graphs=os.environ.get("OE_BENCH_DECODE_GRAPHS", "1") == "1")      # both stages replayed from per-shape HIP graphs after the first call
         torch.cuda.synchronize()
         if it > 0:
             times.append(time.perf_counter() - t0)
     model.train()
+    _ops.PARALLEL_DECODERS, _ops.POS_PROJ_AHEAD = forks
     best = min(times)
     return {"rtf": best / (n_utt * seconds), "wall_s": best, "utterances": n_utt, "seconds_each": seconds, "beam": beam,
             "ctc_weight": 0.5, "reverse_weight": 0.3,

@@ -23,6 +23,39 @@ from openeat_amd.utils.mask import make_pad_mask, mask_finished_preds, mask_fini
 # The CTC prefix recursion on the device (beam.hip, one wave per utterance); 0: the native host implementation
 # (beam_host.cpp, same algorithm, the device kernel's checker).
 DEVICE_BEAM = os.environ.get("OE_DEVICE_BEAM", "1") != "0"
+DECODE_GRAPHS = os.environ.get("OE_DECODE_GRAPHS", "0") == "1"
+DECODE_GRAPH_SLOTS = 8
+
+
+def _graph_call(cache, key, fn, args):
+    """fn(*args) through a per-key HIP graph: first call eager (lazy state must exist before a capture) and captured for
+    the next time, later calls copy the arguments into the capture's static inputs and replay.  Outputs are the capture's
+    own tensors (valid until the next replay of the same key).  A key whose capture failed stays eager."""
+    rec = cache.get(key, False)
+    if rec is None:
+        return fn(*args)
+    if rec is False:
+        out = fn(*args)                                            # the real result of this call
+        static = tuple(a.clone() for a in args)
+        g = torch.cuda.CUDAGraph()
+        try:
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g):
+                sout = fn(*static)
+            cache[key] = (g, static, sout)
+        except Exception as e:                                     # noqa: BLE001 - whatever the capture objected to: stay eager
+            import warnings
+            warnings.warn(f"decode stage {key[0]} {key[1]} is not capturable ({type(e).__name__}: {str(e)[:200]}); it keeps running eagerly")
+            cache[key] = None
+        stage = [k for k in cache if k[0] == key[0]]
+        for k in stage[:-DECODE_GRAPH_SLOTS]:
+            del cache[k]
+        return out
+    g, static, sout = rec
+    for s_, a in zip(static, args):
+        s_.copy_(a)
+    g.replay()
+    return sout
 
 
 class ASRModel(torch.nn.Module):
@@ -237,58 +270,94 @@ class ASRModel(torch.nn.Module):
     @torch.no_grad()
     def attention_rescoring_batch(self, features: torch.Tensor, features_length: torch.Tensor, beam_size: int,
                                   ctc_weight: float = 0.0, reverse_weight: float = 0.0,
-                                  lm: Optional[torch.nn.Module] = None, lm_weight: float = 0.0) -> List[List[int]]:
+                                  lm: Optional[torch.nn.Module] = None, lm_weight: float = 0.0,
+                                  use_graphs: Optional[bool] = None) -> List[List[int]]:
         """Batched form of attention_rescoring (the reference handles one utterance per call,
-        asr_model.py:444): ONE encoder pass and ONE per-frame top-k for the whole batch, the prefix
-        recursion per utterance in native host code on its own valid frames, then ONE bi-decoder pass
-        over all B x beam hypotheses and the same score mix (asr_model.py:504-528)."""
+        asr_model.py:444): ONE encoder pass and ONE fused log-softmax top-k for the whole batch, the prefix
+        recursion of every utterance on its own valid frames (one wave each on the device; OE_DEVICE_BEAM=0: native host
+        code), then ONE bi-decoder pass over all B x beam hypotheses and the same score mix (asr_model.py:504-528).
+        use_graphs (default: OE_DECODE_GRAPHS, off): replay the two stages from HIP graphs cached per shape."""
         from openeat_amd import hip
         device = features.device
         B = features.shape[0]
+        R = B * beam_size
+        if reverse_weight > 0 and self.decoder.r_num_blocks == 0:
+            raise IndexError("reverse_weight > 0 needs r_decoder_num_blocks > 0 (as in the reference)")
+        on_device = DEVICE_BEAM and beam_size <= 16
+        graphs = DECODE_GRAPHS if use_graphs is None else bool(use_graphs)
+        if on_device and graphs:
+            return self._rescoring_batch_graphs(features, features_length, beam_size, ctc_weight, reverse_weight, lm, lm_weight)
+        if on_device:
+            encoder_out, encoder_mask, pre, plen, ctc_scores, bad = self._rescore_stage1(features, features_length, beam_size)
+            Lm = max(int(plen.max()), 1)                           # the one host sync of the n-best stage
+            if int(bad):
+                raise RuntimeError("oe_ctc_prefix_beam: a prefix exceeded max_len")
+            toks, n, mean_len = self._rescore_stage2(encoder_out, encoder_mask, pre, plen, ctc_scores, Lm, beam_size, ctc_weight,
+                                                     reverse_weight, lm, lm_weight)
+            self.last_nbest_mean_len = float(mean_len)
+            toks, n = toks.cpu(), n.cpu().tolist()
+            return [toks[b, : n[b]].tolist() for b in range(B)]
         encoder_out, encoder_mask, _ = self._encode(features, features_length)
         lens = encoder_mask.squeeze(1).sum(1)
         top_p, top_i = ops.topk_rows(self.ctc.logits(encoder_out), beam_size, log_softmax=True)
+        nbest = hip.ctc_prefix_beam_host_batch(top_p.cpu(), top_i.cpu(), lens.cpu().tolist(), beam_size)
+        for b in range(B):                                         # a very short utterance can yield fewer than `beam` prefixes
+            while len(nbest[b]) < beam_size:
+                nbest[b].append((nbest[b][-1][0], -float("inf")))
+        flat = [h for nb in nbest for h in nb]
+        self.last_nbest_mean_len = sum(len(h[0]) for h in flat) / max(len(flat), 1)
+        hl = torch.tensor([len(h[0]) for h in flat], dtype=torch.long)
+        Lm = max(int(hl.max()), 1)
+        ori = torch.full((R, Lm), self.ignore_id, dtype=torch.long)
+        for i, h in enumerate(flat):
+            if h[0]:
+                ori[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long)
+        ctc_scores = torch.tensor([h[1] for h in flat], dtype=torch.float64, device=device)
+        best = self._rescore_scores(encoder_out, encoder_mask, ori.to(device), hl.to(device), ctc_scores, torch.isinf(ctc_scores), Lm,
+                                    beam_size, ctc_weight, reverse_weight, lm, lm_weight).cpu().tolist()
+        return [list(nbest[b][best[b]][0]) for b in range(B)]
+
+    # ---- the pieces of the batched rescoring (each of fixed shape given (B, T) resp. (B, T', L): capturable) --------------
+    def _rescore_stage1(self, features, features_length, beam_size):
+        """Encoder, CTC projection, fused log-softmax top-k, prefix recursion - all on the device, no host sync.
+        Returns encoder_out, encoder_mask, prefixes (R, T') int32, lengths (R) int32 (-1: the slot does not exist), CTC
+        scores (R) float64, status word."""
+        from openeat_amd import hip
+        encoder_out, encoder_mask, _ = self._encode(features, features_length)
+        lens = encoder_mask.squeeze(1).sum(1)
+        top_p, top_i = ops.topk_rows(self.ctc.logits(encoder_out), beam_size, log_softmax=True)
+        pre, plen, ctc_scores, bad = hip.ctc_prefix_beam_device(top_p, top_i, lens.to(torch.int32), beam_size, raw=True)
+        R = pre.shape[0] * beam_size
+        return encoder_out, encoder_mask, pre.view(R, -1), plen.view(R), ctc_scores.view(R), bad
+
+    def _rescore_stage2(self, encoder_out, encoder_mask, pre, plen, ctc_scores, Lm, beam_size, ctc_weight, reverse_weight, lm, lm_weight):
+        """The n-best lists as device tensors -> (tokens (B, Lm) of the rescored pick, their lengths (B), mean n-best length).
+        Lm >= the longest hypothesis (any padding is ignore_id and masked)."""
+        device = pre.device
+        B = encoder_out.shape[0]
+        missing = plen < 0
+        hl = plen.clamp(min=0).long()
+        ori = pre[:, :Lm].long()
+        ori = ori.masked_fill(torch.arange(Lm, device=device).unsqueeze(0) >= hl.unsqueeze(1), self.ignore_id)
+        ctc_scores = ctc_scores.masked_fill(missing, -float("inf"))
+        best = self._rescore_scores(encoder_out, encoder_mask, ori, hl, ctc_scores, missing, Lm, beam_size, ctc_weight, reverse_weight,
+                                    lm, lm_weight)
+        pick = best + torch.arange(B, device=device) * beam_size
+        return ori.index_select(0, pick), hl.index_select(0, pick), hl.float().mean()
+
+    def _rescore_scores(self, encoder_out, encoder_mask, ori, hl, ctc_scores, missing, Lm, beam_size, ctc_weight, reverse_weight, lm,
+                        lm_weight):
+        """asr_model.py:504-528 for all B x beam hypotheses at once: index of the best hypothesis per utterance."""
+        device = ori.device
+        B = encoder_out.shape[0]
         R = B * beam_size
-        on_device = DEVICE_BEAM and beam_size <= 16
-        if on_device:
-            # the n-best lists never leave the device: prefixes (B, beam, T') int32, lengths (-1: fewer than `beam` prefixes
-            # exist - such a slot scores -inf below), CTC scores float64
-            pre, plen, ctc_scores, bad = hip.ctc_prefix_beam_device(top_p, top_i, lens.to(torch.int32), beam_size, raw=True)
-            plen = plen.view(R)
-            missing = plen < 0
-            hl = plen.clamp(min=0).long()
-            Lm = max(int(hl.max()), 1)                           # the one host sync of the n-best stage
-            if int(bad):
-                raise RuntimeError("oe_ctc_prefix_beam: a prefix exceeded max_len")
-            ori = pre.view(R, -1)[:, :Lm].long()
-            ori = ori.masked_fill(torch.arange(Lm, device=device).unsqueeze(0) >= hl.unsqueeze(1), self.ignore_id)
-            ctc_scores = ctc_scores.view(R).masked_fill(missing, -float("inf"))
-            self.last_nbest_mean_len = float(hl.float().mean())
-            nbest = None
-        else:
-            nbest = hip.ctc_prefix_beam_host_batch(top_p.cpu(), top_i.cpu(), lens.cpu().tolist(), beam_size)
-            for b in range(B):                                     # a very short utterance can yield fewer than `beam` prefixes
-                while len(nbest[b]) < beam_size:
-                    nbest[b].append((nbest[b][-1][0], -float("inf")))
-            flat = [h for nb in nbest for h in nb]
-            self.last_nbest_mean_len = sum(len(h[0]) for h in flat) / max(len(flat), 1)
-            hl = torch.tensor([len(h[0]) for h in flat], dtype=torch.long)
-            Lm = max(int(hl.max()), 1)
-            ori = torch.full((R, Lm), self.ignore_id, dtype=torch.long)
-            for i, h in enumerate(flat):
-                if h[0]:
-                    ori[i, : len(h[0])] = torch.tensor(h[0], dtype=torch.long)
-            ori, hl = ori.to(device), hl.to(device)
-            ctc_scores = torch.tensor([h[1] for h in flat], dtype=torch.float64, device=device)
-            missing = torch.isinf(ctc_scores)
         hyps_pad, _ = add_sos_eos(ori, self.sos, self.eos, self.ignore_id)
         L = hyps_pad.size(1)
         hyps_mask = (~make_pad_mask(hl + 1, L)).unsqueeze(1) & subsequent_mask(L, device=device).unsqueeze(0)
         enc = encoder_out.repeat_interleave(beam_size, dim=0)
         enc_mask = encoder_mask.repeat_interleave(beam_size, dim=0)
-        r_hyps_pad, _ = add_sos_eos(reverse_pad_list(ori, hl, self.ignore_id), self.sos, self.eos, self.ignore_id)
-        if reverse_weight > 0 and self.decoder.r_num_blocks == 0:
-            raise IndexError("reverse_weight > 0 needs r_decoder_num_blocks > 0 (as in the reference)")
+        r_ori = reverse_pad_list(ori, hl, self.ignore_id)
+        r_hyps_pad, _ = add_sos_eos(r_ori, self.sos, self.eos, self.ignore_id)
         l_x, r_x, _ = self.decoder(enc, enc_mask, hyps_pad, r_hyps_pad, hyps_mask)
         pos = torch.arange(L, device=device).unsqueeze(0)
         valid = pos < hl.unsqueeze(1)                                            # token positions j < len
@@ -302,8 +371,7 @@ class ASRModel(torch.nn.Module):
 
         score = seq_score(l_x, tok)
         if reverse_weight > 0:
-            r_tok = torch.cat([reverse_pad_list(ori, hl, self.ignore_id).long(),
-                               ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)
+            r_tok = torch.cat([r_ori.long(), ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)
             score = score * (1 - reverse_weight) + seq_score(r_x, r_tok) * reverse_weight
         score = score + ctc_scores * ctc_weight
         if lm is not None and lm_weight > 0:                                      # neural-LM shallow fusion (asr_model.py:490-527)
@@ -311,13 +379,35 @@ class ASRModel(torch.nn.Module):
             lm_tok = lm_lp.gather(2, tok.unsqueeze(2)).squeeze(2)
             score = score + (lm_tok * valid).sum(1).double() * lm_weight
         score = score.masked_fill(missing, -float("inf"))         # (0 * -inf above would be nan: the slot is out whatever the weights)
-        best = score.view(B, beam_size).argmax(1)
-        if nbest is None:
-            pick = best + torch.arange(B, device=device) * beam_size
-            toks, n = ori.index_select(0, pick).cpu(), hl.index_select(0, pick).cpu().tolist()
-            return [toks[b, : n[b]].tolist() for b in range(B)]
-        best = best.cpu().tolist()
-        return [list(nbest[b][best[b]][0]) for b in range(B)]
+        return score.view(B, beam_size).argmax(1)
+
+    def _rescoring_batch_graphs(self, features, features_length, beam_size, ctc_weight, reverse_weight, lm, lm_weight):
+        """The same two stages replayed from HIP graphs (decode is launch-bound: ~1500 small launches for 64 utterances):
+        stage 1 keyed by the feature shape, stage 2 by the n-best length rounded up to a multiple of 16; between them the one
+        host read of the longest hypothesis.  A shape is run eagerly the first time it is seen and captured for the next;
+        a stage that cannot be captured keeps running eagerly.  At most DECODE_GRAPH_SLOTS graphs per stage are kept."""
+        from openeat_amd.utils import common
+        B = features.shape[0]
+        cache = self.__dict__.setdefault("_decode_graphs", {})
+        static_before = common.STATIC_SHAPES
+        common.STATIC_SHAPES = True                                # label bookkeeping of fixed width: nothing reads a length on the host
+        try:
+            k1 = ("s1", tuple(features.shape), beam_size)
+            out1 = _graph_call(cache, k1, lambda f, fl: self._rescore_stage1(f, fl, beam_size), (features, features_length))
+            encoder_out, encoder_mask, pre, plen, ctc_scores, bad = out1
+            Lm = max(int(plen.max()), 1)
+            if int(bad):
+                raise RuntimeError("oe_ctc_prefix_beam: a prefix exceeded max_len")
+            Lb = min(-(-Lm // 16) * 16, pre.shape[1])
+            k2 = ("s2", tuple(encoder_out.shape), beam_size, Lb, float(ctc_weight), float(reverse_weight), id(lm), float(lm_weight))
+            toks, n, mean_len = _graph_call(
+                cache, k2, lambda eo, em, p, pl, cs: self._rescore_stage2(eo, em, p, pl, cs, Lb, beam_size, ctc_weight, reverse_weight,
+                                                                         lm, lm_weight), (encoder_out, encoder_mask, pre, plen, ctc_scores))
+        finally:
+            common.STATIC_SHAPES = static_before
+        self.last_nbest_mean_len = float(mean_len)
+        toks, n = toks.cpu(), n.cpu().tolist()
+        return [toks[b, : n[b]].tolist() for b in range(B)]
 
     def recognize(self, features: torch.Tensor, features_length: torch.Tensor, beam_size: int = 10) -> torch.Tensor:
         """asr_model.py:205-295: batched attention beam search (incl. the reference's un-reordered cache)."""

@@ -389,6 +389,32 @@ def test_batched_rescoring_on_ragged_batch_equals_per_utterance_rescoring():
     assert len({len(h) for h in single}) > 1
 
 
+def test_batched_rescoring_from_cached_graphs_equals_eager():
+    """attention_rescoring_batch(use_graphs=True): stage 1 (encoder .. prefix beam) and stage 2 (bi-decoder + scoring) replayed
+    from HIP graphs cached per shape.  First call of a shape runs eagerly and captures; the replays, fed DIFFERENT inputs of
+    the same shape (ragged lengths included), must return what the eager path returns for those inputs."""
+    g = load_golden("f12_tiny_conformer")
+    meta = load_golden_json("f12_tiny_conformer")
+    model = ASRModel(80, meta["V"], **meta["kwargs"])
+    model.load_state_dict(g["sd"])
+    model = model.to(DEV).eval()
+    cases = []
+    for seed, lens in ((41, [97, 83, 64, 41, 23]), (42, [97, 97, 97, 97, 97]), (43, [50, 97, 30, 88, 61])):
+        torch.manual_seed(seed)
+        feats = torch.randn(len(lens), 97, 80, device=DEV)
+        for b, n in enumerate(lens):
+            feats[b, n:] = 0.0
+        cases.append((feats, torch.tensor(lens, dtype=torch.int32, device=DEV)))
+    with torch.no_grad():
+        want = [model.attention_rescoring_batch(f, l, 4, ctc_weight=0.5, reverse_weight=0.3, use_graphs=False) for f, l in cases]
+        got = [model.attention_rescoring_batch(f, l, 4, ctc_weight=0.5, reverse_weight=0.3, use_graphs=True) for f, l in cases]
+        again = [model.attention_rescoring_batch(f, l, 4, ctc_weight=0.5, reverse_weight=0.3, use_graphs=True) for f, l in cases]
+    assert got == want and again == want
+    recs = model._decode_graphs
+    assert any(k[0] == "s1" and v is not None for k, v in recs.items())          # stage 1 really was captured
+    assert any(k[0] == "s2" and v is not None for k, v in recs.items())
+
+
 def test_native_prefix_beam_matches_python_recursion():
     from openeat_amd import hip
     from oracle import asr as O
