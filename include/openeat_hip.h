@@ -123,6 +123,14 @@ size_t oe_ffn_packed_bytes(int d, int ff, int precision);
 int oe_ffn_supported(int d, int ff, int precision, int act);
 int oe_ffn_pack_weights(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, void* stream);
 int oe_ffn_fwd(const oe_ffn_args* args, void* stream);
+/* The feed-forward's input gradient on the same kernel skeleton (autograd of positionwise_feed_forward.py:43):
+ *   dH = (dY W2) * dropout mask(drop_in, seed_in) * act'(pre),  dX = dH W1.
+ * oe_ffn_pack_weights_bwd packs W2^T in W1's role and W1^T in W2's role (buffers of oe_ffn_packed_bytes each).
+ * oe_ffn_bwd reads oe_ffn_args as: x = dY (rows, d) after the output dropout / scale, w1p / w2p = those two streams,
+ * pre_out = the forward's pre-activation (rows, ff) - an INPUT here -, act_out = dH (rows, ff) OUTPUT (the weight
+ * gradient of W1 consumes it), y = dX (rows, d); b1, b2, residual unset, drop_out 0, beta 1. */
+int oe_ffn_pack_weights_bwd(const float* w1, const float* w2, int d, int ff, int precision, void* w2t_packed, void* w1t_packed, void* stream);
+int oe_ffn_bwd(const oe_ffn_args* a, void* stream);
 
 /* column sums: out[n] (+)= alpha * sum_m x[m,n]  - bias gradients of every
  * Linear (autograd of aten::addmm).  alpha_dev optional device scalar. */

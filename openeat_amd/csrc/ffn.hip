@@ -40,6 +40,11 @@ __device__ __forceinline__ int ffn_acc_row(int r, int lk) { return (r & 3) + 8 *
 // W1 (ff, d) -> [ft][ks][plane][lane][8]:  W1[32 ft + (lane & 31)][16 ks + 8 (lane >> 5) + e]
 // W2 (d, ff) -> [ft][dt][s][plane][lane][8]:  W2[32 dt + (lane & 31)][32 ft + 16 s + 8 (e >> 2) + 4 (lane >> 5) + (e & 3)]
 // plane 0 = bf16(x), plane 1 = bf16(x - plane 0) (only with precision 3).
+// TRANSPOSED = false: w1 = W1 (ff, d), w2 = W2 (d, ff) - the forward's operands.
+// TRANSPOSED = true (the backward's operands, oe_ffn_bwd): the first packed stream is W2^T in W1's role (dH = dY W2) and
+// the second W1^T in W2's role (dX = dH W1): the same fragment layouts read through swapped strides - a lane's eight
+// elements are then strided in memory, but consecutive lanes (rows of the fragment) stay on consecutive addresses.
+template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, int d, int ff,
                                                        int planes, __bf16* __restrict__ w1p, __bf16* __restrict__ w2p) {
     const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per (fragment, both planes)
@@ -50,16 +55,28 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
     __bf16* dst;
     if (piece < n1) {
         const int ft = (int)(piece / KS), ks = (int)(piece % KS);
-        const float* src = w1 + (long)(32 * ft + (lane & 31)) * d + 16 * ks + 8 * (lane >> 5);
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        const int row = 32 * ft + (lane & 31), col = 16 * ks + 8 * (lane >> 5);          // element (row, col + e) of the (ff, d) operand
+        if (!TRANSPOSED) {
+            const float* src = w1 + (long)row * d + col;
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = w2[(long)(col + e) * ff + row];               // W2^T[row][col + e]
+        }
         dst = w1p + (piece * planes) * 512 + lane * 8;
     } else if (piece < n1 + n2) {
         const long q = piece - n1;
         const int s = (int)(q & 1), dt = (int)((q >> 1) % DT), ft = (int)((q >> 1) / DT);
-        const float* src = w2 + (long)(32 * dt + (lane & 31)) * ff + 32 * ft + 16 * s + 4 * (lane >> 5);
-        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 8);
-        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        const int row = 32 * dt + (lane & 31), col = 32 * ft + 16 * s + 4 * (lane >> 5);   // elements (row, col + {0..3, 8..11}) of the (d, ff) operand
+        if (!TRANSPOSED) {
+            const float* src = w2 + (long)row * ff + col;
+            const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 8);
+            x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = w1[(long)(col + (e & 3) + 8 * (e >> 2)) * d + row];     // W1^T[row][col + ..]
+        }
         dst = w2p + (q * planes) * 512 + lane * 8;
     } else {
         return;
@@ -113,7 +130,10 @@ __device__ __forceinline__ void ffn_split(const float (&x)[8], WFrag<TERMS>& f) 
 // and hipcc counts the waits itself.  The first version streamed the pieces through a wave-private LDS-DMA ring: alone the
 // stream ran at ~57 GB/s per CU (35 us for the 2 MiB), the MFMAs alone take 12 us, together 67 us - DMA issue, LDS-DMA
 // writes, fragment reads and MFMAs of one wave serialise on a SIMD that holds nothing else (tools/ffn_bench.py).
-template <int D, int TERMS, int NOUT>
+// BWD = true is the feed-forward's input gradient on the same skeleton (oe_ffn_bwd): x = dY (after the output dropout /
+// scale), stream 1 = W2^T, epilogue 1 = dH = (dY W2) * dropout mask * act'(pre) with the forward's pre-activation read back
+// through the patch and dH written out (the weight gradient of W1 needs it), stream 2 = W1^T, epilogue 2 = plain store of dX.
+template <int D, int TERMS, int NOUT, bool BWD = false>
 __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
     constexpr int PL = TERMS == 3 ? 2 : 1;
     constexpr int KS = D / 16, DT = D / 32;
@@ -192,6 +212,14 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
         f32x16 hacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+        float4 prev[4];                                              // BWD: this tile's pre-activation rows, issued ahead of the product
+        if (BWD) {
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const long gr = min(m0 + ps * 8 + (lane >> 3), (long)p.rows - 1);
+                prev[ps] = *reinterpret_cast<const float4*>(p.pre + gr * p.ff + ft * 32 + (lane & 7) * 4);
+            }
+        }
         static_for<0, NS1>([&](auto st_c) {
             constexpr int st = decltype(st_c)::value;
             constexpr int cu = st % NSET, pf = (st + NSET - 1) % NSET;
@@ -222,8 +250,20 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
                     *reinterpret_cast<float4*>(out + (m0 + row) * p.ff + ft * 32 + c4) = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
             }
         };
-        if (NOUT >= 1 && p.pre) store_tile(p.pre);
-        if (p.act == OE_ACT_SWISH) {
+        if (BWD) {
+            // the pre-activation tile, coalesced into the patch and read back transposed (fc on the registers, m on the lane)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<float4*>(&patch[(ps * 8 + (lane >> 3)) * 36 + (lane & 7) * 4]) = prev[ps];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] *= act_bwd(p.act, patch[lq * 36 + ffn_acc_row(r, lk)]);
+        }
+        if (!BWD && NOUT >= 1 && p.pre) store_tile(p.pre);
+        if (BWD) {
+        } else if (p.act == OE_ACT_SWISH) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) hv[r] *= sigmoidf_(hv[r]);
         } else if (p.act == OE_ACT_RELU) {
@@ -239,7 +279,7 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
                 hv[4 * g4 + 2] *= drop_field(h.y, 0, dp_in); hv[4 * g4 + 3] *= drop_field(h.y, 1, dp_in);
             }
         }
-        if (NOUT == 2 && p.act_out) store_tile(p.act_out);
+        if ((BWD || NOUT == 2) && p.act_out) store_tile(p.act_out);
         WFrag<TERMS> af[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -307,15 +347,25 @@ extern "C" int oe_ffn_supported(int d, int ff, int precision, int act) {
            (act == OE_ACT_NONE || act == OE_ACT_RELU || act == OE_ACT_SWISH);
 }
 
-extern "C" int oe_ffn_pack_weights(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, void* stream) {
+static int ffn_pack(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, bool transposed, void* stream) {
     OE_REQUIRE(w1 && w2 && w1p && w2p, "oe_ffn_pack_weights: null pointer");
     OE_REQUIRE(oe_ffn_supported(d, ff, precision, 0), "oe_ffn_pack_weights: unsupported shape d=%d ff=%d precision=%d", d, ff, precision);
     OE_REQUIRE(((((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)w1p) | ((uintptr_t)w2p)) & 15) == 0, "oe_ffn_pack_weights: 16-byte alignment required");
     const long pieces = (long)(ff / 32) * (d / 16) + (long)(ff / 32) * (d / 32) * 2;
-    hipLaunchKernelGGL(ffn_pack_kernel, dim3(oe_cdiv(pieces, 4)), dim3(256), 0, (hipStream_t)stream, w1, w2, d, ff, precision == 3 ? 2 : 1,
-                       (__bf16*)w1p, (__bf16*)w2p);
+    if (transposed)
+        hipLaunchKernelGGL(ffn_pack_kernel<true>, dim3(oe_cdiv(pieces, 4)), dim3(256), 0, (hipStream_t)stream, w1, w2, d, ff,
+                           precision == 3 ? 2 : 1, (__bf16*)w1p, (__bf16*)w2p);
+    else
+        hipLaunchKernelGGL(ffn_pack_kernel<false>, dim3(oe_cdiv(pieces, 4)), dim3(256), 0, (hipStream_t)stream, w1, w2, d, ff,
+                           precision == 3 ? 2 : 1, (__bf16*)w1p, (__bf16*)w2p);
     OE_LAUNCH_CHECK("oe_ffn_pack_weights");
     return 0;
+}
+extern "C" int oe_ffn_pack_weights(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, void* stream) {
+    return ffn_pack(w1, w2, d, ff, precision, w1p, w2p, false, stream);
+}
+extern "C" int oe_ffn_pack_weights_bwd(const float* w1, const float* w2, int d, int ff, int precision, void* w2tp, void* w1tp, void* stream) {
+    return ffn_pack(w1, w2, d, ff, precision, w2tp, w1tp, true, stream);
 }
 
 template <int D, int TERMS>
@@ -347,4 +397,36 @@ extern "C" int oe_ffn_fwd(const oe_ffn_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (a->d == 256) return a->precision == 3 ? ffn_launch<256, 3>(p, nout, st) : ffn_launch<256, 1>(p, nout, st);
     return a->precision == 3 ? ffn_launch<128, 3>(p, nout, st) : ffn_launch<128, 1>(p, nout, st);
+}
+
+// The feed-forward's input gradient in one launch (autograd of positionwise_feed_forward.py:43):
+//   dH = (dY W2) * dropout mask(drop_in, seed_in) * act'(pre),   dX = dH W1
+// oe_ffn_args fields as used here: x = dY (rows, d), w1p / w2p = the two streams of oe_ffn_pack_weights_bwd, pre_out = the
+// forward's pre-activation (rows, ff) - an INPUT -, act_out = dH (rows, ff) output, y = dX (rows, d); b1, b2, residual,
+// drop_out must be unset.
+extern "C" int oe_ffn_bwd(const oe_ffn_args* a, void* stream) {
+    OE_REQUIRE(a && a->x && a->w1p && a->w2p && a->y && a->pre_out && a->act_out, "oe_ffn_bwd: null pointer");
+    OE_REQUIRE(oe_ffn_supported(a->d, a->ff, a->precision, a->act), "oe_ffn_bwd: unsupported d=%d ff=%d precision=%d act=%d", a->d, a->ff,
+               a->precision, a->act);
+    OE_REQUIRE(!a->b1 && !a->b2 && !a->residual && a->drop_out == 0.f && a->beta == 1.f, "oe_ffn_bwd: bias / residual / output dropout do not apply");
+    OE_REQUIRE(a->rows > 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0, "oe_ffn_bwd: bad rows / strides");
+    OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->pre_out) | ((uintptr_t)a->act_out) | ((uintptr_t)a->w1p) |
+                 ((uintptr_t)a->w2p)) & 15) == 0, "oe_ffn_bwd: 16-byte alignment required");
+    OE_REQUIRE(a->drop_in >= 0.f && a->drop_in < 1.f, "oe_ffn_bwd: dropout rate out of range");
+    FfnParams p{};
+    p.x = a->x; p.ldx = a->ldx; p.w1p = (const __bf16*)a->w1p; p.w2p = (const __bf16*)a->w2p;
+    p.pre = a->pre_out; p.act_out = a->act_out; p.beta = 1.f; p.y = a->y; p.ldy = a->ldy;
+    p.rows = a->rows; p.ff = a->ff; p.act = a->act; p.p_in = a->drop_in; p.seed_in = a->seed_in; p.seed_dev = a->seed_dev;
+    const dim3 grid(oe_cdiv(p.rows, FFN_ROWS)), block(FFN_THREADS);
+    const size_t dyn = (size_t)p.ff * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (a->d == 256) {
+        if (a->precision == 3) hipLaunchKernelGGL((ffn_fwd_kernel<256, 3, 1, true>), grid, block, dyn, st, p);
+        else hipLaunchKernelGGL((ffn_fwd_kernel<256, 1, 1, true>), grid, block, dyn, st, p);
+    } else {
+        if (a->precision == 3) hipLaunchKernelGGL((ffn_fwd_kernel<128, 3, 1, true>), grid, block, dyn, st, p);
+        else hipLaunchKernelGGL((ffn_fwd_kernel<128, 1, 1, true>), grid, block, dyn, st, p);
+    }
+    OE_LAUNCH_CHECK("oe_ffn_bwd");
+    return 0;
 }

@@ -116,7 +116,9 @@ _SIGNATURES = {
     "oe_ffn_packed_bytes": (SZ, [I, I, I]),
     "oe_ffn_supported": (I, [I, I, I, I]),
     "oe_ffn_pack_weights": (I, [P, P, I, I, I, P, P, P]),
+    "oe_ffn_pack_weights_bwd": (I, [P, P, I, I, I, P, P, P]),
     "oe_ffn_fwd": (I, [C.POINTER(FfnArgs), P]),
+    "oe_ffn_bwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
@@ -275,6 +277,27 @@ def ffn_fwd(x2, w1p, b1, w2p, b2, rows, d, ff, act, *, drop_in=0.0, seed_in=0, d
         PROFILE.append((e0, e1, 4.0 * rows * d * ff, ("ffn_fwd", rows, d, ff, 0, 0, 1)))
         return
     check(lib().oe_ffn_fwd(C.byref(a), stream()), "oe_ffn_fwd")
+
+
+def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_dev=None, pre=None, dh=None, dx=None, precision=None):
+    """dH = (dY W2) * mask * act'(pre), dX = dH W1 in one launch (oe_ffn_bwd)."""
+    a = FfnArgs()
+    dp = lambda t: None if t is None else t.data_ptr()
+    a.x, a.ldx = dy2.data_ptr(), dy2.stride(0)
+    a.w1p, a.b1, a.w2p, a.b2 = w2tp.data_ptr(), None, w1tp.data_ptr(), None
+    a.rows, a.d, a.ff, a.act = rows, d, ff, act
+    a.precision = GEMM_PRECISION if precision is None else precision
+    a.drop_in, a.seed_in, a.drop_out, a.seed_out, a.seed_dev = drop_in, seed_in, 0.0, 0, dp(seed_dev)
+    a.pre_out, a.act_out, a.residual, a.ldr, a.beta = pre.data_ptr(), dh.data_ptr(), None, 0, 1.0
+    a.y, a.ldy = dx.data_ptr(), dx.stride(0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().oe_ffn_bwd(C.byref(a), stream()), "oe_ffn_bwd")
+        e1.record()
+        PROFILE.append((e0, e1, 4.0 * rows * d * ff, ("ffn_bwd", rows, d, ff, 0, 0, 1)))
+        return
+    check(lib().oe_ffn_bwd(C.byref(a), stream()), "oe_ffn_bwd")
 
 
 def call(name, *args):

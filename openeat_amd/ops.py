@@ -677,6 +677,7 @@ FUSED_FFN = os.environ.get("OE_FUSED_FFN", "1") == "1"
 # chip (config 2: 7936 rows = 248 blocks, 71 us incl. the weight packing against 79 us for the two GEMMs); the decoders'
 # 992 rows are 31 blocks that each still take the full ~56 us, against 41 us for their two small GEMMs.
 FUSED_FFN_MIN_ROWS = int(os.environ.get("OE_FUSED_FFN_MIN_ROWS", "4096"))
+FUSED_FFN_BWD = os.environ.get("OE_FUSED_FFN_BWD", "0") == "1"         # the input gradient in one launch too: measured slower in the step (profiles/r02_experiments.md), off
 
 
 def _ffn_fused_ok(x2, w1, w2, act, res2):
@@ -723,7 +724,9 @@ class FeedForwardFn(torch.autograd.Function):
             ctx.save_for_backward(x2, w1, w2, pre, a)
             ctx.biases = (b1, b2)
             ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
+            ctx.fused = True
             return _tag_out_drop(y.view(*x.shape[:-1], w2.shape[0]), out_scale, p_out, s_out)
+        ctx.fused = False
         pre = _new(M, ff, like=x)
         if act in GEMM_FUSED_ACTS:
             a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
@@ -749,6 +752,18 @@ class FeedForwardFn(torch.autograd.Function):
         g2 = dy2 if (p_out == 0 and out_scale == 1.0) else _out_drop_grad(dy2, out_scale, p_out, s_out)
         b1, b2 = ctx.biases
         dw2, db2 = wgrad_bias(w2, b2, g2, a)
+        if ctx.fused and FUSED_FFN_BWD and g2.stride(0) % 4 == 0:
+            # both input-gradient GEMMs in one launch (csrc/ffn.hip, oe_ffn_bwd): dH is written once and never re-read here
+            M, d, ff = g2.shape[0], w2.shape[0], w1.shape[0]
+            prec = hip.GEMM_PRECISION
+            nbytes = hip.lib().oe_ffn_packed_bytes(d, ff, prec)
+            w2tp = torch.empty(nbytes, dtype=torch.uint8, device=g2.device)
+            w1tp = torch.empty(nbytes, dtype=torch.uint8, device=g2.device)
+            hip.call("oe_ffn_pack_weights_bwd", w1, w2, d, ff, prec, w2tp, w1tp)
+            dh, dx = _new(M, ff, like=g2), _new(M, d, like=g2)
+            hip.ffn_bwd(g2, w2tp, w1tp, M, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=_seed_dev, pre=pre, dh=dh, dx=dx)
+            dw1, db1 = wgrad_bias(w1, b1, dh, x2)
+            return dx.view(in_shape), dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
         if act in GEMM_FUSED_ACTS:
             dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
         else:

@@ -497,6 +497,40 @@ def test_fused_feed_forward_kernel(rows, d, ff, act, prec, p_in, p_out, nout):
             assert torch.equal(aout == 0, m_in == 0) or float(((aout == 0) != (m_in == 0)).float().mean()) < 1e-4      # (a itself can be exactly 0)
 
 
+@pytest.mark.parametrize("rows,d,ff,act,prec,p_in", [(7936, 256, 1024, 2, 3, 0.1), (333, 256, 512, 1, 3, 0.0), (100, 128, 256, 2, 3, 0.2),
+                                                      (4100, 256, 1024, 2, 1, 0.1), (64, 128, 128, 0, 3, 0.0)])
+def test_fused_feed_forward_input_gradient_kernel(rows, d, ff, act, prec, p_in):
+    """oe_ffn_bwd (csrc/ffn.hip, backward mode) against float64: dH = (dY W2) * mask * act'(pre), dX = dH W1, the mask being
+    the one oe_ffn_fwd / oe_gemm_f32 draw for the same (seed, counter, element)."""
+    torch.manual_seed(61)
+    dy = torch.randn(rows, d)
+    w1, w2 = torch.randn(ff, d) / math.sqrt(d), torch.randn(d, ff) / math.sqrt(ff)
+    pre = torch.randn(rows, ff) * 1.5
+    s_in = 0x3333
+    L = hip.lib()
+    nb = L.oe_ffn_packed_bytes(d, ff, prec)
+    w2tp, w1tp = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dyd, w1d, w2d, pred = cu(dy), cu(w1), cu(w2), cu(pre)
+    hip.call("oe_ffn_pack_weights_bwd", w1d, w2d, d, ff, prec, w2tp, w1tp)
+    dh = torch.full((rows, ff), float("nan"), device=DEV)
+    dx = torch.full((rows, d), float("nan"), device=DEV)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    hip.ffn_bwd(dyd, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pred, dh=dh, dx=dx, precision=prec)
+    sync()
+    ones = torch.ones(rows, ff, device=DEV)
+    m_in = torch.empty_like(ones)
+    hip.call("oe_dropout_scale", ones, ones.numel(), ff, 1.0, p_in, s_in, ctr, None, m_in)
+    sync()
+    h = pre.double()
+    sg = torch.sigmoid(h)
+    dact = sg * (1 + h * (1 - sg)) if act == 2 else (h > 0).double() if act == 1 else torch.ones_like(h)
+    want_dh = (dy.double() @ w2.double()) * m_in.cpu().double() * dact
+    want_dx = want_dh @ w1.double()
+    t = (lambda ref: dict(rtol=2e-4, atol=3e-5 * float(ref.abs().max()))) if prec == 3 else (lambda ref: dict(rtol=3e-2, atol=2e-2 * float(ref.abs().max())))
+    torch.testing.assert_close(dh.cpu().double(), want_dh, **t(want_dh))
+    torch.testing.assert_close(dx.cpu().double(), want_dx, **t(want_dx))
+
+
 @pytest.mark.parametrize("rows,V,k", [(37, 3246, 10), (5, 100, 10), (3, 11000, 16), (2, 25000, 4), (9, 7, 7), (130, 65, 1)])
 def test_topk_rows_kernel(rows, V, k):
     """oe_topk_rows against log_softmax_rows -> torch.topk (asr_model.py:251, 258, 358): same values, same indices."""

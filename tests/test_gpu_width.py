@@ -69,6 +69,7 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
     from openeat_amd import hip, ops
     c = _setup()
     old_min, ops.FUSED_FFN_MIN_ROWS = ops.FUSED_FFN_MIN_ROWS, (0 if fused_ffn else 1 << 30)
+    old_bwd, ops.FUSED_FFN_BWD = ops.FUSED_FFN_BWD, bool(fused_ffn)          # the one-launch input gradient rides along when forced
     model = ASRModel(80, V, **CONF)
     model.load_state_dict(c["sd"])
     model = model.to(DEV).eval()
@@ -83,6 +84,7 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
     finally:
         hip.GEMM_PRECISION = old
         ops.FUSED_FFN_MIN_ROWS = old_min
+        ops.FUSED_FFN_BWD = old_bwd
     assert abs(float(loss) - c["loss"]) <= 2e-4 * abs(c["loss"]), (float(loss), c["loss"])
     assert abs(float(acc) - c["acc"]) <= 1e-6
     bad = []
