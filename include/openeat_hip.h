@@ -296,6 +296,12 @@ int oe_act_grad(const float* dy, const float* pre, long n, int act, float* out, 
 
 /* log_softmax over the last dim (ctc.py:56-64; asr_model.py:484-488). */
 int oe_log_softmax(const float* x, long rows, int V, float* out, void* stream);
+/* The decoders' token bookkeeping of a training step in one launch (asr_model.py:162-176 with common.py:61-132 and
+ * mask.py:9-69): from the labels ys_pad (B, L) i32 (ignore_id where there is none) and their lengths (B) i32, at the fixed
+ * width W = L + 1: ys_in = [sos, labels, eos...], ys_out = [labels, eos, ignore...] (both (B, W) i64), the same for the
+ * reversed labels (r_ys_in / r_ys_out, or both NULL), and tgt_mask (B, W, W) u8 = (j < len + 1) && (j <= i). */
+int oe_att_inputs(const int* ys_pad, const int* ys_lens, int B, int L, int sos, int eos, int ignore_id, long long* ys_in,
+                  long long* ys_out, long long* r_ys_in, long long* r_ys_out, unsigned char* tgt_mask, void* stream);
 /* Per-row top-k, sorted descending, of x (rows, V) or - log_softmax != 0 - of its row-wise log-softmax, fused
  * (asr_model.py:251, 358 `log_softmax(...).topk(beam_size)`; :258 `scores.topk`).  vals (rows, k) f32, idx (rows, k) i64;
  * ties go to the lowest index.  k <= V <= 40000. */

@@ -472,6 +472,62 @@ extern "C" int oe_topk_rows(const float* x, long rows, int V, int k, int log_sof
     return 0;
 }
 
+// Decoder token bookkeeping of a training step in ONE launch (asr_model.py:162-176: add_sos_eos of the labels and of their
+// reversal, reverse_pad_list, the target mask) - as index arithmetic in torch it was ~70 four-microsecond launches that the
+// captured graph ran ahead of the encoder.  One block per utterance.  Semantics (common.py:61-132, mask.py:9-69), fixed
+// width W = L + 1:
+//   kept(y)  = the entries of a row that are != ignore_id, in order (n of them)
+//   ys_in    = [sos, kept..., eos, eos, ...]            ys_out   = [kept..., eos, ignore, ...]
+//   r        = the first min(len, L) entries of the row reversed, the rest ignore_id;  r_ys_in / r_ys_out = the same from r
+//   mask[b, i, j] = (j < len + 1) && (j <= i)
+__global__ __launch_bounds__(64) void att_inputs_kernel(const int* __restrict__ ys, const int* __restrict__ lens, int L, int sos, int eos,
+                                                        int ignore_id, long long* __restrict__ ys_in, long long* __restrict__ ys_out,
+                                                        long long* __restrict__ r_in, long long* __restrict__ r_out,
+                                                        unsigned char* __restrict__ mask) {
+    extern __shared__ int att_s[];                      // kept tokens of the row, then of its reversal
+    int* fwd = att_s;
+    int* rev = att_s + L;
+    __shared__ int n_fwd, n_rev;
+    const int b = blockIdx.x, W = L + 1;
+    const int* row = ys + (long)b * L;
+    const int len = min(max(lens[b], 0), L);
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int i = 0; i < L; ++i)
+            if (row[i] != ignore_id) fwd[n++] = row[i];
+        n_fwd = n;
+        n = 0;
+        for (int i = len - 1; i >= 0; --i)              // reverse_pad_list, then the same compaction
+            if (row[i] != ignore_id) rev[n++] = row[i];
+        n_rev = n;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < W; j += 64) {
+        const long o = (long)b * W + j;
+        ys_in[o] = j == 0 ? sos : (j - 1 < n_fwd ? fwd[j - 1] : eos);
+        ys_out[o] = j < n_fwd ? fwd[j] : (j == n_fwd ? eos : ignore_id);
+        if (r_in) {
+            r_in[o] = j == 0 ? sos : (j - 1 < n_rev ? rev[j - 1] : eos);
+            r_out[o] = j < n_rev ? rev[j] : (j == n_rev ? eos : ignore_id);
+        }
+    }
+    const int valid = lens[b] + 1;
+    for (int e = threadIdx.x; e < W * W; e += 64) {
+        const int i = e / W, j = e - i * W;
+        mask[(long)b * W * W + e] = (j < valid && j <= i) ? 1 : 0;
+    }
+}
+extern "C" int oe_att_inputs(const int* ys_pad, const int* ys_lens, int B, int L, int sos, int eos, int ignore_id, long long* ys_in,
+                             long long* ys_out, long long* r_ys_in, long long* r_ys_out, unsigned char* tgt_mask, void* stream) {
+    OE_REQUIRE(ys_pad && ys_lens && ys_in && ys_out && tgt_mask && B > 0 && L >= 0, "oe_att_inputs: bad arguments");
+    OE_REQUIRE((r_ys_in == nullptr) == (r_ys_out == nullptr), "oe_att_inputs: the reversed outputs come together");
+    OE_REQUIRE(L <= 8000, "oe_att_inputs: label rows of %d entries do not fit in LDS", L);
+    hipLaunchKernelGGL(att_inputs_kernel, dim3(B), dim3(64), (size_t)2 * max(L, 1) * sizeof(int), (hipStream_t)stream, ys_pad, ys_lens, L, sos,
+                       eos, ignore_id, ys_in, ys_out, r_ys_in, r_ys_out, tgt_mask);
+    OE_LAUNCH_CHECK("att_inputs");
+    return 0;
+}
+
 // y = act(x) (stand-alone activation module, swish.py:15-17)
 __global__ void act_fwd_kernel(const float* __restrict__ x, long n, int act, float* __restrict__ y) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

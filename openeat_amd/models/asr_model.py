@@ -25,6 +25,7 @@ from openeat_amd.utils.mask import make_pad_mask, mask_finished_preds, mask_fini
 DEVICE_BEAM = os.environ.get("OE_DEVICE_BEAM", "1") != "0"
 DECODE_GRAPHS = os.environ.get("OE_DECODE_GRAPHS", "0") == "1"
 DECODE_GRAPH_SLOTS = 8
+ATT_INPUTS_KERNEL = os.environ.get("OE_ATT_INPUTS_KERNEL", "1") != "0"      # decoder token bookkeeping as one launch (fixed widths)
 
 
 def _graph_call(cache, key, fn, args):
@@ -143,6 +144,19 @@ class ASRModel(torch.nn.Module):
 
     def _att_inputs(self, ys_pad, ys_pad_lens):
         """asr_model.py:162-176: decoder inputs / targets of both directions and the target mask (token bookkeeping only)."""
+        from openeat_amd.utils import common
+        if ATT_INPUTS_KERNEL and common.STATIC_SHAPES and ys_pad.is_cuda and ys_pad.dtype == torch.int32 and ys_pad_lens.dtype == torch.int32 \
+                and ys_pad.dim() == 2 and ys_pad.shape[1] <= 8000:
+            # fixed width (a captured step): one launch instead of ~70 index-arithmetic launches
+            from openeat_amd import hip
+            B, L = ys_pad.shape
+            W = L + 1
+            rev = self.reverse_weight > 0
+            out = torch.empty(4 if rev else 2, B, W, dtype=torch.long, device=ys_pad.device)
+            tgt_mask = torch.empty(B, W, W, dtype=torch.bool, device=ys_pad.device)
+            hip.call("oe_att_inputs", ys_pad.contiguous(), ys_pad_lens.contiguous(), B, L, self.sos, self.eos, self.ignore_id, out[0], out[1],
+                     out[2] if rev else None, out[3] if rev else None, tgt_mask)
+            return out[0], out[1], tgt_mask, (out[2] if rev else None), (out[3] if rev else None)
         ys_in_pad, ys_out_pad = add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
         ys_in_lens = ys_pad_lens + 1
         L = ys_in_pad.size(1)

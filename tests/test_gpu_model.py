@@ -415,6 +415,37 @@ def test_batched_rescoring_from_cached_graphs_equals_eager():
     assert any(k[0] == "s2" and v is not None for k, v in recs.items())
 
 
+@pytest.mark.parametrize("reverse_weight", [0.3, 0.0])
+def test_att_inputs_kernel_equals_the_index_arithmetic(reverse_weight):
+    """oe_att_inputs (one launch, fixed width) == add_sos_eos / reverse_pad_list / masks (asr_model.py:162-176) written as
+    torch index arithmetic: ragged lengths, an empty label row, ignore_id entries INSIDE a row (the reference drops them
+    wherever they are), a length shorter than the row's labels (reverse_pad_list reverses only that many)."""
+    from openeat_amd.utils import common
+    meta = load_golden_json("f12_tiny_conformer")
+    kw = dict(meta["kwargs"], reverse_weight=reverse_weight)
+    model = ASRModel(80, meta["V"], **kw).to(DEV)
+    g = torch.Generator().manual_seed(5)
+    B, L = 7, 11
+    ys = torch.randint(2, meta["V"] - 1, (B, L), generator=g, dtype=torch.int32)
+    lens = torch.tensor([11, 7, 0, 3, 9, 1, 5], dtype=torch.int32)
+    for b in range(B):
+        ys[b, int(lens[b]):] = -1
+    ys[4, 2] = -1                                        # a hole inside the labels
+    lens[6] = 3                                          # fewer than the row holds: the reversal covers three, the rest stays
+    old = common.STATIC_SHAPES
+    common.STATIC_SHAPES = True
+    try:
+        got = model._att_inputs(ys.to(DEV), lens.to(DEV))                  # int32 on the device at fixed width: the kernel
+        want = model._att_inputs(ys.long().to(DEV), lens.long().to(DEV))   # int64: the index arithmetic
+    finally:
+        common.STATIC_SHAPES = old
+    for a, b in zip(got, want):
+        if b is None:
+            assert a is None
+        else:
+            assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b)
+
+
 def test_native_prefix_beam_matches_python_recursion():
     from openeat_amd import hip
     from oracle import asr as O
