@@ -37,6 +37,10 @@ int oe_abi_version(void);
  * reference's step is not captured. */
 int oe_capture_unjoined_streams(void* origin, void* const* sides, int n_sides, int* unjoined_index);
 
+/* Diagnostic: when `stream` reaches this point, write the device's constant-rate wall clock (100 MHz ticks) into
+ * buf[slot] (device memory).  Captured into a graph it times the replay's phases without a profiler. */
+int oe_stamp(long long* buf, int slot, void* stream);
+
 /* ------------------------------------------------------------------------- *
  * GEMM with fused epilogue.  C[m,n] = epi( alpha * sum_k A(m,k) B(n,k) )
  * Replaces aten::addmm/mm/bmm behind every torch.nn.Linear and 1x1 Conv1d of

@@ -71,3 +71,16 @@ extern "C" int oe_capture_unjoined_streams(void* origin, void* const* sides, int
     }
     return bad;
 }
+
+
+// ---- phase stamps (diagnostic: tools/phase_stamps.py) ------------------------------------------------------------------
+// One thread writes the constant-rate wall clock (100 MHz) into slot `slot` of `buf` when the stream reaches this point:
+// captured into the step's graph it gives the un-profiled timeline of the replay at the chosen points (a kernel trace
+// changes what overlaps).  Never launched by the product path unless OE_PHASE_STAMPS is set.
+__global__ void stamp_kernel(long long* buf, int slot) { buf[slot] = wall_clock64(); }
+extern "C" int oe_stamp(long long* buf, int slot, void* stream) {
+    OE_REQUIRE(buf && slot >= 0, "oe_stamp: bad arguments");
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, buf, slot);
+    OE_LAUNCH_CHECK("stamp");
+    return 0;
+}

@@ -75,11 +75,15 @@ class TrainEngine:
     # one micro-step: loss (already divided by accum_grad) and its backward
     def _fwd_bwd(self, batch):
         ops.predrop_clear()
+        ops.stamp("step starts")
         loss, acc = self.model(**batch)
         loss = loss / self.accum_grad if self.accum_grad != 1 else loss
+        ops.stamp("fwd: losses done")
         loss.backward()
+        ops.stamp("bwd: main chain done")
         ops.join_side_stream()                 # weight-gradient GEMMs running beside the backward chain
         ops.ln_table_flush()                   # captured graph: every LayerNorm's parameter-gradient partials in one launch
+        ops.stamp("bwd: side streams joined")
         return loss.detach(), None if acc is None else acc.detach()
 
     def _finish(self):
@@ -88,6 +92,7 @@ class TrainEngine:
         # those taken beside a captured graph) it is the optimizer's current param_groups value
         self.optimizer.step(lr_from_device=self._capturing or self._replaying)
         self.seed_counter.add_(1)
+        ops.stamp("optimizer done")
 
     _capturing = False
     _replaying = False

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "oe_last_error": (C.c_char_p, []),
     "oe_abi_version": (I, []),
     "oe_capture_unjoined_streams": (I, [P, C.POINTER(C.c_void_p), I, C.POINTER(I)]),
+    "oe_stamp": (I, [P, I, P]),
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
     "oe_ffn_packed_bytes": (SZ, [I, I, I]),
     "oe_ffn_supported": (I, [I, I, I, I]),

@@ -120,6 +120,8 @@ class ASRModel(torch.nn.Module):
             for t in prep:
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
+        ops.stamp("fwd: encoder done")
+        ops.stamp_grad(encoder_out, "bwd: heads done")
         hooks = getattr(self, "grad_ready_hooks", None)          # set by TrainEngine for multi-GPU overlap
         if hooks and encoder_out.requires_grad:
             cb = hooks["encoder_out"]

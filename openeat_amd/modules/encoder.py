@@ -108,7 +108,11 @@ class TransformerEncoder(torch.nn.Module):
                         att._pp_ahead = (pp, ev)
                         ahead.append(att)
         try:
+            ops.stamp("fwd: input layer done")
             for i, layer in enumerate(self.encoders):
+                if i % 3 == 0:
+                    ops.stamp(f"fwd: encoder layer {i} starts")
+                    ops.stamp_grad(xs, f"bwd: encoder layers >= {i} done")
                 if hooks and i in hooks and xs.requires_grad:
                     xs.register_hook(lambda g, cb=hooks[i]: cb())     # gradient of layer i's input ready = layers >= i done
                     xs = ops.cut(xs, f"enc{i}")                       # segmented capture: the tape ends here (identity otherwise)
