@@ -160,6 +160,27 @@ def side_stream():
     return _side_stream
 
 
+# ---- phase stamps (diagnostic, tools/phase_stamps.py): STAMPS = {"buf": int64 device tensor, "tags": [...]} or None ----------
+STAMPS = None
+
+
+def stamp(tag: str):
+    """Record the wall clock when the current stream gets here (no-op unless a tool switched STAMPS on)."""
+    if STAMPS is None:
+        return
+    slot = len(STAMPS["tags"])
+    if slot >= STAMPS["buf"].numel():
+        return
+    STAMPS["tags"].append(tag)
+    hip.call("oe_stamp", STAMPS["buf"], slot)
+
+
+def stamp_grad(x: torch.Tensor, tag: str) -> None:
+    """Stamp when backward has produced the gradient of x."""
+    if STAMPS is not None and x.requires_grad:
+        x.register_hook(lambda g, tag=tag: stamp(tag))
+
+
 # ---- cut points for a step captured in segments (TrainEngine.capture with several ranks) ---------------------------------
 # At a cut the forward value passes through unchanged, but the autograd tape is severed: the engine first differentiates
 # from the loss down to the last cut (its gradient lands in `leaf.grad`), then resumes from each cut's upstream side
