@@ -27,4 +27,5 @@ timeout -k 10 300 python tools/config5_bench.py --mode eager --utts 2200 --steps
 timeout -k 10 300 python tools/config5_bench.py --model 12L256 --budget 32000 --mode cached --utts 1500 --steps 40 > $OUT/c5s_cached.json 2> $OUT/c5s_cached.err || { tail -5 $OUT/c5s_cached.err; exit 1; }
 timeout -k 10 300 python tools/config5_bench.py --model 12L256 --budget 32000 --mode eager --utts 1500 --steps 40 > $OUT/c5s_eager.json 2> $OUT/c5s_eager.err || { tail -5 $OUT/c5s_eager.err; exit 1; }
 echo "[13] decode breakdown"; timeout -k 10 300 python tools/decode_breakdown.py > $OUT/${TAG}_decode_breakdown.txt 2>/dev/null
+echo "[14] un-profiled phase timeline of the captured step"; timeout -k 10 300 python tools/phase_stamps.py > $OUT/${TAG}_phase_stamps.txt 2>/dev/null
 ls $OUT $OUT/trace $OUT/pmc

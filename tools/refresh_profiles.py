@@ -42,7 +42,7 @@ for a, b in ((f"{tag}_bench_p3.json", f"{tag}_bench_p3.json"), (f"{tag}_bench_p3
              (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p3.txt"), (f"{tag}_ctc_bench.txt", f"{tag}_ctc_bench.txt"),
              (f"{tag}_mfma_busy_northstar.md", f"{tag}_mfma_busy_northstar.md"), (f"{tag}_attn_bench.txt", f"{tag}_attn_bench.txt"),
              (f"{tag}_tn_bench.txt", f"{tag}_tn_bench.txt"), (f"{tag}_bench_northstar_shape.json", f"{tag}_bench_northstar_shape.json"),
-             (f"{tag}_decode_breakdown.txt", f"{tag}_decode_breakdown.txt")):
+             (f"{tag}_decode_breakdown.txt", f"{tag}_decode_breakdown.txt"), (f"{tag}_phase_stamps.txt", f"{tag}_phase_stamps.txt")):
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"{dst}/{b}")
 if os.path.exists(f"{src}/c5_cached.json"):

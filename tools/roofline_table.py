@@ -31,7 +31,7 @@ ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 blo
 classes = [
     ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`, `ffn_fwd_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n,
      f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
-    ("attention (`attn_qtile`, `attn_ktile_bwd`, `attn_delta`)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
+    ("attention (`attn_planes_q`, `attn_planes_k`; `attn_qtile`, `attn_ktile_bwd` for short axes)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
     ("CTC (`ctc_rows`, `ctc_alphabeta`, `ctc_labels`)", "hbm", 2 * M * V * f4 + 4 * M * (2 * 30 + 1) * f4, lambda n: "ctc_" in n and "greedy" not in n,
      "logits read once + gradient written once + alpha/beta"),
