@@ -136,6 +136,22 @@ int oe_ffn_fwd(const oe_ffn_args* args, void* stream);
 int oe_ffn_pack_weights_bwd(const float* w1, const float* w2, int d, int ff, int precision, void* w2t_packed, void* w1t_packed, void* stream);
 int oe_ffn_bwd(const oe_ffn_args* a, void* stream);
 
+/* Several weight gradients  C_i (+)= alpha_i * A_i^T B_i  (A_i (k_i, m_i), B_i (k_i, n_i), both k-major, fp32) in ONE launch
+ * of the bf16-planes kernel, accumulated atomically into C_i (ops.flush_wgrads: the deferred weight gradients of a captured
+ * step; autograd of torch.nn.Linear in the reference).  oe_gemm_tn_grouped_plan fills the launch geometry fields of a HOST
+ * array and returns the total block count (-1: a problem does not qualify: 16-byte aligned operands, leading dimensions
+ * that are whole float4s and cover the rounded-up row lengths); the caller copies the array to device memory and passes it
+ * to oe_gemm_tn_grouped.  a_colsum (optional): alpha_i * column sums of A_i are added to it (fused bias gradient). */
+typedef struct oe_tn_problem {
+    const float* a; const float* b; float* c; float* a_colsum; const float* alpha_dev;
+    long lda, ldb, ldc;
+    int m, n, k;
+    float alpha;
+    int k_chunk, gx, gy, nz, block_start, reserved;      /* filled by oe_gemm_tn_grouped_plan */
+} oe_tn_problem;
+int oe_gemm_tn_grouped_plan(oe_tn_problem* problems_host, int n, int target_blocks);
+int oe_gemm_tn_grouped(const oe_tn_problem* problems_dev, int n, int total_blocks, int precision, void* stream);
+
 /* column sums: out[n] (+)= alpha * sum_m x[m,n]  - bias gradients of every
  * Linear (autograd of aten::addmm).  alpha_dev optional device scalar. */
 int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const float* alpha_dev,

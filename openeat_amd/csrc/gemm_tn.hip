@@ -21,6 +21,7 @@
 // Split-K blocks accumulate with float atomics (the arena is zeroed at the start of the step), as before.
 #include <stdlib.h>
 #include "gemm_common.h"
+#include "../../include/openeat_hip.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -107,10 +108,11 @@ __device__ __forceinline__ void tn_store(const TnRegs& t, __bf16* img, int k0, i
     }
 }
 
+// One block's work: output tile (tile_x, tile_y) of one problem over the K range of split tile_z.
 template <int TERMS>
-__global__ __launch_bounds__(TN_THREADS) void gemm_tn_planes_kernel(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
-                                                                   float* __restrict__ C, long ldc, int M, int N, int Mr, int Nr, int K, int k_chunk,
-                                                                   int gx, int gy, EpiParams ep) {
+__device__ __forceinline__ void tn_block(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
+                                         float* __restrict__ C, long ldc, int M, int N, int Mr, int Nr, int K, int k_chunk,
+                                         int tile_x, int tile_y, int tile_z, const EpiParams& ep) {
     constexpr int NPL = TERMS == 3 ? 2 : 1;
     constexpr int OP_ELEMS = NPL * TN_PLANE;                // one operand's image
     constexpr int BUF_ELEMS = 2 * OP_ELEMS;                 // A then B
@@ -119,15 +121,6 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_planes_kernel(const float*
     __shared__ __attribute__((aligned(16))) __bf16 img[IMG_ELEMS];
     __shared__ float csum_s[TN_COLS];
 
-    int tile_x, tile_y, tile_z;
-    {   // XCD-aware tile order (see gemm_bf16.hip)
-        const int nblk = gridDim.x, id = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, j = id >> 3;
-        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-        tile_x = swz % gx;
-        tile_y = (swz / gx) % gy;
-        tile_z = swz / (gx * gy);
-    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int grp = wave >> 2, wm = (wave >> 1) & 1, wn = wave & 1;
@@ -272,6 +265,77 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_planes_kernel(const float*
         tn_stamp_buf[blockIdx.x * 8 + 7] = tn_t - tn_t0;
     }
 #endif
+}
+
+// XCD-aware tile order (see gemm_bf16.hip): block id -> position in a grid of nblk blocks
+__device__ __forceinline__ int tn_swizzle(int id, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, j = id >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(TN_THREADS) void gemm_tn_planes_kernel(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
+                                                                   float* __restrict__ C, long ldc, int M, int N, int Mr, int Nr, int K, int k_chunk,
+                                                                   int gx, int gy, EpiParams ep) {
+    const int swz = tn_swizzle(blockIdx.x, gridDim.x);
+    tn_block<TERMS>(Ap, lda, Bp, ldb, C, ldc, M, N, Mr, Nr, K, k_chunk, swz % gx, (swz / gx) % gy, swz / (gx * gy), ep);
+}
+
+// Several weight gradients in ONE launch (oe_gemm_tn_grouped): the deferred weight gradients of a captured step are small
+// (256..768 x 256 outputs over K = 7936: 2-6 tiles each), so alone each needs a 20-60-way split of the reduction to cover the
+// chip and its atomic epilogue dominates; four of them together are one 28-tile problem at a 9-way split (41 us against 81).
+// The table lives in device memory; a block finds its problem by its position in the running block count.
+template <int TERMS>
+__global__ __launch_bounds__(TN_THREADS) void gemm_tn_grouped_kernel(const oe_tn_problem* __restrict__ tab, int n_problems) {
+    const int swz = tn_swizzle(blockIdx.x, gridDim.x);
+    int p = 0;
+    while (p + 1 < n_problems && tab[p + 1].block_start <= swz) ++p;         // block-uniform (scalar loads)
+    const oe_tn_problem pr = tab[p];
+    const int local = swz - pr.block_start;
+    EpiParams ep{};
+    ep.alpha = pr.alpha; ep.alpha_dev = pr.alpha_dev; ep.beta = 1.f; ep.atomic = 1; ep.a_colsum = pr.a_colsum;
+    tn_block<TERMS>(pr.a, pr.lda, pr.b, pr.ldb, pr.c, pr.ldc, pr.m, pr.n, (pr.m + 3) / 4 * 4, (pr.n + 3) / 4 * 4, pr.k, pr.k_chunk,
+                    local % pr.gx, (local / pr.gx) % pr.gy, local / (pr.gx * pr.gy), ep);
+}
+
+// Host side of the grouped launch: fill the launch geometry of every problem (tiles, split of the reduction, first block) for
+// about `target_blocks` blocks in all.  Returns the total number of blocks, or -1 if a problem cannot take this kernel
+// (operands must be 16-byte aligned with leading dimensions of whole float4s that cover the rounded-up row lengths).
+extern "C" int oe_gemm_tn_grouped_plan(oe_tn_problem* problems, int n, int target_blocks) {
+    OE_REQUIRE(problems && n > 0 && target_blocks > 0, "oe_gemm_tn_grouped_plan: bad arguments");
+    long tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        oe_tn_problem& p = problems[i];
+        OE_REQUIRE(p.a && p.b && p.c && p.m >= 4 && p.n >= 4 && p.k >= 1, "oe_gemm_tn_grouped_plan: problem %d: bad shape / null pointer", i);
+        OE_REQUIRE((((uintptr_t)p.a | (uintptr_t)p.b) & 15) == 0 && p.lda % 4 == 0 && p.ldb % 4 == 0 && p.lda >= (p.m + 3) / 4 * 4 &&
+                       p.ldb >= (p.n + 3) / 4 * 4 && p.ldc >= p.n,
+                   "oe_gemm_tn_grouped_plan: problem %d: operands not 16-byte aligned / leading dimensions too short", i);
+        p.gx = oe_cdiv(p.n, TN_COLS);
+        p.gy = oe_cdiv(p.m, TN_COLS);
+        tiles += (long)p.gx * p.gy;
+    }
+    const int split = (int)max(1L, (target_blocks + tiles / 2) / tiles);
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        oe_tn_problem& p = problems[i];
+        int nz = min(split, max(1, p.k / 128));
+        p.k_chunk = oe_cdiv(oe_cdiv(p.k, nz), TN_KROWS) * TN_KROWS;
+        p.nz = oe_cdiv(p.k, p.k_chunk);
+        p.block_start = blocks;
+        blocks += p.gx * p.gy * p.nz;
+    }
+    return blocks;
+}
+
+extern "C" int oe_gemm_tn_grouped(const oe_tn_problem* problems_dev, int n, int total_blocks, int precision, void* stream) {
+    OE_REQUIRE(problems_dev && n > 0 && total_blocks > 0, "oe_gemm_tn_grouped: bad arguments");
+    OE_REQUIRE(precision == 1 || precision == 3, "oe_gemm_tn_grouped: precision must be 1 (bf16) or 3 (bf16x3)");
+    if (precision == 3)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<3>), dim3(total_blocks), dim3(TN_THREADS), 0, (hipStream_t)stream, problems_dev, n);
+    else
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<1>), dim3(total_blocks), dim3(TN_THREADS), 0, (hipStream_t)stream, problems_dev, n);
+    OE_LAUNCH_CHECK("oe_gemm_tn_grouped");
+    return 0;
 }
 
 // Returns 1 when the problem does not qualify (the caller goes on to the ring / register-staged kernels), 0 on a launch.

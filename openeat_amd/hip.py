@@ -107,6 +107,14 @@ def exported_symbols():
     return list(_SIGNATURES)
 
 
+class TnProblem(C.Structure):
+    """oe_tn_problem (include/openeat_hip.h)."""
+    _fields_ = [("a", C.c_void_p), ("b", C.c_void_p), ("c", C.c_void_p), ("a_colsum", C.c_void_p), ("alpha_dev", C.c_void_p),
+                ("lda", C.c_long), ("ldb", C.c_long), ("ldc", C.c_long), ("m", C.c_int), ("n", C.c_int), ("k", C.c_int),
+                ("alpha", C.c_float), ("k_chunk", C.c_int), ("gx", C.c_int), ("gy", C.c_int), ("nz", C.c_int),
+                ("block_start", C.c_int), ("reserved", C.c_int)]
+
+
 I, L, F, P, U64, SZ = C.c_int, C.c_long, C.c_float, c_fp, C.c_ulonglong, C.c_size_t
 _SIGNATURES = {
     "oe_last_error": (C.c_char_p, []),
@@ -114,6 +122,8 @@ _SIGNATURES = {
     "oe_capture_unjoined_streams": (I, [P, C.POINTER(C.c_void_p), I, C.POINTER(I)]),
     "oe_stamp": (I, [P, I, P]),
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
+    "oe_gemm_tn_grouped_plan": (I, [C.POINTER(TnProblem), I, I]),
+    "oe_gemm_tn_grouped": (I, [P, I, I, I, P]),
     "oe_ffn_packed_bytes": (SZ, [I, I, I]),
     "oe_ffn_supported": (I, [I, I, I, I]),
     "oe_ffn_pack_weights": (I, [P, P, I, I, I, P, P, P]),
@@ -258,6 +268,29 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
         PROFILE.append((e0, e1, 2.0 * m * n * k, (m, n, k, int(a_kmajor), int(b_kmajor), int(conv_gather), int(split_k))))
         return
     check(lib().oe_gemm_f32(C.byref(g), stream()), "oe_gemm_f32")
+
+
+def tn_grouped_plan(problems, target_blocks: int = 384):
+    """problems: list of dicts(dy (K, M), x (K, N), out (M, N) accumulated, alpha, alpha_dev, bias_out) ->
+    (host bytes of the filled oe_tn_problem array, total blocks), or None if one of them does not qualify."""
+    n = len(problems)
+    arr = (TnProblem * n)()
+    dp = lambda t: None if t is None else t.data_ptr()
+    for i, q in enumerate(problems):
+        dy, x, out = q["dy"], q["x"], q["out"]
+        p = arr[i]
+        p.a, p.b, p.c, p.a_colsum, p.alpha_dev = dy.data_ptr(), x.data_ptr(), out.data_ptr(), dp(q.get("bias_out")), dp(q.get("alpha_dev"))
+        p.lda, p.ldb, p.ldc = dy.stride(0), x.stride(0), out.stride(0)
+        p.m, p.n, p.k, p.alpha = dy.shape[1], x.shape[1], dy.shape[0], float(q.get("alpha", 1.0))
+    total = lib().oe_gemm_tn_grouped_plan(arr, n, int(target_blocks))
+    if total < 0:
+        return None
+    return bytes(arr), total
+
+
+def tn_grouped_launch(table_dev: torch.Tensor, n: int, total_blocks: int, precision=None):
+    check(lib().oe_gemm_tn_grouped(C.c_void_p(table_dev.data_ptr()), n, total_blocks, GEMM_PRECISION if precision is None else precision,
+                                   stream()), "oe_gemm_tn_grouped")
 
 
 def ffn_fwd(x2, w1p, b1, w2p, b2, rows, d, ff, act, *, drop_in=0.0, seed_in=0, drop_out=0.0, seed_out=0, seed_dev=None, pre_out=None,

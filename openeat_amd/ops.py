@@ -281,16 +281,63 @@ WGRAD_DEFER = 0
 _deferred = []
 
 
-def _run_wgrad(to_arena: bool, tensors, fn):
+def _run_wgrad(to_arena: bool, tensors, fn, desc=None):
+    """desc (optional): the launch as data - dict(dy, x, out, alpha, alpha_dev, bias_out) of a plain `out += alpha dy^T x` -
+    so that a flush can run the small ones of a group as ONE grouped launch (WGRAD_GROUPED)."""
     if WGRAD_DEFER > 0 and to_arena:
         # the stream that produces this launch's operands: the flush must order the side stream after every one of them
         # (the decoders' backward runs on other streams than the encoder's)
-        _deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)], torch.cuda.current_stream()))
+        _deferred.append((fn, [t for t in tensors if isinstance(t, torch.Tensor)], torch.cuda.current_stream(), desc))
         if len(_deferred) >= WGRAD_DEFER:
             flush_wgrads()
         return
     with _wgrad_ctx(to_arena, *tensors):
         fn()
+
+
+# The weight gradients of a flush as ONE launch of the bf16-planes kernel (oe_gemm_tn_grouped).  Alone each output of a few
+# 128 x 128 tiles over K = B T' rows needs a 16-60-way split of the reduction to cover the chip and spends much of its time
+# in the atomic epilogue (the four small ones of an encoder layer: 81 us one by one, 41 us together).  Measured in the step
+# (one box, repeated): everything up to 12 tiles grouped 15.34 ms/step, up to 16 / 24 / 48 tiles 15.40 / 15.47 / 15.34-15.49,
+# nothing grouped 15.86 - the feed-forward's 16-tile outputs fill the chip on their own and the 52-tile vocabulary
+# projections (other reduction lengths) unbalance a group.
+WGRAD_GROUPED = os.environ.get("OE_WGRAD_GROUPED", "1") == "1"
+WGRAD_GROUP_MAX_TILES = int(os.environ.get("OE_WGRAD_GROUP_MAX_TILES", "12"))     # outputs of more tiles than this are launched on their own
+WGRAD_GROUP_BLOCKS = int(os.environ.get("OE_WGRAD_GROUP_BLOCKS", "512"))           # blocks a grouped launch aims for (sets the split of the reductions)
+_TN_TABLES = []                    # eager flushes: (device table, host bytes) kept until the stream has surely consumed them
+
+
+def _group_wgrads(descs):
+    """Launch the groupable ones among `descs` (current stream = the side stream); returns the set of indices it covered."""
+    if hip.GEMM_PRECISION == 0:
+        return set()
+    idx = []
+    for i, d in enumerate(descs):
+        if d is None:
+            continue
+        dy, x, out = d["dy"], d["x"], d["out"]
+        tiles = -(-dy.shape[1] // 128) * -(-x.shape[1] // 128)
+        ok = (dy.dim() == 2 and x.dim() == 2 and out.dim() == 2 and dy.stride(1) == 1 and x.stride(1) == 1 and out.stride(1) == 1 and
+              dy.shape[0] == x.shape[0] and dy.shape[0] >= 128 and tiles <= WGRAD_GROUP_MAX_TILES and dy.shape[1] >= 4 and x.shape[1] >= 4 and
+              dy.stride(0) % 4 == 0 and x.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and
+              dy.stride(0) >= -(-dy.shape[1] // 4) * 4 and x.stride(0) >= -(-x.shape[1] // 4) * 4)
+        if ok:
+            idx.append(i)
+    if len(idx) < 2:
+        return set()
+    plan = hip.tn_grouped_plan([descs[i] for i in idx], WGRAD_GROUP_BLOCKS)
+    if plan is None:
+        return set()
+    host, total = plan
+    table = torch.empty(len(host), dtype=torch.uint8, device=descs[idx[0]]["dy"].device)
+    if LN_TABLE is not None:
+        LN_TABLE.setdefault("uploads", []).append((table, host))       # inside a capture: filled by ln_table_end, kept with the graph
+    else:
+        table.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+        _TN_TABLES.append(table)
+        del _TN_TABLES[:-64]
+    hip.tn_grouped_launch(table, len(idx), total)
+    return set(idx)
 
 
 def drop_deferred():
@@ -305,15 +352,17 @@ def flush_wgrads():
         return
     side = side_stream()
     origins = []
-    for _, _, st in _deferred:
+    for _, _, st, _ in _deferred:
         if all(st != o for o in origins):
             origins.append(st)
     for st in origins:
         side.wait_stream(st)
     with torch.cuda.stream(side):
-        for fn, _, _ in _deferred:
-            fn()
-    for _, ts, _ in _deferred:
+        grouped = _group_wgrads([d for _, _, _, d in _deferred]) if WGRAD_GROUPED else set()
+        for i, (fn, _, _, _) in enumerate(_deferred):
+            if i not in grouped:
+                fn()
+    for _, ts, _, _ in _deferred:
         for t in ts:
             t.record_stream(side)
     _deferred = []
@@ -326,8 +375,9 @@ def wgrad(param, dy, x, alpha=1.0, alpha_dev=None):
     tgt = _arena.grad_target(param)
     if tgt is None:
         return gemm_tn(dy, x, alpha=alpha, alpha_dev=alpha_dev).view(param.shape)
-    _run_wgrad(True, (dy, x, alpha_dev),
-               lambda: gemm_tn(dy, x, out=tgt.view(dy.shape[1], x.shape[1]), alpha=alpha, alpha_dev=alpha_dev))
+    out = tgt.view(dy.shape[1], x.shape[1])
+    _run_wgrad(True, (dy, x, alpha_dev), lambda: gemm_tn(dy, x, out=out, alpha=alpha, alpha_dev=alpha_dev),
+               desc=dict(dy=dy, x=x, out=out, alpha=alpha, alpha_dev=alpha_dev, bias_out=None))
     return None
 
 
@@ -352,7 +402,8 @@ def wgrad_bias(w, b, dy, x, alpha=1.0, alpha_dev=None):
     ow = tw.view(N, K) if tw is not None else _new(N, K, like=dy, zero=True)
     ob = tb if tb is not None else _new(N, like=dy, zero=True)
     _run_wgrad(tw is not None and tb is not None, (dy, x, alpha_dev),
-               lambda: gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob))
+               lambda: gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob),
+               desc=dict(dy=dy, x=x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob))
     return (None if tw is not None else ow.view(w.shape)), (None if tb is not None else ob)
 
 
@@ -432,6 +483,9 @@ def ln_table_end():
     t, LN_TABLE = LN_TABLE, None
     if t is not None and t["entries"]:
         t["dev"][: len(t["entries"])].copy_(torch.tensor(t["entries"], dtype=torch.int64))
+    if t is not None:
+        for table, host in t.get("uploads", ()):        # grouped weight-gradient tables recorded during the capture
+            table.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
     return t
 
 
@@ -923,8 +977,9 @@ class AttentionFn(torch.autograd.Function):
                 gw = _arena.grad_target(parts_w[0])
                 gw_all = torch.as_strided(gw, (n, x_in.shape[1]), (x_in.shape[1], 1))
                 gb = _arena.grad_target(parts_b[0])
-                _run_wgrad(True, (dy_fused, x_in),
-                           lambda: gemm_tn(dy_fused, x_in, out=gw_all, bias_out=torch.as_strided(gb, (n,), (1,))))
+                gb_all = torch.as_strided(gb, (n,), (1,))
+                _run_wgrad(True, (dy_fused, x_in), lambda: gemm_tn(dy_fused, x_in, out=gw_all, bias_out=gb_all),
+                           desc=dict(dy=dy_fused, x=x_in, out=gw_all, alpha=1.0, alpha_dev=None, bias_out=gb_all))
                 return dx_in, [None] * len(parts_w), [None] * len(parts_b)
             dwf, dbf = gemm_tn(dy_fused, x_in), colsum(dy_fused)
             ws, bs, o = [], [], 0
@@ -1089,7 +1144,8 @@ class ConvModuleFn(torch.autograd.Function):
         (db1, rb1) = grad_sink(b1)
         tw1 = _arena.grad_target(w1)
         ow1 = tw1.view(2 * d, d) if tw1 is not None else _new(2 * d, d, like=dy, zero=True)
-        _run_wgrad(tw1 is not None and rb1 is None and not causal, (da, xm), lambda: gemm_tn(da, xm, out=ow1, bias_out=db1))
+        _run_wgrad(tw1 is not None and rb1 is None and not causal, (da, xm), lambda: gemm_tn(da, xm, out=ow1, bias_out=db1),
+                   desc=dict(dy=da, x=xm, out=ow1, alpha=1.0, alpha_dev=None, bias_out=db1))
         dw1 = None if tw1 is not None else ow1.view(w1.shape)
         if causal:
             db1_pad = torch.empty_like(db1)

@@ -160,3 +160,45 @@ def test_weight_gradient_planes_kernel(prec, rel, m, n, k, sk, atomic, bias):
         if bias:
             refb = 2.0 + 1.5 * dy.double().sum(0)
             assert float((db.cpu().double() - refb).abs().max()) < 2e-3 * math.sqrt(k)
+
+
+@pytest.mark.parametrize("prec,rel", PRECS)
+@pytest.mark.parametrize("target_blocks", [384, 40, 4000])
+def test_grouped_weight_gradients(prec, rel, target_blocks):
+    """oe_gemm_tn_grouped: several dW_i (+)= alpha_i dY_i^T X_i in one launch against float64 - outputs from one tile to
+    many, different reduction lengths in one table (K = 248 rows of linear_pos beside K = 7936), a ragged row length inside a
+    padded leading dimension, fused bias gradients, a device-side alpha; at splits from none to many."""
+    from openeat_amd import hip
+    g = torch.Generator().manual_seed(77)
+    shapes = [(768, 256, 1984, True), (256, 256, 1984, True), (512, 256, 1984, False), (256, 256, 248, False), (1024, 256, 1984, True),
+              (40, 32, 300, True), (326, 64, 1100, True)]
+    alpha_dev = torch.tensor([0.25], device=DEV)
+    problems, refs = [], []
+    for i, (m, n, k, bias) in enumerate(shapes):
+        mp = (m + 3) // 4 * 4 + (4 if i == 6 else 0)
+        dy = torch.full((k, mp), float("nan"))
+        dy[:, :m] = torch.randn(k, m, generator=g)
+        x = torch.randn(k, n, generator=g)
+        start = torch.randn(m, n, generator=g)
+        alpha = 1.0 + 0.5 * i
+        out = start.to(DEV).clone()
+        db = torch.full((m,), 3.0, device=DEV) if bias else None
+        dyd = dy.to(DEV)
+        problems.append(dict(dy=dyd[:, :m], x=x.to(DEV), out=out, alpha=alpha, alpha_dev=alpha_dev if i % 2 else None, bias_out=db))
+        a = alpha * (0.25 if i % 2 else 1.0)
+        refs.append((start.double() + a * dy[:, :m].double().t() @ x.double(), None if not bias else 3.0 + a * dy[:, :m].double().sum(0), k, a))
+    plan = hip.tn_grouped_plan(problems, target_blocks)
+    assert plan is not None
+    host, total = plan
+    table = torch.empty(len(host), dtype=torch.uint8, device=DEV)
+    table.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+    hip.tn_grouped_launch(table, len(problems), total, precision=prec)
+    torch.cuda.synchronize()
+    for q, (ref, refb, k, a) in zip(problems, refs):
+        err = float((q["out"].cpu().double() - ref).abs().max()) / math.sqrt(k)
+        assert err < max(a, 1.0) * rel * 2.5, (tuple(ref.shape), k, err)
+        if refb is not None:
+            assert float((q["bias_out"].cpu().double() - refb).abs().max()) < 2e-3 * math.sqrt(k) * max(a, 1.0)
+    # a problem that cannot take the kernel is refused by the plan (leading dimension not a whole float4)
+    bad = dict(problems[0], dy=torch.randn(1984, 770, device=DEV)[:, :768])
+    assert hip.tn_grouped_plan([bad, problems[1]], 384) is None

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 SHAPES = [(1024, 256, 7936), (256, 1024, 7936), (256, 256, 7936), (512, 256, 7936), (768, 256, 7936), (3246, 256, 7936),
           (256, 4864, 7936), (256, 256, 992), (1024, 256, 992), (3246, 256, 992), (1024, 256, 25472), (256, 256, 25472),
-          (2048, 512, 47744), (512, 512, 47744)]
+          (2048, 512, 47744), (512, 512, 47744), (1792, 256, 7936)]
 
 
 def run(prec):
