@@ -33,10 +33,10 @@ MODEL_CONF = dict(encoder_num_blocks=12, decoder_num_blocks=3, r_decoder_num_blo
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 KERNEL_NAMES = {0: "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)",
-                1: "gemm_dma_kernel + gemm_bf16_kernel + ffn_fwd_kernel <terms=1> (the kernels behind oe_gemm_f32 / oe_ffn_fwd precision 1, "
-                   "v_mfma_f32_32x32x16_bf16)",
-                3: "gemm_dma_kernel + gemm_bf16_kernel + ffn_fwd_kernel <terms=3> (the kernels behind oe_gemm_f32 / oe_ffn_fwd precision 3: "
-                   "hi*hi+hi*lo+lo*hi, v_mfma_f32_32x32x16_bf16)"}
+                1: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=1> (the kernels behind "
+                   "oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd precision 1, v_mfma_f32_32x32x16_bf16)",
+                3: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=3> (the kernels behind "
+                   "oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd precision 3: hi*hi+hi*lo+lo*hi, v_mfma_f32_32x32x16_bf16)"}
 DTYPE_NAMES = {0: "f32", 1: "bf16 (MFMA inputs; fp32 storage, accumulate, softmax, norms, losses, optimizer)",
                3: "bf16x3 (matrix products as hi*hi+hi*lo+lo*hi on bf16 MFMA: ~2^-17 relative error per product, fp32 accumulate - "
                   "narrower than the reference's fp32 products, wider than bf16; fp32 storage and fp32 everywhere else)"}
@@ -185,6 +185,11 @@ def main():
     model = ASRModel(80, V, **conf).to(dev).train()
     engine = TrainEngine(model, lr=1e-3, grad_clip=5.0, static_shapes=True, async_wgrad=not args.single_stream,
                          parallel_decoders=not (args.serial_decoders or args.single_stream))
+    if args.single_stream:
+        # profile runs (`--single-stream --no-graph`): the eager step launches what the captured step holds, one kernel after
+        # the other - weight gradients collected in groups of 48, the small ones of a group as one grouped launch
+        from openeat_amd import ops as _ops0
+        _ops0.WGRAD_DEFER, _ops0.WGRAD_FLUSH_INLINE = 48, True
     fb = Fbank(80, device=dev)
     wav, tgt, tlen = synth_batch(args.batch, args.seconds, args.target_len, seed=rank, device=dev)
     T = fb.num_frames(wav.shape[1])
@@ -292,6 +297,10 @@ def main():
     from openeat_amd import ops as _ops
     saved_streams = (_ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, engine.parallel)
     _ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, engine.parallel = False, False, False
+    # ... and with the captured step's launch structure: weight gradients collected in groups of 48, the small ones of a
+    # group as one grouped launch, flushed in line
+    saved_defer = (_ops.WGRAD_DEFER, _ops.WGRAD_FLUSH_INLINE)
+    _ops.WGRAD_DEFER, _ops.WGRAD_FLUSH_INLINE = 48, True
     for _ in range(2):
         # park the GPU behind a ~0.15 s spin kernel while the host enqueues the whole eager step: the launches then run
         # back to back and an event pair measures the kernel, not the host's time between record() and launch
@@ -299,6 +308,7 @@ def main():
         engine.step(batch)                                      # eager steps on EVERY rank (they contain the collective);
     torch.cuda.synchronize()                                    # rank 0 brackets each GEMM launch with events
     _ops.PARALLEL_DECODERS, _ops.ASYNC_WGRAD, engine.parallel = saved_streams
+    _ops.WGRAD_DEFER, _ops.WGRAD_FLUSH_INLINE = saved_defer
     if rank == 0:
         recs, hip.PROFILE = hip.PROFILE, None
         recs = recs[len(recs) // 2:]                            # second step only

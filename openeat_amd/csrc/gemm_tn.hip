@@ -314,7 +314,8 @@ extern "C" int oe_gemm_tn_grouped_plan(oe_tn_problem* problems, int n, int targe
         p.gy = oe_cdiv(p.m, TN_COLS);
         tiles += (long)p.gx * p.gy;
     }
-    const int split = (int)max(1L, (target_blocks + tiles / 2) / tiles);
+    // never more than 16 ways: a 37-way split of a five-problem leftover group spent 264 us in its atomic epilogues
+    const int split = (int)min(16L, max(1L, (target_blocks + tiles / 2) / tiles));
     int blocks = 0;
     for (int i = 0; i < n; ++i) {
         oe_tn_problem& p = problems[i];

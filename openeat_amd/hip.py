@@ -288,7 +288,15 @@ def tn_grouped_plan(problems, target_blocks: int = 384):
     return bytes(arr), total
 
 
-def tn_grouped_launch(table_dev: torch.Tensor, n: int, total_blocks: int, precision=None):
+def tn_grouped_launch(table_dev: torch.Tensor, n: int, total_blocks: int, precision=None, flops: float = 0.0):
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().oe_gemm_tn_grouped(C.c_void_p(table_dev.data_ptr()), n, total_blocks, GEMM_PRECISION if precision is None else precision,
+                                       stream()), "oe_gemm_tn_grouped")
+        e1.record()
+        PROFILE.append((e0, e1, flops, ("tn_grouped", n, total_blocks, 0, 1, 1, 0)))
+        return
     check(lib().oe_gemm_tn_grouped(C.c_void_p(table_dev.data_ptr()), n, total_blocks, GEMM_PRECISION if precision is None else precision,
                                    stream()), "oe_gemm_tn_grouped")
 

@@ -333,10 +333,14 @@ def _group_wgrads(descs):
     if LN_TABLE is not None:
         LN_TABLE.setdefault("uploads", []).append((table, host))       # inside a capture: filled by ln_table_end, kept with the graph
     else:
-        table.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
-        _TN_TABLES.append(table)
+        # stream-ordered upload from pinned memory: the host never waits for the stream (bench.py's bracketed steps park the GPU
+        # while the host enqueues the whole step)
+        pinned = torch.frombuffer(bytearray(host), dtype=torch.uint8).pin_memory()
+        table.copy_(pinned, non_blocking=True)
+        _TN_TABLES.append((table, pinned))
         del _TN_TABLES[:-64]
-    hip.tn_grouped_launch(table, len(idx), total)
+    hip.tn_grouped_launch(table, len(idx), total,
+                          flops=sum(2.0 * descs[i]["dy"].shape[0] * descs[i]["dy"].shape[1] * descs[i]["x"].shape[1] for i in idx))
     return set(idx)
 
 
@@ -346,9 +350,21 @@ def drop_deferred():
     _deferred = []
 
 
+# Measurement aid (bench.py's event-bracketed steps, `--single-stream` profile runs): run a flush on the CURRENT stream, so that
+# an eager step launches exactly the kernels a captured step holds - the grouped weight gradients included - one after the other.
+WGRAD_FLUSH_INLINE = False
+
+
 def flush_wgrads():
     global _deferred
     if not _deferred:
+        return
+    if WGRAD_FLUSH_INLINE:
+        grouped = _group_wgrads([d for _, _, _, d in _deferred]) if WGRAD_GROUPED else set()
+        for i, (fn, _, _, _) in enumerate(_deferred):
+            if i not in grouped:
+                fn()
+        _deferred = []
         return
     side = side_stream()
     origins = []

@@ -29,7 +29,7 @@ attn_enc = 12 * (4 + 14) * B * H * Tp * Tp * (d // H)                    # fwd 4
 attn_dec = 6 * (4 + 14) * B * H * (L1 * L1 + L1 * Tp) * (d // H)         # self + source attention of 2 x 3 decoder layers
 ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 block norms + conv-module norm per layer, after_norm
 classes = [
-    ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`, `ffn_fwd_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n,
+    ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`, `ffn_fwd_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n,   # gemm_tn_grouped_kernel included
      f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
     ("attention (`attn_planes_q`, `attn_planes_k`; `attn_qtile`, `attn_ktile_bwd` for short axes)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
