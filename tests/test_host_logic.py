@@ -214,3 +214,24 @@ def test_no_pos_fails_like_the_reference():
     from openeat_amd.modules.encoder import TransformerEncoder
     with pytest.raises(NameError):
         TransformerEncoder(80, pos_enc_layer_type="no_pos", d_model=16, attention_heads=4, linear_units=32, num_blocks=1)
+
+
+def test_pad_targets_and_cut_are_inert_on_the_host():
+    """engine.pad_targets pads label matrices with ignore_id to a multiple (fewer distinct shapes for step_cached);
+    ops.cut is the identity unless a segmented capture is recording cut points."""
+    import torch
+    from openeat_amd import ops
+    from openeat_amd.engine import pad_targets
+    t = torch.tensor([[3, 4, 5], [6, -1, -1]], dtype=torch.int32)
+    p = pad_targets(t, 4)
+    assert p.shape == (2, 4) and p.dtype == t.dtype and p[:, :3].equal(t) and p[:, 3].tolist() == [-1, -1]
+    assert pad_targets(p, 4) is p
+    x = torch.ones(2, 3, requires_grad=True) * 2
+    assert ops.CUTS is None and ops.cut(x, "heads") is x
+    ops.CUTS = []
+    try:
+        y = ops.cut(x, "heads")
+        assert y is not x and y.requires_grad and y.grad_fn is None and torch.equal(y, x) and ops.CUTS[0][0] == "heads"
+        assert ops.cut(x.detach(), "enc3").requires_grad is False and len(ops.CUTS) == 1       # nothing to cut on a constant
+    finally:
+        ops.CUTS = None

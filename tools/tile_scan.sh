@@ -1,3 +1,4 @@
+# GPU box: microbenchmark of the skinny x @ W^T / dy @ W GEMMs at every block tile and both kernel families (tools/gemm_bench.py run()).
 cd $GRAFT_REPO_ROOT
 for dma in 1 2; do for tile in 11 12 21 22; do
 echo "== OE_GEMM_DMA=$dma OE_GEMM_TILE=$tile"
