@@ -307,7 +307,7 @@ def test_step_cached_replays_one_graph_per_batch_shape():
     for g, r in zip(got, ref):
         assert abs(g - r) < 2e-4 * abs(r) + 1e-4, (got, ref)
     check_updates(m2.state_dict(), m1.state_dict(), None, steps=len(seq))
-    e3 = TrainEngine(m3, lr=1e-3, grad_clip=5.0)
+    e3 = TrainEngine(m3, lr=1e-3, grad_clip=5.0, segmented=True)       # the multi-rank form of the capture, per shape, LRU of one
     try:
         got3 = [float(e3.step_cached(b, max_graphs=1)[0]) for b in batches]
         torch.cuda.synchronize()
