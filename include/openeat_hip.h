@@ -316,6 +316,10 @@ int oe_act_grad(const float* dy, const float* pre, long n, int act, float* out, 
 
 /* log_softmax over the last dim (ctc.py:56-64; asr_model.py:484-488). */
 int oe_log_softmax(const float* x, long rows, int V, float* out, void* stream);
+/* log_softmax(x)[row, idx_a[row]] (0 where idx_a is out of range) and, if out_b is given, log_softmax(x)[row, idx_b] for one
+ * fixed column - the hypothesis' token and <eos> log-probabilities attention rescoring sums (asr_model.py:504-528) - without
+ * writing the (rows, V) log-probability tensor. */
+int oe_logprob_gather(const float* x, long rows, int V, const long long* idx_a, int idx_b, float* out_a, float* out_b, void* stream);
 /* The decoders' token bookkeeping of a training step in one launch (asr_model.py:162-176 with common.py:61-132 and
  * mask.py:9-69): from the labels ys_pad (B, L) i32 (ignore_id where there is none) and their lengths (B) i32, at the fixed
  * width W = L + 1: ys_in = [sos, labels, eos...], ys_out = [labels, eos, ignore...] (both (B, W) i64), the same for the

@@ -405,6 +405,38 @@ extern "C" int oe_masked_softmax_bwd(const float* y, const float* dout, long row
     return 0;
 }
 
+// log_softmax(x)[row, idx] without the (rows, V) log-probability tensor: what attention rescoring reads from the decoders'
+// and the LM's outputs (asr_model.py:504-528: the hypothesis' token and <eos> at every position).  One wave per row, the
+// same log-sum-exp arithmetic as log_softmax_kernel (bit-identical values); one read of the logits, 4-8 bytes written.
+__global__ __launch_bounds__(256) void logprob_gather_kernel(const float* __restrict__ x, long rows, int V, const long long* __restrict__ idx_a,
+                                                             int idx_b, float* __restrict__ out_a, float* __restrict__ out_b) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* p = x + row * V;
+    float m = -INFINITY, s = 0.f;
+    for (int i = lane; i < V; i += 64) {
+        const float v = p[i];
+        const float mn = fmaxf(m, v);
+        s = s * __expf(m - mn) + __expf(v - mn);
+        m = mn;
+    }
+    if (m == -INFINITY) s = 0.f;
+    wave_lse(m, s);
+    const float lse = m + __logf(s);
+    if (lane == 0) {
+        const long long a = idx_a[row];
+        out_a[row] = (a >= 0 && a < V) ? p[a] - lse : 0.f;
+        if (out_b) out_b[row] = p[idx_b] - lse;
+    }
+}
+extern "C" int oe_logprob_gather(const float* x, long rows, int V, const long long* idx_a, int idx_b, float* out_a, float* out_b, void* stream) {
+    OE_REQUIRE(x && idx_a && out_a && rows > 0 && V > 0 && (!out_b || (idx_b >= 0 && idx_b < V)), "oe_logprob_gather: bad arguments");
+    hipLaunchKernelGGL(logprob_gather_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, rows, V, idx_a, idx_b, out_a, out_b);
+    OE_LAUNCH_CHECK("logprob_gather");
+    return 0;
+}
+
 // Per-row top-k, optionally of the row's log-softmax (asr_model.py:251, 358: `logp.topk(beam_size)` after log_softmax; :258
 // `scores.topk`).  One wave per row: the row is staged in LDS while the online log-sum-exp runs (the same arithmetic as
 // log_softmax_kernel; the values equal log_softmax -> topk to the last bit or two), every lane remembers the best of its own strided

@@ -158,6 +158,7 @@ _SIGNATURES = {
     "oe_act_grad": (I, [P, P, L, I, P, P]),
     "oe_log_softmax": (I, [P, L, I, P, P]),
     "oe_topk_rows": (I, [P, L, I, I, I, P, P, P]),
+    "oe_logprob_gather": (I, [P, L, I, P, I, P, P, P]),
     "oe_att_inputs": (I, [P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "oe_masked_softmax_fwd": (I, [P, P, L, L, I, I, I, I, F, U64, P, P, P, P]),
     "oe_masked_softmax_bwd": (I, [P, P, L, I, F, U64, P, P, P]),

@@ -380,9 +380,9 @@ class ASRModel(torch.nn.Module):
         tok = torch.cat([ori, ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)
 
         def seq_score(logits, tokens_at):
-            lp = ops.log_softmax_rows(logits)
-            tok_lp = lp.gather(2, tokens_at.unsqueeze(2)).squeeze(2)
-            eos_lp = lp[torch.arange(R, device=device), hl, self.eos]
+            # the token's and <eos>'s log-probability at every position, straight from the logits (no (R, L, V) log-softmax)
+            tok_lp, eos_all = ops.logprob_gather(logits, tokens_at, also=self.eos)
+            eos_lp = eos_all.gather(1, hl.unsqueeze(1)).squeeze(1)
             return (tok_lp * valid).sum(1).double() + eos_lp.double()
 
         score = seq_score(l_x, tok)
@@ -391,8 +391,8 @@ class ASRModel(torch.nn.Module):
             score = score * (1 - reverse_weight) + seq_score(r_x, r_tok) * reverse_weight
         score = score + ctc_scores * ctc_weight
         if lm is not None and lm_weight > 0:                                      # neural-LM shallow fusion (asr_model.py:490-527)
-            lm_lp = lm.log_probs(hyps_pad, hl + 1)
-            lm_tok = lm_lp.gather(2, tok.unsqueeze(2)).squeeze(2)
+            lm_tok = ops.logprob_gather(lm.logits(hyps_pad, hl + 1), tok) if hasattr(lm, "logits") else \
+                lm.log_probs(hyps_pad, hl + 1).gather(2, tok.unsqueeze(2)).squeeze(2)
             score = score + (lm_tok * valid).sum(1).double() * lm_weight
         score = score.masked_fill(missing, -float("inf"))         # (0 * -inf above would be nan: the slot is out whatever the weights)
         return score.view(B, beam_size).argmax(1)

@@ -61,6 +61,10 @@ class LanguageModel(torch.nn.Module):
         """-> logits (B, L, V) (language_model.py:109-125)."""
         return ops.linear(self._hidden(tokens, lengths), self.proj_layer.weight, self.proj_layer.bias)
 
+    def logits(self, tokens: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
+        """Un-normalised scores (B, L, V): rescoring takes its log-probabilities from them one token at a time (ops.logprob_gather)."""
+        return self._forward_encoder(tokens, lengths)
+
     def log_probs(self, tokens: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
         """log_softmax of the logits: what attention rescoring indexes as lm_output[i][j][w] (asr_model.py:498-499)."""
         return ops.log_softmax_rows(self._forward_encoder(tokens, lengths))

@@ -1495,6 +1495,20 @@ def topk_rows(x, k: int, log_softmax: bool = False):
     return vals, idx
 
 
+def logprob_gather(logits, idx, also: int = None):
+    """log_softmax(logits)[..., idx] (+ log_softmax(logits)[..., also] for one fixed column) without materialising the
+    log-probabilities: logits (..., V) float32, idx (...) int64 (out-of-range entries give 0).  Returns tensors shaped like idx."""
+    x = _chk(logits, "logprob_gather")
+    V = x.shape[-1]
+    rows = x.numel() // V
+    idx = idx.to(torch.int64).contiguous()
+    assert idx.numel() == rows
+    out_a = torch.empty(idx.shape, dtype=torch.float32, device=x.device)
+    out_b = torch.empty(idx.shape, dtype=torch.float32, device=x.device) if also is not None else None
+    hip.call("oe_logprob_gather", x, rows, V, idx, 0 if also is None else int(also), out_a, out_b)
+    return out_a if also is None else (out_a, out_b)
+
+
 def log_softmax_rows(x):
     """log_softmax over the last dim (ctc.py:56-64, asr_model.py:484-488) on device."""
     x = _chk(x, "log_softmax")

@@ -590,3 +590,21 @@ def test_device_prefix_beam_equals_the_host_recursion(B, T, V, beam, sharp):
     want_all = hip.ctc_prefix_beam_host_batch(top_p.cpu(), top_i.cpu(), [T] * B, beam)
     got_all = hip.ctc_prefix_beam_device(top_p, top_i, None, beam)
     assert [[p for p, _ in u] for u in got_all] == [[p for p, _ in u] for u in want_all]
+
+
+def test_logprob_gather_kernel():
+    """oe_logprob_gather == log_softmax_rows(...).gather(...), bit for bit (the same log-sum-exp arithmetic), plus the fixed
+    <eos> column; out-of-range indices give 0."""
+    from openeat_amd import ops
+    g = torch.Generator().manual_seed(9)
+    x = (torch.randn(7, 13, 3246, generator=g) * 4).cuda()
+    idx = torch.randint(0, 3246, (7, 13), generator=g).cuda()
+    lp = ops.log_softmax_rows(x)
+    a, b = ops.logprob_gather(x, idx, also=3245)
+    assert torch.equal(a, lp.gather(2, idx.unsqueeze(2)).squeeze(2)) and torch.equal(b, lp[..., 3245])
+    only = ops.logprob_gather(x, idx)
+    assert torch.equal(only, a)
+    bad = idx.clone()
+    bad[0, 0], bad[1, 1] = -1, 3246
+    z = ops.logprob_gather(x, bad)
+    assert float(z[0, 0]) == 0.0 and float(z[1, 1]) == 0.0 and torch.equal(z[2:], a[2:])
