@@ -290,7 +290,7 @@ class TrainEngine:
             try:
                 self.capture(batch, pool=self._pool, _warm=True)
                 rec = (self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep)
-            except RuntimeError:
+            except Exception:                    # noqa: BLE001 - whatever the capture objected to (capture() has cleaned up after itself)
                 rec = None                       # this shape does not capture: it keeps running eagerly
             self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
             self._cache[key] = rec
