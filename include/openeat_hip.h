@@ -259,6 +259,9 @@ typedef struct oe_attn_args {
     /* matrix-core arithmetic of the score / context products, as oe_gemm_args.precision:
      * 0 = fp32 MFMA (exact products), 1 = bf16 inputs, 3 = three-term bf16 split (fp32-grade) */
     int precision;
+    /* hint, forward: the (B, T1, T2) mask is zero above the diagonal (a decoder's self-attention): key blocks that lie wholly
+     * above it are not visited.  Results are identical with or without the hint; ignored unless a full mask is given. */
+    int causal;
 } oe_attn_args;
 
 int oe_attention_fwd(const oe_attn_args* args, void* stream);

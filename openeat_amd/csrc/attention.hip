@@ -681,6 +681,7 @@ static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {
     p.keybias = a->keybias; p.dkeybias = a->dkeybias;
     p.B = a->B; p.H = a->H; p.T1 = a->T1; p.T2 = a->T2; p.D = a->D;
     p.scale = a->scale; p.drop_p = a->drop_p; p.seed = a->seed; p.seed_dev = a->seed_dev;
+    p.causal = a->causal && a->mask && a->mask_rstride != 0 && a->T1 == a->T2;       // only with a full (B, T1, T2) mask that says so too
     return 0;
 }
 

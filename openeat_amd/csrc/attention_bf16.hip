@@ -305,7 +305,10 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_q_kernel(AttnParams
         chunk_store<DPAD, TERMS>(vreg, imgs + (buf * 2 + 1) * IMG, j0, p.T2, p.D);
         if (kb_wave) kb_s[buf][lane] = (j0 + lane < p.T2 && km_raw != 0) ? kb_raw : NEG_INF;
     };
-    const int nchunks = (p.T2 + PL_ROWS - 1) / PL_ROWS;
+    // causal hint (forward only): no query of this block looks past key (blockIdx.x + 1) * 128 - 1, the mask zeroes the rest
+    // anyway - the chunks that hold nothing but such keys are not visited (identical sums: their terms are exp(-inf) = 0)
+    const int T2e = (MODE == 0 && p.causal) ? min(p.T2, (int)(blockIdx.x + 1) * 128) : p.T2;
+    const int nchunks = (T2e + PL_ROWS - 1) / PL_ROWS;
     prefetch(0);
     PL_ACC(0);                                          // Q fragments + first prefetch issue
     commit(0, 0);

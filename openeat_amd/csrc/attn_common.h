@@ -24,6 +24,7 @@ struct AttnParams {
     int B, H, T1, T2, D;
     float scale;
     float drop_p; unsigned long long seed; const unsigned long long* seed_dev;
+    int causal;                          // hint: mask[b, i, j] = 0 for every j > i, so key chunks past a block's last query can be skipped
 };
 __device__ __forceinline__ unsigned long long eff_seed(unsigned long long seed, const unsigned long long* dev) {
     return seed + (dev ? *dev * 0x9E3779B97F4A7C15ull : 0ull);

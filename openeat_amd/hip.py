@@ -68,7 +68,7 @@ class AttnArgs(C.Structure):
         ("scale", C.c_float),
         ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("seed_dev", c_fp),
         ("d_out", c_fp), ("dq", c_fp), ("dk", c_fp), ("dv", c_fp), ("dkeybias", c_fp), ("delta", c_fp),
-        ("precision", C.c_int),
+        ("precision", C.c_int), ("causal", C.c_int),
     ]
 
 
@@ -357,7 +357,7 @@ def call(name, *args):
 
 def attn_args(q, k, v, out, lse, B, H, T1, T2, D, scale, *, q_strides, k_strides, v_strides, o_strides, mask=None,
               mask_strides=(0, 0), keybias=None, drop_p=0.0, seed=0, seed_dev=None, d_out=None, dq=None, dk=None, dv=None,
-              dkeybias=None, delta=None, precision=None):
+              dkeybias=None, delta=None, precision=None, causal=False):
     a = AttnArgs()
     a.precision = GEMM_PRECISION if precision is None else precision
     dp = lambda t: None if t is None else t.data_ptr()
@@ -372,6 +372,7 @@ def attn_args(q, k, v, out, lse, B, H, T1, T2, D, scale, *, q_strides, k_strides
     a.scale, a.drop_p, a.seed = scale, drop_p, seed
     a.seed_dev = dp(seed_dev)
     a.d_out, a.dq, a.dk, a.dv, a.dkeybias, a.delta = dp(d_out), dp(dq), dp(dk), dp(dv), dp(dkeybias), dp(delta)
+    a.causal = int(bool(causal))
     return a
 
 

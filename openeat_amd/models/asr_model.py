@@ -374,7 +374,8 @@ class ASRModel(torch.nn.Module):
         enc_mask = encoder_mask.repeat_interleave(beam_size, dim=0)
         r_ori = reverse_pad_list(ori, hl, self.ignore_id)
         r_hyps_pad, _ = add_sos_eos(r_ori, self.sos, self.eos, self.ignore_id)
-        l_x, r_x, _ = self.decoder(enc, enc_mask, hyps_pad, r_hyps_pad, hyps_mask)
+        with ops.causal_self_attention():                                        # hyps_mask is causal: key blocks above the diagonal are skipped
+            l_x, r_x, _ = self.decoder(enc, enc_mask, hyps_pad, r_hyps_pad, hyps_mask)
         pos = torch.arange(L, device=device).unsqueeze(0)
         valid = pos < hl.unsqueeze(1)                                            # token positions j < len
         tok = torch.cat([ori, ori.new_full((R, L - Lm), self.ignore_id)], 1).clamp(min=0)

@@ -54,7 +54,11 @@ class LanguageModel(torch.nn.Module):
             mask = mask & subsequent_mask(L, device=tokens.device).unsqueeze(0)
         pos = self.pos_encoding.table(tokens.device, L)
         xs = ops.embed(tokens, self.embedding.weight, pos.reshape(L, -1).contiguous(), self.pos_encoding.xscale)
-        xs, _, _ = self.encoder(xs, mask, pos)
+        if self.autoregressive:
+            with ops.causal_self_attention():
+                xs, _, _ = self.encoder(xs, mask, pos)
+        else:
+            xs, _, _ = self.encoder(xs, mask, pos)
         return xs
 
     def _forward_encoder(self, tokens: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:

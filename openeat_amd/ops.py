@@ -883,6 +883,23 @@ def _mask_u8(mask: Optional[torch.Tensor]):
     return m, (m.shape[1] * m.shape[2], 0 if m.shape[1] == 1 else m.shape[2])
 
 
+# Set (by the caller that built the masks: decode paths, the LM) while every self-attention mask in flight is causal - a
+# (B, L, L) mask that is zero above the diagonal: the forward kernel then skips the key blocks above it.  A hint only: the
+# mask is still applied, the results are identical.
+CAUSAL_SELF_ATTENTION = False
+
+
+class causal_self_attention:
+    def __enter__(self):
+        global CAUSAL_SELF_ATTENTION
+        self.old, CAUSAL_SELF_ATTENTION = CAUSAL_SELF_ATTENTION, True
+
+    def __exit__(self, *exc):
+        global CAUSAL_SELF_ATTENTION
+        CAUSAL_SELF_ATTENTION = self.old
+        return False
+
+
 class AttentionFn(torch.autograd.Function):
     """attention.py:99-117 (MultiHeadedAttention.forward) and :166-209
     (RelPositionMultiHeadedAttention.forward) incl. linear_q/k/v/out, with an
@@ -932,7 +949,7 @@ class AttentionFn(torch.autograd.Function):
         lse = _new(B, H, T1, like=xq)
         a = hip.attn_args(q, k_att, v, att, lse, B, H, T1, T2, D, scale, q_strides=qs, k_strides=k_att_s, v_strides=vs,
                           o_strides=(T1 * d, d), mask=m8, mask_strides=mstr, keybias=keybias, drop_p=p_attn, seed=s_att,
-                          seed_dev=_seed_dev)
+                          seed_dev=_seed_dev, causal=CAUSAL_SELF_ATTENTION and self_attn)
         hip.attention_fwd(a)
         res2 = None if residual is None else _chk(residual, "residual").view(-1, d)
         y = gemm_nt(att.view(-1, d), wo, bo, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, residual=res2,

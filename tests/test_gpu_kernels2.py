@@ -608,3 +608,29 @@ def test_logprob_gather_kernel():
     bad[0, 0], bad[1, 1] = -1, 3246
     z = ops.logprob_gather(x, bad)
     assert float(z[0, 0]) == 0.0 and float(z[1, 1]) == 0.0 and torch.equal(z[2:], a[2:])
+
+
+@pytest.mark.parametrize("T", [300, 129, 97])
+def test_attention_causal_hint_changes_nothing(T):
+    """oe_attn_args.causal: with a (B, T, T) mask that is zero above the diagonal (plus ragged lengths) the forward kernel may
+    skip the key blocks above the diagonal - output and log-sum-exp identical to the run without the hint, bit for bit."""
+    torch.manual_seed(T)
+    B, H, D = 3, 4, 64
+    q, k, v = (torch.randn(B, T, H, D, device=DEV) for _ in range(3))
+    lens = torch.tensor([T, T - 40, T // 2], device=DEV)
+    idx = torch.arange(T, device=DEV)
+    mask = ((idx[None, None, :] <= idx[None, :, None]) & (idx[None, None, :] < lens[:, None, None])).to(torch.uint8).contiguous()
+    st = (T * H * D, H * D)
+    outs = []
+    for causal in (False, True):
+        out = torch.full_like(q, float("nan"))
+        lse = torch.full((B, H, T), float("nan"), device=DEV)
+        a = hip.attn_args(q, k, v, out, lse, B, H, T, T, D, 1 / math.sqrt(D), q_strides=st, k_strides=st, v_strides=st, o_strides=st,
+                          mask=mask, mask_strides=(T * T, T), precision=3, causal=causal)
+        hip.attention_fwd(a)
+        sync()
+        outs.append((out, lse))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.softmax((torch.einsum("bihd,bjhd->bhij", q, k) / math.sqrt(D)).masked_fill(mask[:, None] == 0, float("-inf")), -1)
+    want = torch.einsum("bhij,bjhd->bihd", ref, v)
+    torch.testing.assert_close(outs[1][0], want, rtol=2e-4, atol=1e-4)
