@@ -32,12 +32,18 @@ MODEL_CONF = dict(encoder_num_blocks=12, decoder_num_blocks=3, r_decoder_num_blo
                   ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3, length_normalized_loss=False)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
+TERMS = {0: 1, 1: 1, 3: 3, 6: 6}     # bf16 MFMAs issued per algorithmic product in each arithmetic mode
 KERNEL_NAMES = {0: "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)",
+                6: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel <terms=6> (the kernels behind oe_gemm_f32 / "
+                   "oe_gemm_tn_grouped precision 6: three exact bf16 pieces per operand, hh+hm+mh+mm+hl+lh on v_mfma_f32_32x32x16_bf16)",
                 1: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=1> (the kernels behind "
                    "oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd precision 1, v_mfma_f32_32x32x16_bf16)",
                 3: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=3> (the kernels behind "
                    "oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd precision 3: hi*hi+hi*lo+lo*hi, v_mfma_f32_32x32x16_bf16)"}
 DTYPE_NAMES = {0: "f32", 1: "bf16 (MFMA inputs; fp32 storage, accumulate, softmax, norms, losses, optimizer)",
+               6: "f32 (storage, accumulate, softmax, norms, losses, optimizer all fp32; every matrix product is the fp32 product to within "
+                  "one fp32 rounding, computed as six exact bf16 x bf16 MFMA products of three-piece operand splits h+m+l = x, "
+                  "dropped terms < 2^-24 |a||b| - tests hold it to the exact-fp32 mode's tolerances)",
                3: "bf16x3 (matrix products as hi*hi+hi*lo+lo*hi on bf16 MFMA: ~2^-17 relative error per product, fp32 accumulate - "
                   "narrower than the reference's fp32 products, wider than bf16; fp32 storage and fp32 everywhere else)"}
 
@@ -163,7 +169,7 @@ def main():
     args = ap.parse_args()
 
     from openeat_amd import ddp, hip
-    hip.GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "3"))      # default: fp32-grade 3-term bf16 split
+    hip.GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "6"))      # default: the reference-precision 6-term bf16 split
     rank, local, world = ddp.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (openeat_amd has no CPU path)"
@@ -336,12 +342,15 @@ def main():
             for key, (cnt, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
                 log(f"  {str(key):44s} x{cnt:3d} {us / cnt:9.1f} us {us / 1e3:7.3f} ms {fl * cnt / us / 1e6:7.1f}")
         prec = hip.GEMM_PRECISION
-        peak = PEAK_FP32_MFMA_TFLOPS if prec == 0 else PEAK_BF16_MFMA_TFLOPS
-        mfma_flops = flops * (3 if prec == 3 else 1)            # the 3-term split issues 3 MFMAs per algorithmic product
+        # peak for ALGORITHMIC flops: the dense bf16 MFMA rate divided by the MFMAs a mode issues per product (6 in the
+        # reference-precision mode: 2500 / 6 = 416.7 TFLOP/s, against 157.3 on the fp32-input MFMA)
+        terms = TERMS[prec]
+        peak = PEAK_FP32_MFMA_TFLOPS if prec == 0 else PEAK_BF16_MFMA_TFLOPS / terms
+        mfma_flops = flops * terms
         # HBM bytes per launch: PMC counters cannot be read from inside this process - the figure is the one of the
         # committed rocprofv3 --pmc passes of this same command (tools/final_profiles.sh), and the line says so
         traffic, traffic_src = None, None
-        for name in ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
@@ -355,14 +364,16 @@ def main():
                 "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": len(recs),
                 "avg_launch_us": secs / max(len(recs), 1) * 1e6, "gemm_ms_per_step": secs * 1e3,
                 "algorithmic_gflop_per_step": flops / 1e9, "mfma_issue_tflops": mfma_flops / secs / 1e12,
+                "mfma_terms_per_product": terms, "peak_dense_bf16_mfma": PEAK_BF16_MFMA_TFLOPS,
+                "frac_of_dense_bf16_issue": mfma_flops / secs / 1e12 / PEAK_BF16_MFMA_TFLOPS,
                 "event_pair_overhead_us": pair_ms * 1e3}
 
-    # ---- the same step in the other arithmetic modes (one GPU only): mode 0 = exact-fp32 matrix products, the arithmetic
-    # that equals the reference's; mode 1 = plain bf16 MFMA inputs.  A fresh HIP graph per mode, 2 + 5 replays.
+    # ---- the same step in the other arithmetic modes (one GPU only): mode 0 = fp32-input MFMA, mode 3 = three-term bf16
+    # split (~2^-17 per product), mode 1 = plain bf16 MFMA inputs.  A fresh HIP graph per mode, 2 + 5 replays.
     other = {}
     if world == 1 and not args.no_other_modes and not args.no_graph:
         main_prec = hip.GEMM_PRECISION
-        for mode, key in ((0, "dtype_reference_equal"), (1, "dtype_bf16")):
+        for mode, key in ((0, "dtype_f32_mfma"), (3, "dtype_bf16x3"), (1, "dtype_bf16")):
             if mode == main_prec:
                 continue
             try:

@@ -82,7 +82,10 @@ typedef struct oe_gemm_args {
     float* a_colsum; /* optional (precision != 0, k-major A): a_colsum[m] += alpha * sum_k A(m,k), i.e. the bias
                         gradient fused into the weight-gradient GEMM (adders per address = split_k) */
     int precision;   /* 0: fp32-input MFMA (exact fp32 products); 1: bf16 inputs, fp32 accumulate;
-                        3: 3-term bf16 split hi*hi+hi*lo+lo*hi (fp32-grade, ~2^-17 per product) */
+                        3: 3-term bf16 split hi*hi+hi*lo+lo*hi (~2^-17 relative error per product);
+                        6: 6-term bf16 split - three exact bf16 pieces per operand, h+m+l = x, products
+                           hh+hm+mh+mm+hl+lh: what is dropped is < 2^-24 |a||b|, one fp32 rounding - the mode
+                           that stands in for the reference's fp32 Linear / Conv products */
     int conv_k, conv_s;   /* kernel size / stride of the gathered conv; 0 = 3 / 2 (Conv2dSubsampling4/8); 5 / 3 is
                              Conv2dSubsampling6's second conv (subsampling.py:136) */
     int conv_kh;          /* kernel HEIGHT when it differs from conv_k (= width); 0 = square.  The gathered window may be

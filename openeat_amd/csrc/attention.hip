@@ -670,7 +670,7 @@ static int fill_params(AttnParams& p, const oe_attn_args* a, const char* who) {
         return -1;
     }
     if (!(a->drop_p >= 0.f && a->drop_p < 1.f)) { oe_set_error("%s: drop_p out of range", who); return -1; }
-    if (!(a->precision == 0 || a->precision == 1 || a->precision == 3)) { oe_set_error("%s: precision must be 0, 1 or 3", who); return -1; }
+    if (!(a->precision == 0 || a->precision == 1 || a->precision == 3 || a->precision == 6)) { oe_set_error("%s: precision must be 0, 1, 3 or 6", who); return -1; }
     p.q = a->q; p.q_bs = a->q_bstride; p.q_rs = a->q_rstride;
     p.k = a->k; p.k_bs = a->k_bstride; p.k_rs = a->k_rstride;
     p.v = a->v; p.v_bs = a->v_bstride; p.v_rs = a->v_rstride;
@@ -700,6 +700,7 @@ extern "C" int oe_attention_fwd(const oe_attn_args* a, void* stream) {
         if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0, TT, 2>), grid, dim3(ATT_GROUP * 2), 0, st, p); \
         else hipLaunchKernelGGL((attn_qtile_kernel<64, 0, TT, 2>), grid, dim3(ATT_GROUP * 2), 0, st, p);        \
     } while (0)
+    // precision 6 where the planes kernel does not fit (short query axes: the decoders): exact fp32 products
     if (a->precision == 3) ATT_FWD(3); else if (a->precision == 1) ATT_FWD(1); else ATT_FWD(0);
 #undef ATT_FWD
     OE_LAUNCH_CHECK("oe_attention_fwd");
@@ -727,6 +728,7 @@ extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
             else hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, TT, 1>), gk, dim3(ATT_GROUP), 0, st, p);   \
         }                                                                                                 \
     } while (0)
+    // precision 6: dQ on three planes where it fits; everything else of this call on exact fp32 products
     if (a->precision == 3) ATT_BWD(3); else if (a->precision == 1) ATT_BWD(1); else ATT_BWD(0);
 #undef ATT_BWD
     OE_LAUNCH_CHECK("oe_attention_bwd");

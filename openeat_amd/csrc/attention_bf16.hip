@@ -1,6 +1,8 @@
 // Fused multi-head attention on the bf16 matrix cores with the streamed operand kept in LDS as bf16 PLANES
 // (attention.py:65-97,112-117,189-209 and their autograd; precision 1 = hi plane only, precision 3 = hi + lo planes and
-// the three-term product hi*hi + hi*lo + lo*hi, as oe_gemm_args.precision).
+// the three-term product hi*hi + hi*lo + lo*hi, precision 6 = three planes and the six-term product of oe_common.h for
+// the forward and dQ kernels - as oe_gemm_args.precision; the dK/dV kernel keeps four resident and four streamed images,
+// which at three planes each is more than a CU's LDS: precision 6 takes the exact-fp32 kernel of attention.hip there).
 //
 // What changed against the first generation of bf16 kernels (attention.hip, still used for small problems and for the
 // exact-fp32 mode): those kept fp32 tiles in LDS and split every fragment to bf16 on EVERY use (each of the waves that
@@ -53,22 +55,21 @@ extern "C" int oe_debug_set_attn_planes_stamp_buffer(void* p) {
 #define PL_ACC(slot) do { } while (0)
 #endif
 
-template <int TERMS> struct PFrag { bf16x8 hi, lo; };
+template <int TERMS> struct PFrag { bf16x8 p[oe_npl<TERMS>::N]; };
 
 template <int TERMS>
 __device__ __forceinline__ f32x16 pmma(const PFrag<TERMS>& a, const PFrag<TERMS>& b, f32x16 c) {
-    if (TERMS == 3) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-    }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    return oe_mma_terms<TERMS>(a, b, c);
 }
 template <int TERMS>
 __device__ __forceinline__ void psplit(const float (&x)[8], PFrag<TERMS>& f) {
+    constexpr int NPL = oe_npl<TERMS>::N;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        f.hi[e] = (__bf16)x[e];
-        if (TERMS == 3) f.lo[e] = (__bf16)(x[e] - (float)f.hi[e]);
+        __bf16 q[NPL];
+        oe_split_bf16<NPL>(x[e], q);
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) f.p[n][e] = q[n];
     }
 }
 
@@ -77,12 +78,13 @@ template <int DPAD, int TERMS>
 struct Plane {
     static constexpr int PITCH = DPAD + 8;
     static constexpr int PLANE_ELEMS = PL_ROWS * PITCH;
-    static constexpr int ELEMS = PLANE_ELEMS * (TERMS == 3 ? 2 : 1);
+    static constexpr int NPL = oe_npl<TERMS>::N;
+    static constexpr int ELEMS = PLANE_ELEMS * NPL;
     // row fragment: A[row][16 s + 8 g + e], e = 0..7
     static __device__ __forceinline__ void row_frag(const __bf16* img, int row, int s, int g, PFrag<TERMS>& f) {
         const __bf16* p = img + row * PITCH + 16 * s + 8 * g;
-        f.hi = *reinterpret_cast<const bf16x8*>(p);
-        if (TERMS == 3) f.lo = *reinterpret_cast<const bf16x8*>(p + PLANE_ELEMS);
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(p + n * PLANE_ELEMS);
     }
     // column fragment: A[row0 + acc_row(8 s + e, g)][col], e = 0..7 - two transposing reads of 4 rows x 16 columns per
     // 16-lane group: lane 4q + pp of a group supplies the address of row q, columns 4pp..4pp+3 of the group's block and
@@ -92,16 +94,12 @@ struct Plane {
         const int g = grp >> 1;
         const __bf16* p = img + (row0 + 16 * s + 4 * g + (i >> 2)) * PITCH + col32 + 16 * (grp & 1) + 4 * (i & 3);
         typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * PITCH));
-        union { s16x4 h[2]; bf16x8 v; } u;
-        u.h[0] = a0; u.h[1] = a1;
-        f.hi = u.v;
-        if (TERMS == 3) {
-            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + PLANE_ELEMS));
-            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + PLANE_ELEMS + 8 * PITCH));
-            u.h[0] = b0; u.h[1] = b1;
-            f.lo = u.v;
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            union { s16x4 h[2]; bf16x8 v; } u;
+            u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + n * PLANE_ELEMS));
+            u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + n * PLANE_ELEMS + 8 * PITCH));
+            f.p[n] = u.v;
         }
     }
 };
@@ -150,15 +148,17 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs<DPAD>& t, __bf16* im
         const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
         const bool live = (r0 + row < nrows_total) && (c4 < D);          // zero what chunk_load's fast path over-read
         const float x[4] = {live ? t.v[i].x * mul : 0.f, live ? t.v[i].y * mul : 0.f, live ? t.v[i].z * mul : 0.f, live ? t.v[i].w * mul : 0.f};
-        bf16x4 hi, lo;
+        bf16x4 pl[P::NPL];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            hi[k] = (__bf16)x[k];
-            if (TERMS == 3) lo[k] = (__bf16)(x[k] - (float)hi[k]);
+            __bf16 q[P::NPL];
+            oe_split_bf16<P::NPL>(x[k], q);
+#pragma unroll
+            for (int n = 0; n < P::NPL; ++n) pl[n][k] = q[n];
         }
         __bf16* d = img + row * P::PITCH + c4;
-        *reinterpret_cast<bf16x4*>(d) = hi;
-        if (TERMS == 3) *reinterpret_cast<bf16x4*>(d + P::PLANE_ELEMS) = lo;
+#pragma unroll
+        for (int n = 0; n < P::NPL; ++n) *reinterpret_cast<bf16x4*>(d + n * P::PLANE_ELEMS) = pl[n];
     }
 }
 
@@ -687,8 +687,13 @@ static int planes_mode() {
 static bool planes_fit(int resident_rows) { return planes_mode() != 0 && resident_rows > 64; }
 
 int oe_attn_planes_fwd_try(const AttnParams& p, int terms, hipStream_t st) {
-    if (!planes_fit(p.T1) || (terms != 1 && terms != 3)) return 1;
+    if (!planes_fit(p.T1) || (terms != 1 && terms != 3 && terms != 6)) return 1;
     dim3 grid(oe_cdiv(p.T1, 128), p.H, p.B);
+    if (terms == 6) {          // three planes per streamed tensor: 110 KiB of LDS at D = 64
+        if (p.D <= 32) hipLaunchKernelGGL((attn_planes_q_kernel<32, 6, 0>), grid, dim3(PL_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((attn_planes_q_kernel<64, 6, 0>), grid, dim3(PL_THREADS), 0, st, p);
+        return 0;
+    }
     if (p.D <= 32) {
         if (terms == 3) hipLaunchKernelGGL((attn_planes_q_kernel<32, 3, 0>), grid, dim3(PL_THREADS), 0, st, p);
         else hipLaunchKernelGGL((attn_planes_q_kernel<32, 1, 0>), grid, dim3(PL_THREADS), 0, st, p);
@@ -699,8 +704,13 @@ int oe_attn_planes_fwd_try(const AttnParams& p, int terms, hipStream_t st) {
     return 0;
 }
 int oe_attn_planes_dq_try(const AttnParams& p, int terms, hipStream_t st) {
-    if (!planes_fit(p.T1) || (terms != 1 && terms != 3)) return 1;
+    if (!planes_fit(p.T1) || (terms != 1 && terms != 3 && terms != 6)) return 1;
     dim3 grid(oe_cdiv(p.T1, 128), p.H, p.B);
+    if (terms == 6) {
+        if (p.D <= 32) hipLaunchKernelGGL((attn_planes_q_kernel<32, 6, 1>), grid, dim3(PL_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((attn_planes_q_kernel<64, 6, 1>), grid, dim3(PL_THREADS), 0, st, p);
+        return 0;
+    }
     if (p.D <= 32) {
         if (terms == 3) hipLaunchKernelGGL((attn_planes_q_kernel<32, 3, 1>), grid, dim3(PL_THREADS), 0, st, p);
         else hipLaunchKernelGGL((attn_planes_q_kernel<32, 1, 1>), grid, dim3(PL_THREADS), 0, st, p);

@@ -230,7 +230,8 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     }
     OE_REQUIRE(!g->a_colsum || (g->precision != 0 && g->a_kmajor && g->conv_gather != OE_GATHER_A), "oe_gemm_f32: a_colsum needs the bf16 path and a k-major A");
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
-    OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3, "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16) or 3 (bf16x3)");
+    OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3 || g->precision == 6,
+               "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16), 3 (bf16x3) or 6 (bf16x6)");
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
     const int tile = (b22 >= 200 && M >= 128 && N >= 128) ? 22 : (b12 >= 160 && N >= 128) ? 12 : 11;

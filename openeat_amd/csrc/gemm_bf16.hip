@@ -4,7 +4,9 @@
 // every other kernel of the path is unchanged.  Two precisions:
 //   terms = 1 : a*b ~ hi(a)*hi(b)                       (bf16 products, ~3e-3 relative)
 //   terms = 3 : a*b ~ hi*hi + hi*lo + lo*hi, lo = bf16(x - hi(x))
-//               (error ~2^-17 per product: fp32-grade results at 3/16 of the fp32-MFMA cost)
+//               (error ~2^-17 per product at 3/16 of the fp32-MFMA cost)
+//   terms = 6 : three exact pieces per operand, six products (oe_common.h): the fp32 product to within one fp32
+//               rounding at 6/16 of the fp32-MFMA cost - the arithmetic that stands in for the reference's fp32 GEMMs
 // Same operand addressing (plain / conv2 im2col gather) and epilogue as gemm.hip.
 //
 // Tiling: 256 threads = 2x2 waves, each wave TM x TN tiles of 32x32; K-tile 32.
@@ -23,10 +25,26 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define BK2 32
 #define PITCH 40   // bf16 elements per LDS row (32 data + 8 pad) = 80 bytes
 
-__device__ __forceinline__ void split4(const float4& v, bf16x4& hi, bf16x4& lo) {
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+template <int NPL> struct Frag { bf16x8 p[NPL]; };
+
+template <int NPL>
+__device__ __forceinline__ void split4(const float4& v, bf16x4 (&pl)[NPL]) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 q[NPL];
+        oe_split_bf16<NPL>(x[e], q);
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) pl[n][e] = q[n];
+    }
+}
+// the NPL pieces of four values to plane n at `dst + n * plane_stride`
+template <int NPL>
+__device__ __forceinline__ void store4(const float4& v, __bf16* dst, int plane_stride) {
+    bf16x4 pl[NPL];
+    split4<NPL>(v, pl);
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) *reinterpret_cast<bf16x4*>(dst + n * plane_stride) = pl[n];
 }
 
 // One operand's staging state: ROWS x 32 tile.
@@ -190,31 +208,28 @@ struct Stage {
             }
         }
     }
+    // tile = plane 0 of this operand's LDS image; plane n follows at n * plane_stride elements
     template <int TERMS>
-    __device__ __forceinline__ void store(__bf16* hi_tile, __bf16* lo_tile) {
+    __device__ __forceinline__ void store(__bf16* tile, int plane_stride) {
+        constexpr int NPL = oe_npl<TERMS>::N;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int idx = threadIdx.x + s * 256;
             if (!PARTIAL || idx < NIDX) {
             if (!KMAJOR) {
                 const int row = idx >> 3, kq = (idx & 7) * 4;
-                bf16x4 h, l;
-                split4(reg[s][0], h, l);
-                *reinterpret_cast<bf16x4*>(hi_tile + row * PITCH + kq) = h;
-                if (TERMS == 3) *reinterpret_cast<bf16x4*>(lo_tile + row * PITCH + kq) = l;
+                store4<NPL>(reg[s][0], tile + row * PITCH + kq, plane_stride);
             } else {
                 const int kb = idx & 7;
                 const int mb = ((idx >> 3) & 7) + 8 * (idx >> 6);
                 const float4 r0 = reg[s][0], r1 = reg[s][1], r2 = reg[s][2], r3 = reg[s][3];
                 const float4 t0 = make_float4(r0.x, r1.x, r2.x, r3.x), t1 = make_float4(r0.y, r1.y, r2.y, r3.y);
                 const float4 t2 = make_float4(r0.z, r1.z, r2.z, r3.z), t3 = make_float4(r0.w, r1.w, r2.w, r3.w);
-                bf16x4 h, l;
-                __bf16* hp = hi_tile + (4 * mb) * PITCH + 4 * kb;
-                __bf16* lp = lo_tile + (4 * mb) * PITCH + 4 * kb;
-                split4(t0, h, l); *reinterpret_cast<bf16x4*>(hp) = h;             if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp) = l;
-                split4(t1, h, l); *reinterpret_cast<bf16x4*>(hp + PITCH) = h;     if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp + PITCH) = l;
-                split4(t2, h, l); *reinterpret_cast<bf16x4*>(hp + 2 * PITCH) = h; if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp + 2 * PITCH) = l;
-                split4(t3, h, l); *reinterpret_cast<bf16x4*>(hp + 3 * PITCH) = h; if (TERMS == 3) *reinterpret_cast<bf16x4*>(lp + 3 * PITCH) = l;
+                __bf16* hp = tile + (4 * mb) * PITCH + 4 * kb;
+                store4<NPL>(t0, hp, plane_stride);
+                store4<NPL>(t1, hp + PITCH, plane_stride);
+                store4<NPL>(t2, hp + 2 * PITCH, plane_stride);
+                store4<NPL>(t3, hp + 3 * PITCH, plane_stride);
             }
             }
         }
@@ -237,15 +252,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, Operan
     }
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr int A_TILE = BM * PITCH, B_TILE = BN * PITCH;            // bf16 elements
-    constexpr int NT = (TERMS == 3) ? 2 : 1;                            // hi (+ lo) copies
+    constexpr int NT = oe_npl<TERMS>::N;                                // planes per operand: hi (+ lo | + mid, lo)
     constexpr int STAGE_ELEMS = NT * (A_TILE + B_TILE);
     constexpr int LDS_BYTES = (2 * STAGE_ELEMS * 2 > 4 * 32 * 36 * 4) ? 2 * STAGE_ELEMS * 2 : 4 * 32 * 36 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
     __bf16* lds16 = reinterpret_cast<__bf16*>(lds_raw);
-    auto a_hi = [&](int buf) { return lds16 + buf * STAGE_ELEMS; };
-    auto a_lo = [&](int buf) { return lds16 + buf * STAGE_ELEMS + A_TILE; };
-    auto b_hi = [&](int buf) { return lds16 + buf * STAGE_ELEMS + NT * A_TILE; };
-    auto b_lo = [&](int buf) { return lds16 + buf * STAGE_ELEMS + NT * A_TILE + B_TILE; };
+    auto a_hi = [&](int buf) { return lds16 + buf * STAGE_ELEMS; };                   // planes of A: stride A_TILE
+    auto b_hi = [&](int buf) { return lds16 + buf * STAGE_ELEMS + NT * A_TILE; };     // planes of B: stride B_TILE
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -283,8 +296,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, Operan
         if (fast) { if (fast_ga) sa.load_fast_gather(A, k_begin); else sa.load_fast(A.ld); sb.load_fast(B.ld); }
         else { sa.load(A, m0, M, k_begin, k_end); sb.load(B, n0, N, k_begin, k_end); }
         if (do_csum) sa.add_csum();
-        sa.template store<TERMS>(a_hi(0), a_lo(0));
-        sb.template store<TERMS>(b_hi(0), b_lo(0));
+        sa.template store<TERMS>(a_hi(0), A_TILE);
+        sb.template store<TERMS>(b_hi(0), B_TILE);
     }
     __syncthreads();
 
@@ -296,37 +309,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(OperandDesc A, Operan
             else { sa.load(A, m0, M, k_begin + (kt + 1) * BK2, k_end); sb.load(B, n0, N, k_begin + (kt + 1) * BK2, k_end); }
         }
         const __bf16* ah = a_hi(buf) + (wm * 32 * TM + frow) * PITCH + fk;
-        const __bf16* al = a_lo(buf) + (wm * 32 * TM + frow) * PITCH + fk;
         const __bf16* bh = b_hi(buf) + (wn * 32 * TN + frow) * PITCH + fk;
-        const __bf16* bl = b_lo(buf) + (wn * 32 * TN + frow) * PITCH + fk;
 #pragma unroll
         for (int ks = 0; ks < BK2 / 16; ++ks) {
-            bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                fah[i] = *reinterpret_cast<const bf16x8*>(ah + i * 32 * PITCH + ks * 16);
-                if (TERMS == 3) fal[i] = *reinterpret_cast<const bf16x8*>(al + i * 32 * PITCH + ks * 16);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                fbh[j] = *reinterpret_cast<const bf16x8*>(bh + j * 32 * PITCH + ks * 16);
-                if (TERMS == 3) fbl[j] = *reinterpret_cast<const bf16x8*>(bl + j * 32 * PITCH + ks * 16);
-            }
+            Frag<NT> fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (TERMS == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int n = 0; n < NT; ++n) fa[i].p[n] = *reinterpret_cast<const bf16x8*>(ah + n * A_TILE + i * 32 * PITCH + ks * 16);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) fb[j].p[n] = *reinterpret_cast<const bf16x8*>(bh + n * B_TILE + j * 32 * PITCH + ks * 16);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = oe_mma_terms<TERMS>(fa[i], fb[j], acc[i][j]);
         }
         if (kt + 1 < nk) {
             if (do_csum) sa.add_csum();
-            sa.template store<TERMS>(a_hi(buf ^ 1), a_lo(buf ^ 1));
-            sb.template store<TERMS>(b_hi(buf ^ 1), b_lo(buf ^ 1));
+            sa.template store<TERMS>(a_hi(buf ^ 1), A_TILE);
+            sb.template store<TERMS>(b_hi(buf ^ 1), B_TILE);
         }
         __syncthreads();
     }
@@ -382,6 +385,11 @@ int oe_gemm_bf16_dispatch(const OperandDesc& A, const OperandDesc& B, float* C, 
     }
 #define OE_DISP(AK, BKM, GA, GB)                                                                                 \
     do {                                                                                                         \
+        if (terms == 6) {                                                                                        \
+            if (tile == 22) return launch_bf16<2, 2, AK, BKM, GA, GB, 6>(A, B, C, ldc, M, N, K, sk, ep, st);     \
+            if (tile == 12) return launch_bf16<1, 2, AK, BKM, GA, GB, 6>(A, B, C, ldc, M, N, K, sk, ep, st);     \
+            return launch_bf16<1, 1, AK, BKM, GA, GB, 6>(A, B, C, ldc, M, N, K, sk, ep, st);                     \
+        }                                                                                                        \
         if (terms == 3) {                                                                                        \
             if (tile == 22) return launch_bf16<2, 2, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);     \
             if (tile == 12) return launch_bf16<1, 2, AK, BKM, GA, GB, 3>(A, B, C, ldc, M, N, K, sk, ep, st);     \

@@ -44,12 +44,15 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N_OUTSTANDING) : "memory");
 }
 
-template <int TERMS>
-__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+template <int NPL> struct DFrag { bf16x8 p[NPL]; };
+template <int NPL>
+__device__ __forceinline__ void split8(const float (&x)[8], DFrag<NPL>& f) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        hi[e] = (__bf16)x[e];
-        if (TERMS == 3) lo[e] = (__bf16)(x[e] - (float)hi[e]);
+        __bf16 q[NPL];
+        oe_split_bf16<NPL>(x[e], q);
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) f.p[n][e] = q[n];
     }
 }
 
@@ -196,30 +199,25 @@ __global__ __launch_bounds__(256, (NST == 2 && TM * TN <= 4) ? 2 : 1) void gemm_
         const float* bt = lds + (kt % NST) * STAGE_FLOATS + A_FLOATS + (B_KMAJOR ? wn * 32 * TN : wn * 32 * TN * DBK);
 #pragma unroll
         for (int ks = 0; ks < DBK / 16; ++ks) {
-            bf16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+            constexpr int NPL = oe_npl<TERMS>::N;
+            DFrag<NPL> fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 float x[8];
                 read_frag<A_KMAJOR, BM>(at + (A_KMAJOR ? i * 32 : i * 32 * DBK), frow, fhalf, ks, x);
                 if (A_KMAJOR && do_csum) csum[i] += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                split8<TERMS>(x, fah[i], fal[i]);
+                split8<NPL>(x, fa[i]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float x[8];
                 read_frag<B_KMAJOR, BN>(bt + (B_KMAJOR ? j * 32 : j * 32 * DBK), frow, fhalf, ks, x);
-                split8<TERMS>(x, fbh[j], fbl[j]);
+                split8<NPL>(x, fb[j]);
             }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (TERMS == 3) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fal[i], fbh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbl[j], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fah[i], fbh[j], acc[i][j], 0, 0, 0);
-                }
+                for (int j = 0; j < TN; ++j) acc[i][j] = oe_mma_terms<TERMS>(fa[i], fb[j], acc[i][j]);
         }
     }
     OE_STAMP(3);
@@ -279,6 +277,10 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
         int kc = oe_cdiv(oe_cdiv(K, sk), DBK) * DBK;
         if (kc <= 0) kc = DBK;
         const int nz = oe_cdiv(K, kc);
+        if (terms == 6) {
+            if (tile == 22) return launch_dma<2, 2, true, true, 6, 4, true>(A, B, C, ldc, M, N, K, kc, nz, ep, st);
+            return launch_dma<1, 1, true, true, 6, 4, true>(A, B, C, ldc, M, N, K, kc, nz, ep, st);
+        }
         if (terms == 3) {
             if (tile == 22) return launch_dma<2, 2, true, true, 3, 4, true>(A, B, C, ldc, M, N, K, kc, nz, ep, st);
             return launch_dma<1, 1, true, true, 3, 4, true>(A, B, C, ldc, M, N, K, kc, nz, ep, st);
@@ -305,7 +307,7 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
         if (tile == 11) return launch_dma<1, 1, AK, BKM, T, 4>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
         return 1;                                                                                                    \
     } while (0)
-#define OE_DMA(AK, BKM) do { if (terms == 3) OE_DMA_T(AK, BKM, 3); else OE_DMA_T(AK, BKM, 1); } while (0)
+#define OE_DMA(AK, BKM) do { if (terms == 6) OE_DMA_T(AK, BKM, 6); else if (terms == 3) OE_DMA_T(AK, BKM, 3); else OE_DMA_T(AK, BKM, 1); } while (0)
     if (!a_kmajor && !b_kmajor) OE_DMA(false, false);
     if (!a_kmajor && b_kmajor) OE_DMA(false, true);
     OE_DMA(true, true);

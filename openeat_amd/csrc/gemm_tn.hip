@@ -49,7 +49,7 @@ extern "C" int oe_debug_set_tn_stamp_buffer(void* p) { return (int)hipMemcpyToSy
 #define TN_ACC(slot) do { } while (0)
 #endif
 
-template <int TERMS> struct TFrag { bf16x8 hi, lo; };
+template <int TERMS> struct TFrag { bf16x8 p[oe_npl<TERMS>::N]; };
 
 // fragment of 32 columns (col32 ..) x 16 k-rows (16 s ..) of one operand image: lane l of a 16-lane group supplies the
 // address of row (l >> 2), columns 4 (l & 3) .. of the group's 4-row x 16-column block and receives column (l & 15) of
@@ -60,24 +60,18 @@ __device__ __forceinline__ void tn_frag(const __bf16* img, int col32, int s, int
     const int i = lane & 15, grp = lane >> 4;
     const __bf16* p = img + (16 * s + 4 * (grp >> 1) + (i >> 2)) * TN_PITCH + col32 + 16 * (grp & 1) + 4 * (i & 3);
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-    union { s16x4 h[2]; bf16x8 v; } u;
-    u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
-    u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * TN_PITCH));
-    f.hi = u.v;
-    if (TERMS == 3) {
-        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + TN_PLANE));
-        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + TN_PLANE + 8 * TN_PITCH));
-        f.lo = u.v;
+#pragma unroll
+    for (int n = 0; n < oe_npl<TERMS>::N; ++n) {
+        union { s16x4 h[2]; bf16x8 v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + n * TN_PLANE));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + n * TN_PLANE + 8 * TN_PITCH));
+        f.p[n] = u.v;
     }
 }
 
 template <int TERMS>
 __device__ __forceinline__ f32x16 tn_mma(const TFrag<TERMS>& a, const TFrag<TERMS>& b, f32x16 c) {
-    if (TERMS == 3) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-    }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    return oe_mma_terms<TERMS>(a, b, c);
 }
 
 // this thread's share of a chunk of one operand: rows (tid >> 5) and (tid >> 5) + 16, columns 4 (tid & 31) ..
@@ -96,15 +90,18 @@ __device__ __forceinline__ void tn_store(const TnRegs& t, __bf16* img, int k0, i
         const int row = (int)(threadIdx.x >> 5) + 16 * i;
         const bool live = k0 + row < k_end;                                          // ... and are zeroed here
         const float x[4] = {live ? t.v[i].x : 0.f, live ? t.v[i].y : 0.f, live ? t.v[i].z : 0.f, live ? t.v[i].w : 0.f};
-        bf16x4 hi, lo;
+        constexpr int NPL = oe_npl<TERMS>::N;
+        bf16x4 pl[NPL];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            hi[e] = (__bf16)x[e];
-            if (TERMS == 3) lo[e] = (__bf16)(x[e] - (float)hi[e]);
+            __bf16 q[NPL];
+            oe_split_bf16<NPL>(x[e], q);
+#pragma unroll
+            for (int n = 0; n < NPL; ++n) pl[n][e] = q[n];
         }
         __bf16* d = img + row * TN_PITCH + 4 * (threadIdx.x & 31);
-        *reinterpret_cast<bf16x4*>(d) = hi;
-        if (TERMS == 3) *reinterpret_cast<bf16x4*>(d + TN_PLANE) = lo;
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) *reinterpret_cast<bf16x4*>(d + n * TN_PLANE) = pl[n];
     }
 }
 
@@ -113,7 +110,7 @@ template <int TERMS>
 __device__ __forceinline__ void tn_block(const float* __restrict__ Ap, long lda, const float* __restrict__ Bp, long ldb,
                                          float* __restrict__ C, long ldc, int M, int N, int Mr, int Nr, int K, int k_chunk,
                                          int tile_x, int tile_y, int tile_z, const EpiParams& ep) {
-    constexpr int NPL = TERMS == 3 ? 2 : 1;
+    constexpr int NPL = oe_npl<TERMS>::N;
     constexpr int OP_ELEMS = NPL * TN_PLANE;                // one operand's image
     constexpr int BUF_ELEMS = 2 * OP_ELEMS;                 // A then B
     constexpr int XCH_BYTES = 4 * 2 * 32 * 64 * 4;          // the accumulator exchange at the end overlays the images
@@ -330,8 +327,10 @@ extern "C" int oe_gemm_tn_grouped_plan(oe_tn_problem* problems, int n, int targe
 
 extern "C" int oe_gemm_tn_grouped(const oe_tn_problem* problems_dev, int n, int total_blocks, int precision, void* stream) {
     OE_REQUIRE(problems_dev && n > 0 && total_blocks > 0, "oe_gemm_tn_grouped: bad arguments");
-    OE_REQUIRE(precision == 1 || precision == 3, "oe_gemm_tn_grouped: precision must be 1 (bf16) or 3 (bf16x3)");
-    if (precision == 3)
+    OE_REQUIRE(precision == 1 || precision == 3 || precision == 6, "oe_gemm_tn_grouped: precision must be 1 (bf16), 3 (bf16x3) or 6 (bf16x6)");
+    if (precision == 6)
+        hipLaunchKernelGGL((gemm_tn_grouped_kernel<6>), dim3(total_blocks), dim3(TN_THREADS), 0, (hipStream_t)stream, problems_dev, n);
+    else if (precision == 3)
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<3>), dim3(total_blocks), dim3(TN_THREADS), 0, (hipStream_t)stream, problems_dev, n);
     else
         hipLaunchKernelGGL((gemm_tn_grouped_kernel<1>), dim3(total_blocks), dim3(TN_THREADS), 0, (hipStream_t)stream, problems_dev, n);
@@ -367,7 +366,9 @@ int oe_gemm_tn_planes_try(const OperandDesc& A, const OperandDesc& B, float* C, 
     }
     int kc = oe_cdiv(oe_cdiv(K, nz), TN_KROWS) * TN_KROWS;
     nz = oe_cdiv(K, kc);
-    if (terms == 3)
+    if (terms == 6)
+        hipLaunchKernelGGL((gemm_tn_planes_kernel<6>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, Mr, Nr, K, kc, gx, gy, ep);
+    else if (terms == 3)
         hipLaunchKernelGGL((gemm_tn_planes_kernel<3>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, Mr, Nr, K, kc, gx, gy, ep);
     else
         hipLaunchKernelGGL((gemm_tn_planes_kernel<1>), dim3(gx * gy * nz), dim3(TN_THREADS), 0, st, A.p, A.ld, B.p, B.ld, C, ldc, M, N, Mr, Nr, K, kc, gx, gy, ep);

@@ -124,6 +124,39 @@ __device__ __forceinline__ void drop_block8(unsigned long long seed, unsigned lo
     m[4] = drop_field(r.z, 0, d); m[5] = drop_field(r.z, 1, d); m[6] = drop_field(r.w, 0, d); m[7] = drop_field(r.w, 1, d);
 }
 
+// ---- fp32 -> bf16 pieces for the split matrix products ---------------------------------------------------------
+// A product of two fp32 values on the bf16 matrix cores is a sum of TERMS bf16 x bf16 products (each exact in the fp32
+// accumulator) of round-to-nearest pieces p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1):
+//   TERMS 1: a0 b0                                             (plain bf16 inputs, ~2^-9 per product)
+//   TERMS 3: a0 b0 + a0 b1 + a1 b0                             (two pieces, ~2^-17 per product)
+//   TERMS 6: a0 b0 + a0 b1 + a1 b0 + a1 b1 + a0 b2 + a2 b0     (three pieces: x = p0 + p1 + p2 EXACTLY - 8 + 8 + 8
+//            significant bits cover the 24 of an fp32 - and what is dropped, a1 b2 + a2 b1 + a2 b2, is below
+//            2^-24 |a||b|, one fp32 rounding of the product: the reference's fp32 arithmetic at 6/16 of the fp32-MFMA cost)
+template <int TERMS> struct oe_npl { static constexpr int N = (TERMS == 6) ? 3 : (TERMS == 3) ? 2 : 1; };
+template <int NPL>
+__device__ __forceinline__ void oe_split_bf16(float x, __bf16 (&p)[NPL]) {
+    p[0] = (__bf16)x;
+    if constexpr (NPL > 1) {
+        const float r1 = x - (float)p[0];            // exact
+        p[1] = (__bf16)r1;
+        if constexpr (NPL > 2) p[2] = (__bf16)(r1 - (float)p[1]);   // exact, and representable: at most 8 significant bits are left
+    }
+}
+// the TERMS products of one fragment pair, smallest first; F holds NPL fragments f.p[0..NPL)
+template <int TERMS, class F, class ACC>
+__device__ __forceinline__ ACC oe_mma_terms(const F& a, const F& b, ACC c) {
+    if constexpr (TERMS == 6) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[2], b.p[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[2], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[1], c, 0, 0, 0);
+    }
+    if constexpr (TERMS >= 3) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[1], b.p[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[1], c, 0, 0, 0);
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
+}
+
 // ---- activations ------------------------------------------------------------
 // ids follow the reference's table (utils/common.py:160-173): relu, swish, tanh, hardtanh, selu, gelu (erf form)
 enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2, OE_ACT_TANH = 3, OE_ACT_HARDTANH = 4, OE_ACT_SELU = 5, OE_ACT_GELU = 6 };

@@ -17,7 +17,8 @@ import torch
 # (start, end, algorithmic flops) is appended: bench.py's live roofline measurement.
 PROFILE = None
 
-# Default GEMM arithmetic: 0 = fp32-input MFMA (exact), 1 = bf16 inputs, 3 = 3-term bf16 split (fp32-grade).
+# Default GEMM arithmetic: 0 = fp32-input MFMA (exact), 1 = bf16 inputs, 3 = 3-term bf16 split (~2^-17 per product),
+# 6 = 6-term split of three exact bf16 pieces per operand (the fp32 product to within one fp32 rounding: bench.py's mode).
 GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "0"))
 
 # OE_HIP_LIB: diagnostic builds only (tools/gemm_stamps.py loads the stamped variant of the library)

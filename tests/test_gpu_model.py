@@ -27,11 +27,13 @@ from openeat_amd.modules.swish import Swish  # noqa: E402
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=[0, 3], ids=["fp32-mfma", "bf16x3-mfma"])
+@pytest.fixture(autouse=True, params=[0, 6, 3], ids=["fp32-mfma", "bf16x6-mfma", "bf16x3-mfma"])
 def gemm_precision(request):
-    """Every test of this file runs twice: with exact-fp32 matrix products (oe_gemm_args.precision 0: gemm_f32_kernel and
-    the fp32 attention variants) and in the arithmetic bench.py times (precision 3: gemm_dma_kernel / gemm_bf16_kernel and
-    the bf16x3 attention kernels) - same goldens, same tolerances, same bit-exact id checks."""
+    """Every test of this file runs three times: with exact-fp32 matrix products (oe_gemm_args.precision 0: gemm_f32_kernel
+    and the fp32 attention variants), in the arithmetic bench.py's headline times (precision 6: three exact bf16 pieces per
+    operand, six products - within one fp32 rounding of the fp32 product; the SAME tolerances as precision 0, nothing
+    widened) and in the narrower three-term mode (precision 3, an extra key of the bench line: absolute floor widened, see
+    close()) - same goldens, same bit-exact id checks."""
     from openeat_amd import hip
     old = hip.GEMM_PRECISION
     hip.GEMM_PRECISION = request.param
@@ -46,7 +48,7 @@ def load_into(module, sd, prefix):
 
 
 def close(a, b, rtol=1e-4, atol=5e-5, msg=""):
-    """precision 0: as given.  precision 3: a sum of K bf16x3 products carries ~2^-17 x sum|a_k||b_k|, i.e. an error
+    """precision 0 and 6: as given.  precision 3: a sum of K bf16x3 products carries ~2^-17 x sum|a_k||b_k|, i.e. an error
     relative to the magnitudes that went INTO the sum, not to a (possibly cancelled) result: the absolute floor is tied to
     the tensor's scale, 2e-5 x max|reference| (conv outputs of magnitude ~100 are off by up to ~1e-3 there)."""
     from openeat_amd import hip
