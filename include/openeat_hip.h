@@ -96,9 +96,27 @@ typedef struct oe_gemm_args {
      * writes the input gradient in place (no column buffer): the (parity) base offsets go into the c / actgrad_in
      * pointers.  Not with atomic_out / accumulate / preact_out / residual / rowmask / dropout. */
     int out_scatter; int sc_t1, sc_f1, sc_t2, sc_f2, sc_s;
+    /* Pre-split operands (precision 6 only; all optional, null = absent).  a_planes / b_planes: plane 0 of a copy of A / B
+     * as three bf16 planes p0 + p1 + p2 = x (oe_split_planes, or a producer's planes output), same logical layout and
+     * leading dimensions as a / b, plane n at + n * plane_stride ELEMENTS; when both are given and the problem qualifies
+     * (16-byte alignment, leading dimensions and K multiples of 8 / the K-tile) the product runs on gemm_pl.hip - tiles
+     * by LDS-DMA, no conversion in the loop.  c_planes: ALSO write the output as planes (row stride ldcp): the next GEMM's
+     * operand without a pass over it. */
+    const void* a_planes; long a_plane_stride;
+    const void* b_planes; long b_plane_stride;
+    void* c_planes; long c_plane_stride; long ldcp;
 } oe_gemm_args;
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);
+
+/* x (rows, cols) fp32, row stride ld -> three bf16 planes p0 + p1 + p2 = x EXACTLY (round-to-nearest pieces of 8 significant
+ * bits each), plane n at planes + n * plane_stride elements, row stride ldp: the pre-split operand format of oe_gemm_f32
+ * precision 6 (a_planes / b_planes).  cols % 8 == 0, 16-byte aligned pointers.  Replaces the in-kernel splitting of
+ * every consumer by one pass (Linear operands: positionwise_feed_forward.py:36-43, attention.py:36-63). */
+int oe_split_planes(const float* x, long ld, long rows, long cols, void* planes, long ldp, long plane_stride, void* stream);
+/* how many oe_gemm_f32 calls of this process ran on the pre-split kernel (gemm_pl.hip) so far: tests and tools check that a
+ * problem they meant for it did not silently take the splitting kernels */
+long oe_gemm_pl_launches(void);
 
 /* ------------------------------------------------------------------------- *
  * Position-wise feed forward as one kernel (positionwise_feed_forward.py:36-43 with the caller's residual / dropout of
@@ -169,6 +187,9 @@ int oe_colsum_f32(const float* x, long ldx, int m, int n, float alpha, const flo
  * act: activation applied to the normalised output (convolution.py:110:
  * activation(norm(x))); backward then needs beta to rebuild the pre-activation.
  * ------------------------------------------------------------------------- */
+/* as oe_layernorm_fwd, plus y_planes (optional): y also as three bf16 planes (rows, d), plane_stride elements apart */
+int oe_layernorm_fwd_pl(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
+                        const unsigned char* rowmask, int act, float* y, float* stats, void* y_planes, long plane_stride, void* stream);
 int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
                      const unsigned char* rowmask, int act, float* y, float* stats, void* stream);
 /* dx = LN'(dy) (+ add, optional: the residual branch's gradient of the
@@ -200,6 +221,13 @@ int oe_layernorm_bwd_dx_drop(const float* dy, const float* x, const float* gamma
                              float* gout, float g_alpha, float g_p, unsigned long long g_seed,
                              const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
                              void* stream);
+/* ... plus out_planes (optional): three bf16 planes (rows, d) of gout when gout is given, else of dx - the tensor the
+ * previous block's GEMMs read as an operand (oe_gemm_args.a_planes) */
+int oe_layernorm_bwd_dx_drop_pl(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                                const float* stats, int rows, int d, const unsigned char* rowmask, const float* add, float* dx,
+                                float* gout, float g_alpha, float g_p, unsigned long long g_seed,
+                                const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
+                                void* out_planes, long plane_stride, void* stream);
 
 /* ------------------------------------------------------------------------- *
  * CTC head: log_softmax + CTCLoss(reduction='sum', zero_infinity=True) and

@@ -55,7 +55,7 @@ def arena_units(model: torch.nn.Module):
 
 
 class ParamArena:
-    ALIGN = 4  # floats (16 bytes)
+    ALIGN = 8  # floats (32 bytes): a parameter's bf16 planes (planes.py) then start on 16-byte boundaries too
 
     def __init__(self, model: torch.nn.Module):
         from openeat_amd.modules.attention import MultiHeadedAttention
@@ -101,6 +101,11 @@ class ParamArena:
             self.unit_start.setdefault(u, o)
         self.by_ptr: Dict[int, torch.Tensor] = {}
         self.enabled = True
+        # the weights as three bf16 planes (precision 6 GEMM operands, planes.py): allocated on first use, refreshed by
+        # refresh_planes() after every optimizer step (TrainEngine) and whenever the fp32 arena was written through torch
+        self.planes: Optional[torch.Tensor] = None
+        self.planes_stride = total
+        self._planes_version = -1
         with torch.no_grad():
             for p, o in zip(params, offs):
                 view = self.flat[o:o + p.numel()].view(p.shape)
@@ -113,7 +118,26 @@ class ParamArena:
     def activate(self):
         global _ACTIVE
         _ACTIVE = self
+        from . import planes as _planes
+        if _planes.active() and self.planes is None:
+            self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)
         return self
+
+    def refresh_planes(self):
+        """fp32 arena -> bf16 planes (one launch over all parameters; capturable)."""
+        from . import hip, planes as _planes
+        if not _planes.active():
+            return
+        if self.planes is None:
+            self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)
+        hip.call("oe_split_planes", self.flat, self.numel, 1, self.numel, self.planes, self.numel, self.planes_stride)
+        self._planes_version = self.flat._version
+
+    def ensure_planes(self):
+        """Refresh if torch wrote the arena since the last refresh (load_state_dict, broadcast, init); raw kernels (Adam)
+        do not bump the version - their caller refreshes."""
+        if self.planes is None or self._planes_version != self.flat._version:
+            self.refresh_planes()
 
     def deactivate(self):
         global _ACTIVE

@@ -207,6 +207,39 @@ extern "C" int oe_dropout_scale(const float* x, long n, int cols, float alpha, f
     return 0;
 }
 
+// ------------------------------------------------------- fp32 -> bf16 planes ----
+// x (rows, cols) fp32 -> three bf16 planes p0 + p1 + p2 = x exactly (oe_common.h): the operand format of gemm_pl.hip.
+// One thread per 8 consecutive elements: two float4 in, one 16-byte store per plane.
+typedef __bf16 oe_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long ld, long rows, int cols8, __bf16* __restrict__ pl, long ldp,
+                                                           long pstride) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= rows * cols8) return;
+    const long r = idx / cols8;
+    const int c = (int)(idx - r * cols8) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(x + r * ld + c), b = *reinterpret_cast<const float4*>(x + r * ld + c + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    oe_bf16x8 o[3];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 q[3];
+        oe_split_bf16<3>(v[e], q);
+        o[0][e] = q[0]; o[1][e] = q[1]; o[2][e] = q[2];
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x8*>(pl + n * pstride + r * ldp + c) = o[n];
+}
+extern "C" int oe_split_planes(const float* x, long ld, long rows, long cols, void* planes, long ldp, long plane_stride, void* stream) {
+    OE_REQUIRE(x && planes && rows > 0 && cols > 0, "oe_split_planes: bad arguments");
+    OE_REQUIRE(cols % 8 == 0 && ld % 4 == 0 && ldp % 8 == 0 && plane_stride % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)planes)) & 15) == 0,
+               "oe_split_planes: cols must be a multiple of 8, rows and planes 16-byte aligned");
+    const long n = rows * (cols / 8);
+    hipLaunchKernelGGL(split_planes_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, rows, (int)(cols / 8), (__bf16*)planes, ldp,
+                       plane_stride);
+    OE_LAUNCH_CHECK("split_planes");
+    return 0;
+}
+
 // -------------------------------------------------------------- embedding ----
 // out[r,:] = table[tok[r],:]*xscale + pe[r % L,:]   (decoder.py:144-147,186 ; embedding.py:59)
 __global__ void embed_fwd_kernel(const long long* __restrict__ tok, const float* __restrict__ table, const float* __restrict__ pe,

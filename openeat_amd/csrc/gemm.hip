@@ -222,6 +222,10 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
     ep.accumulate = g->accumulate; ep.atomic = g->atomic_out; ep.a_colsum = g->a_colsum;
     ep.scatter = g->out_scatter; ep.sc_t1 = g->sc_t1; ep.sc_f1 = g->sc_f1; ep.sc_t2 = g->sc_t2; ep.sc_f2 = g->sc_f2; ep.sc_s = g->sc_s;
+    ep.c_planes = (__bf16*)g->c_planes; ep.c_pstride = g->c_plane_stride; ep.ld_cp = g->ldcp ? g->ldcp : g->ldc;
+    OE_REQUIRE(!g->c_planes || (!g->atomic_out && !g->accumulate && !g->out_scatter && ep.ld_cp % 4 == 0 && g->c_plane_stride % 4 == 0 &&
+                                (((uintptr_t)g->c_planes) & 7) == 0),
+               "oe_gemm_f32: c_planes needs a plain (non-atomic, non-scattered) output, 8-byte aligned planes and strides of whole 4-element groups");
     if (g->out_scatter) {
         OE_REQUIRE(!g->atomic_out && !g->accumulate && !g->preact_out && !g->residual && !g->rowmask && g->drop_p <= 0.f,
                    "oe_gemm_f32: out_scatter supports alpha / bias / activation / act-grad epilogues only");
@@ -232,6 +236,11 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
     OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3 || g->precision == 6,
                "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16), 3 (bf16x3) or 6 (bf16x6)");
+    if (g->precision == 6 && g->a_planes && g->b_planes) {       // pre-split operands: tiles by LDS-DMA, no conversion in the loop
+        const int r = oe_gemm_pl_try(A, B, g->a_planes, g->a_plane_stride, g->b_planes, g->b_plane_stride, g->c, g->ldc, M, N, K, sk, ep,
+                                     g->a_kmajor, g->b_kmajor, ga, gb, st);
+        if (r != 1) return r;
+    }
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
     const int tile = (b22 >= 200 && M >= 128 && N >= 128) ? 22 : (b12 >= 160 && N >= 128) ? 12 : 11;

@@ -94,6 +94,9 @@ struct EpiParams {
     int atomic;
     float* a_colsum;   // optional: out[m] += alpha * sum_k A(m,k) for a k-major A (bias gradient fused into wgrad)
     int scatter, sc_t1, sc_f1, sc_t2, sc_f2, sc_s;   // output row scatter (oe_gemm_args.out_scatter)
+    __bf16* c_planes;  // optional: the output ALSO as three bf16 planes (oe_common.h), for a consumer on gemm_pl.hip
+    long c_pstride;    // elements between planes
+    long ld_cp;        // row stride of a plane
 };
 
 // physical row of logical row r = (b, t, f) over (sc_t2, sc_f2) when the output (and the act-grad source) is a strided
@@ -136,6 +139,9 @@ int oe_gemm_tn_planes_try(const OperandDesc& A, const OperandDesc& B, float* C, 
                           int terms, hipStream_t st);
 int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep,
                     bool a_kmajor, bool b_kmajor, bool gather_b, int terms, int tile, hipStream_t st);
+// pre-split operands (gemm_pl.hip): returns 1 when the problem does not qualify
+int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
+                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st);
 
 // One output value: x = acc*alpha + bias -> (pre-activation kept) -> act fwd, or times act'(aux) in a
 // backward GEMM -> dropout mask -> dead-row zeroing -> res + beta*x.
@@ -202,7 +208,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     // Plain outputs (alpha, bias, activation, optional pre-activation copy; nothing to load, no dropout): store straight
     // from the accumulators.  Register r of a 32x32 tile is two full 128-byte row segments per wave-instruction, so the
     // LDS round trip of the general path buys nothing here.
-    if (interior && !ep.scatter && !ep.accumulate && !ep.actgrad_in && !ep.residual && !ep.rowmask && ep.drop_p <= 0.f && ep.beta == 1.f) {
+    if (interior && !ep.scatter && !ep.accumulate && !ep.actgrad_in && !ep.residual && !ep.rowmask && ep.drop_p <= 0.f && ep.beta == 1.f && !ep.c_planes) {
         static_for<0, TM * TN>([&](auto tile_idx) {
             constexpr int i = decltype(tile_idx)::value / TN, j = decltype(tile_idx)::value % TN;
             const long col = n0 + wn * (32 * TN) + j * 32 + lrow;
@@ -377,6 +383,11 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
 #pragma unroll
                     for (int p = 0; p < 4; ++p) *reinterpret_cast<float4*>(cdst + 8 * p * ldc) = x[p];
                 }
+                if (ep.c_planes) {
+                    __bf16* pd = ep.c_planes + row0 * ep.ld_cp + col;
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) store_planes4(pd + 8 * p * ep.ld_cp, ep.c_pstride, x[p]);
+                }
                 if (i == 0 && j == 0) OE_STAMP(7);
             }
         });
@@ -439,6 +450,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                     *reinterpret_cast<float4*>(dst) = o;
                 } else {
                     for (int e = 0; e < ncol; ++e) dst[e] = ep.accumulate ? dst[e] + v[e] : v[e];
+                }
+                if (ep.c_planes) {
+                    for (int e = 0; e < ncol; ++e) store_planes1(ep.c_planes + row * ep.ld_cp + col + e, ep.c_pstride, v[e]);
                 }
             }
         }

@@ -1,0 +1,329 @@
+// GEMM on PRE-SPLIT operands: both matrices arrive as three bf16 planes in HBM (x = p0 + p1 + p2 exactly, oe_common.h),
+// written ONCE by whoever produced the tensor (LayerNorm / GEMM epilogues / oe_split_planes; weights: once per optimizer
+// step), and the product is the six-term sum of oe_mma_terms<6> - the fp32 product to one rounding (precision 6).
+//
+// Why a kernel of its own.  The other bf16 kernels take fp32 operands and split them on the way: gemm_bf16.hip once per
+// staged element (global -> registers -> VALU split -> ds_write, one tile of prefetch: the memory round trip of every
+// K-tile is exposed), gemm_dma.hip on every fragment use (LDS-DMA ring hides the memory, but the split is redone by each
+// consuming wave: ~44 vector instructions per fragment at three pieces).  With six MFMAs per fragment pair the matrix
+// pipe is where the time should go, so everything else leaves the loop: tiles travel global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, no ds_write, no conversion), NST stages in flight across raw
+// s_barriers with counted vmcnt, fragments are plain ds_read_b128 (row-major operands) or ds_read_b64_tr_b16 (k-major
+// operands: gfx950's transposing LDS read) - the loop is DMA issue, LDS reads and MFMAs only.
+//
+// LDS image of one stage: [A plane 0..2][B plane 0..2], each plane tile
+//   row-major operand (k contiguous): [rows][BK] bf16, BK*2-byte rows; the 16-byte chunk c of row r sits at position
+//       c ^ f(r), f = (r >> 2) & 3 for 64-byte rows (BK 32), (r >> 3) & 1 for 32-byte rows (BK 16): conflict-free b128
+//       fragment reads.  The permutation is applied to the per-lane SOURCE address (the DMA destination is lane-linear);
+//   k-major operand (rows contiguous): [BK][128] bf16, 256-byte rows, chunk c of k-row r at c ^ (((r & 3) << 2) | ((r >> 2) & 3)):
+//       conflict-free transposing reads of 4 k-rows x 16 columns per 16-lane group.  The address pattern hands lane half h
+//       the k-slots 8h..8h+7 of a 16-deep step - the order the b128 read of a row-major operand has - so the two kinds mix.
+// Ragged M / N edges re-read the last valid row / the last whole chunk (the bounds-checked epilogue never stores what that
+// yields); K must be a multiple of BK (host check).
+#include <stdlib.h>
+#include "gemm_common.h"
+#include "../../include/openeat_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+struct PlOperand {
+    const __bf16* p;       // plane 0; plane n at p + n * plane_stride
+    long ld;               // elements between consecutive rows of the stored matrix
+    long plane_stride;
+    int rows_total;        // row-major: rows of the logical operand (M or N); k-major: columns (M or N)
+    // im2col gather (row-major A of a conv forward / parity-class input gradient, k-major B of a conv weight gradient)
+    int T1, F1, T2, F2, C, KS, S;
+};
+
+__device__ __forceinline__ void pl_dma16(const __bf16* src, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+}
+template <int N_OUTSTANDING>
+__device__ __forceinline__ void pl_wait_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(N_OUTSTANDING) : "memory");
+}
+
+template <int BK> __device__ __forceinline__ int pl_fsw(int row) { return BK == 32 ? ((row >> 2) & 3) : ((row >> 3) & 1); }
+__device__ __forceinline__ int pl_gsw(int krow) { return ((krow & 3) << 2) | ((krow >> 2) & 3); }
+
+struct PlFrag { bf16x8 p[3]; };
+
+// fragment of 32 rows x 16 k of a row-major operand tile ([rows][BK] bf16 per plane, planes PLANE_BYTES apart)
+template <int BK>
+__device__ __forceinline__ void pl_row_frag(const unsigned char* tile, int plane_bytes, int row, int half, int ks, PlFrag& f) {
+    const int pos = (2 * ks + half) ^ pl_fsw<BK>(row);
+    const unsigned char* p = tile + row * (BK * 2) + pos * 16;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(p + n * plane_bytes);
+}
+// fragment of 32 columns (col32 ..) x 16 k-rows (16 ks ..) of a k-major operand tile ([BK][128] bf16 per plane)
+__device__ __forceinline__ void pl_col_frag(const unsigned char* tile, int plane_bytes, int col32, int ks, int lane, PlFrag& f) {
+    const int i = lane & 15, grp = lane >> 4;
+    const int kr0 = 16 * ks + 8 * (grp >> 1) + (i >> 2);
+    const int ch = (col32 >> 3) + 2 * (grp & 1) + ((i & 3) >> 1);
+    const unsigned char* p0 = tile + kr0 * 256 + 16 * (ch ^ pl_gsw(kr0)) + 8 * (i & 1);
+    const unsigned char* p1 = tile + (kr0 + 4) * 256 + 16 * (ch ^ pl_gsw(kr0 + 4)) + 8 * (i & 1);
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        union { s16x4 h[2]; bf16x8 v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + n * plane_bytes));
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1 + n * plane_bytes));
+        f.p[n] = u.v;
+    }
+}
+
+// sum of the 24 bf16 values of a fragment (three planes x eight k-slots) added to c: v_dot2c_f32_bf16 against (1, 1)
+__device__ __forceinline__ float pl_frag_sum(const PlFrag& f, float c) {
+    bf16x2 ones;
+    ones[0] = (__bf16)1.0f; ones[1] = (__bf16)1.0f;
+#pragma unroll
+    for (int n = 0; n < 3; ++n) {
+        union { bf16x8 v; bf16x2 q[4]; } u;
+        u.v = f.p[n];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_fdot2_f32_bf16(u.q[e], ones, c, false);
+    }
+    return c;
+}
+
+__device__ __forceinline__ int pl_div_small(int k, int d, float rd, int& rem) {     // floor(k / d), 0 <= k < 2^24 (gemm_dma.hip)
+    int q = (int)((float)k * rd);
+    rem = k - q * d;
+    if (rem >= d) { ++q; rem -= d; }
+    if (rem < 0) { --q; rem += d; }
+    return q;
+}
+
+// GA: A is the im2col gather of a conv forward (row-major: rows = output positions, k = (kh, kw, ci)).
+// GB: B is the im2col gather of a conv weight gradient (k-major: k = output position, columns = (kh, kw, ci)).
+template <int TM, int TN, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
+__global__ __launch_bounds__(256, (NST * 3 * (64 * TM + 64 * TN) * BK * 2 <= 80 * 1024) ? 2 : 1)
+void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
+    int tile_x, tile_y, tile_z;
+    {   // XCD-aware tile order (gemm_bf16.hip)
+        const int nblk = gridDim.x, id = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = id & 7, j = id >> 3;
+        const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+        tile_x = swz % gx;
+        tile_y = (swz / gx) % gy;
+        tile_z = swz / (gx * gy);
+    }
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    static_assert(!AK || BM == 128, "k-major tiles are 128 columns wide");
+    static_assert(!BKM || BN == 128, "k-major tiles are 128 columns wide");
+    constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2;              // bytes of one plane tile
+    constexpr int STAGE = 3 * (A_T + B_T);
+    constexpr int PA = A_T / 1024, PB = B_T / 1024;                  // DMA pieces (1 KiB) per plane tile
+    constexpr int PTOT = 3 * (PA + PB), PPW = PTOT / 4;              // pieces per stage / per wave
+    static_assert(PTOT % 4 == 0 && A_T % 1024 == 0 && B_T % 1024 == 0, "piece count must split over four waves");
+    constexpr int LDS_BYTES = (NST * STAGE > 4 * 32 * 36 * 4) ? NST * STAGE : 4 * 32 * 36 * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)tile_y * BM, n0 = (long)tile_x * BN;
+    const int k_begin = tile_z * k_chunk;
+    const int k_end = min(K, k_begin + k_chunk);
+    const int nk = (k_end - k_begin) / BK;
+
+    // ---- this wave's pieces: piece g = wave * PPW + j -> (operand, plane, sub-piece)
+    const __bf16* src[PPW];
+    unsigned dst[PPW];             // byte offset inside a stage (wave-uniform)
+    long step[PPW];                // elements the source advances per K-tile (wave-uniform); gathers: see issue()
+    int kpos[PPW];                 // GB pieces: output position (= k index) of this lane's row in the next tile
+    bool is_ga[PPW], is_gb[PPW];
+    const float rF2 = GB ? 1.0f / (float)B.F2 : 0.f, rT2 = GB ? 1.0f / (float)B.T2 : 0.f;
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int g = wave * PPW + j;
+        const bool isA = g < 3 * PA;
+        const int gg = isA ? g : g - 3 * PA;
+        const int P = isA ? PA : PB;
+        const int plane = gg / P, sub = gg - plane * P;
+        const PlOperand& X = isA ? A : B;
+        const bool km = isA ? AK : BKM;
+        const long x0 = isA ? m0 : n0;
+        dst[j] = (unsigned)((isA ? 0 : 3 * A_T) + plane * (isA ? A_T : B_T) + sub * 1024);
+        is_ga[j] = GA && isA;
+        is_gb[j] = GB && !isA;
+        kpos[j] = 0;
+        const __bf16* base = X.p + plane * X.plane_stride;
+        if (!km) {
+            constexpr int CPR = BK * 2 / 16, RPP = 1024 / (BK * 2);
+            const int row = sub * RPP + lane / CPR, cpos = lane % CPR;
+            const int csrc = cpos ^ pl_fsw<BK>(row);
+            const long grow = min(x0 + row, (long)X.rows_total - 1);
+            long rb;
+            if (GA && isA) {
+                const int f = (int)(grow % X.F2);
+                const long q = grow / X.F2;
+                const int t = (int)(q % X.T2);
+                const long b = q / X.T2;
+                rb = ((b * X.T1 + X.S * t) * (long)X.F1 + X.S * f) * X.C;         // k offsets are added per tile (issue)
+                src[j] = base + rb + csrc * 8;
+            } else {
+                rb = grow * X.ld;
+                src[j] = base + rb + k_begin + csrc * 8;
+            }
+            step[j] = BK;
+        } else {
+            const int krow = sub * 4 + (lane >> 4), cpos = lane & 15;
+            const int csrc = cpos ^ pl_gsw(krow);
+            const long col = min(x0 + csrc * 8, (long)X.rows_total - 8);
+            if (GB && !isA) {
+                // columns = (kh, kw, ci) of the im2col row: linear inside a kernel row, + kh * F1 * C across rows
+                const int seg = X.KS * X.C;
+                const int kh = (int)(col / seg);
+                src[j] = base + (long)kh * X.F1 * X.C + (col - (long)kh * seg);
+                kpos[j] = k_begin + krow;
+            } else {
+                src[j] = base + (long)(k_begin + krow) * X.ld + col;
+            }
+            step[j] = (long)BK * X.ld;
+        }
+    }
+    // running K position of a gathered A: kernel row kh and offset inside it (k = kh * KS * C + rem), wave-uniform
+    int ga_kh = 0, ga_rem = 0;
+    if (GA) { const int seg = A.KS * A.C; ga_kh = k_begin / seg; ga_rem = k_begin - ga_kh * seg; }
+    const unsigned lds_base = (unsigned)(uintptr_t)lds;
+    auto issue = [&](int stage) {
+        const unsigned sb = lds_base + (unsigned)(stage * STAGE);
+        const long ga_off = GA ? (long)ga_kh * A.F1 * A.C + ga_rem : 0;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            if (is_ga[j]) {
+                pl_dma16(src[j] + ga_off, sb + dst[j]);
+            } else if (is_gb[j]) {
+                int f, t;
+                const int q = pl_div_small(kpos[j], B.F2, rF2, f);
+                const int b = pl_div_small(q, B.T2, rT2, t);
+                pl_dma16(src[j] + (((long)b * B.T1 + B.S * t) * B.F1 + B.S * f) * B.C, sb + dst[j]);
+                kpos[j] += BK;
+            } else {
+                pl_dma16(src[j], sb + dst[j]);
+                src[j] += step[j];
+            }
+        }
+        if (GA) { ga_rem += BK; if (ga_rem >= A.KS * A.C) { ga_rem -= A.KS * A.C; ++ga_kh; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fused bias gradient of a weight gradient (k-major A = dY): column sums of A, taken from the fragments the MFMAs read
+    const bool do_csum = AK && ep.a_colsum != nullptr && tile_x == 0 && wn == 0;        // wave-uniform
+    float csum[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) csum[i] = 0.f;
+
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) issue(t);
+
+    const int frow = lane & 31, fhalf = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt has landed once at most the younger tiles' pieces are outstanding; the barrier then (a) publishes every
+        // wave's pieces of tile kt and (b) retires all reads of tile kt-1's stage, which the next issue overwrites
+        const int younger = min(nk, kt + NST - 1) - (kt + 1);
+        if (NST >= 4 && younger >= 2) pl_wait_and_barrier<2 * PPW>();
+        else if (NST >= 3 && younger >= 1) pl_wait_and_barrier<PPW>();
+        else pl_wait_and_barrier<0>();
+        if (kt + NST - 1 < nk) issue((kt + NST - 1) % NST);
+        const unsigned char* at = lds + (kt % NST) * STAGE;
+        const unsigned char* bt = at + 3 * A_T;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            PlFrag fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (!AK) pl_row_frag<BK>(at, A_T, wm * 32 * TM + i * 32 + frow, fhalf, ks, fa[i]);
+                else pl_col_frag(at, A_T, wm * 32 * TM + i * 32, ks, lane, fa[i]);
+                if (AK && do_csum) csum[i] = pl_frag_sum(fa[i], csum[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (!BKM) pl_row_frag<BK>(bt, B_T, wn * 32 * TN + j * 32 + frow, fhalf, ks, fb[j]);
+                else pl_col_frag(bt, B_T, wn * 32 * TN + j * 32, ks, lane, fb[j]);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = oe_mma_terms<6>(fa[i], fb[j], acc[i][j]);
+        }
+    }
+    if (AK && do_csum) {
+        float al = ep.alpha;
+        if (ep.alpha_dev) al *= *ep.alpha_dev;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+            const long row = m0 + wm * 32 * TM + i * 32 + frow;
+            if (fhalf == 0 && row < M) atomicAdd(ep.a_colsum + row, v * al);
+        }
+    }
+    gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds), C, ldc, M, N, m0, n0, ep, tile_z);
+}
+
+static long pl_launches = 0;
+extern "C" long oe_gemm_pl_launches(void) { return pl_launches; }
+
+template <int TM, int TN, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
+static int launch_pl(const PlOperand& A, const PlOperand& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep, hipStream_t st) {
+    int kc = oe_cdiv(oe_cdiv(K, sk), BK) * BK;
+    if (kc <= 0) kc = BK;
+    const int nz = oe_cdiv(K, kc);
+    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 64 * TM);
+    hipLaunchKernelGGL((gemm_pl_kernel<TM, TN, AK, BKM, BK, NST, GA, GB>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
+    OE_LAUNCH_CHECK("oe_gemm (bf16x6 planes)");
+    ++pl_launches;
+    return 0;
+}
+
+// Returns 1 when the problem does not qualify (the caller goes on to the kernels that split fp32 operands themselves),
+// 0 on a launch.  Ap / Bp: plane 0 of the operands' pre-split copies (plane strides in elements), same logical layout and
+// leading dimensions as the fp32 operands they mirror.
+int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
+                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st) {
+    static const int mode = getenv("OE_GEMM_PL") ? atoi(getenv("OE_GEMM_PL")) : 1;            // 0 = never (A/B comparisons)
+    if (!mode || !Ap || !Bp) return 1;
+    if (a_kmajor && !b_kmajor) return 1;
+    if (ep.a_colsum && !a_kmajor) return 1;
+    PlOperand a{}, b{};
+    a.p = (const __bf16*)Ap; a.ld = A.ld; a.plane_stride = a_pstride; a.rows_total = M;
+    b.p = (const __bf16*)Bp; b.ld = B.ld; b.plane_stride = b_pstride; b.rows_total = N;
+    auto aligned = [](const void* p, long ld, long ps) { return (((uintptr_t)p) & 15) == 0 && ld % 8 == 0 && ps % 8 == 0; };
+    if (ga) { a.T1 = A.T1; a.F1 = A.F1; a.T2 = A.T2; a.F2 = A.F2; a.C = A.C; a.KS = A.KS; a.S = A.S; a.ld = 0; }
+    if (gb) { b.T1 = B.T1; b.F1 = B.F1; b.T2 = B.T2; b.F2 = B.F2; b.C = B.C; b.KS = B.KS; b.S = B.S; b.ld = 0; }
+    if (!aligned(Ap, ga ? 8 : A.ld, a_pstride) || !aligned(Bp, gb ? 8 : B.ld, b_pstride)) return 1;
+    if ((a_kmajor && (M % 8 || M < 8)) || (b_kmajor && (N % 8 || N < 8))) return 1;
+    if (ga && (a_kmajor || b_kmajor || A.C % 32 || (A.KS * A.C) % 32)) return 1;
+    if (gb && (!(a_kmajor && b_kmajor) || B.C % 8 || (B.KS * B.C) % 128 || N % 128 || K >= (1 << 24))) return 1;
+    // K-tile: 32 where the reduction is long (fewer barriers, 3 stages = 144 KiB: one block per CU), 16 otherwise (3 stages
+    // = 72 KiB: two blocks per CU overlap each other's prologue and epilogue on the short-K problems)
+    static const int forced_bk = getenv("OE_PL_BK") ? atoi(getenv("OE_PL_BK")) : 0;
+    int kc = oe_cdiv(K, sk);
+    const int bk = forced_bk ? forced_bk : (kc >= 1024 ? 32 : 16);
+    if (K % bk) return 1;
+    if (sk > 1 && oe_cdiv(oe_cdiv(K, sk), bk) * bk * (sk - 1) >= K) return 1;          // a split would be left empty
+#define OE_PL(AK, BKM, GA, GB)                                                                                        \
+    do {                                                                                                              \
+        if (bk == 32) return launch_pl<2, 2, AK, BKM, 32, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);              \
+        return launch_pl<2, 2, AK, BKM, 16, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);                            \
+    } while (0)
+    if (!a_kmajor && !b_kmajor) { if (ga) OE_PL(false, false, true, false); else OE_PL(false, false, false, false); }
+    if (!a_kmajor && b_kmajor) OE_PL(false, true, false, false);
+    if (gb) OE_PL(true, true, false, true);
+    OE_PL(true, true, false, false);
+#undef OE_PL
+}

@@ -10,7 +10,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int rows, int d,
                                                              const unsigned char* __restrict__ rowmask, int act,
-                                                             float* __restrict__ y, float* __restrict__ stats) {
+                                                             float* __restrict__ y, float* __restrict__ stats,
+                                                             __bf16* __restrict__ ypl, long pstride) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 o.w = act_fwd(act, (v[j].w - mean) * rstd * g.w + bb.w);
             }
             yr[i] = o;
+            if (ypl) store_planes4(ypl + row * d + 4 * i, pstride, o);       // the output as bf16 planes too (gemm_pl.hip operand)
         }
     }
 }
@@ -70,7 +72,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              float* __restrict__ partial, float* __restrict__ gout, float g_alpha,
                                                              float g_p, unsigned long long g_seed,
                                                              const unsigned long long* __restrict__ g_seed_dev,
-                                                             const unsigned char* __restrict__ g_rowmask) {
+                                                             const unsigned char* __restrict__ g_rowmask,
+                                                             __bf16* __restrict__ opl, long opl_stride) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][d]
     // optional second output gout = g_alpha * dropout_mask(g_seed) * dx (oe_dropout_scale's definition: element idx belongs
     // to Philox call idx >> 3): the gradient the PREVIOUS block's backward starts from, i.e. its `residual + dropout(.)`
@@ -153,6 +156,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                             o.w += rstd[k] * (g[j].w - c1 - xh[j].w * c2);
                         }
                         dxr[i] = o;
+                        // bf16 planes of what the previous block's GEMMs will read: the dropped copy if there is one, else dx
+                        if (opl && !gout) store_planes4(opl + (w0 + rb + k) * d + 4 * i, opl_stride, o);
                         if (gout) {
                             const long grow = w0 + rb + k;
                             const unsigned long long e0 = (unsigned long long)grow * d + 4 * i;
@@ -166,6 +171,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                             }
                             if (g_rowmask && !g_rowmask[grow]) gq = make_float4(0.f, 0.f, 0.f, 0.f);
                             reinterpret_cast<float4*>(gout + grow * d)[i] = gq;
+                            if (opl) store_planes4(opl + grow * d + 4 * i, opl_stride, gq);
                         }
                     }
                 }
@@ -204,12 +210,20 @@ __global__ __launch_bounds__(256) void ln_param_reduce_kernel(const float* __res
     }
 }
 
+extern "C" int oe_layernorm_fwd_pl(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
+                                   const unsigned char* rowmask, int act, float* y, float* stats, void* y_planes, long plane_stride, void* stream);
 extern "C" int oe_layernorm_fwd(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
                                 const unsigned char* rowmask, int act, float* y, float* stats, void* stream) {
+    return oe_layernorm_fwd_pl(x, gamma, beta, eps, rows, d, rowmask, act, y, stats, nullptr, 0, stream);
+}
+// y_planes (optional): y also as three bf16 planes (rows, d) each, plane_stride elements apart
+extern "C" int oe_layernorm_fwd_pl(const float* x, const float* gamma, const float* beta, float eps, int rows, int d,
+                                   const unsigned char* rowmask, int act, float* y, float* stats, void* y_planes, long plane_stride, void* stream) {
     OE_REQUIRE(x && gamma && beta && y, "oe_layernorm_fwd: null pointer");
+    OE_REQUIRE(!y_planes || ((((uintptr_t)y_planes) & 7) == 0 && plane_stride % 4 == 0), "oe_layernorm_fwd_pl: planes must be 8-byte aligned");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
 #define LN_FWD(NVV) hipLaunchKernelGGL(layernorm_fwd_kernel<NVV>, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, \
-                                       beta, eps, rows, d, rowmask, act, y, stats)
+                                       beta, eps, rows, d, rowmask, act, y, stats, (__bf16*)y_planes, plane_stride)
     if (d <= 256) LN_FWD(1); else if (d <= 512) LN_FWD(2); else if (d <= 1024) LN_FWD(4); else LN_FWD(8);
 #undef LN_FWD
     OE_LAUNCH_CHECK("layernorm_fwd");
@@ -221,11 +235,26 @@ extern "C" size_t oe_layernorm_bwd_workspace_floats(int rows, int d) { return (s
 // dx and the per-block partial sums of the parameter gradients (into the workspace).  oe_layernorm_bwd = this + the
 // reduction of those partials; a caller that keeps the workspaces of many calls alive can reduce them all with ONE launch
 // of oe_layernorm_param_reduce_table instead (93 reductions of 4.6 us each per step at config 2).
+extern "C" int oe_layernorm_bwd_dx_drop_pl(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                                           const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
+                                           float* dx, float* gout, float g_alpha, float g_p, unsigned long long g_seed,
+                                           const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
+                                           void* out_planes, long plane_stride, void* stream);
 extern "C" int oe_layernorm_bwd_dx_drop(const float* dy, const float* x, const float* gamma, const float* beta, int act,
                                         const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
                                         float* dx, float* gout, float g_alpha, float g_p, unsigned long long g_seed,
                                         const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
                                         void* stream) {
+    return oe_layernorm_bwd_dx_drop_pl(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, gout, g_alpha, g_p, g_seed, g_seed_dev,
+                                       g_rowmask, workspace, nullptr, 0, stream);
+}
+// out_planes (optional): bf16 planes of gout when gout is given, else of dx - the tensor the previous block's GEMMs consume
+extern "C" int oe_layernorm_bwd_dx_drop_pl(const float* dy, const float* x, const float* gamma, const float* beta, int act,
+                                           const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
+                                           float* dx, float* gout, float g_alpha, float g_p, unsigned long long g_seed,
+                                           const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace,
+                                           void* out_planes, long plane_stride, void* stream) {
+    OE_REQUIRE(!out_planes || ((((uintptr_t)out_planes) & 7) == 0 && plane_stride % 4 == 0), "oe_layernorm_bwd_dx_drop_pl: planes must be 8-byte aligned");
     OE_REQUIRE(dy && x && gamma && stats && dx && (beta || !act), "oe_layernorm_bwd: null pointer");
     OE_REQUIRE(!gout || (d % 8 == 0 && g_p >= 0.f && g_p < 1.f && gout != dx), "oe_layernorm_bwd_dx_drop: the dropped output needs d %% 8 == 0, 0 <= p < 1");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
@@ -233,7 +262,7 @@ extern "C" int oe_layernorm_bwd_dx_drop(const float* dy, const float* x, const f
     const int nb = oe_cdiv(rows, LNB_ROWS);
 #define LN_BWD(NVV, RBB) hipLaunchKernelGGL((layernorm_bwd_kernel<NVV, RBB>), dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
                                             dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace, gout, g_alpha, g_p,  \
-                                            g_seed, g_seed_dev, g_rowmask)
+                                            g_seed, g_seed_dev, g_rowmask, (__bf16*)out_planes, plane_stride)
     if (d <= 256) LN_BWD(1, 4); else if (d <= 512) LN_BWD(2, 2); else if (d <= 1024) LN_BWD(4, 1); else LN_BWD(8, 1);
 #undef LN_BWD
     OE_LAUNCH_CHECK("layernorm_bwd");

@@ -157,6 +157,26 @@ __device__ __forceinline__ ACC oe_mma_terms(const F& a, const F& b, ACC c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.p[0], b.p[0], c, 0, 0, 0);
 }
 
+typedef __bf16 oe_bf16x4 __attribute__((ext_vector_type(4)));
+// four consecutive values -> their three bf16 pieces, one 8-byte store per plane (planes `pstride` elements apart)
+__device__ __forceinline__ void store_planes4(__bf16* dst, long pstride, const float4& v) {
+    const float x[4] = {v.x, v.y, v.z, v.w};
+    oe_bf16x4 pl[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 q[3];
+        oe_split_bf16<3>(x[e], q);
+        pl[0][e] = q[0]; pl[1][e] = q[1]; pl[2][e] = q[2];
+    }
+#pragma unroll
+    for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4*>(dst + n * pstride) = pl[n];
+}
+__device__ __forceinline__ void store_planes1(__bf16* dst, long pstride, float v) {
+    __bf16 q[3];
+    oe_split_bf16<3>(v, q);
+    dst[0] = q[0]; dst[pstride] = q[1]; dst[2 * pstride] = q[2];
+}
+
 // ---- activations ------------------------------------------------------------
 // ids follow the reference's table (utils/common.py:160-173): relu, swish, tanh, hardtanh, selu, gelu (erf form)
 enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2, OE_ACT_TANH = 3, OE_ACT_HARDTANH = 4, OE_ACT_SELU = 5, OE_ACT_GELU = 6 };

@@ -91,6 +91,7 @@ class TrainEngine:
         # inside a capture the learning rate is whatever replay() puts into lr_dev; everywhere else (eager steps, also
         # those taken beside a captured graph) it is the optimizer's current param_groups value
         self.optimizer.step(lr_from_device=self._capturing or self._replaying)
+        self.arena.refresh_planes()            # precision 6: the new weights as bf16 planes, once per step (planes.py)
         self.seed_counter.add_(1)
         ops.stamp("optimizer done")
 

@@ -53,6 +53,8 @@ class GemmArgs(C.Structure):
         ("conv_k", C.c_int), ("conv_s", C.c_int),
         ("conv_kh", C.c_int),
         ("out_scatter", C.c_int), ("sc_t1", C.c_int), ("sc_f1", C.c_int), ("sc_t2", C.c_int), ("sc_f2", C.c_int), ("sc_s", C.c_int),
+        ("a_planes", c_fp), ("a_plane_stride", C.c_long), ("b_planes", c_fp), ("b_plane_stride", C.c_long),
+        ("c_planes", c_fp), ("c_plane_stride", C.c_long), ("ldcp", C.c_long),
     ]
 
 
@@ -123,6 +125,8 @@ _SIGNATURES = {
     "oe_capture_unjoined_streams": (I, [P, C.POINTER(C.c_void_p), I, C.POINTER(I)]),
     "oe_stamp": (I, [P, I, P]),
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
+    "oe_split_planes": (I, [P, L, L, L, P, L, L, P]),
+    "oe_gemm_pl_launches": (L, []),
     "oe_gemm_tn_grouped_plan": (I, [C.POINTER(TnProblem), I, I]),
     "oe_gemm_tn_grouped": (I, [P, I, I, I, P]),
     "oe_ffn_packed_bytes": (SZ, [I, I, I]),
@@ -133,12 +137,14 @@ _SIGNATURES = {
     "oe_ffn_bwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
+    "oe_layernorm_fwd_pl": (I, [P, P, P, F, I, I, P, I, P, P, P, L, P]),
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
     "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P, P]),
     "oe_layernorm_bwd_dx": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P]),
     "oe_layernorm_param_reduce": (I, [P, I, I, P, P, P]),
     "oe_layernorm_param_reduce_table": (I, [P, I, I, I, P]),
     "oe_layernorm_bwd_dx_drop": (I, [P, P, P, P, I, P, I, I, P, P, P, P, F, F, U64, P, P, P, P]),
+    "oe_layernorm_bwd_dx_drop_pl": (I, [P, P, P, P, I, P, I, I, P, P, P, P, F, F, U64, P, P, P, P, L, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
@@ -233,7 +239,8 @@ def _dev_f32(t: torch.Tensor, name: str):
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
          bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, seed_dev=None, rowmask=None,
          residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None, a_colsum=None,
-         conv_kh=0, scatter=None):
+         conv_kh=0, scatter=None, a_planes=None, b_planes=None, c_planes=None):
+    """a_planes / b_planes / c_planes: Planes (openeat_amd.planes) of A / B (pre-split copies, precision 6) and for the output."""
     g = GemmArgs()
     g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
     g.b, g.ldb, g.b_kmajor = b.data_ptr(), ldb, int(b_kmajor)
@@ -256,6 +263,12 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.precision = GEMM_PRECISION if precision is None else precision
     g.a_colsum = None if (a_colsum is None or g.precision == 0) else a_colsum.data_ptr()
     g.conv_kh = conv_kh
+    if g.precision == 6:
+        if a_planes is not None and b_planes is not None:
+            g.a_planes, g.a_plane_stride = a_planes.ptr, a_planes.stride
+            g.b_planes, g.b_plane_stride = b_planes.ptr, b_planes.stride
+        if c_planes is not None:
+            g.c_planes, g.c_plane_stride, g.ldcp = c_planes.ptr, c_planes.stride, c_planes.ld
     if scatter is not None:                      # (T1, F1, T2, F2, S): output rows (b, t, f) -> (b*T1 + S*t)*F1 + S*f
         g.out_scatter = 1
         g.sc_t1, g.sc_f1, g.sc_t2, g.sc_f2, g.sc_s = scatter

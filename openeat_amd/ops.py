@@ -17,6 +17,7 @@ import torch
 
 from . import hip
 from . import arena as _arena
+from . import planes as _planes
 
 ACT_NONE, ACT_RELU, ACT_SWISH, ACT_TANH, ACT_HARDTANH, ACT_SELU, ACT_GELU = 0, 1, 2, 3, 4, 5, 6      # oe_common.h
 ACT_IDS = {"relu": ACT_RELU, "swish": ACT_SWISH, "tanh": ACT_TANH, "hardtanh": ACT_HARDTANH, "selu": ACT_SELU, "gelu": ACT_GELU,
@@ -77,23 +78,38 @@ def _split_k(out_rows: int, out_cols: int, k: int) -> int:
     return int(max(1, min(want, 24, k // 256 if k >= 512 else 1)))
 
 
-def gemm_nt(x, w, bias=None, out=None, **epi):
-    """y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue)."""
+def _operand_planes(act2d, w2d):
+    """Pre-split copies (planes.py) of an activation operand and a weight operand of one GEMM - both or neither."""
+    if not _planes.active():
+        return None, None
+    ap = _planes.of(act2d)
+    if ap is None:
+        return None, None
+    bp = _planes.weight(w2d)
+    return (ap, bp) if bp is not None else (None, None)
+
+
+def gemm_nt(x, w, bias=None, out=None, out_planes=False, **epi):
+    """y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue).  out_planes: the output is a later GEMM's operand - write its bf16 planes too."""
     M, K = x.shape
     N = w.shape[0]
     if out is None:
         out = _new(M, N, like=x)
-    hip.gemm(x, w, out, M, N, K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, **epi)
+    ap, bp = _operand_planes(x, w)
+    cp = _planes.new_output(out) if (out_planes and _planes.active() and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
+    hip.gemm(x, w, out, M, N, K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, a_planes=ap, b_planes=bp, c_planes=cp, **epi)
     return out
 
 
-def gemm_nn(dy, w, out=None, **epi):
+def gemm_nn(dy, w, out=None, out_planes=False, **epi):
     """dx[M,K] = dy[M,N] @ w[N,K]."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = _new(M, K, like=dy)
-    hip.gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, **epi)
+    ap, bp = _operand_planes(dy, w)
+    cp = _planes.new_output(out) if (out_planes and _planes.active() and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
+    hip.gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, a_planes=ap, b_planes=bp, c_planes=cp, **epi)
     return out
 
 
@@ -118,18 +134,29 @@ def gemm_nn_deep(dy, w, alpha_dev=None):
     return out
 
 
-def gemm_tn(dy, x, out=None, alpha=1.0, alpha_dev=None, bias_out=None):
+def wgrad_planes(dy, x):
+    """Pre-split copies of both operands of a weight gradient dy^T x (both activations), or (None, None)."""
+    if not _planes.active():
+        return None, None
+    ap = _planes.of(dy)
+    bp = _planes.of(x) if ap is not None else None
+    return (ap, bp) if bp is not None else (None, None)
+
+
+def gemm_tn(dy, x, out=None, alpha=1.0, alpha_dev=None, bias_out=None, planes=None):
     """dw[N,K] (+)= dy[M,N]^T @ x[M,K]  (split-K, atomic accumulation into `out`).
     bias_out (optional, [N], accumulated): alpha * column sums of dy - fused into the GEMM on the
-    bf16 paths, a separate column-sum launch on the exact-fp32 path."""
+    bf16 paths, a separate column-sum launch on the exact-fp32 path.
+    planes: (dy planes, x planes) resolved by the caller (deferred launches resolve them when the gradient is requested)."""
     M, N = dy.shape
     K = x.shape[1]
     if out is None:
         out = _new(N, K, like=dy, zero=True)
     fused = bias_out is not None and hip.GEMM_PRECISION != 0
+    ap, bp = planes if planes is not None else wgrad_planes(dy, x)
     hip.gemm(dy, x, out, N, K, M, lda=dy.stride(0), ldb=x.stride(0), ldc=out.stride(0), a_kmajor=True, b_kmajor=True,
              split_k=_split_k(N, K, M), atomic_out=True, alpha=alpha, alpha_dev=alpha_dev,
-             a_colsum=bias_out if fused else None)
+             a_colsum=bias_out if fused else None, a_planes=ap, b_planes=bp)
     if bias_out is not None and not fused:
         colsum(dy, alpha, alpha_dev, N, out=bias_out)
     return out
@@ -392,9 +419,15 @@ def wgrad(param, dy, x, alpha=1.0, alpha_dev=None):
     if tgt is None:
         return gemm_tn(dy, x, alpha=alpha, alpha_dev=alpha_dev).view(param.shape)
     out = tgt.view(dy.shape[1], x.shape[1])
-    _run_wgrad(True, (dy, x, alpha_dev), lambda: gemm_tn(dy, x, out=out, alpha=alpha, alpha_dev=alpha_dev),
+    pl = wgrad_planes(dy, x)
+    _run_wgrad(True, (dy, x, alpha_dev) + _pl_tensors(pl), lambda: gemm_tn(dy, x, out=out, alpha=alpha, alpha_dev=alpha_dev, planes=pl),
                desc=dict(dy=dy, x=x, out=out, alpha=alpha, alpha_dev=alpha_dev, bias_out=None))
     return None
+
+
+def _pl_tensors(pl):
+    """The bf16 tensors behind a (dy planes, x planes) pair, for stream bookkeeping."""
+    return tuple(q.t for q in pl if q is not None) if pl is not None else ()
 
 
 def _sink_swapped(param, src, A, Bd, Cd):
@@ -417,8 +450,9 @@ def wgrad_bias(w, b, dy, x, alpha=1.0, alpha_dev=None):
     tw, tb = _arena.grad_target(w), _arena.grad_target(b)
     ow = tw.view(N, K) if tw is not None else _new(N, K, like=dy, zero=True)
     ob = tb if tb is not None else _new(N, like=dy, zero=True)
-    _run_wgrad(tw is not None and tb is not None, (dy, x, alpha_dev),
-               lambda: gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob),
+    pl = wgrad_planes(dy, x)
+    _run_wgrad(tw is not None and tb is not None, (dy, x, alpha_dev) + _pl_tensors(pl),
+               lambda: gemm_tn(dy, x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob, planes=pl),
                desc=dict(dy=dy, x=x, out=ow, alpha=alpha, alpha_dev=alpha_dev, bias_out=ob))
     return (None if tw is not None else ow.view(w.shape)), (None if tb is not None else ob)
 
@@ -463,6 +497,15 @@ def dropout_scale(x, alpha=1.0, p=0.0, seed=0, rowmask=None, cols=None):
 # --------------------------------------------------------------------------- #
 def _ln_ws(like, rows, d):
     return _new(hip.lib().oe_layernorm_bwd_workspace_floats(rows, d), like=like)
+
+
+def _ln_fwd(x, gamma, beta, eps, rows, d, rowmask, act, y, stats, planes_out=True):
+    """LayerNorm forward; in the pre-split mode the output also leaves as bf16 planes (it feeds a GEMM)."""
+    pl = _planes.new_output(y.view(rows, d)) if (planes_out and _planes.active() and rows * d >= _planes.MIN_SPLIT_ELEMS) else None
+    if pl is None:
+        hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, act, y, stats)
+    else:
+        hip.call("oe_layernorm_fwd_pl", x, gamma, beta, eps, rows, d, rowmask, act, y, stats, pl.t, pl.stride)
 
 
 # While a training step is being captured into a HIP graph, LayerNorm backward leaves the reduction of its per-block
@@ -519,7 +562,10 @@ _PREDROP = {}
 
 
 def predrop_clear():
+    """Called where a new step starts (ASRModel.forward / LanguageModel.forward / TrainEngine): drops the previous step's
+    leftovers - dropped-gradient copies and the registry of pre-split GEMM operands."""
     _PREDROP.clear()
+    _planes.clear()
 
 
 def _tag_out_drop(out, out_scale, p_out, s_out, rowmask=None):
@@ -550,8 +596,14 @@ def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, t
     if prev_drop is not None and FUSE_OUT_DROP and d % 8 == 0:
         g = torch.empty_like(dx)
         alpha, p, seed, gmask = prev_drop
-        hip.call("oe_layernorm_bwd_dx_drop", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, g, alpha, p, seed, _seed_dev,
-                 gmask, ws)
+        # g is what the previous block's backward GEMMs read: in the pre-split mode it leaves as bf16 planes too
+        pl = _planes.new_output(g.view(rows, d)) if (_planes.active() and rows * d >= _planes.MIN_SPLIT_ELEMS) else None
+        if pl is None:
+            hip.call("oe_layernorm_bwd_dx_drop", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, g, alpha, p, seed, _seed_dev,
+                     gmask, ws)
+        else:
+            hip.call("oe_layernorm_bwd_dx_drop_pl", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, g, alpha, p, seed, _seed_dev,
+                     gmask, ws, pl.t, pl.stride)
         _PREDROP[dx.data_ptr()] = (g, prev_drop, dx, dx._version)
     else:
         hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, ws)
@@ -572,7 +624,7 @@ class LayerNormFn(torch.autograd.Function):
         rows = x.numel() // d
         y = torch.empty_like(x)
         stats = _new(rows, 2, like=x)
-        hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, act, y, stats)
+        _ln_fwd(x, gamma, beta, eps, rows, d, rowmask, act, y, stats)
         ctx.save_for_backward(x, gamma, beta, stats, rowmask)
         ctx.act = act
         # only when the caller vouches that x feeds nothing else: with a second consumer autograd SUMS the gradients of x
@@ -609,7 +661,7 @@ class PreNormFn(torch.autograd.Function):
         rows = x.numel() // d
         y = torch.empty_like(x)
         stats = _new(rows, 2, like=x)
-        hip.call("oe_layernorm_fwd", x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
+        _ln_fwd(x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
         ctx.save_for_backward(x, gamma, beta, stats, rowmask)
         ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
         return x.view_as(x), y
@@ -820,7 +872,7 @@ class FeedForwardFn(torch.autograd.Function):
         ctx.fused = False
         pre = _new(M, ff, like=x)
         if act in GEMM_FUSED_ACTS:
-            a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+            a = gemm_nt(x2, w1, b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=_seed_dev, out_planes=True)
         else:
             gemm_nt(x2, w1, b1, out=pre)
             a = torch.empty_like(pre)
@@ -856,7 +908,7 @@ class FeedForwardFn(torch.autograd.Function):
             dw1, db1 = wgrad_bias(w1, b1, dh, x2)
             return dx.view(in_shape), dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
         if act in GEMM_FUSED_ACTS:
-            dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev)
+            dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev, out_planes=True)
         else:
             dh = gemm_nn(g2, w2)
             if p_in > 0:
@@ -1011,7 +1063,8 @@ class AttentionFn(torch.autograd.Function):
                 gw_all = torch.as_strided(gw, (n, x_in.shape[1]), (x_in.shape[1], 1))
                 gb = _arena.grad_target(parts_b[0])
                 gb_all = torch.as_strided(gb, (n,), (1,))
-                _run_wgrad(True, (dy_fused, x_in), lambda: gemm_tn(dy_fused, x_in, out=gw_all, bias_out=gb_all),
+                pl = wgrad_planes(dy_fused, x_in)
+                _run_wgrad(True, (dy_fused, x_in) + _pl_tensors(pl), lambda: gemm_tn(dy_fused, x_in, out=gw_all, bias_out=gb_all, planes=pl),
                            desc=dict(dy=dy_fused, x=x_in, out=gw_all, alpha=1.0, alpha_dev=None, bias_out=gb_all))
                 return dx_in, [None] * len(parts_w), [None] * len(parts_b)
             dwf, dbf = gemm_tn(dy_fused, x_in), colsum(dy_fused)
@@ -1145,7 +1198,7 @@ class ConvModuleFn(torch.autograd.Function):
         hip.call("oe_dwconv_glu_fwd", a, wd, bd, gpad, B, T, d, K, int(causal), yc)
         z = torch.empty_like(yc)
         stats = _new(B * T, 2, like=x)
-        hip.call("oe_layernorm_fwd", yc, g, b, 1e-5, B * T, d, None, act, z, stats)
+        _ln_fwd(yc, g, b, 1e-5, B * T, d, None, act, z, stats)
         s_out = next_seed() if p_out > 0 else 0
         res2 = None if residual is None else _chk(residual, "residual").view(-1, d)
         y = gemm_nt(z, w2m, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, rowmask=rowmask, residual=res2,
@@ -1177,7 +1230,8 @@ class ConvModuleFn(torch.autograd.Function):
         (db1, rb1) = grad_sink(b1)
         tw1 = _arena.grad_target(w1)
         ow1 = tw1.view(2 * d, d) if tw1 is not None else _new(2 * d, d, like=dy, zero=True)
-        _run_wgrad(tw1 is not None and rb1 is None and not causal, (da, xm), lambda: gemm_tn(da, xm, out=ow1, bias_out=db1),
+        pl = wgrad_planes(da, xm)
+        _run_wgrad(tw1 is not None and rb1 is None and not causal, (da, xm) + _pl_tensors(pl), lambda: gemm_tn(da, xm, out=ow1, bias_out=db1, planes=pl),
                    desc=dict(dy=da, x=xm, out=ow1, alpha=1.0, alpha_dev=None, bias_out=db1))
         dw1 = None if tw1 is not None else ow1.view(w1.shape)
         if causal:
@@ -1212,6 +1266,7 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
     hip.call("oe_conv_dgrad_k3s2_weights", wk, C, wcls)
     dyin = torch.empty_like(yin)
     flat_in, flat_out, flat_y = dyp.view(-1), dyin.view(-1), yin.reshape(-1)
+    dyp_pl = _planes.of(dyp.view(-1, C)) if _planes.active() else None          # pre-split mode: one pass over the padded dy
     w_off = 0
     for pt in (0, 1):
         KH = 2 if pt == 0 else 1                       # window row 0 is dy row i - 1 (tap 2), row 1 is dy row i (tap 0); odd t1: tap 1
@@ -1223,9 +1278,14 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
             w_off += KH * KW * C * C
             a_off = (pt * (Fo + 2) + pf) * C           # odd classes start one padded row / column further
             o_off = (pt * Fi + pf) * C
+            ap = bp = None
+            if dyp_pl is not None:
+                bp = _planes.of(wsel, force=True)
+                if bp is not None:             # the class's window into the padded dy: the same planes, a_off elements in
+                    ap = _planes.Planes(dyp_pl.t, dyp_pl.ptr + 2 * a_off, dyp_pl.stride, C, dyp_pl.rows, C)
             hip.gemm(flat_in[a_off:], wsel, flat_out[o_off:], B * ni * nj, C, KH * KW * C, lda=0, ldb=KH * KW * C, ldc=C,
                      act=ACT_RELU, actgrad_in=flat_y[o_off:], ld_aux=C, conv=(To + 2, Fo + 2, ni, nj, C, KW, 1), conv_gather=hip.GATHER_A,
-                     conv_kh=KH, scatter=(Ti, Fi, ni, nj, 2))
+                     conv_kh=KH, scatter=(Ti, Fi, ni, nj, 2), a_planes=ap, b_planes=bp)
     return dyin
 
 
@@ -1259,8 +1319,15 @@ class ConvSubsamplingFn(torch.autograd.Function):
             wg = _new(C, kk * C, like=x)                            # [co][kh][kw][ci]
             hip.call("oe_swap_last2", wk, C, C, kk, wg, 0)
             yo = _new(B * To * Fo, C, like=x)
+            ap = bp = cp = None
+            if _planes.active():               # pre-split mode: the NHWC activation and the re-laid weights as bf16 planes
+                ap = _planes.of(acts[-1].view(-1, C))
+                bp = _planes.of(wg, force=True) if ap is not None else None
+                if bp is None:
+                    ap = None
+                cp = _planes.new_output(yo)    # the next stage / the Linear reads it as an operand
             hip.gemm(acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
-                     conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A)
+                     conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A, a_planes=ap, b_planes=bp, c_planes=cp)
             dims.append((To, Fo))
             acts.append(yo.view(B, To, Fo, C))
             wgs.append(wg)
@@ -1290,7 +1357,7 @@ class ConvSubsamplingFn(torch.autograd.Function):
         dwlg = gemm_tn(do2, ylv, alpha=xscale, bias_out=dbl_buf)
         dwl = _sink_swapped(wl, dwlg, d, FL, C)
         # gradient w.r.t. the last conv's pre-activation: the Linear's dgrad with the ReLU mask fused
-        dy = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=ylv, ld_aux=FL * C).view(B * TL * FL, C)
+        dy = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=ylv, ld_aux=FL * C, out_planes=True).view(B * TL * FL, C)
         fused = hip.GEMM_PRECISION != 0
         stage_grads = [None] * (2 * n)
         for k in range(n - 1, -1, -1):
@@ -1303,9 +1370,10 @@ class ConvSubsamplingFn(torch.autograd.Function):
             yin = acts[k]
             dwg = _new(C, kk * C, like=do2, zero=True)
             (dbk_buf, dbk) = grad_sink(bk)
+            ap, bp = wgrad_planes(dy, yin.view(-1, C))
             hip.gemm(dy, yin, dwg, C, kk * C, Mo, lda=C, ldb=0, ldc=kk * C, a_kmajor=True, b_kmajor=True,
                      split_k=_split_k(C, kk * C, Mo), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
-                     a_colsum=dbk_buf if fused else None)
+                     a_colsum=dbk_buf if fused else None, a_planes=ap, b_planes=bp)
             if not fused:
                 colsum(dy, out=dbk_buf)
             stage_grads[2 * k], stage_grads[2 * k + 1] = _sink_swapped(wk, dwg, C, kk, C), dbk

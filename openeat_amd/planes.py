@@ -1,0 +1,137 @@
+"""Pre-split GEMM operands (precision 6).
+
+A matrix product in the reference-precision mode is six bf16 MFMA products of three exact bf16 pieces per operand
+(csrc/oe_common.h).  Splitting fp32 -> pieces inside every consuming GEMM block costs more vector instructions than the
+matrix work itself, so tensors that feed GEMMs carry a second copy, three bf16 PLANES p0 + p1 + p2 = x, written once:
+
+* activations / gradients: by the kernel that produces them (LayerNorm forward / backward, GEMM epilogues:
+  ``c_planes``) or by one pass of ``oe_split_planes``;
+* weights: the whole parameter arena is split once per optimizer step (``ParamArena.refresh_planes``); weights outside
+  an arena are split on first use and cached by (address, version).
+
+``csrc/gemm_pl.hip`` then moves tiles global -> LDS by LDS-DMA and its loop is DMA issue, LDS reads and MFMAs only.
+Everything here is optional: an operand without planes sends the GEMM to the kernels that split in the loop.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from . import hip
+
+ENABLED = os.environ.get("OE_PLANES", "1") == "1"
+# below this many elements a tensor is not worth a split pass of its own (the decoders' 992-row activations)
+MIN_SPLIT_ELEMS = int(os.environ.get("OE_PLANES_MIN", str(1 << 19)))
+
+
+def active() -> bool:
+    return ENABLED and hip.GEMM_PRECISION == 6
+
+
+class Planes:
+    """Three bf16 planes of a (rows, cols) fp32 matrix: tensor `t` of shape (3, rows, cols) or a view into a larger buffer."""
+    __slots__ = ("t", "ptr", "stride", "ld", "rows", "cols")
+
+    def __init__(self, t: torch.Tensor, ptr: int, stride: int, ld: int, rows: int, cols: int):
+        self.t, self.ptr, self.stride, self.ld, self.rows, self.cols = t, ptr, stride, ld, rows, cols
+
+
+def alloc(rows: int, cols: int, device) -> Planes:
+    t = torch.empty(3, rows, cols, dtype=torch.bfloat16, device=device)
+    return Planes(t, t.data_ptr(), rows * cols, cols, rows, cols)
+
+
+# ---- activations: registry by device address ----------------------------------------------------------------------------
+# An entry keeps its source tensor alive, so the address cannot be handed to another tensor while the entry exists; the
+# registry is emptied when a new step starts (ops.predrop_clear's call sites).  Planes that backward needs are kept by the
+# autograd functions themselves (ctx), not looked up again.
+from collections import OrderedDict
+
+_REG: "OrderedDict[int, tuple]" = OrderedDict()
+_NO_GRAD_KEEP = 64     # inference: a tensor's planes are consumed right after they are made - keep a short FIFO only
+
+
+def clear():
+    _REG.clear()
+
+
+def _dense2d(t: torch.Tensor) -> bool:
+    return t.dim() == 2 and t.stride(1) == 1 and t.stride(0) == t.shape[1] and t.shape[1] % 8 == 0 and t.data_ptr() % 16 == 0
+
+
+def register(t2d: torch.Tensor, pl: Planes):
+    _REG[t2d.data_ptr()] = (pl, t2d, t2d._version)
+    if not torch.is_grad_enabled():
+        while len(_REG) > _NO_GRAD_KEEP:
+            _REG.popitem(last=False)
+
+
+def lookup(t2d: torch.Tensor) -> Optional[Planes]:
+    e = _REG.get(t2d.data_ptr())
+    if e is None:
+        return None
+    pl, src, ver = e
+    if src._version != ver or not _dense2d(t2d) or pl.rows * pl.cols != t2d.numel():
+        return None
+    if pl.rows != t2d.shape[0]:          # another dense 2-D view of the same memory: same planes, other row length
+        return Planes(pl.t, pl.ptr, pl.stride, t2d.shape[1], t2d.shape[0], t2d.shape[1])
+    return pl
+
+
+def of(t2d: torch.Tensor, make: bool = True, force: bool = False) -> Optional[Planes]:
+    """Planes of a dense (rows, cols) fp32 CUDA tensor: the producer's, or (make) one oe_split_planes pass."""
+    if not active() or not _dense2d(t2d):
+        return None
+    pl = lookup(t2d)
+    if pl is not None or not make:
+        return pl
+    if t2d.numel() < MIN_SPLIT_ELEMS and not force:
+        return None
+    pl = alloc(t2d.shape[0], t2d.shape[1], t2d.device)
+    hip.call("oe_split_planes", t2d, t2d.stride(0), t2d.shape[0], t2d.shape[1], pl.t, pl.ld, pl.stride)
+    register(t2d, pl)
+    return pl
+
+
+def new_output(out2d: torch.Tensor) -> Optional[Planes]:
+    """Planes buffer for a GEMM / LayerNorm output about to be written (registered now; the producer fills it)."""
+    if not active() or not _dense2d(out2d):
+        return None
+    pl = alloc(out2d.shape[0], out2d.shape[1], out2d.device)
+    register(out2d, pl)
+    return pl
+
+
+# ---- weights ----------------------------------------------------------------------------------------------------------
+_WCACHE = {}       # data_ptr -> (Planes, weight tensor, version)
+_WCACHE_MAX = 4096
+
+
+def weight(w2d: torch.Tensor) -> Optional[Planes]:
+    """Planes of a weight matrix (rows, cols) with row stride `w2d.stride(0)`: a window of the arena's planes, or a cached split."""
+    if not active() or w2d.dim() != 2 or w2d.stride(1) != 1 or w2d.stride(0) % 8 or w2d.shape[1] % 8:
+        return None
+    from . import arena as _arena
+    a = _arena.active()
+    ptr = w2d.data_ptr()
+    if a is not None and a.planes is not None:
+        off = (ptr - a.flat.data_ptr()) // 4
+        if 0 <= off < a.numel and ptr % 32 == 0:
+            a.ensure_planes()
+            return Planes(a.planes, a.planes.data_ptr() + 2 * off, a.planes_stride, w2d.stride(0), w2d.shape[0], w2d.shape[1])
+    if ptr % 16 or w2d.stride(0) != w2d.shape[1]:
+        return None
+    e = _WCACHE.get(ptr)
+    if e is not None and e[2] == w2d._version and e[0].rows == w2d.shape[0] and e[0].cols == w2d.shape[1] and not torch.is_grad_enabled():
+        return e[0]
+    # training outside an arena: parameters change through optimizers whose in-place updates bump the version, but raw
+    # kernels do not - only trust the cache under no_grad (decode / eval), else split afresh
+    pl = alloc(w2d.shape[0], w2d.shape[1], w2d.device)
+    hip.call("oe_split_planes", w2d, w2d.stride(0), w2d.shape[0], w2d.shape[1], pl.t, pl.ld, pl.stride)
+    if not torch.is_grad_enabled():
+        if len(_WCACHE) >= _WCACHE_MAX:
+            _WCACHE.clear()
+        _WCACHE[ptr] = (pl, w2d, w2d._version)
+    return pl

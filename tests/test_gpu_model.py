@@ -27,18 +27,24 @@ from openeat_amd.modules.swish import Swish  # noqa: E402
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=[0, 6, 3], ids=["fp32-mfma", "bf16x6-mfma", "bf16x3-mfma"])
+@pytest.fixture(autouse=True, params=[0, 6, 60, 3], ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x3-mfma"])
 def gemm_precision(request):
     """Every test of this file runs three times: with exact-fp32 matrix products (oe_gemm_args.precision 0: gemm_f32_kernel
     and the fp32 attention variants), in the arithmetic bench.py's headline times (precision 6: three exact bf16 pieces per
     operand, six products - within one fp32 rounding of the fp32 product; the SAME tolerances as precision 0, nothing
     widened) and in the narrower three-term mode (precision 3, an extra key of the bench line: absolute floor widened, see
     close()) - same goldens, same bit-exact id checks."""
-    from openeat_amd import hip
-    old = hip.GEMM_PRECISION
-    hip.GEMM_PRECISION = request.param
+    # "planes-forced": precision 6 with every GEMM operand pre-split however small (planes.MIN_SPLIT_ELEMS = 0), so that the
+    # goldens' tiny shapes go through oe_split_planes, the producers' planes outputs and gemm_pl.hip wherever they qualify
+    from openeat_amd import hip, planes
+    old, old_min = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS
+    hip.GEMM_PRECISION = 6 if request.param == 60 else request.param
+    if request.param == 60:
+        planes.MIN_SPLIT_ELEMS = 0
+    planes.clear()
     yield request.param
-    hip.GEMM_PRECISION = old
+    hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS = old, old_min
+    planes.clear()
 
 
 def load_into(module, sd, prefix):

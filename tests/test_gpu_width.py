@@ -62,8 +62,8 @@ def _setup():
     return _CACHE
 
 
-@pytest.mark.parametrize("prec,fused_ffn", [(0, False), (6, False), (3, False), (3, True)],
-                         ids=["fp32-mfma", "bf16x6-mfma", "bf16x3-mfma", "bf16x3-mfma-fused-ffn"])
+@pytest.mark.parametrize("prec,fused_ffn", [(0, False), (6, False), (60, False), (3, False), (3, True)],
+                         ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x3-mfma", "bf16x3-mfma-fused-ffn"])
 def test_config2_width_model_matches_oracle(prec, fused_ffn):
     """fused_ffn: the one-kernel feed forward (csrc/ffn.hip) forced on at this batch's 1984 rows (by default it takes over from
     4096 rows on, i.e. at bench.py's batch) - the same tolerances end to end."""
@@ -74,8 +74,11 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
     model = ASRModel(80, V, **CONF)
     model.load_state_dict(c["sd"])
     model = model.to(DEV).eval()
-    old = hip.GEMM_PRECISION
-    hip.GEMM_PRECISION = prec
+    from openeat_amd import planes
+    old, old_pmin = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS
+    hip.GEMM_PRECISION = 6 if prec == 60 else prec
+    if prec == 60:
+        planes.MIN_SPLIT_ELEMS = 0               # every operand pre-split: gemm_pl.hip wherever the shapes qualify
     try:
         loss, acc = model(c["feats"], c["nfr"], c["tgt"].to(DEV), c["tlen"].to(DEV))
         loss.backward()
@@ -83,7 +86,8 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
             greedy = model.ctc_greedy_search(c["feats"], c["nfr"])
         torch.cuda.synchronize()
     finally:
-        hip.GEMM_PRECISION = old
+        hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS = old, old_pmin
+        planes.clear()
         ops.FUSED_FFN_MIN_ROWS = old_min
         ops.FUSED_FFN_BWD = old_bwd
     assert abs(float(loss) - c["loss"]) <= 2e-4 * abs(c["loss"]), (float(loss), c["loss"])
