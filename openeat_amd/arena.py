@@ -118,15 +118,12 @@ class ParamArena:
     def activate(self):
         global _ACTIVE
         _ACTIVE = self
-        from . import planes as _planes
-        if _planes.active() and self.planes is None:
-            self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)
         return self
 
     def refresh_planes(self):
         """fp32 arena -> bf16 planes (one launch over all parameters; capturable)."""
         from . import hip, planes as _planes
-        if not _planes.active():
+        if not _planes.active():          # only the general Linear plumbing reads weight planes (the conv path splits its re-laid copies)
             return
         if self.planes is None:
             self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)

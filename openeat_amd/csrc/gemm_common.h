@@ -167,7 +167,9 @@ __device__ __forceinline__ float epi_value(const EpiParams& ep, float v, float a
 // once a branch separates load and use.  So the paths below keep their loads out of branches that also
 // hold stores: blocks that are interior and 16-byte aligned take straight-line code with every auxiliary
 // load of a 32x32 tile issued ahead of the tile's stores; only ragged-edge blocks take the bounds-checked path.
-template <int TM, int TN>
+// WM = waves along M (2: the 256-thread kernels; 4: gemm_pl.hip's 512-thread blocks, whose lds must then hold 8 patches);
+// two waves along N always: the block tile is (32 TM WM) x (64 TN).
+template <int TM, int TN, int WM = 2>
 __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds, float* __restrict__ C, long ldc, int M, int N,
                                               long m0, long n0, const EpiParams& ep, int tile_z) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -178,7 +180,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
     const DropParams dpar = drop_params(ep.drop_p);
     const unsigned long long seed = ep.seed + (ep.seed_dev ? *ep.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const bool first_split = (tile_z == 0);
-    const bool interior = (m0 + 64 * TM <= M) && (n0 + 64 * TN <= N);          // block-uniform
+    const bool interior = (m0 + 32 * TM * WM <= M) && (n0 + 64 * TN <= N);     // block-uniform
     constexpr int EP_LD = 36;
     if (ep.atomic) {
         // split-K accumulation: atomics straight from the accumulators.  Register r of a 32x32 tile is two

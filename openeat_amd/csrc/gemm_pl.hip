@@ -101,8 +101,15 @@ __device__ __forceinline__ int pl_div_small(int k, int d, float rd, int& rem) { 
 
 // GA: A is the im2col gather of a conv forward (row-major: rows = output positions, k = (kh, kw, ci)).
 // GB: B is the im2col gather of a conv weight gradient (k-major: k = output position, columns = (kh, kw, ci)).
-template <int TM, int TN, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
-__global__ __launch_bounds__(256, (NST * 3 * (64 * TM + 64 * TN) * BK * 2 <= 80 * 1024) ? 2 : 1)
+// Block = WM x 2 waves, each TM x TN accumulator tiles of 32 x 32: block tile (32 TM WM) x (64 TN).  WM = 4 puts two waves on
+// every SIMD, so one wave's DMA issue and fragment reads run under its partner's MFMAs.
+//
+// The K-loop is ONE basic block: every iteration issues the DMA pieces of tile kt + NST - 1 (past the end of the range the
+// source pointers stop advancing: the last tile is read again into a stage nobody reads - no branch, a constant vmcnt),
+// and the pieces are placed BETWEEN the MFMA groups (a piece's issue cost hides in the matrix pipe's shadow instead of
+// standing in front of the fragment reads).
+template <int TM, int TN, int WM, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
+__global__ __launch_bounds__(WM * 128, (WM == 2 && NST * 3 * (32 * TM * WM + 64 * TN) * BK * 2 <= 80 * 1024) ? 2 : (WM == 4 ? 2 : 1))
 void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
     int tile_x, tile_y, tile_z;
     {   // XCD-aware tile order (gemm_bf16.hip)
@@ -113,15 +120,17 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
         tile_y = (swz / gx) % gy;
         tile_z = swz / (gx * gy);
     }
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int NW = WM * 2;                                       // waves per block
+    constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     static_assert(!AK || BM == 128, "k-major tiles are 128 columns wide");
     static_assert(!BKM || BN == 128, "k-major tiles are 128 columns wide");
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2;              // bytes of one plane tile
     constexpr int STAGE = 3 * (A_T + B_T);
     constexpr int PA = A_T / 1024, PB = B_T / 1024;                  // DMA pieces (1 KiB) per plane tile
-    constexpr int PTOT = 3 * (PA + PB), PPW = PTOT / 4;              // pieces per stage / per wave
-    static_assert(PTOT % 4 == 0 && A_T % 1024 == 0 && B_T % 1024 == 0, "piece count must split over four waves");
-    constexpr int LDS_BYTES = (NST * STAGE > 4 * 32 * 36 * 4) ? NST * STAGE : 4 * 32 * 36 * 4;
+    constexpr int PTOT = 3 * (PA + PB), PPW = PTOT / NW;             // pieces per stage / per wave
+    static_assert(PTOT % NW == 0 && A_T % 1024 == 0 && B_T % 1024 == 0, "piece count must split over the waves");
+    constexpr int EPI_BYTES = NW * 32 * 36 * 4;                      // gemm_epilogue: one 32 x 36 fp32 patch per wave
+    constexpr int LDS_BYTES = (NST * STAGE > EPI_BYTES) ? NST * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
     const int lane = threadIdx.x & 63;
@@ -135,7 +144,7 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
     // ---- this wave's pieces: piece g = wave * PPW + j -> (operand, plane, sub-piece)
     const __bf16* src[PPW];
     unsigned dst[PPW];             // byte offset inside a stage (wave-uniform)
-    long step[PPW];                // elements the source advances per K-tile (wave-uniform); gathers: see issue()
+    long step[PPW];                // elements the source advances per K-tile (wave-uniform); gathers: see issue_piece()
     int kpos[PPW];                 // GB pieces: output position (= k index) of this lane's row in the next tile
     bool is_ga[PPW], is_gb[PPW];
     const float rF2 = GB ? 1.0f / (float)B.F2 : 0.f, rT2 = GB ? 1.0f / (float)B.T2 : 0.f;
@@ -159,17 +168,14 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
             const int row = sub * RPP + lane / CPR, cpos = lane % CPR;
             const int csrc = cpos ^ pl_fsw<BK>(row);
             const long grow = min(x0 + row, (long)X.rows_total - 1);
-            long rb;
             if (GA && isA) {
                 const int f = (int)(grow % X.F2);
                 const long q = grow / X.F2;
                 const int t = (int)(q % X.T2);
                 const long b = q / X.T2;
-                rb = ((b * X.T1 + X.S * t) * (long)X.F1 + X.S * f) * X.C;         // k offsets are added per tile (issue)
-                src[j] = base + rb + csrc * 8;
+                src[j] = base + ((b * X.T1 + X.S * t) * (long)X.F1 + X.S * f) * X.C + csrc * 8;     // k offsets are added per tile
             } else {
-                rb = grow * X.ld;
-                src[j] = base + rb + k_begin + csrc * 8;
+                src[j] = base + grow * X.ld + k_begin + csrc * 8;
             }
             step[j] = BK;
         } else {
@@ -192,25 +198,32 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
     int ga_kh = 0, ga_rem = 0;
     if (GA) { const int seg = A.KS * A.C; ga_kh = k_begin / seg; ga_rem = k_begin - ga_kh * seg; }
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
-    auto issue = [&](int stage) {
-        const unsigned sb = lds_base + (unsigned)(stage * STAGE);
-        const long ga_off = GA ? (long)ga_kh * A.F1 * A.C + ga_rem : 0;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            if (is_ga[j]) {
-                pl_dma16(src[j] + ga_off, sb + dst[j]);
-            } else if (is_gb[j]) {
-                int f, t;
-                const int q = pl_div_small(kpos[j], B.F2, rF2, f);
-                const int b = pl_div_small(q, B.T2, rT2, t);
-                pl_dma16(src[j] + (((long)b * B.T1 + B.S * t) * B.F1 + B.S * f) * B.C, sb + dst[j]);
-                kpos[j] += BK;
-            } else {
-                pl_dma16(src[j], sb + dst[j]);
-                src[j] += step[j];
-            }
+    int tiles_issued = 0;           // tiles whose pieces have been issued so far (wave-uniform); the last one is re-issued past the end
+    unsigned stage_off = 0;         // stage the next issue writes
+    long ga_off = 0;
+    auto begin_issue = [&]() { ga_off = GA ? (long)ga_kh * A.F1 * A.C + ga_rem : 0; };
+    auto issue_piece = [&](int j) {
+        const unsigned sb = lds_base + stage_off;
+        const bool advance = tiles_issued + 1 < nk;                  // wave-uniform: a select, not a branch
+        if (is_ga[j]) {
+            pl_dma16(src[j] + ga_off, sb + dst[j]);
+        } else if (is_gb[j]) {
+            int f, t;
+            const int q = pl_div_small(kpos[j], B.F2, rF2, f);
+            const int b = pl_div_small(q, B.T2, rT2, t);
+            pl_dma16(src[j] + (((long)b * B.T1 + B.S * t) * B.F1 + B.S * f) * B.C, sb + dst[j]);
+            kpos[j] += advance ? BK : 0;
+        } else {
+            pl_dma16(src[j], sb + dst[j]);
+            src[j] += advance ? step[j] : 0;
         }
-        if (GA) { ga_rem += BK; if (ga_rem >= A.KS * A.C) { ga_rem -= A.KS * A.C; ++ga_kh; } }
+    };
+    auto end_issue = [&]() {
+        const bool advance = tiles_issued + 1 < nk;
+        if (GA && advance) { ga_rem += BK; if (ga_rem >= A.KS * A.C) { ga_rem -= A.KS * A.C; ++ga_kh; } }
+        ++tiles_issued;
+        stage_off += STAGE;
+        if (stage_off == NST * STAGE) stage_off = 0;
     };
 
     f32x16 acc[TM][TN];
@@ -228,40 +241,53 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
     for (int i = 0; i < TM; ++i) csum[i] = 0.f;
 
 #pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
-        if (t < nk) issue(t);
+    for (int t = 0; t < NST - 1; ++t) {
+        begin_issue();
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(j);
+        end_issue();
+    }
 
+    constexpr int KS = BK / 16, NG = KS * TM * TN;                   // MFMA groups (six MFMAs each) per K-tile
+    constexpr int PPG = (PPW + NG - 1) / NG;                         // pieces issued behind each of the first groups
     const int frow = lane & 31, fhalf = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt has landed once at most the younger tiles' pieces are outstanding; the barrier then (a) publishes every
-        // wave's pieces of tile kt and (b) retires all reads of tile kt-1's stage, which the next issue overwrites
-        const int younger = min(nk, kt + NST - 1) - (kt + 1);
-        if (NST >= 4 && younger >= 2) pl_wait_and_barrier<2 * PPW>();
-        else if (NST >= 3 && younger >= 1) pl_wait_and_barrier<PPW>();
-        else pl_wait_and_barrier<0>();
-        if (kt + NST - 1 < nk) issue((kt + NST - 1) % NST);
+        // tile kt has landed once at most the NST - 2 younger tiles' pieces are outstanding; the barrier then (a) publishes
+        // every wave's pieces of tile kt and (b) retires all reads of tile kt-1's stage, which this iteration's issue overwrites
+        pl_wait_and_barrier<(NST - 2) * PPW>();
         const unsigned char* at = lds + (kt % NST) * STAGE;
         const unsigned char* bt = at + 3 * A_T;
+        PlFrag fa[KS][TM], fb[KS][TN];
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            PlFrag fa[TM], fb[TN];
+        for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                if (!AK) pl_row_frag<BK>(at, A_T, wm * 32 * TM + i * 32 + frow, fhalf, ks, fa[i]);
-                else pl_col_frag(at, A_T, wm * 32 * TM + i * 32, ks, lane, fa[i]);
-                if (AK && do_csum) csum[i] = pl_frag_sum(fa[i], csum[i]);
+                if (!AK) pl_row_frag<BK>(at, A_T, wm * 32 * TM + i * 32 + frow, fhalf, ks, fa[ks][i]);
+                else pl_col_frag(at, A_T, wm * 32 * TM + i * 32, ks, lane, fa[ks][i]);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (!BKM) pl_row_frag<BK>(bt, B_T, wn * 32 * TN + j * 32 + frow, fhalf, ks, fb[j]);
-                else pl_col_frag(bt, B_T, wn * 32 * TN + j * 32, ks, lane, fb[j]);
+                if (!BKM) pl_row_frag<BK>(bt, B_T, wn * 32 * TN + j * 32 + frow, fhalf, ks, fb[ks][j]);
+                else pl_col_frag(bt, B_T, wn * 32 * TN + j * 32, ks, lane, fb[ks][j]);
             }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = oe_mma_terms<6>(fa[i], fb[j], acc[i][j]);
         }
+        begin_issue();
+        static_for<0, NG>([&](auto gi) {
+            constexpr int g = decltype(gi)::value;
+            constexpr int ks = g / (TM * TN), i = (g / TN) % TM, j = g % TN;
+            acc[i][j] = oe_mma_terms<6>(fa[ks][i], fb[ks][j], acc[i][j]);
+            if (AK && j == 0 && do_csum) csum[i] = pl_frag_sum(fa[ks][i], csum[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, PPG>([&](auto qi) {
+                constexpr int pj = g * PPG + decltype(qi)::value;
+                if constexpr (pj < PPW) issue_piece(pj);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        end_issue();
     }
+    // the surplus pieces (issued past the end of the range) must have landed before the epilogue reuses the LDS
+    pl_wait_and_barrier<0>();
     if (AK && do_csum) {
         float al = ep.alpha;
         if (ep.alpha_dev) al *= *ep.alpha_dev;
@@ -272,19 +298,32 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
             if (fhalf == 0 && row < M) atomicAdd(ep.a_colsum + row, v * al);
         }
     }
-    gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds), C, ldc, M, N, m0, n0, ep, tile_z);
+    gemm_epilogue<TM, TN, WM>(acc, reinterpret_cast<float*>(lds), C, ldc, M, N, m0, n0, ep, tile_z);
 }
 
 static long pl_launches = 0;
 extern "C" long oe_gemm_pl_launches(void) { return pl_launches; }
 
-template <int TM, int TN, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
+// dispatch knobs (tests and tools/pl_bench.py; -1 keeps a value): min_blocks = smallest grid the kernel accepts, tile =
+// forced tile (22 / 11, 0 = automatic), bk = forced K-tile of the 128 x 128 tiles (16 / 32, 0 = automatic), waves = 8 or 4
+static int pl_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static int pl_min_blocks = pl_env("OE_PL_MIN_BLOCKS", 96), pl_forced_tile = pl_env("OE_PL_TILE", 0), pl_forced_bk = pl_env("OE_PL_BK", 0),
+           pl_waves = pl_env("OE_PL_WAVES", 8);
+extern "C" int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves) {
+    if (min_blocks >= 0) pl_min_blocks = min_blocks;
+    if (tile >= 0) pl_forced_tile = tile;
+    if (bk >= 0) pl_forced_bk = bk;
+    if (waves >= 0) pl_waves = waves;
+    return 0;
+}
+
+template <int TM, int TN, int WM, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
 static int launch_pl(const PlOperand& A, const PlOperand& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep, hipStream_t st) {
     int kc = oe_cdiv(oe_cdiv(K, sk), BK) * BK;
     if (kc <= 0) kc = BK;
     const int nz = oe_cdiv(K, kc);
-    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 64 * TM);
-    hipLaunchKernelGGL((gemm_pl_kernel<TM, TN, AK, BKM, BK, NST, GA, GB>), dim3(gx * gy * nz), dim3(256), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
+    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 32 * TM * WM);
+    hipLaunchKernelGGL((gemm_pl_kernel<TM, TN, WM, AK, BKM, BK, NST, GA, GB>), dim3(gx * gy * nz), dim3(WM * 128), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm (bf16x6 planes)");
     ++pl_launches;
     return 0;
@@ -309,19 +348,39 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     if ((a_kmajor && (M % 8 || M < 8)) || (b_kmajor && (N % 8 || N < 8))) return 1;
     if (ga && (a_kmajor || b_kmajor || A.C % 32 || (A.KS * A.C) % 32)) return 1;
     if (gb && (!(a_kmajor && b_kmajor) || B.C % 8 || (B.KS * B.C) % 128 || N % 128 || K >= (1 << 24))) return 1;
-    // K-tile: 32 where the reduction is long (fewer barriers, 3 stages = 144 KiB: one block per CU), 16 otherwise (3 stages
-    // = 72 KiB: two blocks per CU overlap each other's prologue and epilogue on the short-K problems)
-    static const int forced_bk = getenv("OE_PL_BK") ? atoi(getenv("OE_PL_BK")) : 0;
-    int kc = oe_cdiv(K, sk);
-    const int bk = forced_bk ? forced_bk : (kc >= 1024 ? 32 : 16);
-    if (K % bk) return 1;
-    if (sk > 1 && oe_cdiv(oe_cdiv(K, sk), bk) * bk * (sk - 1) >= K) return 1;          // a split would be left empty
+    // Tile and K-tile.  128 x 128 x 16 with three stages (72 KiB: two blocks per CU overlap each other's prologue and epilogue
+    // on the short-K problems) while the grid still covers the chip; 128 x 128 x 32 (144 KiB, one block per CU) for long
+    // reductions; 64 x 64 x 32 (72 KiB) where 128 x 128 tiles would leave CUs idle (N = 256 outputs).  k-major tiles are 128
+    // columns wide, so a k-major operand pins its side of the tile.
+    const int forced_bk = pl_forced_bk, forced_tile = pl_forced_tile;
+    const int kc0 = oe_cdiv(K, sk);
+    const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
+    int tile = 22;
+    if (!a_kmajor && !b_kmajor && !ga && b22 < 320) tile = 11;
+    if (forced_tile) tile = forced_tile;
+    if ((a_kmajor || b_kmajor || ga) && tile != 22) return 1;
+    int bk = (tile == 22) ? (kc0 >= 1024 ? 32 : 16) : 32;
+    if (forced_bk && tile == 22) bk = forced_bk;
+    if (K % bk) { if (tile == 22 && bk == 32 && K % 16 == 0) bk = 16; else return 1; }
+    if (sk > 1 && (long)oe_cdiv(oe_cdiv(K, sk), bk) * bk * (sk - 1) >= K) return 1;          // a split would be left empty
+    // too few blocks to occupy the chip: the splitting kernels have smaller tiles and split the reduction
+    const int min_blocks = pl_min_blocks;
+    if ((long)oe_cdiv(M, tile == 22 ? 128 : 64) * oe_cdiv(N, tile == 22 ? 128 : 64) * sk < min_blocks) return 1;
+    // 128 x 128 tiles: 8 waves (4 x 2 of 32 x 64 each, two per SIMD) by default; OE_PL_WAVES=4 takes the 2 x 2 arrangement
+    const int waves = pl_waves;
 #define OE_PL(AK, BKM, GA, GB)                                                                                        \
     do {                                                                                                              \
-        if (bk == 32) return launch_pl<2, 2, AK, BKM, 32, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);              \
-        return launch_pl<2, 2, AK, BKM, 16, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);                            \
+        if (waves == 8) {                                                                                             \
+            if (bk == 32) return launch_pl<1, 2, 4, AK, BKM, 32, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);       \
+            return launch_pl<1, 2, 4, AK, BKM, 16, 4, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);                     \
+        }                                                                                                             \
+        if (bk == 32) return launch_pl<2, 2, 2, AK, BKM, 32, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);           \
+        return launch_pl<2, 2, 2, AK, BKM, 16, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st);                         \
     } while (0)
-    if (!a_kmajor && !b_kmajor) { if (ga) OE_PL(false, false, true, false); else OE_PL(false, false, false, false); }
+    if (!a_kmajor && !b_kmajor) {
+        if (tile == 11) return launch_pl<1, 1, 2, false, false, 32, 3, false, false>(a, b, C, ldc, M, N, K, sk, ep, st);
+        if (ga) OE_PL(false, false, true, false); else OE_PL(false, false, false, false);
+    }
     if (!a_kmajor && b_kmajor) OE_PL(false, true, false, false);
     if (gb) OE_PL(true, true, false, true);
     OE_PL(true, true, false, false);

@@ -1266,7 +1266,7 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
     hip.call("oe_conv_dgrad_k3s2_weights", wk, C, wcls)
     dyin = torch.empty_like(yin)
     flat_in, flat_out, flat_y = dyp.view(-1), dyin.view(-1), yin.reshape(-1)
-    dyp_pl = _planes.of(dyp.view(-1, C)) if _planes.active() else None          # pre-split mode: one pass over the padded dy
+    dyp_pl = _planes.of(dyp.view(-1, C)) if _planes.available() else None       # pre-split mode: one pass over the padded dy
     w_off = 0
     for pt in (0, 1):
         KH = 2 if pt == 0 else 1                       # window row 0 is dy row i - 1 (tap 2), row 1 is dy row i (tap 0); odd t1: tap 1
@@ -1320,12 +1320,12 @@ class ConvSubsamplingFn(torch.autograd.Function):
             hip.call("oe_swap_last2", wk, C, C, kk, wg, 0)
             yo = _new(B * To * Fo, C, like=x)
             ap = bp = cp = None
-            if _planes.active():               # pre-split mode: the NHWC activation and the re-laid weights as bf16 planes
+            if _planes.available():            # pre-split mode: the NHWC activation and the re-laid weights as bf16 planes
                 ap = _planes.of(acts[-1].view(-1, C))
                 bp = _planes.of(wg, force=True) if ap is not None else None
                 if bp is None:
                     ap = None
-                cp = _planes.new_output(yo)    # the next stage / the Linear reads it as an operand
+                cp = _planes.new_output(yo) if (k + 1 < n or _planes.active()) else None    # a next conv stage reads it as an operand
             hip.gemm(acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
                      conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A, a_planes=ap, b_planes=bp, c_planes=cp)
             dims.append((To, Fo))

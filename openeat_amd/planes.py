@@ -21,13 +21,26 @@ import torch
 
 from . import hip
 
-ENABLED = os.environ.get("OE_PLANES", "1") == "1"
+# Where operands are pre-split (measured on MI355X, tools/pl_bench.py + bench.py, profiles/r03_experiments.md):
+#   "conv" (default): the subsampling front end only - the conv1 output feeds conv2's forward gather 9/4 times over and its
+#                     weight gradient again, the padded dy feeds four parity-class input gradients: one split pass pays;
+#   "all":            every Linear of the encoder too (LayerNorm / GEMM epilogues write planes).  The GEMMs gain 10-25 %
+#                     each, but a feed-forward's (rows, ff) intermediate costs 1.5 x its fp32 bytes again as planes: a wash
+#                     at config 2 (the step as a whole measured slower), so not the default;
+#   "0":              never.
+POLICY = os.environ.get("OE_PLANES", "conv")
 # below this many elements a tensor is not worth a split pass of its own (the decoders' 992-row activations)
 MIN_SPLIT_ELEMS = int(os.environ.get("OE_PLANES_MIN", str(1 << 19)))
 
 
+def available() -> bool:
+    """Pre-split operands exist at all in the current arithmetic (explicit oe_split_planes users, the conv front end)."""
+    return POLICY != "0" and hip.GEMM_PRECISION == 6
+
+
 def active() -> bool:
-    return ENABLED and hip.GEMM_PRECISION == 6
+    """The general Linear / LayerNorm plumbing of ops.py pre-splits its operands."""
+    return POLICY == "all" and hip.GEMM_PRECISION == 6
 
 
 class Planes:
@@ -82,7 +95,7 @@ def lookup(t2d: torch.Tensor) -> Optional[Planes]:
 
 def of(t2d: torch.Tensor, make: bool = True, force: bool = False) -> Optional[Planes]:
     """Planes of a dense (rows, cols) fp32 CUDA tensor: the producer's, or (make) one oe_split_planes pass."""
-    if not active() or not _dense2d(t2d):
+    if not available() or not _dense2d(t2d):
         return None
     pl = lookup(t2d)
     if pl is not None or not make:
@@ -97,7 +110,7 @@ def of(t2d: torch.Tensor, make: bool = True, force: bool = False) -> Optional[Pl
 
 def new_output(out2d: torch.Tensor) -> Optional[Planes]:
     """Planes buffer for a GEMM / LayerNorm output about to be written (registered now; the producer fills it)."""
-    if not active() or not _dense2d(out2d):
+    if not available() or not _dense2d(out2d):
         return None
     pl = alloc(out2d.shape[0], out2d.shape[1], out2d.device)
     register(out2d, pl)
@@ -111,7 +124,7 @@ _WCACHE_MAX = 4096
 
 def weight(w2d: torch.Tensor) -> Optional[Planes]:
     """Planes of a weight matrix (rows, cols) with row stride `w2d.stride(0)`: a window of the arena's planes, or a cached split."""
-    if not active() or w2d.dim() != 2 or w2d.stride(1) != 1 or w2d.stride(0) % 8 or w2d.shape[1] % 8:
+    if not available() or w2d.dim() != 2 or w2d.stride(1) != 1 or w2d.stride(0) % 8 or w2d.shape[1] % 8:
         return None
     from . import arena as _arena
     a = _arena.active()

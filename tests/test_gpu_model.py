@@ -37,13 +37,15 @@ def gemm_precision(request):
     # "planes-forced": precision 6 with every GEMM operand pre-split however small (planes.MIN_SPLIT_ELEMS = 0), so that the
     # goldens' tiny shapes go through oe_split_planes, the producers' planes outputs and gemm_pl.hip wherever they qualify
     from openeat_amd import hip, planes
-    old, old_min = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS
+    old, old_min, old_pol = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY
     hip.GEMM_PRECISION = 6 if request.param == 60 else request.param
     if request.param == 60:
-        planes.MIN_SPLIT_ELEMS = 0
+        planes.MIN_SPLIT_ELEMS, planes.POLICY = 0, "all"
+        hip.lib().oe_gemm_pl_config(0, -1, -1, -1)
     planes.clear()
     yield request.param
-    hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS = old, old_min
+    hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY = old, old_min, old_pol
+    hip.lib().oe_gemm_pl_config(96, 0, 0, 8)
     planes.clear()
 
 

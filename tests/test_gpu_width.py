@@ -75,10 +75,11 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
     model.load_state_dict(c["sd"])
     model = model.to(DEV).eval()
     from openeat_amd import planes
-    old, old_pmin = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS
+    old, old_pmin, old_pol = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY
     hip.GEMM_PRECISION = 6 if prec == 60 else prec
     if prec == 60:
-        planes.MIN_SPLIT_ELEMS = 0               # every operand pre-split: gemm_pl.hip wherever the shapes qualify
+        planes.MIN_SPLIT_ELEMS, planes.POLICY = 0, "all"   # every operand pre-split: gemm_pl.hip wherever the shapes qualify
+        hip.lib().oe_gemm_pl_config(0, -1, -1, -1)
     try:
         loss, acc = model(c["feats"], c["nfr"], c["tgt"].to(DEV), c["tlen"].to(DEV))
         loss.backward()
@@ -86,7 +87,8 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
             greedy = model.ctc_greedy_search(c["feats"], c["nfr"])
         torch.cuda.synchronize()
     finally:
-        hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS = old, old_pmin
+        hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY = old, old_pmin, old_pol
+        hip.lib().oe_gemm_pl_config(96, 0, 0, 8)
         planes.clear()
         ops.FUSED_FFN_MIN_ROWS = old_min
         ops.FUSED_FFN_BWD = old_bwd
