@@ -1,6 +1,6 @@
 // Kaldi-compatible log-mel filterbank on device, one wavefront per frame:
 // framing (snip_edges) -> *scale -> DC removal -> pre-emphasis -> povey window ->
-// 512-point FFT in LDS (Stockham radix-2) -> power spectrum -> triangular mel
+// power-of-two FFT in LDS (Stockham radix-2; 512 points for 25 ms @ 16 kHz) -> power spectrum -> triangular mel
 // filters -> log(max(., eps)) [-> global CMVN].  Plus per-utterance mean/std
 // normalisation.  Replaces the torchaudio.compliance.kaldi.fbank call of
 // /root/reference/openeat/dataset/dataset.py:93-100 and
@@ -10,8 +10,8 @@
 #include "oe_common.h"
 #include "../../include/openeat_hip.h"
 
-#define FB_NFFT 512
 #define FB_WAVES 4
+#define FB_MAX_NFFT 1024      // window <= 1024 samples (dataset.py:93-100 passes the corpus's sample_frequency: 8 kHz -> 256 points)
 
 // Each wave works on its own pair of LDS buffers, so the stages are ordered by a wave-level fence (the wave's LDS
 // operations complete in order; s_waitcnt makes its writes visible to its own later reads) - a block barrier would make
@@ -21,6 +21,7 @@
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        \
         __builtin_amdgcn_wave_barrier();                          \
     } while (0)
+template <int FB_NFFT>
 __global__ __launch_bounds__(64 * FB_WAVES) void fbank_kernel(const float* __restrict__ wav, const int* __restrict__ nsamples,
                                                               int B, long wav_stride, int Tmax, int win, int hop, int n_mel,
                                                               float scale, float preemph, const float* __restrict__ window,
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank_kernel(const float* __res
         Bf[i] = make_float2(v, 0.f);
     }
     FB_WAVE_SYNC();
-    // ---- 512-point FFT, Stockham autosort radix-2: Bf -> A -> Bf ...
+    // ---- FB_NFFT-point FFT, Stockham autosort radix-2: Bf -> A -> Bf ...
     float2* s0 = Bf;
     float2* s1 = A;
 #pragma unroll 1
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(64 * FB_WAVES) void fbank_kernel(const float* __res
         FB_WAVE_SYNC();
         float2* tmp = s0; s0 = s1; s1 = tmp;
     }
-    // result in s0; power spectrum of bins 0..256 into s1[].x
+    // result in s0; power spectrum of bins 0..FB_NFFT/2 into s1[].x
     for (int i = lane; i <= FB_NFFT / 2; i += 64) {
         const float2 c = s0[i];
         s1[i].x = c.x * c.x + c.y * c.y;
@@ -126,13 +127,16 @@ extern "C" int oe_fbank_dither(const float* wav, const int* nsamples, int B, lon
                                const int* mel_off, const float* mel_w, float floor_eps, const float* cmvn_mean,
                                const float* cmvn_istd, float dither, unsigned long long seed, float* out, void* stream) {
     OE_REQUIRE(wav && window && twiddle && mel_start && mel_off && mel_w && out, "oe_fbank: null pointer");
-    OE_REQUIRE(B > 0 && Tmax > 0 && win > 0 && win <= FB_NFFT && hop > 0 && n_mel > 0, "oe_fbank: bad shape (window must be <= %d samples)", FB_NFFT);
+    OE_REQUIRE(B > 0 && Tmax > 0 && win > 0 && win <= FB_MAX_NFFT && hop > 0 && n_mel > 0, "oe_fbank: bad shape (window must be <= %d samples)", FB_MAX_NFFT);
     OE_REQUIRE(nsamples || wav_stride >= (long)(Tmax - 1) * hop + win, "oe_fbank: Tmax frames do not fit in wav_stride samples");
     OE_REQUIRE((cmvn_mean == nullptr) == (cmvn_istd == nullptr), "oe_fbank: cmvn mean/istd must come together");
     const long frames = (long)B * Tmax;
-    hipLaunchKernelGGL(fbank_kernel, dim3(oe_cdiv(frames, FB_WAVES)), dim3(64 * FB_WAVES), 0, (hipStream_t)stream, wav, nsamples,
-                       B, wav_stride, Tmax, win, hop, n_mel, scale, preemph, window, twiddle, mel_start, mel_off, mel_w, floor_eps,
-                       cmvn_mean, cmvn_istd, out, dither, seed);
+    // FFT length = the window rounded up to a power of two (kaldi's round_to_power_of_two); `twiddle` holds its nfft / 2 factors
+#define FB_LAUNCH(NF) hipLaunchKernelGGL(fbank_kernel<NF>, dim3(oe_cdiv(frames, FB_WAVES)), dim3(64 * FB_WAVES), 0, (hipStream_t)stream, wav, nsamples, \
+                       B, wav_stride, Tmax, win, hop, n_mel, scale, preemph, window, twiddle, mel_start, mel_off, mel_w, floor_eps,                  \
+                       cmvn_mean, cmvn_istd, out, dither, seed)
+    if (win <= 128) FB_LAUNCH(128); else if (win <= 256) FB_LAUNCH(256); else if (win <= 512) FB_LAUNCH(512); else FB_LAUNCH(1024);
+#undef FB_LAUNCH
     OE_LAUNCH_CHECK("fbank");
     return 0;
 }

@@ -49,6 +49,7 @@ class TrainEngine:
         self._cache: "OrderedDict[tuple, Optional[tuple]]" = OrderedDict()
         self._pool = None
         self.cache_hits = self.cache_misses = 0
+        self.cache_uncapturable = 0              # shapes whose capture was refused: they run eagerly (step_cached warns once per shape)
 
     def _install_overlap_hooks(self):
         """Start the gradient all-reduce of the arena tail whose gradients are final while backward is still running:
@@ -291,8 +292,20 @@ class TrainEngine:
             try:
                 self.capture(batch, pool=self._pool, _warm=True)
                 rec = (self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep)
-            except Exception:                    # noqa: BLE001 - whatever the capture objected to (capture() has cleaned up after itself)
-                rec = None                       # this shape does not capture: it keeps running eagerly
+            except Exception as e:               # noqa: BLE001 - capture() has cleaned up after itself
+                # A shape that does not capture keeps running eagerly (~1.7x slower at config 2) - never silently: warn once
+                # per shape and count it.  What is NOT a property of the shape is re-raised: a fork that never rejoined is a
+                # bug in the step's stream handling, a HIP / launch error is a broken device state.
+                msg = f"{type(e).__name__}: {e}"
+                if ("had not rejoined" in msg or "HIP error" in msg or "hipError" in msg or "CUDA error" in msg or "launch failed" in msg
+                        or isinstance(e, (torch.cuda.OutOfMemoryError, MemoryError))):
+                    self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
+                    raise
+                import warnings
+                self.cache_uncapturable += 1
+                warnings.warn(f"TrainEngine.step_cached: batch shape {[tuple(v.shape) for v in batch.values()]} does not capture "
+                              f"({msg}); it will run eagerly every time", RuntimeWarning, stacklevel=2)
+                rec = None
             self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
             self._cache[key] = rec
             while len(self._cache) > max(1, max_graphs):

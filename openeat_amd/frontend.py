@@ -21,9 +21,9 @@ class Fbank:
         self.n_mel = num_mel_bins
         self.win = int(sample_rate * frame_length_ms * 0.001)
         self.hop = int(sample_rate * frame_shift_ms * 0.001)
-        self.nfft = 1 << (self.win - 1).bit_length()
-        if self.nfft != 512:
-            raise NotImplementedError("the fbank kernel is specialised for a 512-point FFT (25 ms @ 16 kHz)")
+        self.nfft = max(128, 1 << (self.win - 1).bit_length())    # kaldi: round_to_power_of_two (the kernel's smallest FFT is 128)
+        if self.nfft > 1024:
+            raise NotImplementedError("the fbank kernel takes windows of up to 1024 samples (64 ms @ 16 kHz)")
         self.preemph, self.scale = preemph, scale
         # tables, built once on the host with the kaldi/torchaudio float32 formulas
         window = torch.hann_window(self.win, periodic=False, dtype=torch.float32).pow(0.85)

@@ -29,10 +29,20 @@ class ConvolutionModule(nn.Module):
                 cache: torch.Tensor = torch.zeros((0, 0, 0)), residual: torch.Tensor = None, out_dropout: float = 0.0,
                 input_masked: bool = False) -> torch.Tensor:
         """x (B,T,C); mask_pad (B,1,T) non-zero = real frame, empty (the reference's default, convolution.py:75) = no
-        mask.  (The streaming ``cache`` of the causal variant is not part of the training/offline path: a non-empty one
-        is refused.)"""
-        if cache is not None and cache.numel() > 0:
-            raise NotImplementedError("streaming cache is outside the accelerated path")
+        mask.  cache (B,C,lorder), causal variant only (convolution.py:92-104): the previous chunk's last `lorder` input
+        frames stand where the zero padding would; the module then runs on [cache; x] and the first lorder outputs - whose
+        windows reach into the (second) padding - are dropped: the remaining T outputs see exactly the frames the reference's
+        `torch.cat((cache, x), dim=2)` gives them."""
+        if cache is not None and cache.numel() > 0 and self.lorder > 0:
+            assert cache.size(0) == x.size(0) and cache.size(1) == x.size(2)        # equal batch, equal channel (convolution.py:99-100)
+            B, T, _ = x.shape
+            if mask_pad is not None and mask_pad.numel() > 0:                          # the reference masks x before the concatenation
+                x = x.masked_fill(~mask_pad.to(torch.bool).transpose(1, 2), 0.0)
+                mask_pad = torch.cat((torch.ones(B, 1, cache.size(2), dtype=mask_pad.dtype, device=mask_pad.device), mask_pad), dim=2)
+            xc = torch.cat((cache.transpose(1, 2).to(x.dtype), x), dim=1).contiguous()
+            res = None if residual is None else torch.cat((residual.new_zeros(B, cache.size(2), residual.size(2)), residual), dim=1)
+            y = self.forward(xc, mask_pad, torch.zeros((0, 0, 0)), res, out_dropout, input_masked=False)
+            return y[:, cache.size(2):]
         rowmask = None
         if mask_pad is not None and mask_pad.numel() > 0:
             m = mask_pad if mask_pad.dtype == torch.uint8 else mask_pad.to(torch.uint8)

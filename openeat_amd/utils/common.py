@@ -100,6 +100,13 @@ def log_add(args: List[float]) -> float:
     return top + math.log(sum(math.exp(a - top) for a in args))
 
 
+def get_subsample(config):
+    """common.py:176-184: the input layer's frame-rate reduction."""
+    input_layer = config["encoder_conf"]["input_layer"]
+    assert input_layer in ["conv2d", "conv2d6", "conv2d8"]
+    return {"conv2d": 4, "conv2d6": 6, "conv2d8": 8}[input_layer]
+
+
 def get_activation(act):
     """common.py:160-173 (same table; unknown names raise KeyError as there)."""
     from openeat_amd.modules.swish import Swish

@@ -301,14 +301,18 @@ def relpos_mha(sd, pfx: str, h: int, x: Tensor, mask: Optional[Tensor], pos_emb:
     return _attend(sd, pfx, v, scores, mask, p_drop, training)
 
 
-def conv_module(sd, pfx: str, cfg: Config, x: Tensor, mask_pad: Tensor, act) -> Tensor:
-    """modules/convolution.py:72-120 (LayerNorm variant, eps 1e-5)."""
+def conv_module(sd, pfx: str, cfg: Config, x: Tensor, mask_pad: Tensor, act, cache: Optional[Tensor] = None) -> Tensor:
+    """modules/convolution.py:72-120 (LayerNorm variant, eps 1e-5).  cache (B, C, K-1), causal only (:92-104): the previous
+    chunk's last input frames in place of the left zero padding."""
     K = cfg.cnn_module_kernel
     y = x.transpose(1, 2)
     if mask_pad.size(2) > 0:
         y = y.masked_fill(~mask_pad, 0.0)
     if cfg.causal:
-        y = F.pad(y, (K - 1, 0), "constant", 0.0)
+        if cache is None or cache.size(2) == 0:
+            y = F.pad(y, (K - 1, 0), "constant", 0.0)
+        else:
+            y = torch.cat((cache, y), dim=2)
     y = F.conv1d(y, sd[pfx + ".pointwise_conv1.weight"], sd[pfx + ".pointwise_conv1.bias"])
     y = F.glu(y, dim=1)
     y = F.conv1d(y, sd[pfx + ".depthwise_conv.weight"], sd[pfx + ".depthwise_conv.bias"],

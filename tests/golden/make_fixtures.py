@@ -165,6 +165,23 @@ def f4_conv_module():
                       "out": {"y": y}, "grad": {**grads_of(m, "conv."), "x": x.grad}})
 
 
+def f24_conv_module_cache():
+    """The causal conv module fed chunk by chunk: `cache` = the previous chunk's last lorder input frames
+    (convolution.py:92-104).  Stored: the second chunk's output and gradients with the first chunk's tail as cache."""
+    torch.manual_seed(124)
+    m = ConvolutionModule(32, 15, Swish(), True)
+    randomize(m, 24)
+    B, T = 3, 19
+    x = torch.randn(B, T, 32, requires_grad=True)
+    cache = torch.randn(B, 32, 14)                    # (batch, channel, lorder)
+    mask = ragged_mask([19, 11, 4], T)
+    y = m(x * 1.0, mask, cache)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    save("f24_conv_module_cache", **{"in": {"x": x, "mask": mask, "cache": cache, "w": w}, "sd": sd_of(m, "conv."),
+                                     "out": {"y": y}, "grad": {**grads_of(m, "conv."), "x": x.grad}})
+
+
 def _encoder(conformer, cmvn, seed, blocks=2, d=32):
     torch.manual_seed(seed)
     gc = None
@@ -563,4 +580,4 @@ if __name__ == "__main__":
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
         f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations(); f20_e2e_adapters(); f21_encoder_conv2d6()
-        f22_api_signatures(); f23_e2e_nonzero_accuracy()
+        f22_api_signatures(); f23_e2e_nonzero_accuracy(); f24_conv_module_cache()

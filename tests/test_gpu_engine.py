@@ -47,6 +47,24 @@ def test_fbank_and_utt_norm_match_oracle():
     np.testing.assert_allclose(f3[0].cpu().numpy(), ((feats[0].cpu() - mean) * istd).numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("rate,frame_ms,n_mel", [(8000.0, 25.0, 40), (16000.0, 20.0, 80), (16000.0, 32.0, 64), (16000.0, 50.0, 80), (8000.0, 10.0, 23)])
+def test_fbank_other_sample_rates_and_frame_lengths(rate, frame_ms, n_mel):
+    """dataset.py:93-100 passes the corpus's sample_frequency: 8 kHz telephone speech is a 200-sample window on a 256-point
+    FFT; other frame lengths give 128 / 512 / 1024 points (kaldi rounds the window up to a power of two)."""
+    torch.manual_seed(31)
+    n = int(rate * 1.3)
+    wav = (torch.rand(2, n) - 0.5) * 0.8
+    lens = [n, int(0.61 * n)]
+    fb = Fbank(n_mel, sample_rate=rate, frame_length_ms=frame_ms, device=DEV)
+    feats, nfr = fb(wav.to(DEV), torch.tensor(lens, device=DEV))
+    torch.cuda.synchronize()
+    for b, ln in enumerate(lens):
+        ref = FB.fbank(wav[b, :ln], num_mel_bins=n_mel, sample_rate=rate, frame_length_ms=frame_ms)
+        assert int(nfr[b]) == ref.shape[0]
+        np.testing.assert_allclose(feats[b, : ref.shape[0]].cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-3)
+        assert torch.all(feats[b, ref.shape[0]:] == 0)
+
+
 def tiny(seed=0, dropout=0.0):
     torch.manual_seed(seed)
     return ASRModel(80, 40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32,
@@ -320,6 +338,37 @@ def test_step_cached_replays_one_graph_per_batch_shape():
     for g, r in zip(got3, ref):
         assert abs(g - r) < 2e-4 * abs(r) + 1e-4
     check_updates(m3.state_dict(), m1.state_dict(), None, steps=len(seq))
+
+
+def test_step_cached_reports_shapes_that_do_not_capture():
+    """A capture refusal leaves the shape on the eager path WITH a warning and a counter (once per shape); a fork that never
+    rejoined or a device error is not a property of the shape and is re-raised."""
+    import warnings
+    m = tiny(seed=33).to(DEV).train()
+    e = TrainEngine(m, lr=1e-3, grad_clip=5.0)
+    b = batch_of(seed=50, B=2, T=83, L=6)
+    real_capture = e.capture
+    try:
+        def refuse(*a, **k):
+            raise RuntimeError("operation not permitted when stream is capturing")
+        e.capture = refuse
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            l1 = float(e.step_cached(b)[0])                       # first sight: eager step + refused capture
+            l2 = float(e.step_cached(b)[0])                       # known-uncapturable shape: eager, no second warning
+        assert e.cache_uncapturable == 1 and sum("does not capture" in str(x.message) for x in w) == 1
+        assert l2 < l1 and e.cache_hits == 0
+
+        def broken(*a, **k):
+            raise RuntimeError("TrainEngine.capture: 1 forked stream(s) had not rejoined the capturing stream at the end of the step")
+        e.capture = broken
+        b2 = batch_of(seed=51, B=3, T=59, L=5)
+        with pytest.raises(RuntimeError, match="had not rejoined"):
+            e.step_cached(b2)
+    finally:
+        e.capture = real_capture
+        e.arena.deactivate()
+        ops.set_seed_device_counter(None)
 
 
 @pytest.mark.parametrize("parallel", [False, True])

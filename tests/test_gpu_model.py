@@ -131,6 +131,18 @@ def test_f04_conv_module(name, causal):
     check_param_grads(m, g["grad"], "conv.")
 
 
+def test_f24_conv_module_with_streaming_cache():
+    """The causal module with the reference's `cache` argument (convolution.py:92-104), output and every gradient."""
+    g = load_golden("f24_conv_module_cache")
+    m = load_into(ConvolutionModule(32, 15, Swish(), True), g["sd"], "conv.")
+    x = g["in"]["x"].to(DEV).requires_grad_()
+    y = m(x, g["in"]["mask"].to(DEV), g["in"]["cache"].to(DEV))
+    close(y, g["out"]["y"], msg="y")
+    (y * g["in"]["w"].to(DEV)).sum().backward()
+    close(x.grad, g["grad"]["x"], rtol=1e-3, atol=2e-4, msg="dx")
+    check_param_grads(m, g["grad"], "conv.")
+
+
 def build_encoder(name, sd):
     conformer = "conformer" in name
     gc = None

@@ -87,6 +87,19 @@ def test_f04_conv_module(name, causal):
     torch.testing.assert_close(x.grad, g["grad"]["x"], **TOL)
 
 
+def test_f24_conv_module_with_streaming_cache():
+    """convolution.py:92-104: the previous chunk's last lorder input frames stand where the causal zero padding would."""
+    g = load_golden("f24_conv_module_cache")
+    sd = req(g["sd"])
+    x = g["in"]["x"].clone().requires_grad_()
+    cfg = O.Config(d_model=32, cnn_module_kernel=15, causal=True)
+    y = O.conv_module(sd, "conv", cfg, x, g["in"]["mask"], O._act("swish"), cache=g["in"]["cache"])
+    torch.testing.assert_close(y, g["out"]["y"], **TOL)
+    (y * g["in"]["w"]).sum().backward()
+    check_grads(sd, g["grad"])
+    torch.testing.assert_close(x.grad, g["grad"]["x"], **TOL)
+
+
 ENC_CFGS = {
     "f06_encoder_conformer": dict(pos_enc_layer_type="rel_pos", activation_type="swish", macaron_style=True,
                                   use_cnn_module=True, has_cmvn=False),
