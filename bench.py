@@ -97,6 +97,45 @@ def cpu_baseline(B, seconds, L, steps):
                       f"timed steps, median step {med:.2f} s (BASELINE.md section 3 protocol); threads = this box's CPU share, capped at 16"}
 
 
+def decode_cpu_baseline(model, lm, n_utt, seconds, beam, lm_weight):
+    """The oracle's attention rescoring (oracle/asr.py: the reference's one-utterance algorithm, asr_model.py:418-534, incl. the
+    pure-Python prefix recursion of :359-396) timed on this box's host cores on a bounded sample: n_utt utterances of the decode
+    workload, fbank + per-utterance norm + encoder + prefix beam + bi-decoder + LM + scoring, one utterance at a time as the
+    reference decodes.  RTF = wall seconds / audio seconds."""
+    from oracle import asr as O
+    from oracle import fbank as FB
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("OE_CPU_BASELINE_THREADS", "16"))))
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    cfg = O.Config(input_size=80, vocab_size=V, **MODEL_CONF)
+    lm_sd = {k: v.detach().cpu().clone() for k, v in lm.state_dict().items()}
+    lm_cfg = O.Config(vocab_size=V, macaron_style=False, use_cnn_module=False, pos_enc_layer_type="abs_pos", encoder_num_blocks=6,
+                      d_model=256, attention_heads=4, linear_units=1024)
+    g = torch.Generator().manual_seed(123)
+    wav = (torch.rand(n_utt, int(16000 * seconds), generator=g) - 0.5)          # the first utterances of the GPU run's batch
+    times, lens = [], []
+    with torch.no_grad():
+        for b in range(n_utt):
+            t0 = time.perf_counter()
+            feats = FB.utt_normalize(FB.fbank(wav[b])).unsqueeze(0)
+            flen = torch.tensor([feats.shape[1]], dtype=torch.int32)
+            hyp, _, _ = O.attention_rescoring(sd, cfg, feats, flen, beam, 0.5, 0.3, lm=(lm_sd, lm_cfg), lm_weight=lm_weight)
+            times.append(time.perf_counter() - t0)
+            lens.append(len(hyp))
+            log(f"  cpu decode utterance {b}: {times[-1]:.1f} s, {lens[-1]} tokens")
+    wall = sum(times[1:]) if n_utt > 1 else times[0]                             # the first utterance warms the thread pool up
+    n = max(n_utt - 1, 1)
+    return {"rtf": wall / (n * seconds), "unit": "wall s / audio s", "cores": cores, "kind": "port",
+            "sample": f"{n} utterances x {seconds:g} s (after 1 warm-up utterance) of the GPU run's batch, one at a time as the reference "
+                      f"decodes (asr_model.py:444 asserts batch 1): fbank + norm + encoder + Python prefix beam {beam} + bi-decoder "
+                      "+ 6-layer LM + scoring, ctc 0.5 / reverse 0.3 / lm " + f"{lm_weight}; threads = this box's CPU share, capped at 16",
+            "mean_best_len": sum(lens) / len(lens)}
+
+
 def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3, lm=None, lm_weight=0.0):
     """BASELINE.json configs[3]: attention-rescoring decode of n_utt synthetic utterances on one GPU
     (ctc_weight 0.5, reverse_weight 0.3 as in examples/aishell/run.sh:69-72; LM = the build-defined 6-layer d=256
@@ -128,6 +167,7 @@ def decode_rtf(model, fb, utt_norm, n_utt, seconds, beam, dev, reps=3, lm=None, 
     _ops.PARALLEL_DECODERS, _ops.POS_PROJ_AHEAD = forks
     best = min(times)
     return {"rtf": best / (n_utt * seconds), "wall_s": best, "utterances": n_utt, "seconds_each": seconds, "beam": beam,
+            "hip_graph": os.environ.get("OE_BENCH_DECODE_GRAPHS", "1") == "1",      # both stages replayed from per-shape graphs (the library default is eager)
             "ctc_weight": 0.5, "reverse_weight": 0.3,
             "lm": None if lm is None else "6-layer d=256 h=4 ff=1024 Transformer LM (seeded init), shallow fusion", "lm_weight": lm_weight,
             "mean_best_len": sum(len(h) for h in hyps) / len(hyps),
@@ -165,6 +205,7 @@ def main():
     ap.add_argument("--decode-utts", type=int, default=64)
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-decode-utts", type=int, default=16, help="utterances of the decode workload the CPU baseline rescoring times (the first warms up)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra ms/step measurements in arithmetic modes 0 (fp32) and 1 (bf16)")
     args = ap.parse_args()
 
@@ -226,7 +267,7 @@ def main():
     eager = lambda: engine.step(batch)
 
     def agree(ms):                                   # same number on every rank
-        if world == 1:
+        if not torch.distributed.is_initialized():
             return ms
         t = torch.tensor([ms], device=dev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -256,7 +297,7 @@ def main():
     # meanwhile) and any capture error falls back to eager.  Rehearsed with 2 ranks over gloo on one GPU
     # (profiles/r02_multi_gpu_rehearsal.md); RCCL itself needs > 1 GPU.
     if not args.no_graph and (world == 1 or args.graph_multi):
-        n_trial = 10 if world == 1 else 5
+        n_trial = 10 if not torch.distributed.is_initialized() else 5
         t_eager = trial(eager, n_trial)              # before the capture: the graph's private memory pool changes allocator state
         try:
             engine.capture(batch, warmup=max(1, args.warmup))
@@ -275,7 +316,7 @@ def main():
             run()
 
     def barrier():
-        if world > 1:
+        if torch.distributed.is_initialized():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -412,6 +453,10 @@ def main():
         from openeat_amd.models.language_model import LanguageModel
         lm = LanguageModel(V, encoder_num_blocks=6, d_model=256, attention_heads=4, linear_units=1024).to(dev)
         dec = decode_rtf(dec_model, fb, utt_normalize_, args.decode_utts, args.seconds, 10, dev, lm=lm, lm_weight=0.3)
+        if not args.no_cpu_baseline:
+            log("decode cpu baseline (oracle rescoring on host cores) ...")
+            dec["cpu_baseline"] = decode_cpu_baseline(dec_model, lm, args.cpu_decode_utts, args.seconds, 10, 0.3)
+            log(f"decode cpu baseline done: RTF {dec['cpu_baseline']['rtf']:.3f} on {dec['cpu_baseline']['cores']} threads")
         del dec_model, lm
         engine.arena.enabled = True
         log(f"decode done: RTF {dec['rtf']:.5f} ({dec['wall_s'] * 1e3:.0f} ms for {dec['utterances']} x {args.seconds:g} s)")
@@ -423,11 +468,13 @@ def main():
                 "config": {"workload": "configs[1]: 12L Conformer d=256 (12+3+3, h=4, ff=1024, K=15, V=3246), "
                                        f"B={args.batch}/GPU x {args.seconds:g} s 16 kHz wav (T={T} frames), L={args.target_len}, "
                                        "CTC+attention joint loss, fbank+fwd+bwd+clip+Adam, dropout 0.1",
-                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph},
+                           "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                           **({"ddp_forced_with_one_rank": "OE_DDP_FORCE=1: RCCL process group, hooks and all-reduces (over a group of one) "
+                                                           "inside the timed step"} if ddp.forced() else {})},
                 **({"invalid": f"dropout overridden to {args.dropout}"} if args.dropout is not None else {}),
                 "loss": loss, "roofline": roof, "cpu_baseline": cpu, **other, "decode": dec}
         print(json.dumps(line))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

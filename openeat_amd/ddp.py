@@ -19,12 +19,21 @@ import torch
 import torch.distributed as dist
 
 
+def forced() -> bool:
+    """OE_DDP_FORCE=1: run the whole data-parallel machinery - process group, hooks, all-reduces of the arena tails between the
+    segment graphs, ReduceOp.AVG - also with ONE rank.  A one-GPU box can then execute every RCCL call of the N > 1 path
+    (the collectives are real RCCL kernels on the stream; with one rank they reduce over a group of one)."""
+    return os.environ.get("OE_DDP_FORCE", "0") == "1"
+
+
 def init_from_env(backend: str = None):
     """torchrun-style env (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if backend is None:
             backend = os.environ.get("OE_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
@@ -38,6 +47,9 @@ class GradAllReduce:
         self.grad = flat_grad
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # collectives are issued when there is more than one rank - or when forced (one-rank rehearsal of the RCCL path)
+        self.active = self.world > 1 or (forced() and dist.is_initialized())
+        self.issued = 0                # all-reduce calls handed to the backend so far (tests)
         n = flat_grad.numel()
         step = -(-n // max(1, n_chunks))
         step = (step + 1023) // 1024 * 1024
@@ -51,7 +63,7 @@ class GradAllReduce:
 
     def broadcast_parameters(self, flat_params: torch.Tensor, src: int = 0):
         """DDP's construction-time parameter broadcast."""
-        if self.world > 1:
+        if self.active:
             dist.broadcast(flat_params, src=src, group=self.group)
 
     def _issue(self, t: torch.Tensor):
@@ -63,11 +75,12 @@ class GradAllReduce:
             # kernels ordered by stream events and never come here.
             torch.cuda.current_stream().synchronize()
         self._works.append(dist.all_reduce(t, op=op, group=self.group, async_op=True))
+        self.issued += 1
 
     def reduce_tail(self, start: int):
         """Gradients of floats [start, end of what is still pending) are final: start their all-reduce now (async; the
         collective is ordered after everything already enqueued on the current stream)."""
-        if self.world == 1 or not self.overlap_enabled or start >= self._done_from:
+        if not self.active or not self.overlap_enabled or start >= self._done_from:
             return
         if start > 0:
             start = (start + 1023) // 1024 * 1024      # 4 KiB aligned slices; the few floats skipped go with the next tail
@@ -78,7 +91,7 @@ class GradAllReduce:
 
     def agree_min(self, value: int) -> int:
         """MIN over the ranks of a small integer (the loop's "do we all have a batch" handshake)."""
-        if self.world == 1:
+        if not self.active:
             return value
         t = torch.tensor([value], dtype=torch.int32, device=self.grad.device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
@@ -86,7 +99,7 @@ class GradAllReduce:
 
     def __call__(self):
         """After backward: reduce what no hook has sent yet, wait for everything, average."""
-        if self.world == 1:
+        if not self.active:
             return
         n = self._done_from
         if n > 0:

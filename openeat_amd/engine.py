@@ -31,9 +31,9 @@ class TrainEngine:
         # so that the gradient all-reduces start between the replays (None: exactly when world > 1; True on one rank
         # exercises the same path with no-op collectives)
         import os
-        self.segmented = (self.reducer.world > 1 and os.environ.get("OE_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
+        self.segmented = (self.reducer.active and os.environ.get("OE_SEGMENTED", "1") != "0") if segmented is None else bool(segmented)
         self._segments = None
-        if self.reducer.world > 1 or self.segmented:
+        if self.reducer.active or self.segmented:
             self._install_overlap_hooks()
         self.accum_grad = max(1, int(accum_grad))
         self._micro = 0                          # micro-steps accumulated since the last optimizer step
@@ -108,7 +108,7 @@ class TrainEngine:
         hooks and the final all-reduce), clips, runs Adam - /root/reference/openeat/utils/executor.py:42-63 (no_sync on
         the micro-steps in between, one optimizer step per k batches).  Returns (loss / k, acc) of this call."""
         common.STATIC_SHAPES = self.static_shapes
-        ops.POS_PROJ_AHEAD = self.parallel and self.reducer.world == 1      # not beside the backward hooks' collectives
+        ops.POS_PROJ_AHEAD = self.parallel and (not self.reducer.active)      # not beside the backward hooks' collectives
         if lr is not None:
             self.optimizer.set_lr(lr)
         if self._micro == 0:
@@ -137,7 +137,7 @@ class TrainEngine:
         nothing.  Gradient accumulation (accum_grad > 1) is an eager-step feature: refused here."""
         if self.accum_grad != 1:
             raise NotImplementedError("TrainEngine.capture: accum_grad > 1 is only supported by eager steps")
-        self._split = self.reducer.world > 1
+        self._split = self.reducer.active
         unjoined = 0
         # at least one eager step first: streams, events and lazily initialised state must exist before the capture (a
         # cold capture ended "unjoined"); step_cached() has just made that step itself (_warm)
@@ -172,7 +172,7 @@ class TrainEngine:
             try:
                 # with a process group alive, another thread (the collective backend's watchdog) may touch the device
                 # while we capture: only this thread's calls belong to the capture
-                mode = "thread_local" if self.reducer.world > 1 else "global"
+                mode = "thread_local" if self.reducer.active else "global"
                 ops.ln_table_begin(self.arena.flat.device)
                 try:
                     if self.segmented:

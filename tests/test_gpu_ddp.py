@@ -169,6 +169,87 @@ def test_two_rank_segmented_capture_matches_eager_steps(tmp_path):
     assert abs(got[0]["eager"][1] - got[0]["segmented"][1]) < 1e-3 * abs(got[0]["eager"][1])
 
 
+def worker_rccl_one_rank():
+    """ONE rank, backend nccl (= RCCL), OE_DDP_FORCE=1: every collective of the N > 1 path really runs on the GPU - the
+    parameter broadcast, the arena-tail all-reduces the backward hooks start inside an eager step, ReduceOp.AVG, the
+    all-reduces between the five graphs of the segmented capture (RCCL kernels beside graph replays, the capture in
+    thread-local mode next to RCCL's watchdog thread), clip + Adam behind the last collective.  A reduction over a group of
+    one changes nothing, so both paths must equal a plain single-process engine step for step."""
+    sys.path.insert(0, ROOT)
+    from openeat_amd import ddp, ops
+    from openeat_amd.engine import TrainEngine
+    assert ddp.forced()
+    rank, _, world = ddp.init_from_env(backend="nccl")
+    assert world == 1 and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl"
+    dev = torch.device("cuda:0")
+    batch = _batch(300, dev)
+    out = {}
+    for tag in ("eager", "segmented"):
+        model = _model(dev)
+        eng = TrainEngine(model, lr=1e-2, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+        assert eng.reducer.active and eng.reducer._avg and eng.segmented and hasattr(model, "grad_ready_hooks")
+        n0 = eng.reducer.issued
+        if tag == "eager":
+            for _ in range(3):
+                loss, _ = eng.step(batch)
+            assert eng.reducer.issued - n0 >= 3 * 5              # per step: four tails from the hooks + what is left after backward
+        else:
+            eng.capture(batch, warmup=1)
+            assert len(eng._segments) == 5
+            n1 = eng.reducer.issued
+            for _ in range(2):
+                loss, _ = eng.replay()
+            assert eng.reducer.issued - n1 >= 2 * 5              # four tails between the graphs + the rest, per replay
+        torch.cuda.synchronize()
+        out[tag] = (eng.arena.flat.detach().cpu(), float(loss))
+        eng.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    torch.save(out, os.environ["OE_TEST_OUT"])
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_collectives_run_with_one_rank(tmp_path):
+    """The RCCL branch of the data-parallel path executed on one GPU (see worker_rccl_one_rank) and compared with an engine
+    that has no process group at all: three eager steps / one warm-up step + two segmented replays on the same batch."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "rccl1_out")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", OE_DDP_FORCE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", OE_TEST_OUT=out, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker_rccl_one_rank"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    log = p.communicate(timeout=600)[0]
+    assert p.returncode == 0, log[-4000:]
+    got = torch.load(out)
+    from openeat_amd import ops
+    from openeat_amd.engine import TrainEngine
+    dev = torch.device("cuda:0")
+    model = _model(dev)
+    eng = TrainEngine(model, lr=1e-2, grad_clip=5.0, static_shapes=True, parallel_decoders=True)
+    assert not eng.reducer.active
+    try:
+        for _ in range(3):
+            loss, _ = eng.step(_batch(300, dev))
+        torch.cuda.synchronize()
+        ref = eng.arena.flat.detach().cpu()
+    finally:
+        eng.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        ops.PARALLEL_DECODERS = False
+        ops.POS_PROJ_AHEAD = False
+    lr, steps = 1e-2, 3
+    for tag in ("eager", "segmented"):
+        diff = (got[tag][0] - ref).abs()
+        assert float(diff.max()) <= 2.05 * lr * steps, tag
+        assert float((diff > 0.1 * lr * steps + 1e-3 * ref.abs()).float().mean()) < 0.02, tag
+        assert abs(got[tag][1] - float(loss)) < 1e-3 * abs(float(loss)), tag
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker_rccl_one_rank":
+    worker_rccl_one_rank()
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker":
     worker()
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker_segmented":
