@@ -98,6 +98,8 @@ class TrainEngine:
 
     _capturing = False
     _replaying = False
+    _accum_capture = False      # the captured graph is ONE micro-step of an accumulated step (accum_grad > 1)
+    _opt_graph = None           # ... and this one its clip + Adam
     _seg_keep = None
     _hooks_off = False          # capture()'s warm-up steps: same launch structure as the capture (whole arena reduced after backward)
     _split = False
@@ -134,10 +136,16 @@ class TrainEngine:
         the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph).
         The `warmup` steps that precede the capture are REAL optimizer steps on `example_batch` (parameters, Adam
         moments, step count and dropout counter advance; a scheduler should count them); the capture itself executes
-        nothing.  Gradient accumulation (accum_grad > 1) is an eager-step feature: refused here."""
-        if self.accum_grad != 1:
-            raise NotImplementedError("TrainEngine.capture: accum_grad > 1 is only supported by eager steps")
+        nothing.
+        Gradient accumulation (accum_grad = k > 1, executor.py:42-63): the graph holds ONE micro-step - forward + backward
+        of loss / k accumulating into the gradient arena, no zero-grad, no update - and a second small graph holds clip +
+        Adam; replay() zeroes the arena before the first of k micro-steps, replays the micro-step graph k times (fresh
+        inputs each time) and the update graph after the k-th (behind the gradient all-reduce when there are several
+        ranks: one whole-arena exchange per optimizer step, none on the micro-steps in between - DDP's no_sync)."""
         self._split = self.reducer.active
+        self._accum_capture = self.accum_grad != 1
+        if self._accum_capture and self._micro != 0:
+            raise RuntimeError("TrainEngine.capture: call between optimizer steps, not in the middle of an accumulation")
         unjoined = 0
         # at least one eager step first: streams, events and lazily initialised state must exist before the capture (a
         # cold capture ended "unjoined"); step_cached() has just made that step itself (_warm)
@@ -162,7 +170,10 @@ class TrainEngine:
                 try:
                     for _ in range(warmup):
                         self.arena.zero_grad()
-                        self._fwd_bwd(self._static)
+                        for _m in range(self.accum_grad):
+                            self._fwd_bwd(self._static)
+                            if _m + 1 < self.accum_grad:
+                                self.seed_counter.add_(1)
                         self._finish()
                 finally:
                     self._hooks_off = False
@@ -175,7 +186,9 @@ class TrainEngine:
                 mode = "thread_local" if self.reducer.active else "global"
                 ops.ln_table_begin(self.arena.flat.device)
                 try:
-                    if self.segmented:
+                    if self._accum_capture:
+                        g, unjoined = self._capture_accum(pool, mode)
+                    elif self.segmented:
                         g, unjoined = self._capture_segments(pool, mode)
                     else:
                         with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
@@ -199,6 +212,26 @@ class TrainEngine:
             raise RuntimeError(f"TrainEngine.capture: {unjoined} forked stream(s) had not rejoined the capturing stream at the end "
                                "of the step (a fork without its join); they were joined to close the capture, the graph is dropped")
         self._graph = g
+
+    def _capture_accum(self, pool, mode):
+        """accum_grad > 1: graph 1 = one micro-step (forward + backward into the arena + the dropout counter's tick), graph 2 =
+        clip + Adam (+ the weights' bf16 planes).  Returns (micro-step graph, unjoined-stream count)."""
+        pool = pool if pool is not None else torch.cuda.graph_pool_handle()
+        unjoined = 0
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+            try:
+                self._out = self._fwd_bwd(self._static)
+                self.seed_counter.add_(1)                  # every micro-step draws fresh dropout masks
+            finally:
+                unjoined += self._lead_forks_back()
+        if self._opt_graph is None:                        # shape-independent: one for all cached shapes
+            go = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(go, pool=pool, capture_error_mode=mode):
+                self.optimizer.step(lr_from_device=True)
+                self.arena.refresh_planes()
+            self._opt_graph = go
+        return g, unjoined
 
     def _capture_segments(self, pool, mode):
         """The step as a chain of HIP graphs in one memory pool (DistributedDataParallel's backward/all-reduce overlap,
@@ -266,6 +299,7 @@ class TrainEngine:
         self._out = None
         self._static = {}
         self._ln_table = None
+        self._opt_graph = None
         self._cache.clear()
         self._pool = None
         torch.cuda.empty_cache()
@@ -279,8 +313,6 @@ class TrainEngine:
         them allocate from one memory pool, so the activation memory held is that of the largest shape, not the sum.
         Callers bound the number of distinct shapes by padding to multiples (frames: the bucket's length_multiple;
         targets: pad_targets below)."""
-        if self.accum_grad != 1:
-            return self.step(batch, lr)
         key = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items()))
         rec = self._cache.get(key, False)
         if rec is False:
@@ -289,7 +321,9 @@ class TrainEngine:
             out = self.step(batch, lr)
             if self._pool is None:
                 self._pool = torch.cuda.graph_pool_handle()
+            micro = self._micro                       # an accumulation may be under way: the capture executes nothing and must not disturb it
             try:
+                self._micro = 0
                 self.capture(batch, pool=self._pool, _warm=True)
                 rec = (self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep)
             except Exception as e:               # noqa: BLE001 - capture() has cleaned up after itself
@@ -306,6 +340,8 @@ class TrainEngine:
                 warnings.warn(f"TrainEngine.step_cached: batch shape {[tuple(v.shape) for v in batch.values()]} does not capture "
                               f"({msg}); it will run eagerly every time", RuntimeWarning, stacklevel=2)
                 rec = None
+            finally:
+                self._micro = micro
             self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
             self._cache[key] = rec
             while len(self._cache) > max(1, max_graphs):
@@ -330,6 +366,17 @@ class TrainEngine:
         if lr is not None:
             self.optimizer.set_lr(lr)
         self.optimizer.lr_dev.fill_(float(self.optimizer.param_groups[0]["lr"]))     # the graph's Adam reads lr_dev
+        if self._accum_capture:
+            if self._micro == 0:
+                self.arena.grad.zero_()
+            self._graph.replay()                                  # one micro-step: gradients of loss / k added to the arena
+            if self._micro + 1 >= self.accum_grad:
+                self.reducer()                                    # several ranks: the one exchange of this optimizer step
+                self._opt_graph.replay()
+                self._micro = 0
+            else:
+                self._micro += 1
+            return self._out
         if self._segments:
             for g, final_from in self._segments:
                 g.replay()

@@ -510,27 +510,41 @@ def test_feature_dither_on_device_distribution():
     assert not torch.equal(y[0, :333], y[2, :333])
 
 
-def test_gradient_accumulation_matches_reference_loop():
+@pytest.mark.parametrize("mode", ["eager", "captured", "cached"])
+def test_gradient_accumulation_matches_reference_loop(mode):
     """TrainEngine(accum_grad=2): two micro-steps, ONE optimizer step whose gradient is the sum of the two micro-batch
-    gradients of loss / 2 (executor.py:42-63) - checked against the CPU oracle doing exactly that with torch Adam; then a
-    second accumulated step.  Between the boundaries nothing is exchanged, clipped or applied."""
+    gradients of loss / 2 (executor.py:42-63) - checked against the CPU oracle doing exactly that with torch Adam, over
+    three accumulated steps.  Between the boundaries nothing is exchanged, clipped or applied.
+    eager: TrainEngine.step.  captured: the first optimizer step eager, then the micro-step graph + the clip/Adam graph
+    (TrainEngine.capture / replay).  cached: step_cached all the way (first micro-step eager + capture, the rest replays)."""
     model = tiny(seed=21).to(DEV).train()
     sd0 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    batches = [batch_of(seed=30 + i) for i in range(4)]
-    eng = TrainEngine(model, lr=1e-3, grad_clip=5.0, accum_grad=2)
+    batches = [batch_of(seed=30 + i) for i in range(6)]
+    eng = TrainEngine(model, lr=1e-3, grad_clip=5.0, accum_grad=2, static_shapes=(mode != "eager"))
     try:
         before = eng.arena.flat.clone()
-        l0, _ = eng.step(batches[0])
+        first = eng.step_cached if mode == "cached" else eng.step
+        l0 = first(batches[0])[0].clone()                           # (a replay returns the graph's static output tensor)
         assert torch.equal(eng.arena.flat, before), "a non-boundary micro-step must not move the parameters"
         assert float(eng.optimizer.step_state[0]) == 0.0
-        l1, _ = eng.step(batches[1])
+        l1 = first(batches[1])[0].clone()
         assert float(eng.optimizer.step_state[0]) == 1.0 and not torch.equal(eng.arena.flat, before)
-        l2, _ = eng.step(batches[2])
-        l3, _ = eng.step(batches[3])
+        if mode == "captured":
+            eng.capture(batches[0], _warm=True)                    # executes nothing: the trajectory is untouched
+            nxt = eng.replay
+        else:
+            nxt = first
+        losses = [l0, l1]
+        for i in range(2, 6):
+            mid = eng.arena.flat.clone()
+            l, _ = nxt(batches[i])
+            losses.append(l.clone())
+            if i % 2 == 0:
+                assert torch.equal(eng.arena.flat, mid), "a non-boundary micro-step must not move the parameters"
         torch.cuda.synchronize()
-        assert float(eng.optimizer.step_state[0]) == 2.0
-        with pytest.raises(NotImplementedError):
-            eng.capture(batches[0])
+        assert float(eng.optimizer.step_state[0]) == 3.0
+        if mode == "cached":
+            assert (eng.cache_misses, eng.cache_hits) == (1, 5) and eng.cache_uncapturable == 0
     finally:
         eng.arena.deactivate()
         ops.set_seed_device_counter(None)
@@ -550,9 +564,9 @@ def test_gradient_accumulation_matches_reference_loop():
         if i % 2 == 1:
             torch.nn.utils.clip_grad_norm_(list(sd.values()), 5.0)
             opt.step()
-    for got, want in zip((l0, l1, l2, l3), ref):
+    for got, want in zip(losses, ref):
         assert abs(float(got) - want) < 5e-4 * abs(want), (float(got), want)
-    check_updates(model.state_dict(), sd, sd0, steps=2)
+    check_updates(model.state_dict(), sd, sd0, steps=3)
 
 
 def test_eager_step_beside_a_captured_graph_uses_the_current_learning_rate():
