@@ -357,15 +357,17 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
     int tile = 22;
     if (!a_kmajor && !b_kmajor && !ga && b22 < 320) tile = 11;
+    if (!a_kmajor && !b_kmajor && N % 256 == 0 && K % 32 == 0 && (long)oe_cdiv(M, 128) * (N / 256) * sk >= 512) tile = 24;
     if (forced_tile) tile = forced_tile;
-    if ((a_kmajor || b_kmajor || ga) && tile != 22) return 1;
-    int bk = (tile == 22) ? (kc0 >= 1024 ? 32 : 16) : 32;
+    if ((a_kmajor || b_kmajor) && tile != 22) return 1;
+    if (ga && tile != 22 && tile != 24) return 1;
+    int bk = (tile == 22) ? (kc0 >= 1024 ? 32 : 16) : 32;     // tiles 11 and 24 exist with K-tiles of 32 only
     if (forced_bk && tile == 22) bk = forced_bk;
     if (K % bk) { if (tile == 22 && bk == 32 && K % 16 == 0) bk = 16; else return 1; }
     if (sk > 1 && (long)oe_cdiv(oe_cdiv(K, sk), bk) * bk * (sk - 1) >= K) return 1;          // a split would be left empty
     // too few blocks to occupy the chip: the splitting kernels have smaller tiles and split the reduction
     const int min_blocks = pl_min_blocks;
-    if ((long)oe_cdiv(M, tile == 22 ? 128 : 64) * oe_cdiv(N, tile == 22 ? 128 : 64) * sk < min_blocks) return 1;
+    if ((long)oe_cdiv(M, tile == 11 ? 64 : 128) * oe_cdiv(N, tile == 11 ? 64 : tile == 24 ? 256 : 128) * sk < min_blocks) return 1;
     // 128 x 128 tiles: 8 waves (4 x 2 of 32 x 64 each, two per SIMD) by default; OE_PL_WAVES=4 takes the 2 x 2 arrangement
     const int waves = pl_waves;
 #define OE_PL(AK, BKM, GA, GB)                                                                                        \
@@ -379,6 +381,13 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     } while (0)
     if (!a_kmajor && !b_kmajor) {
         if (tile == 11) return launch_pl<1, 1, 2, false, false, 32, 3, false, false>(a, b, C, ldc, M, N, K, sk, ep, st);
+        // 128 x 256 tiles (8 waves of 32 x 128, K-tile 32, two stages): a whole 256-wide output row per block - A is read
+        // once instead of once per column tile and a K-tile moves 72 KiB for 96 MFMAs per wave instead of 48 KiB for 48.
+        // Worth it where the grid still fills the chip (the conv2 forward / input-gradient GEMMs: ~1200 blocks)
+        if (tile == 24 && K % 32 == 0) {
+            if (ga) return launch_pl<1, 4, 4, false, false, 32, 2, true, false>(a, b, C, ldc, M, N, K, sk, ep, st);
+            return launch_pl<1, 4, 4, false, false, 32, 2, false, false>(a, b, C, ldc, M, N, K, sk, ep, st);
+        }
         if (ga) OE_PL(false, false, true, false); else OE_PL(false, false, false, false);
     }
     if (!a_kmajor && b_kmajor) OE_PL(false, true, false, false);

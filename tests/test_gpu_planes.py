@@ -60,7 +60,7 @@ def _err(got, ref, k):
     return float((got.cpu().double() - ref).abs().max()) / math.sqrt(k)
 
 
-@pytest.mark.parametrize("waves,tile", [(8, 0), (4, 0), (8, 11)])
+@pytest.mark.parametrize("waves,tile", [(8, 0), (4, 0), (8, 11), (8, 24)])
 @pytest.mark.parametrize("M,N,K", [(7936, 1024, 256), (640, 384, 1024), (704, 304, 512), (700, 304, 512), (130, 136, 48), (64, 8, 16)])
 def test_planes_gemm_all_layouts_vs_float64_and_fp32_kernel(M, N, K, waves, tile):
     """x W^T (+ bias, planes output), dy W, dy^T x (split-K atomics + fused column sums) on pre-split operands: error against
@@ -95,7 +95,7 @@ def test_planes_gemm_all_layouts_vs_float64_and_fp32_kernel(M, N, K, waves, tile
     # x W^T always qualifies when K is whole K-tiles (the other two depend on N, M and the forced tile): the numbers
     # above must come from gemm_pl.hip, not from a silent fallback
     ran = hip.lib().oe_gemm_pl_launches() - n0
-    if K % 32 == 0:
+    if K % 32 == 0:                       # (64 x 64 and 128 x 256 tiles take K-tiles of 32)
         assert ran >= 1, "a problem meant for gemm_pl.hip took another kernel"
     if K % 16 == 0 and N % 16 == 0 and M % 16 == 0 and tile == 0:
         assert ran == 3
@@ -156,8 +156,9 @@ def test_layernorm_planes_outputs():
     assert torch.equal((p[0] + p[1] + p[2]).float(), g.cpu())                    # planes follow the dropped copy when there is one
 
 
-@pytest.mark.parametrize("B_,T1,F1,Cc", [(2, 21, 11, 32), (3, 40, 39, 64), (4, 30, 21, 128)])
-def test_planes_conv2_gathers(B_, T1, F1, Cc):
+@pytest.mark.parametrize("tile", [0, 24])
+@pytest.mark.parametrize("B_,T1,F1,Cc", [(2, 21, 11, 32), (3, 40, 39, 64), (4, 30, 21, 128), (4, 37, 33, 256)])
+def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
     """conv2 forward (im2col gather on a row-major A) and weight gradient (gather on a k-major B) on pre-split operands."""
     torch.manual_seed(5)
     T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
@@ -169,6 +170,7 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc):
     Mc = B_ * T2 * F2
     conv = (T1, F1, T2, F2, Cc)
     xp, wp = split(x_nhwc.view(-1, Cc)), split(w_g)
+    hip.lib().oe_gemm_pl_config(-1, tile, -1, -1)            # 24: 128 x 256 tiles (the conv2 forward of the real model, C = 256)
     n0 = hip.lib().oe_gemm_pl_launches()
     out = torch.empty(Mc, Cc, device=DEV)
     hip.gemm(x_nhwc, w_g, out, Mc, Cc, 9 * Cc, lda=0, ldb=9 * Cc, ldc=Cc, conv=conv, conv_gather=hip.GATHER_A, a_planes=xp, b_planes=wp)
@@ -180,6 +182,7 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc):
         dyc = torch.randn(Mc, Cc)
         dycd = cu(dyc)
         dwg = torch.zeros(Cc, 9 * Cc, device=DEV)
+        hip.lib().oe_gemm_pl_config(-1, 0, -1, -1)           # k-major operands: 128 x 128 tiles only
         hip.gemm(dycd, x_nhwc, dwg, Cc, 9 * Cc, Mc, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True, split_k=2, atomic_out=True,
                  conv=conv, conv_gather=hip.GATHER_B, a_planes=split(dycd), b_planes=xp)
         sync()
