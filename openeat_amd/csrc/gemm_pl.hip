@@ -60,10 +60,13 @@ __device__ __forceinline__ void pl_row_frag(const unsigned char* tile, int plane
 #pragma unroll
     for (int n = 0; n < 3; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(p + n * plane_bytes);
 }
-// fragment of 32 columns (col32 ..) x 16 k-rows (16 ks ..) of a k-major operand tile ([BK][128] bf16 per plane)
-__device__ __forceinline__ void pl_col_frag(const unsigned char* tile, int plane_bytes, int col32, int ks, int lane, PlFrag& f) {
+// fragment of 32 columns (col32 ..) x 16 k-rows (16 ks ..) of a k-major operand tile (per plane: sub-tiles of [BK][128] bf16,
+// one per 128 columns, `sub_bytes` = BK * 256 apart)
+__device__ __forceinline__ void pl_col_frag(const unsigned char* tile, int plane_bytes, int sub_bytes, int col32, int ks, int lane, PlFrag& f) {
     const int i = lane & 15, grp = lane >> 4;
     const int kr0 = 16 * ks + 8 * (grp >> 1) + (i >> 2);
+    tile += (col32 >> 7) * sub_bytes;
+    col32 &= 127;
     const int ch = (col32 >> 3) + 2 * (grp & 1) + ((i & 3) >> 1);
     const unsigned char* p0 = tile + kr0 * 256 + 16 * (ch ^ pl_gsw(kr0)) + 8 * (i & 1);
     const unsigned char* p1 = tile + (kr0 + 4) * 256 + 16 * (ch ^ pl_gsw(kr0 + 4)) + 8 * (i & 1);
@@ -122,8 +125,8 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
     }
     constexpr int NW = WM * 2;                                       // waves per block
     constexpr int BM = 32 * TM * WM, BN = 64 * TN;
-    static_assert(!AK || BM == 128, "k-major tiles are 128 columns wide");
-    static_assert(!BKM || BN == 128, "k-major tiles are 128 columns wide");
+    static_assert(!AK || BM % 128 == 0, "k-major tiles are made of 128-column sub-tiles");
+    static_assert(!BKM || BN % 128 == 0, "k-major tiles are made of 128-column sub-tiles");
     constexpr int A_T = BM * BK * 2, B_T = BN * BK * 2;              // bytes of one plane tile
     constexpr int STAGE = 3 * (A_T + B_T);
     constexpr int PA = A_T / 1024, PB = B_T / 1024;                  // DMA pieces (1 KiB) per plane tile
@@ -179,9 +182,11 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
             }
             step[j] = BK;
         } else {
-            const int krow = sub * 4 + (lane >> 4), cpos = lane & 15;
+            // sub-tile (128 columns) s = sub / (BK / 4), k-rows 4 (sub % (BK / 4)) .. + 3 of it
+            const int st = sub / (BK / 4);
+            const int krow = (sub - st * (BK / 4)) * 4 + (lane >> 4), cpos = lane & 15;
             const int csrc = cpos ^ pl_gsw(krow);
-            const long col = min(x0 + csrc * 8, (long)X.rows_total - 8);
+            const long col = min(x0 + st * 128 + csrc * 8, (long)X.rows_total - 8);
             if (GB && !isA) {
                 // columns = (kh, kw, ci) of the im2col row: linear inside a kernel row, + kh * F1 * C across rows
                 const int seg = X.KS * X.C;
@@ -258,23 +263,28 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
         const unsigned char* at = lds + (kt % NST) * STAGE;
         const unsigned char* bt = at + 3 * A_T;
         PlFrag fa[KS][TM], fb[KS][TN];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
+        // fragments are read one MFMA group ahead of their use: the first group's reads stand alone, every later group's
+        // reads fly under the previous group's six MFMAs (all 18 reads up front would put their latency and the LDS's
+        // 256 B / clock in front of the first MFMA of every wave of the CU at once)
+        auto read_group = [&](auto gi) {
+            constexpr int g = decltype(gi)::value;
+            constexpr int ks = g / (TM * TN), i = (g / TN) % TM, j = g % TN;
+            if constexpr (j == 0) {
                 if (!AK) pl_row_frag<BK>(at, A_T, wm * 32 * TM + i * 32 + frow, fhalf, ks, fa[ks][i]);
-                else pl_col_frag(at, A_T, wm * 32 * TM + i * 32, ks, lane, fa[ks][i]);
+                else pl_col_frag(at, A_T, BK * 256, wm * 32 * TM + i * 32, ks, lane, fa[ks][i]);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
+            if constexpr (i == 0) {
                 if (!BKM) pl_row_frag<BK>(bt, B_T, wn * 32 * TN + j * 32 + frow, fhalf, ks, fb[ks][j]);
-                else pl_col_frag(bt, B_T, wn * 32 * TN + j * 32, ks, lane, fb[ks][j]);
+                else pl_col_frag(bt, B_T, BK * 256, wn * 32 * TN + j * 32, ks, lane, fb[ks][j]);
             }
-        }
+        };
+        read_group(std::integral_constant<int, 0>{});
         begin_issue();
         static_for<0, NG>([&](auto gi) {
             constexpr int g = decltype(gi)::value;
             constexpr int ks = g / (TM * TN), i = (g / TN) % TM, j = g % TN;
+            if constexpr (g + 1 < NG) read_group(std::integral_constant<int, g + 1>{});
+            __builtin_amdgcn_sched_barrier(0);
             acc[i][j] = oe_mma_terms<6>(fa[ks][i], fb[ks][j], acc[i][j]);
             if (AK && j == 0 && do_csum) csum[i] = pl_frag_sum(fa[ks][i], csum[i]);
             __builtin_amdgcn_sched_barrier(0);
@@ -358,16 +368,35 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     int tile = 22;
     if (!a_kmajor && !b_kmajor && !ga && b22 < 320) tile = 11;
     if (!a_kmajor && !b_kmajor && N % 256 == 0 && K % 32 == 0 && (long)oe_cdiv(M, 128) * (N / 256) * sk >= 512) tile = 24;
+    // 256 x 256 tiles (8 waves of 64 x 128, K-tile 16, three stages): a K-tile moves 48 KiB for 96 MFMAs per wave - half the
+    // LDS-DMA bytes per MFMA of the 128 x 128 tile, which is what bounds that one (L2 -> LDS fill rate).  For the long,
+    // wide problems whose grid still fills the chip: conv2 (forward, input and weight gradients), the 16 s batches.
+    const long b44 = (long)oe_cdiv(M, 256) * oe_cdiv(N, 256);
+    if (M >= 256 && N >= 256 && N % 256 == 0 && (!a_kmajor || M % 256 == 0) && K % 16 == 0 &&
+        (ep.atomic ? b44 * (K / 2048) >= 200 : b44 >= 1024)) tile = 44;     // (conv2 forward, 589 such tiles = 2.3 rounds: 128 x 256 is faster)
     if (forced_tile) tile = forced_tile;
-    if ((a_kmajor || b_kmajor) && tile != 22) return 1;
-    if (ga && tile != 22 && tile != 24) return 1;
-    int bk = (tile == 22) ? (kc0 >= 1024 ? 32 : 16) : 32;     // tiles 11 and 24 exist with K-tiles of 32 only
+    if ((a_kmajor || b_kmajor) && tile != 22 && tile != 44) return 1;
+    if (ga && tile != 22 && tile != 24 && tile != 44) return 1;
+    if (tile == 44 && ep.atomic && !forced_tile) {
+        // own split of the reduction: about one block per CU, K-ranges of at least 2048 (the output is accumulated with
+        // atomics into a zeroed buffer whatever the caller's split was)
+        sk = (int)max(1L, min((long)(K / 2048), 256 / b44));
+    }
+    int bk = (tile == 22) ? (kc0 >= 1024 ? 32 : 16) : (tile == 44 ? 16 : 32);     // tiles 11 and 24 exist with K-tiles of 32 only
     if (forced_bk && tile == 22) bk = forced_bk;
     if (K % bk) { if (tile == 22 && bk == 32 && K % 16 == 0) bk = 16; else return 1; }
     if (sk > 1 && (long)oe_cdiv(oe_cdiv(K, sk), bk) * bk * (sk - 1) >= K) return 1;          // a split would be left empty
     // too few blocks to occupy the chip: the splitting kernels have smaller tiles and split the reduction
     const int min_blocks = pl_min_blocks;
-    if ((long)oe_cdiv(M, tile == 11 ? 64 : 128) * oe_cdiv(N, tile == 11 ? 64 : tile == 24 ? 256 : 128) * sk < min_blocks) return 1;
+    if ((long)oe_cdiv(M, tile == 11 ? 64 : tile == 44 ? 256 : 128) * oe_cdiv(N, tile == 11 ? 64 : (tile == 24 || tile == 44) ? 256 : 128) * sk < min_blocks) return 1;
+    if (tile == 44) {
+#define OE_PL44(AK, BKM, GA, GB) return launch_pl<2, 4, 4, AK, BKM, 16, 3, GA, GB>(a, b, C, ldc, M, N, K, sk, ep, st)
+        if (!a_kmajor && !b_kmajor) { if (ga) OE_PL44(false, false, true, false); else OE_PL44(false, false, false, false); }
+        if (!a_kmajor && b_kmajor) OE_PL44(false, true, false, false);
+        if (gb) OE_PL44(true, true, false, true);
+        OE_PL44(true, true, false, false);
+#undef OE_PL44
+    }
     // 128 x 128 tiles: 8 waves (4 x 2 of 32 x 64 each, two per SIMD) by default; OE_PL_WAVES=4 takes the 2 x 2 arrangement
     const int waves = pl_waves;
 #define OE_PL(AK, BKM, GA, GB)                                                                                        \

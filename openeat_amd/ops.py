@@ -102,13 +102,15 @@ def gemm_nt(x, w, bias=None, out=None, out_planes=False, **epi):
 
 
 def gemm_nn(dy, w, out=None, out_planes=False, **epi):
-    """dx[M,K] = dy[M,N] @ w[N,K]."""
+    """dx[M,K] = dy[M,N] @ w[N,K].  out_planes: True = with the general pre-split policy, "always" = whenever pre-split
+    operands exist at all (the conv front end's policy)."""
     M, N = dy.shape
     K = w.shape[1]
     if out is None:
         out = _new(M, K, like=dy)
     ap, bp = _operand_planes(dy, w)
-    cp = _planes.new_output(out) if (out_planes and _planes.active() and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
+    want = _planes.available() if out_planes == "always" else (out_planes and _planes.active())
+    cp = _planes.new_output(out) if (want and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
     hip.gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, a_planes=ap, b_planes=bp, c_planes=cp, **epi)
     return out
 
@@ -134,9 +136,10 @@ def gemm_nn_deep(dy, w, alpha_dev=None):
     return out
 
 
-def wgrad_planes(dy, x):
-    """Pre-split copies of both operands of a weight gradient dy^T x (both activations), or (None, None)."""
-    if not _planes.active():
+def wgrad_planes(dy, x, always=False):
+    """Pre-split copies of both operands of a weight gradient dy^T x (both activations), or (None, None).
+    always: under the conv front end's policy too (not only the general one)."""
+    if not (_planes.available() if always else _planes.active()):
         return None, None
     ap = _planes.of(dy)
     bp = _planes.of(x) if ap is not None else None
@@ -1250,6 +1253,9 @@ def conv_module(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residu
 # Conv2d subsampling (1/4) + output Linear + positional scaling
 # --------------------------------------------------------------------------- #
 CONV_DGRAD_IMPLICIT = os.environ.get("OE_CONV_DGRAD", "implicit") != "col2im"
+# the conv weight gradient on pre-split operands too (dy leaves the Linear's input-gradient GEMM with planes): 256 x 256 tiles
+# with the kernel's own split of the 150784-deep reduction, 1454 -> 817 us at config 2 (same-box A/B, step 21.9 -> 21.55 ms)
+CONV_WGRAD_PLANES = os.environ.get("OE_CONV_WGRAD_PLANES", "1") == "1"
 
 
 def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
@@ -1357,7 +1363,8 @@ class ConvSubsamplingFn(torch.autograd.Function):
         dwlg = gemm_tn(do2, ylv, alpha=xscale, bias_out=dbl_buf)
         dwl = _sink_swapped(wl, dwlg, d, FL, C)
         # gradient w.r.t. the last conv's pre-activation: the Linear's dgrad with the ReLU mask fused
-        dy = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=ylv, ld_aux=FL * C, out_planes=True).view(B * TL * FL, C)
+        dy = gemm_nn(do2, wlg, alpha=xscale, act=ACT_RELU, actgrad_in=ylv, ld_aux=FL * C,
+                     out_planes="always" if CONV_WGRAD_PLANES else True).view(B * TL * FL, C)
         fused = hip.GEMM_PRECISION != 0
         stage_grads = [None] * (2 * n)
         for k in range(n - 1, -1, -1):
@@ -1370,7 +1377,7 @@ class ConvSubsamplingFn(torch.autograd.Function):
             yin = acts[k]
             dwg = _new(C, kk * C, like=do2, zero=True)
             (dbk_buf, dbk) = grad_sink(bk)
-            ap, bp = wgrad_planes(dy, yin.view(-1, C))
+            ap, bp = wgrad_planes(dy, yin.view(-1, C), always=CONV_WGRAD_PLANES)
             hip.gemm(dy, yin, dwg, C, kk * C, Mo, lda=C, ldb=0, ldc=kk * C, a_kmajor=True, b_kmajor=True,
                      split_k=_split_k(C, kk * C, Mo), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
                      a_colsum=dbk_buf if fused else None, a_planes=ap, b_planes=bp)

@@ -60,7 +60,7 @@ def _err(got, ref, k):
     return float((got.cpu().double() - ref).abs().max()) / math.sqrt(k)
 
 
-@pytest.mark.parametrize("waves,tile", [(8, 0), (4, 0), (8, 11), (8, 24)])
+@pytest.mark.parametrize("waves,tile", [(8, 0), (4, 0), (8, 11), (8, 24), (8, 44)])
 @pytest.mark.parametrize("M,N,K", [(7936, 1024, 256), (640, 384, 1024), (704, 304, 512), (700, 304, 512), (130, 136, 48), (64, 8, 16)])
 def test_planes_gemm_all_layouts_vs_float64_and_fp32_kernel(M, N, K, waves, tile):
     """x W^T (+ bias, planes output), dy W, dy^T x (split-K atomics + fused column sums) on pre-split operands: error against
@@ -156,7 +156,7 @@ def test_layernorm_planes_outputs():
     assert torch.equal((p[0] + p[1] + p[2]).float(), g.cpu())                    # planes follow the dropped copy when there is one
 
 
-@pytest.mark.parametrize("tile", [0, 24])
+@pytest.mark.parametrize("tile", [0, 24, 44])
 @pytest.mark.parametrize("B_,T1,F1,Cc", [(2, 21, 11, 32), (3, 40, 39, 64), (4, 30, 21, 128), (4, 37, 33, 256)])
 def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
     """conv2 forward (im2col gather on a row-major A) and weight gradient (gather on a k-major B) on pre-split operands."""
@@ -182,7 +182,7 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
         dyc = torch.randn(Mc, Cc)
         dycd = cu(dyc)
         dwg = torch.zeros(Cc, 9 * Cc, device=DEV)
-        hip.lib().oe_gemm_pl_config(-1, 0, -1, -1)           # k-major operands: 128 x 128 tiles only
+        hip.lib().oe_gemm_pl_config(-1, 44 if (tile == 44 and Cc % 256 == 0) else 0, -1, -1)    # k-major operands: 128 x 128 or 256 x 256 tiles
         hip.gemm(dycd, x_nhwc, dwg, Cc, 9 * Cc, Mc, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True, split_k=2, atomic_out=True,
                  conv=conv, conv_gather=hip.GATHER_B, a_planes=split(dycd), b_planes=xp)
         sync()
