@@ -206,8 +206,10 @@ class audio_collate_func(object):
                 if random.random() < rate:
                     speed = _speed_generator(speeds)
                 if 'resample_rate' in conf and conf['resample_rate'] != sr:
-                    # dataset.py:81-84 resamples (torchaudio Resample) after the speed perturbation; both are one pass of
-                    # the same windowed-sinc interpolator here: read sr / resample_rate times faster, times the speed.
+                    # dataset.py:77-90 resamples first (torchaudio Resample to resample_rate), then perturbs the speed at that
+                    # rate; here both are ONE pass of the same windowed-sinc interpolator: read sr / resample_rate times
+                    # faster, times the speed.  Not sample-exact with torchaudio's Resample (another kernel; the output
+                    # length can differ by one sample): distribution-level parity, stated in DESIGN section 7.
                     speed = float(speed) * sr / conf['resample_rate']
                     sr = conf['resample_rate']
                 assert sample_rate in (None, sr), "one sample rate per batch"

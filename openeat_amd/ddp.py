@@ -50,6 +50,7 @@ class GradAllReduce:
         # collectives are issued when there is more than one rank - or when forced (one-rank rehearsal of the RCCL path)
         self.active = self.world > 1 or (forced() and dist.is_initialized())
         self.issued = 0                # all-reduce calls handed to the backend so far (tests)
+        self._cpu_group = None         # host-side group of agree_min (None: not yet made; False: unavailable)
         n = flat_grad.numel()
         step = -(-n // max(1, n_chunks))
         step = (step + 1023) // 1024 * 1024
@@ -90,11 +91,22 @@ class GradAllReduce:
         self._done_from = start
 
     def agree_min(self, value: int) -> int:
-        """MIN over the ranks of a small integer (the loop's "do we all have a batch" handshake)."""
+        """MIN over the ranks of a small integer (the loop's "do we all have a batch" handshake).  Runs on a host-side gloo
+        group (created on first use - a collective call itself, which every rank makes at its first handshake), so the
+        per-batch handshake never synchronises the host with the GPU stream the way an RCCL all-reduce + .item() would."""
         if not self.active:
             return value
-        t = torch.tensor([value], dtype=torch.int32, device=self.grad.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        if self._cpu_group is None:
+            try:
+                self._cpu_group = self.group if dist.get_backend(self.group) == "gloo" else dist.new_group(backend="gloo")
+            except Exception:                    # noqa: BLE001 - no gloo in this build: fall back to the device group
+                self._cpu_group = False
+        if self._cpu_group is False:
+            t = torch.tensor([value], dtype=torch.int32, device=self.grad.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+            return int(t.item())
+        t = torch.tensor([value], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self._cpu_group)
         return int(t.item())
 
     def __call__(self):

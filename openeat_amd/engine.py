@@ -131,6 +131,23 @@ class TrainEngine:
 
     # ---- HIP-graph path: fixed shapes, no host sync inside the step -----------------------------
     def capture(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2, pool=None, _warm: bool = False):
+        """Capture the step (see _capture_impl).  With several ranks the outcome is agreed across them: a capture that fails on
+        one rank only would leave the ranks in different launch modes (graphs with all-reduces between them on some, eager
+        hooks on others) - every rank then drops its graph and raises, and the caller falls back to eager steps everywhere."""
+        err = None
+        try:
+            self._capture_impl(example_batch, warmup, pool, _warm)
+        except Exception as e:                     # noqa: BLE001
+            err = e
+        ok = 0 if err is not None else 1
+        if self.reducer.active and self.reducer.agree_min(ok) == 0:
+            self._graph = self._segments = self._seg_keep = None
+            if err is None:
+                err = RuntimeError("TrainEngine.capture: another rank could not capture this step; staying eager on every rank")
+        if err is not None:
+            raise err
+
+    def _capture_impl(self, example_batch: Dict[str, torch.Tensor], warmup: int = 2, pool=None, _warm: bool = False):
         """Capture the step as a HIP graph.  With one rank the whole step (incl. clip + Adam) is one graph;
         with several ranks the graph holds zero-grad + forward + backward and the gradient all-reduce and
         the 3-kernel optimizer step run right after it on the same stream (RCCL stays outside the graph).

@@ -9,11 +9,29 @@ import subprocess
 import sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+P = sys.argv[2] if len(sys.argv) > 2 else "6"          # arithmetic mode of the headline
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", "final"), os.path.join(ROOT, "profiles")
-subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(src, "pmc"), "5", "3", tag], stdout=subprocess.DEVNULL)
-shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_p3.csv")
-rows = [r for r in csv.DictReader(open(f"{src}/trace/{tag}_kernel_stats.csv")) if "spin_kernel" not in r["Name"]]
+subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), os.path.join(src, "pmc"), "5", P, tag], stdout=subprocess.DEVNULL)
+shutil.copy(f"{src}/trace/{tag}_kernel_stats.csv", f"{dst}/{tag}_kernel_stats_p{P}.csv")
+# per-kernel totals from the TRACE, counting only what follows the first fbank launch: everything before it is process setup
+# (model.to(device), the ParamArena re-homing 620 parameter tensors: ~1000 __amd_rocclr_copyBuffer launches that earlier rounds'
+# tables divided by the step count and showed as "109 per step")
+import collections
+_tr = sorted(csv.DictReader(open(f"{src}/trace/{tag}_kernel_trace.csv")), key=lambda r: int(r["Start_Timestamp"]))
+_first = next((i for i, r in enumerate(_tr) if "fbank_kernel" in r["Kernel_Name"]), 0)
+_agg = collections.defaultdict(lambda: [0, 0])
+for r in _tr[_first:]:
+    if "spin_kernel" in r["Kernel_Name"]:
+        continue
+    _agg[r["Kernel_Name"]][0] += 1
+    _agg[r["Kernel_Name"]][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+rows = [{"Name": k, "Calls": str(v[0]), "TotalDurationNs": str(v[1]), "AverageNs": str(v[1] / max(v[0], 1))}
+        for k, v in sorted(_agg.items(), key=lambda kv: -kv[1][1])]
+with open(f"{dst}/{tag}_kernel_stats_p{P}_steps_only.csv", "w") as f:
+    f.write("Name,Calls,TotalDurationNs,AverageNs\n")
+    for r in rows:
+        f.write(f"\"{r['Name']}\",{r['Calls']},{r['TotalDurationNs']},{r['AverageNs']}\n")
 steps = 10.0
 adam = [int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"]]
 if adam:
@@ -21,15 +39,15 @@ if adam:
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
 gem = [r for r in rows if "gemm_" in r["Name"] or "ffn_fwd_kernel" in r["Name"]]
 gt, gc = sum(int(r["TotalDurationNs"]) for r in gem), sum(int(r["Calls"]) for r in gem)
-line = json.load(open(f"{src}/{tag}_bench_p3.json"))
+line = json.load(open(f"{src}/{tag}_bench_p{P}.json"))
 ro = line["roofline"]
-with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
-    f.write(f"# Round {int(tag[1:])} - rocprofv3 kernel stats, bench config 2, precision 3 (final kernels of the round)\n\n")
+with open(f"{dst}/{tag}_kernel_stats_p{P}.md", "w") as f:
+    f.write(f"# Round {int(tag[1:])} - rocprofv3 kernel stats, bench config 2, precision {P} (final kernels of the round)\n\n")
     f.write("`rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-decode --no-graph --single-stream --steps 5 --warmup 2` "
             f"({steps:g} optimizer steps in the trace, counted by the Adam kernel's launches: first step + warm-up + timed + 2 event-bracketed; the `spin_kernel` launches that park the "
-            f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p3.csv`.\n\n")
+            f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p{P}.csv`.\n\n")
     f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
-            f"**GEMM class (`gemm_dma_kernel` + `gemm_bf16_kernel` + `ffn_fwd_kernel`, the kernels behind `oe_gemm_f32` / `oe_ffn_fwd`): {gc / steps:.0f} launches/step, "
+            f"**GEMM class (`gemm_pl_kernel` + `gemm_dma_kernel` + `gemm_bf16_kernel` + `gemm_tn_planes/grouped_kernel`, the kernels behind `oe_gemm_f32` / `oe_gemm_tn_grouped`): {gc / steps:.0f} launches/step, "
             f"{gt / 1e6 / steps:.2f} ms/step, average launch {gt / gc / 1e3:.2f} us = {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TFLOP/s algorithmic** - "
             f"bench.py's live HIP-event figure (event-pair overhead calibrated out) is {ro['gemm_ms_per_step']:.2f} ms/step, "
             f"{ro['avg_launch_us']:.2f} us average, {ro['achieved']:.1f} TFLOP/s.\n\n")
@@ -38,11 +56,12 @@ with open(f"{dst}/{tag}_kernel_stats_p3.md", "w") as f:
         n = re.sub(r"\(.*", "", r["Name"])[:90]
         f.write(f"| `{n}` | {int(r['Calls']) / steps:.1f} | {float(r['AverageNs']) / 1e3:.1f} | {int(r['TotalDurationNs']) / 1e6 / steps:.3f} | "
                 f"{100 * int(r['TotalDurationNs']) / tot:.2f} |\n")
-for a, b in ((f"{tag}_bench_p3.json", f"{tag}_bench_p3.json"), (f"{tag}_bench_p3.err", f"{tag}_bench_p3.log"), (f"{tag}_gemm_bench.txt", f"{tag}_gemm_bench.txt"),
-             (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p3.txt"), (f"{tag}_ctc_bench.txt", f"{tag}_ctc_bench.txt"),
+for a, b in ((f"{tag}_bench_p{P}.json", f"{tag}_bench_p{P}.json"), (f"{tag}_bench_p{P}.err", f"{tag}_bench_p{P}.log"), (f"{tag}_gemm_bench.txt", f"{tag}_gemm_bench.txt"),
+             (f"{tag}_kernel_trace_summary.txt", f"{tag}_kernel_trace_summary_p{P}.txt"), (f"{tag}_ctc_bench.txt", f"{tag}_ctc_bench.txt"),
              (f"{tag}_mfma_busy_northstar.md", f"{tag}_mfma_busy_northstar.md"), (f"{tag}_attn_bench.txt", f"{tag}_attn_bench.txt"),
              (f"{tag}_tn_bench.txt", f"{tag}_tn_bench.txt"), (f"{tag}_bench_northstar_shape.json", f"{tag}_bench_northstar_shape.json"),
-             (f"{tag}_decode_breakdown.txt", f"{tag}_decode_breakdown.txt"), (f"{tag}_phase_stamps.txt", f"{tag}_phase_stamps.txt")):
+             (f"{tag}_decode_breakdown.txt", f"{tag}_decode_breakdown.txt"), (f"{tag}_phase_stamps.txt", f"{tag}_phase_stamps.txt"),
+             (f"{tag}_pl_bench.txt", f"{tag}_pl_bench.txt")):
     if os.path.exists(f"{src}/{a}"):
         shutil.copy(f"{src}/{a}", f"{dst}/{b}")
 if os.path.exists(f"{src}/c5_cached.json"):

@@ -14,7 +14,9 @@ if _adam:
     steps = float(_adam[0])                      # optimizer steps in the trace = launches of the Adam kernel
 import json
 import os
-_bench = json.load(open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), os.path.basename(sys.argv[1]).split("_")[0] + "_bench_p3.json")))
+PREC = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+TERMS = {0: 1, 1: 1, 3: 3, 6: 6}[PREC]
+_bench = json.load(open(os.path.join(os.path.dirname(os.path.abspath(sys.argv[1])), os.path.basename(sys.argv[1]).split("_")[0] + f"_bench_p{PREC}.json")))
 GEMM_FLOP = _bench["roofline"]["algorithmic_gflop_per_step"] * 1e9
 GEMM_LAUNCHES = _bench["roofline"]["launches_per_step"]
 ms = lambda pred: sum(int(r["TotalDurationNs"]) for r in rows if pred(r["Name"])) / 1e6 / steps
@@ -29,7 +31,7 @@ attn_enc = 12 * (4 + 14) * B * H * Tp * Tp * (d // H)                    # fwd 4
 attn_dec = 6 * (4 + 14) * B * H * (L1 * L1 + L1 * Tp) * (d // H)         # self + source attention of 2 x 3 decoder layers
 ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 block norms + conv-module norm per layer, after_norm
 classes = [
-    ("GEMM kernels (`gemm_dma_kernel`, `gemm_bf16_kernel`, `ffn_fwd_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n,   # gemm_tn_grouped_kernel included
+    ("GEMM kernels (`gemm_pl_kernel`, `gemm_dma_kernel`, `gemm_bf16_kernel`, `gemm_tn_*`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n,   # gemm_tn_grouped_kernel included
      f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
     ("attention (`attn_planes_q`, `attn_planes_k`; `attn_qtile`, `attn_ktile_bwd` for short axes)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
@@ -46,13 +48,14 @@ classes = [
     ("label-smoothing loss rows", "hbm", 2 * 2 * Md * V * f4, lambda n: "lsm_" in n, "logits read + gradient written, two decoders"),
     ("clip + Adam (`sumsq_partial`, `adam_kernel`)", "hbm", 31.3e6 * f4 * 8, lambda n: "adam_kernel" in n or "sumsq" in n, "g read twice; p, m, v read and written"),
 ]
-peak = {"hbm": 8.0e12, "mfma": 2.5e15}
+peak = {"hbm": 8.0e12, "mfma": 2.5e15 / TERMS}      # algorithmic flops: the dense bf16 MFMA rate / MFMAs issued per product
 unit = {"hbm": ("TB/s", 1e12), "mfma": ("TFLOP/s", 1e12)}
 tot = sum(int(r["TotalDurationNs"]) for r in rows if "spin_kernel" not in r["Name"]) / 1e6 / steps
-print("# Roofline by kernel class, config 2 (B=32 x 10 s), precision 3\n")
+print(f"# Roofline by kernel class, config 2 (B=32 x 10 s), precision {PREC}\n")
 print("Kernel time: rocprofv3 `--kernel-trace --stats` of `bench.py --no-graph --single-stream` (every kernel alone on one stream), "
       f"per optimizer step; all kernels {tot:.2f} ms/step.  Work: algorithmic bytes / flops (DESIGN section 4).  Peaks: HBM 8 TB/s, "
-      "dense bf16 MFMA 2.5 PFLOP/s (precision 3 issues three MFMAs per algorithmic product).\n")
+      f"dense bf16 MFMA 2.5 PFLOP/s / {TERMS} = {2500 / TERMS:.0f} TFLOP/s of algorithmic flops (precision {PREC} issues {TERMS} MFMAs per product; "
+      "the attention class's dK/dV and short-axis kernels run on the fp32-input MFMA in this mode and are priced against the same figure).\n")
 print("| class | bound | algorithmic work / step | kernel ms / step | achieved | % of peak | work counted |\n|---|---|---|---|---|---|---|")
 seen = 0.0
 for name, bound, work, pred, note in classes:
