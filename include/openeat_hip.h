@@ -248,6 +248,11 @@ int oe_layernorm_bwd_dx_drop_pl(const float* dy, const float* x, const float* ga
  *   workspace: float[ oe_ctc_workspace_floats(B,T,Lmax) ].
  * ------------------------------------------------------------------------- */
 size_t oe_ctc_workspace_floats(int B, int T, int Lmax);
+/* oe_ctc_loss_fused launch form, for tests and tuning tools (-1 / 0 keeps a value): pipe_mode 0 = rows, alpha/beta, labels one
+ * after the other (default); 1 = for large batches the recursion runs in `chunks` time chunks on two internal streams under
+ * the dense passes' traffic (ordinary stream events; capturable; measured SLOWER on MI355X: each cross-stream edge costs
+ * more than the chain time it hides); 2 = pipelined whatever the size. */
+int oe_ctc_config(int pipe_mode, int chunks);
 int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
                       int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll, float* loss_sum,
                       float* dlogits, float* workspace, void* stream);

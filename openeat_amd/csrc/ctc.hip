@@ -18,6 +18,7 @@
 //                 linked once per utterance by a third wave of k2); rows of infeasible
 //                 utterances are zeroed (zero_infinity)
 // Algorithmic bytes: 2*B*T*V*4 (+ 3 small state arrays), which is what k1 moves.
+#include <stdlib.h>
 #include "oe_common.h"
 #include "../../include/openeat_hip.h"
 
@@ -33,11 +34,13 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* logits, long
                                                         const int* __restrict__ hlens, const int* __restrict__ targets,
                                                         int Lmax, const int* __restrict__ tlens, int Sp, float scale,
                                                         const float* __restrict__ utt_weight, float* __restrict__ lp_out,
-                                                        float* dlogits) {
+                                                        float* dlogits, int t0, int Tc) {
+    // frames t0 .. t0 + Tc - 1 of every utterance (`rows` = B * Tc of them; the whole batch: t0 = 0, Tc = T)
     const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int b = (int)(row / T), t = (int)(row % T);
+    const long rloc = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rloc >= rows) return;
+    const int b = (int)(rloc / Tc), t = t0 + (int)(rloc % Tc);
+    const long row = (long)b * T + t;
     const float* p = logits + row * ldv;
     float* g = WRITE ? dlogits + row * ldv : nullptr;
     const int nv = (V + 3) >> 2;
@@ -184,9 +187,11 @@ __device__ __forceinline__ void ctc_chunk(int c0, int Tb, const long (&ostr)[NS]
 
 // One direction of the recursion for utterance rows [base, base + Tb): NS states per lane; CH frames of lp are fetched
 // at a time, one chunk ahead.  Returns this lane's final values in a[].  dump: one float any lane may scribble on.
+// k0, k1: the steps this call runs, [k0, k1) of the utterance's Tb (step k works on frame FWD ? k : Tb-1-k).  k0 = 0 starts
+// the recursion (first column); k0 > 0 resumes it from the values step k0 - 1 left in out_rows (an earlier launch).
 template <bool FWD, int NS, int CH>
 __device__ __forceinline__ void ctc_recurse(int lane, int Tb, int S, int Sp, const int* __restrict__ tg, const float* __restrict__ lp_rows,
-                                            float* __restrict__ out_rows, float* __restrict__ dump, float (&a)[NS]) {
+                                            float* __restrict__ out_rows, float* __restrict__ dump, float (&a)[NS], int k0, int k1) {
     const int s0 = lane * NS;
     float cap[NS];   // upper bound on the s-2 (alpha) / s+2 (beta) term: that transition exists only between different labels
     bool valid[NS];
@@ -205,21 +210,29 @@ __device__ __forceinline__ void ctc_recurse(int lane, int Tb, int S, int Sp, con
     const long tstride = FWD ? (long)Sp : -(long)Sp;
     const float* lp0 = lp_rows + (long)(FWD ? 0 : Tb - 1) * Sp + s0;      // frame of step 0, this lane's first state
     // states past S store to the dump word with stride 0: the stores of a step need no predicate
+    const int kfirst = k0 > 0 ? k0 - 1 : 0;              // the step whose values a[] holds before the loop
     float* op[NS];
 #pragma unroll
-    for (int j = 0; j < NS; ++j) op[j] = valid[j] ? out_rows + (long)(FWD ? 0 : Tb - 1) * Sp + s0 + j : dump;
+    for (int j = 0; j < NS; ++j) op[j] = valid[j] ? out_rows + (long)(FWD ? 0 : Tb - 1) * Sp + kfirst * tstride + s0 + j : dump;
     long ostr[NS];
 #pragma unroll
     for (int j = 0; j < NS; ++j) ostr[j] = valid[j] ? tstride : 0;
-    // ---- first column
+    if (k0 == 0) {
+        // ---- first column
 #pragma unroll
-    for (int j = 0; j < NS; ++j) {
-        const int s = s0 + j;
-        const bool start = FWD ? (s <= 1) : (s >= S - 2);
-        a[j] = CTC_NEG;
-        if (valid[j] && start) a[j] = lp0[j];
-        *op[j] = a[j];
+        for (int j = 0; j < NS; ++j) {
+            const int s = s0 + j;
+            const bool start = FWD ? (s <= 1) : (s >= S - 2);
+            a[j] = CTC_NEG;
+            if (valid[j] && start) a[j] = lp0[j];
+            *op[j] = a[j];
+        }
+    } else {
+        // ---- resume: the previous launch's last column
+#pragma unroll
+        for (int j = 0; j < NS; ++j) a[j] = valid[j] ? *op[j] : CTC_NEG;
     }
+    const int kb = kfirst + 1;                             // first step of the loop
     // ---- recursion, steps 1 .. Tb-1 in chunks of CH.  States past S carry lp = 0: they stay CTC_NEG (beta's flow is
     // from high s to low s, so they must), and their values go to the dump word.
     float cur[CH][NS], nxt[CH][NS];
@@ -228,22 +241,22 @@ __device__ __forceinline__ void ctc_recurse(int lane, int Tb, int S, int Sp, con
 #pragma unroll
         for (int j = 0; j < NS; ++j) {
             cur[i][j] = 0.f;
-            if (1 + i < Tb && valid[j]) cur[i][j] = lp0[(1 + i) * tstride + j];
+            if (kb + i < k1 && valid[j]) cur[i][j] = lp0[(kb + i) * tstride + j];
         }
 #pragma unroll
     for (int i = 0; i < CH; ++i)
 #pragma unroll
         for (int j = 0; j < NS; ++j) asm volatile("" : "+v"(cur[i][j]));
-    for (int c0 = 1; c0 < Tb; c0 += CH) {
+    for (int c0 = kb; c0 < k1; c0 += CH) {
 #pragma unroll
         for (int i = 0; i < CH; ++i)
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 nxt[i][j] = 0.f;
-                if (c0 + CH + i < Tb && valid[j]) nxt[i][j] = lp0[(c0 + CH + i) * tstride + j];
+                if (c0 + CH + i < k1 && valid[j]) nxt[i][j] = lp0[(c0 + CH + i) * tstride + j];
             }
-        if (c0 + CH <= Tb) ctc_chunk<FWD, NS, CH, true>(c0, Tb, ostr, a, cap, cur, op);
-        else ctc_chunk<FWD, NS, CH, false>(c0, Tb, ostr, a, cap, cur, op);
+        if (c0 + CH <= k1) ctc_chunk<FWD, NS, CH, true>(c0, k1, ostr, a, cap, cur, op);
+        else ctc_chunk<FWD, NS, CH, false>(c0, k1, ostr, a, cap, cur, op);
         // the next chunk becomes current HERE: pinning the values makes the compiler wait for the prefetch once per
         // chunk.  Left to itself it waits lazily at each step's first use of a prefetched register, and with the steps'
         // stores in between that wait is vmcnt(0): every step then sits out its own store's acknowledgement
@@ -289,14 +302,14 @@ __global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __
     } else if (Tb > 0) {
         float a[NS];
         if (wv == 0) {
-            ctc_recurse<true, NS, CH>(lane, Tb, S, Sp, tg, lp + base, alpha + base, dump, a);
+            ctc_recurse<true, NS, CH>(lane, Tb, S, Sp, tg, lp + base, alpha + base, dump, a, 0, Tb);
 #pragma unroll
             for (int j = 0; j < NS; ++j) {
                 if (lane * NS + j == S - 1) fin[0] = a[j];
                 if (lane * NS + j == S - 2) fin[1] = a[j];
             }
         } else {
-            ctc_recurse<false, NS, CH>(lane, Tb, S, Sp, tg, lp + base, beta + base, dump, a);
+            ctc_recurse<false, NS, CH>(lane, Tb, S, Sp, tg, lp + base, beta + base, dump, a, 0, Tb);
         }
     }
     __syncthreads();
@@ -314,6 +327,62 @@ __global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __
     }
 }
 
+// ---- the pipelined form (oe_ctc_loss_fused with T >= CTC_PIPE_MIN_T): the recursion in time chunks, one direction per launch.
+// One wave per utterance runs its direction over the frames [t0, t1) of the chunk: alpha resumes from the column the
+// previous chunk's launch left at frame t0 - 1, beta from frame t1; the launch that reaches the utterance's last frame
+// (alpha) also publishes the log-likelihood.  The host queues alpha chunks 0, 1, .. on one stream and beta chunks NC-1, NC-2,
+// .. on another, each behind the `rows` launch that produced its frames (ordinary stream events), so both chains run under
+// the remaining `rows` traffic instead of after it.
+template <bool FWD, int NS, int CH>
+__global__ __launch_bounds__(64) void ctc_dir_kernel(int T, int t0, int t1, const int* __restrict__ hlens, const int* __restrict__ targets,
+                                                     int Lmax, const int* __restrict__ tlens, int Sp, const float* __restrict__ lp,
+                                                     float* __restrict__ state, float* __restrict__ ll_out, float* __restrict__ nll_out,
+                                                     float* __restrict__ dump) {
+    __shared__ float fin[2];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int Tb = min(hlens[b], T);
+    const int S = 2 * min(tlens[b], Lmax) + 1;
+    const int* tg = targets + (long)b * Lmax;
+    const long base = (long)b * T * Sp;
+    if (FWD && Tb == 0 && t0 == 0 && lane == 0) { ll_out[b] = NEG_INF; nll_out[b] = 0.f; }
+    const int f1 = min(t1, Tb);                       // frames [t0, f1) of this utterance lie in the chunk
+    if (t0 >= f1) return;
+    const int k0 = FWD ? t0 : Tb - f1, k1 = FWD ? f1 : Tb - t0;
+    float a[NS];
+    ctc_recurse<FWD, NS, CH>(lane, Tb, S, Sp, tg, lp + base, state + base, dump, a, k0, k1);
+    if (FWD && f1 == Tb) {                            // the last frame: log2-likelihood (see ctc_alphabeta_kernel)
+        if (lane < 2) fin[lane] = CTC_NEG;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            if (lane * NS + j == S - 1) fin[0] = a[j];
+            if (lane * NS + j == S - 2) fin[1] = a[j];
+        }
+        __syncthreads();
+        if (lane == 0) {
+            const float m = fmaxf(fin[0], fin[1]);
+            const float v = m + ctc_log2(ctc_exp2(fin[0] - m) + ctc_exp2(fin[1] - m));
+            const float ll = (v > 0.5f * CTC_NEG) ? v : NEG_INF;
+            ll_out[b] = ll;
+            nll_out[b] = (ll == NEG_INF) ? 0.f : -ll * CTC_LN2;
+        }
+    }
+}
+// chain[b][s] for odd s (see ctc_alphabeta_kernel): one wave per utterance
+__global__ __launch_bounds__(64) void ctc_chain_kernel(const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens, int Sp,
+                                                       int* __restrict__ chain) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int S = 2 * min(tlens[b], Lmax) + 1;
+    const int* tg = targets + (long)b * Lmax;
+    for (int s = 1 + 2 * lane; s < S; s += 128) {
+        const int c = tg[s >> 1];
+        int head = 1, nx = 0;
+        for (int q = 1; q < s; q += 2) if (tg[q >> 1] == c) { head = 0; break; }
+        for (int q = s + 2; q < S; q += 2) if (tg[q >> 1] == c) { nx = q + 1; break; }
+        chain[(long)b * Sp + s] = nx | (head << 16);
+    }
+}
+
 // ------------------------------------------------------------------ k3 ------
 // One wave per frame (four per block).  k1 has written softmax * scale everywhere; the classes of the target get their
 // occupation term here, and frames of an infeasible utterance (ll = -inf) are zeroed.  Block 0 also sums the loss.
@@ -324,7 +393,8 @@ __global__ __launch_bounds__(256) void ctc_labels_kernel(long rows, int B, int T
                                                           const float* __restrict__ beta, const float* __restrict__ ll_in,
                                                           const int* __restrict__ chain, const float* __restrict__ nll,
                                                           float scale, const float* __restrict__ utt_weight,
-                                                          float* __restrict__ dlogits, float* __restrict__ loss_sum) {
+                                                          float* __restrict__ dlogits, float* __restrict__ loss_sum, int t0, int Tc) {
+    // frames t0 .. t0 + Tc - 1 of every utterance (`rows` = B * Tc; the whole batch: t0 = 0, Tc = T)
     extern __shared__ __attribute__((aligned(16))) float sh[];   // per wave: gam[Sp]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (loss_sum && blockIdx.x == 0 && wv == 0) {
@@ -333,9 +403,10 @@ __global__ __launch_bounds__(256) void ctc_labels_kernel(long rows, int B, int T
         s = wave_sum(s);
         if (lane == 0) loss_sum[0] = s;
     }
-    const long row = (long)blockIdx.x * 4 + wv;
-    const bool inrange = row < rows;
-    const int b = inrange ? (int)(row / T) : 0, t = inrange ? (int)(row % T) : 0;
+    const long rloc = (long)blockIdx.x * 4 + wv;
+    const bool inrange = rloc < rows;
+    const int b = inrange ? (int)(rloc / Tc) : 0, t = inrange ? t0 + (int)(rloc % Tc) : 0;
+    const long row = (long)b * T + t;
     const bool frame = inrange && t < hlens[b];
     const float ll = ll_in[b];
     float* g = dlogits + row * ldv;
@@ -385,6 +456,45 @@ __global__ void ctc_sum_kernel(const float* __restrict__ nll, const float* __res
     if (threadIdx.x == 0) out[0] = s;
 }
 
+// Streams and events of the pipelined form, one set per device, made on first use (a first use is never inside a graph
+// capture: the engine runs an eager step before it captures).  Re-recording an event does not disturb waits already queued.
+#define CTC_MAX_CHUNKS 8
+#define OE_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { oe_set_error("oe_ctc_loss_fused: %s", hipGetErrorString(e_)); return (int)e_; } } while (0)
+struct CtcPipe {
+    hipStream_t sa = nullptr, sb = nullptr;
+    hipEvent_t rows_done[CTC_MAX_CHUNKS], beta_done[CTC_MAX_CHUNKS], alpha_done;
+    bool ok = false;
+};
+static CtcPipe* ctc_pipe() {
+    static CtcPipe pipes[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    CtcPipe& p = pipes[dev];
+    if (!p.ok) {
+        if (hipStreamCreateWithFlags(&p.sa, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&p.sb, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < CTC_MAX_CHUNKS; ++i) {
+            if (hipEventCreateWithFlags(&p.rows_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&p.beta_done[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&p.alpha_done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        p.ok = true;
+    }
+    return &p;
+}
+
+// OE_CTC_PIPE: 0 = never pipeline (default), 1 = where the batch is large enough, 2 = always (tests); OE_CTC_CHUNKS: time chunks.
+// Measured on MI355X (tools/ctc_graph_bench.py, profiles/r03_experiments.md): every cross-stream edge of the pipelined form
+// costs more than the chain time it hides - from a HIP graph 216 us sequential against 335 / 352 / 384 / 436 us with 2 / 3 /
+// 4 / 6 chunks at the north-star shape (eager launches: 209 against 310 with 4) - so it is not the default.
+static int ctc_pipe_mode = getenv("OE_CTC_PIPE") ? atoi(getenv("OE_CTC_PIPE")) : 0;
+static int ctc_pipe_chunks = getenv("OE_CTC_CHUNKS") ? atoi(getenv("OE_CTC_CHUNKS")) : 4;
+extern "C" int oe_ctc_config(int pipe_mode, int chunks) {
+    if (pipe_mode >= 0) ctc_pipe_mode = pipe_mode;
+    if (chunks >= 2) ctc_pipe_chunks = chunks;
+    return 0;
+}
+
 extern "C" size_t oe_ctc_workspace_floats(int B, int T, int Lmax) {
     size_t Sp = 2 * (size_t)Lmax + 1;
     return (size_t)B + 3 * (size_t)B * T * Sp + (size_t)B * Sp + 16;
@@ -411,17 +521,70 @@ extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, in
     const bool vec = (((uintptr_t)logits & 15) == 0) && (!dlogits || ((uintptr_t)dlogits & 15) == 0) && (ldv % 4 == 0) &&
                      (ldv >= (((long)V + 3) & ~3L)) && V <= 256 * 32;
     const int nv4 = !vec ? 0 : V <= 256 * 4 ? 4 : V <= 256 * 8 ? 8 : V <= 256 * 16 ? 16 : 32;
-#define ROWS(NV4, WR)                                                                                                          \
-    hipLaunchKernelGGL((ctc_rows_kernel<NV4, WR>), dim3(oe_cdiv(rows, 4)), dim3(256), 0, st, logits, ldv, rows, T, V, hlens,    \
-                       targets, Lmax, tlens, Sp, grad_scale, utt_weight, lp, dlogits)
-#define ROWS_W(NV4) do { if (dlogits) ROWS(NV4, true); else ROWS(NV4, false); } while (0)
-    switch (nv4) {
-        case 4: ROWS_W(4); break;
-        case 8: ROWS_W(8); break;
-        case 16: ROWS_W(16); break;
-        case 32: ROWS_W(32); break;
-        default: ROWS_W(0); break;
+#define ROWS(NV4, WR, T0, TC)                                                                                                  \
+    hipLaunchKernelGGL((ctc_rows_kernel<NV4, WR>), dim3(oe_cdiv((long)B * (TC), 4)), dim3(256), 0, st, logits, ldv, (long)B * (TC), T, V, \
+                       hlens, targets, Lmax, tlens, Sp, grad_scale, utt_weight, lp, dlogits, T0, TC)
+#define ROWS_W(NV4, T0, TC) do { if (dlogits) ROWS(NV4, true, T0, TC); else ROWS(NV4, false, T0, TC); } while (0)
+    auto launch_rows = [&](int t0, int tc) {
+        switch (nv4) {
+            case 4: ROWS_W(4, t0, tc); break;
+            case 8: ROWS_W(8, t0, tc); break;
+            case 16: ROWS_W(16, t0, tc); break;
+            case 32: ROWS_W(32, t0, tc); break;
+            default: ROWS_W(0, t0, tc); break;
+        }
+    };
+    auto launch_labels = [&](int t0, int tc, float* lsum) {
+        hipLaunchKernelGGL(ctc_labels_kernel, dim3(oe_cdiv((long)B * tc, 4)), dim3(256), (size_t)4 * Sp * sizeof(float), st, (long)B * tc, B, T, V,
+                           ldv, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll, chain, nll, grad_scale, utt_weight, dlogits, lsum, t0, tc);
+    };
+    // ---- pipelined form (opt-in, see ctc_pipe_mode): the recursion in time chunks under the remaining `rows` traffic
+    // (ctc_dir_kernel) - rows 115 us, the two chains 60 us each, label fix-up 30 us at the 16 s north-star batch.
+    const int pipe_mode = ctc_pipe_mode, pipe_chunks = ctc_pipe_chunks;
+    CtcPipe* pp = nullptr;
+    const int NC = min(max(pipe_chunks, 2), CTC_MAX_CHUNKS);
+    if (pipe_mode && dlogits && (pipe_mode == 2 ? T >= 2 * NC : (T >= 32 * NC && (double)rows * V >= 1.5e7))) pp = ctc_pipe();
+    if (pp) {
+        const int Tq = oe_cdiv(T, NC);
+        auto c0 = [&](int c) { return c * Tq; };
+        auto cn = [&](int c) { return min(T, (c + 1) * Tq) - c * Tq; };
+        hipLaunchKernelGGL(ctc_chain_kernel, dim3(B), dim3(64), 0, st, targets, Lmax, tlens, Sp, chain);
+        // rows in the order first, last, second, second-to-last, ...: alpha needs the frames from the front, beta from the back
+        int lo = 0, hi = NC - 1;
+        for (int i = 0; i < NC; ++i) {
+            const int c = (i & 1) ? hi-- : lo++;
+            if (cn(c) > 0) launch_rows(c0(c), cn(c));
+            OE_HIP(hipEventRecord(pp->rows_done[c], st));
+        }
+        OE_LAUNCH_CHECK("ctc_rows");
+#define DIR(FWD, NS, CH, STR, C)                                                                                                   \
+        hipLaunchKernelGGL((ctc_dir_kernel<FWD, NS, CH>), dim3(B), dim3(64), 0, STR, T, c0(C), c0(C) + cn(C), hlens, targets, Lmax, tlens, \
+                           Sp, lp, (FWD) ? alpha : beta, ll, nll, dump + ((FWD) ? 0 : 8))
+#define DIRS(FWD, STR, C) do { if (Sp <= 64) DIR(FWD, 1, 32, STR, C); else if (Sp <= 128) DIR(FWD, 2, 16, STR, C);                 \
+                               else if (Sp <= 256) DIR(FWD, 4, 8, STR, C); else DIR(FWD, 8, 4, STR, C); } while (0)
+        for (int c = 0; c < NC; ++c) {
+            OE_HIP(hipStreamWaitEvent(pp->sa, pp->rows_done[c], 0));
+            if (cn(c) > 0) DIRS(true, pp->sa, c);
+        }
+        OE_HIP(hipEventRecord(pp->alpha_done, pp->sa));
+        for (int c = NC - 1; c >= 0; --c) {
+            OE_HIP(hipStreamWaitEvent(pp->sb, pp->rows_done[c], 0));
+            if (cn(c) > 0) DIRS(false, pp->sb, c);
+            OE_HIP(hipEventRecord(pp->beta_done[c], pp->sb));
+        }
+#undef DIRS
+#undef DIR
+        OE_LAUNCH_CHECK("ctc_dir");
+        // label fix-up per chunk once both directions have passed it (the log-likelihood comes with the end of alpha)
+        OE_HIP(hipStreamWaitEvent(st, pp->alpha_done, 0));
+        for (int c = NC - 1; c >= 0; --c) {
+            OE_HIP(hipStreamWaitEvent(st, pp->beta_done[c], 0));
+            if (cn(c) > 0) launch_labels(c0(c), cn(c), c == 0 ? loss_sum : nullptr);      // chunk 0 is last: every nll is final
+        }
+        OE_LAUNCH_CHECK("ctc_labels");
+        return 0;
     }
+    launch_rows(0, T);
 #undef ROWS_W
 #undef ROWS
     OE_LAUNCH_CHECK("ctc_rows");
@@ -431,9 +594,7 @@ extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, in
 #undef AB
     OE_LAUNCH_CHECK("ctc_alphabeta");
     if (dlogits) {
-        hipLaunchKernelGGL(ctc_labels_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), (size_t)4 * Sp * sizeof(float), st, rows, B, T, V,
-                           ldv, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll, chain, nll, grad_scale, utt_weight, dlogits,
-                           loss_sum);
+        launch_labels(0, T, loss_sum);
         OE_LAUNCH_CHECK("ctc_labels");
     } else if (loss_sum) {
         hipLaunchKernelGGL(ctc_sum_kernel, dim3(1), dim3(64), 0, st, nll, utt_weight, B, loss_sum);

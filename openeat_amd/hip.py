@@ -147,6 +147,7 @@ _SIGNATURES = {
     "oe_layernorm_bwd_dx_drop": (I, [P, P, P, P, I, P, I, I, P, P, P, P, F, F, U64, P, P, P, P]),
     "oe_layernorm_bwd_dx_drop_pl": (I, [P, P, P, P, I, P, I, I, P, P, P, P, F, F, U64, P, P, P, P, L, P]),
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
+    "oe_ctc_config": (I, [I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
     "oe_attention_fwd": (I, [C.POINTER(AttnArgs), P]),

@@ -245,6 +245,17 @@ def test_layernorm_backward_second_output_is_dropout_scale_of_dx(rows, d, p, alp
 
 
 # -------------------------------------------------------------------- CTC ----
+@pytest.fixture(params=[(0, 4), (2, 4), (2, 3), (2, 8)], ids=["default-form", "pipelined-4-chunks", "pipelined-3-chunks", "pipelined-8-chunks"])
+def ctc_form(request):
+    """The CTC tests run in the launch form the size picks (small problems: rows, alpha/beta, labels one after the other) and
+    with the pipelined form forced (the recursion in time chunks on two internal streams, resumed from the columns the
+    previous chunk left: oe_ctc_config) - same numbers either way."""
+    mode, chunks = request.param
+    hip.lib().oe_ctc_config(mode, chunks)
+    yield request.param
+    hip.lib().oe_ctc_config(0, 4)
+
+
 def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_weight=None, want_grad=True):
     B, T, V = logits.shape
     ldv = ldv or V
@@ -266,7 +277,7 @@ def run_ctc(logits, hlens, ys, ylens, ldv=None, scale=1.0, inplace=False, utt_we
     return nll.cpu(), tot.cpu(), (dl[:, :, :V].cpu() if want_grad else None)
 
 
-def test_ctc_golden_f07():
+def test_ctc_golden_f07(ctc_form):
     """The reference's own numbers (fixture F7): infeasible utterance, empty target, repeats."""
     from conftest import load_golden
     g = load_golden("f07_ctc")
@@ -281,7 +292,7 @@ def test_ctc_golden_f07():
 
 @pytest.mark.parametrize("B,T,V,Lmax,ldv", [(6, 50, 37, 9, 40), (4, 120, 3246, 40, 3248), (3, 90, 501, 70, 504),
                                              (2, 300, 100, 140, 100)])
-def test_ctc_vs_oracle(B, T, V, Lmax, ldv):
+def test_ctc_vs_oracle(B, T, V, Lmax, ldv, ctc_form):
     torch.manual_seed(7)
     logits = torch.randn(B, T, V) * 2
     hl = torch.randint(T // 2, T + 1, (B,))
@@ -307,7 +318,7 @@ def test_ctc_vs_oracle(B, T, V, Lmax, ldv):
 # aligned float4s, or wider than 8192); utterance lengths at the edges of the recursion's 32-frame prefetch chunks
 @pytest.mark.parametrize("V,ldv,inplace", [(37, 37, True), (37, 39, False), (37, 40, True), (1500, 1500, False), (3246, 3246, True),
                                            (3246, 3248, False), (5000, 5000, True), (9000, 9000, False)])
-def test_ctc_row_variants_and_chunk_edges(V, ldv, inplace):
+def test_ctc_row_variants_and_chunk_edges(V, ldv, inplace, ctc_form):
     torch.manual_seed(11)
     T, Lmax = 70, 5
     hl = torch.tensor([70, 1, 2, 32, 33, 34, 3, 65, 64])
@@ -330,6 +341,27 @@ def test_ctc_row_variants_and_chunk_edges(V, ldv, inplace):
     assert float(nll[6]) == 0.0 and bool((dl[6] == 0).all())                                   # zero_infinity
     for b in range(B):
         assert bool((dl[b, int(hl[b]):] == 0).all())                                           # padded frames exactly 0
+
+
+def test_ctc_pipelined_form_is_bit_identical_to_the_sequential_one():
+    """Same arithmetic, other launch structure: losses and gradients equal bit for bit (ragged lengths that end inside every
+    chunk, an infeasible utterance, an empty target, repeats)."""
+    torch.manual_seed(12)
+    B, T, V, Lmax = 9, 131, 200, 12
+    hl = torch.tensor([131, 1, 2, 33, 66, 98, 100, 3, 131])
+    yl = torch.tensor([12, 1, 1, 7, 0, 12, 5, 6, 3])          # utterance 7: six labels in three frames -> infeasible
+    ys = torch.randint(1, V, (B, Lmax))
+    ys[0, 1] = ys[0, 0]
+    logits = torch.randn(B, T, V) * 2
+    outs = []
+    for mode, chunks in ((0, 4), (2, 4), (2, 5)):
+        hip.lib().oe_ctc_config(mode, chunks)
+        try:
+            outs.append(run_ctc(logits, hl, ys, yl, scale=0.5))
+        finally:
+            hip.lib().oe_ctc_config(0, 4)
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
 def test_ctc_greedy_matches_topk_and_collapse():
