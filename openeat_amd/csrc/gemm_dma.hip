@@ -262,7 +262,12 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     // ... and very wide outputs (the vocabulary projections): many column blocks re-read the same rows of A.
     const bool small = (long)oe_cdiv(M, 64) * oe_cdiv(N, 64) * sk <= 256;
     const bool wide = N >= 2048 && !a_kmajor;
-    if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small && !wide) return 1;
+    // ... and, with six MFMA terms per product (precision 6), every output at least 512 wide: the register-staged kernel's
+    // exposed K-tile round trip costs more once the matrix work per tile doubles (7936 x 1024 x 256: 32.4 against 43.8 us,
+    // x 768: 29.7 / 41.9, x 512: 21.0 / 27.8, dY W 7936 x 1024 x 256: 36.2 / 52.1; N = 256 outputs measured equal or slower)
+    const bool six = terms == 6 && !a_kmajor && N >= 512;
+    if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small && !wide && !six) return 1;
+    if (six && tile != 22 && M >= 128 && (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk >= 200) tile = 22;
     if (tile == 12) tile = 11;
     const int bm = 64 * (tile / 10), bn = 64 * (tile % 10);
     // pieces are 16 bytes: K a multiple of the K-tile; a k-major operand's row length (M resp. N) a multiple of 4.

@@ -363,11 +363,15 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     // reductions; 64 x 64 x 32 (72 KiB) where 128 x 128 tiles would leave CUs idle (N = 256 outputs).  k-major tiles are 128
     // columns wide, so a k-major operand pins its side of the tile.
     const int forced_bk = pl_forced_bk, forced_tile = pl_forced_tile;
-    const int kc0 = oe_cdiv(K, sk);
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
     int tile = 22;
     if (!a_kmajor && !b_kmajor && !ga && b22 < 320) tile = 11;
-    if (!a_kmajor && !b_kmajor && N % 256 == 0 && K % 32 == 0 && (long)oe_cdiv(M, 128) * (N / 256) * sk >= 512) tile = 24;
+    // 128 x 256: the conv2 GEMMs (~1200 blocks) and the wide-output Linears whose 128 x 256 grid is about one round of the chip
+    // (7936 x 1024 x 256: 248 blocks, 30.6 us against 34.9 with 496 tiles of 128 x 128; 7936 x 768: 25.7 against 29.2)
+    if (!a_kmajor && !b_kmajor && N % 256 == 0 && K % 32 == 0) {
+        const long b24 = (long)oe_cdiv(M, 128) * (N / 256) * sk;
+        if (b24 >= 512 || (N >= 768 && b24 >= 160)) tile = 24;
+    }
     // 256 x 256 tiles (8 waves of 64 x 128, K-tile 16, three stages): a K-tile moves 48 KiB for 96 MFMAs per wave - half the
     // LDS-DMA bytes per MFMA of the 128 x 128 tile, which is what bounds that one (L2 -> LDS fill rate).  For the long,
     // wide problems whose grid still fills the chip: conv2 (forward, input and weight gradients), the 16 s batches.
@@ -382,7 +386,8 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
         // atomics into a zeroed buffer whatever the caller's split was)
         sk = (int)max(1L, min((long)(K / 2048), 256 / b44));
     }
-    int bk = (tile == 22) ? (kc0 >= 1024 ? 32 : 16) : (tile == 44 ? 16 : 32);     // tiles 11 and 24 exist with K-tiles of 32 only
+    // K-tile 32 wherever K allows (measured faster than 16 on every Linear shape, K = 256 included: half the barriers)
+    int bk = (tile == 44) ? 16 : 32;                                               // tiles 11 and 24 exist with K-tiles of 32 only
     if (forced_bk && tile == 22) bk = forced_bk;
     if (K % bk) { if (tile == 22 && bk == 32 && K % 16 == 0) bk = 16; else return 1; }
     if (sk > 1 && (long)oe_cdiv(oe_cdiv(K, sk), bk) * bk * (sk - 1) >= K) return 1;          // a split would be left empty

@@ -82,7 +82,7 @@ def _operand_planes(act2d, w2d):
     """Pre-split copies (planes.py) of an activation operand and a weight operand of one GEMM - both or neither."""
     if not _planes.active():
         return None, None
-    ap = _planes.of(act2d)
+    ap = _planes.of(act2d, make=_planes.split_activations())
     if ap is None:
         return None, None
     bp = _planes.weight(w2d)
@@ -96,7 +96,7 @@ def gemm_nt(x, w, bias=None, out=None, out_planes=False, **epi):
     if out is None:
         out = _new(M, N, like=x)
     ap, bp = _operand_planes(x, w)
-    cp = _planes.new_output(out) if (out_planes and _planes.active() and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
+    cp = _planes.new_output(out) if (out_planes and _planes.split_activations() and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
     hip.gemm(x, w, out, M, N, K, lda=x.stride(0), ldb=w.stride(0), ldc=out.stride(0), bias=bias, a_planes=ap, b_planes=bp, c_planes=cp, **epi)
     return out
 
@@ -109,7 +109,7 @@ def gemm_nn(dy, w, out=None, out_planes=False, **epi):
     if out is None:
         out = _new(M, K, like=dy)
     ap, bp = _operand_planes(dy, w)
-    want = _planes.available() if out_planes == "always" else (out_planes and _planes.active())
+    want = _planes.available() if out_planes == "always" else (out_planes and _planes.split_activations())
     cp = _planes.new_output(out) if (want and out.numel() >= _planes.MIN_SPLIT_ELEMS) else None
     hip.gemm(dy, w, out, M, K, N, lda=dy.stride(0), ldb=w.stride(0), ldc=out.stride(0), b_kmajor=True, a_planes=ap, b_planes=bp, c_planes=cp, **epi)
     return out
@@ -141,8 +141,9 @@ def wgrad_planes(dy, x, always=False):
     always: under the conv front end's policy too (not only the general one)."""
     if not (_planes.available() if always else _planes.active()):
         return None, None
-    ap = _planes.of(dy)
-    bp = _planes.of(x) if ap is not None else None
+    make = always or _planes.split_activations()
+    ap = _planes.of(dy, make=make)
+    bp = _planes.of(x, make=make) if ap is not None else None
     return (ap, bp) if bp is not None else (None, None)
 
 
@@ -1331,7 +1332,7 @@ class ConvSubsamplingFn(torch.autograd.Function):
                 bp = _planes.of(wg, force=True) if ap is not None else None
                 if bp is None:
                     ap = None
-                cp = _planes.new_output(yo) if (k + 1 < n or _planes.active()) else None    # a next conv stage reads it as an operand
+                cp = _planes.new_output(yo) if (k + 1 < n or _planes.split_activations()) else None    # a next conv stage reads it as an operand
             hip.gemm(acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
                      conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A, a_planes=ap, b_planes=bp, c_planes=cp)
             dims.append((To, Fo))

@@ -27,10 +27,16 @@ from . import hip
 #   "all":            every Linear of the encoder too (LayerNorm / GEMM epilogues write planes).  The GEMMs gain 10-25 %
 #                     each, but a feed-forward's (rows, ff) intermediate costs 1.5 x its fp32 bytes again as planes: a wash
 #                     at config 2 (the step as a whole measured slower), so not the default;
+#   "ln":             conv + the operands that come pre-split for (almost) nothing: LayerNorm outputs (forward: x of W1 / QKV /
+#                     pointwise-1; backward: the block-input gradient g that feeds the previous block's input-gradient
+#                     GEMMs) against the arena's weight planes.  No split passes, no planes of GEMM outputs;
 #   "0":              never.
 POLICY = os.environ.get("OE_PLANES", "conv")
 # below this many elements a tensor is not worth a split pass of its own (the decoders' 992-row activations)
 MIN_SPLIT_ELEMS = int(os.environ.get("OE_PLANES_MIN", str(1 << 19)))
+
+
+_DEBUG = bool(os.environ.get("OE_PLANES_DEBUG"))
 
 
 def available() -> bool:
@@ -39,7 +45,13 @@ def available() -> bool:
 
 
 def active() -> bool:
-    """The general Linear / LayerNorm plumbing of ops.py pre-splits its operands."""
+    """The general Linear / LayerNorm plumbing of ops.py uses pre-split operands."""
+    return POLICY in ("all", "ln") and hip.GEMM_PRECISION == 6
+
+
+def split_activations() -> bool:
+    """Activations whose producer wrote no planes get a split pass of their own / GEMM epilogues write planes of their
+    outputs ("all"); under "ln" only what LayerNorm forward / backward wrote on its way (and the weights) is pre-split."""
     return POLICY == "all" and hip.GEMM_PRECISION == 6
 
 
@@ -103,6 +115,9 @@ def of(t2d: torch.Tensor, make: bool = True, force: bool = False) -> Optional[Pl
     if t2d.numel() < MIN_SPLIT_ELEMS and not force:
         return None
     pl = alloc(t2d.shape[0], t2d.shape[1], t2d.device)
+    if _DEBUG:
+        import traceback
+        print("split_planes", tuple(t2d.shape), [f"{f.name}:{f.lineno}" for f in traceback.extract_stack()[-5:-1]], flush=True)
     hip.call("oe_split_planes", t2d, t2d.stride(0), t2d.shape[0], t2d.shape[1], pl.t, pl.ld, pl.stride)
     register(t2d, pl)
     return pl
@@ -129,10 +144,10 @@ def weight(w2d: torch.Tensor) -> Optional[Planes]:
     from . import arena as _arena
     a = _arena.active()
     ptr = w2d.data_ptr()
-    if a is not None and a.planes is not None:
+    if a is not None and (a.planes is not None or active()):
         off = (ptr - a.flat.data_ptr()) // 4
         if 0 <= off < a.numel and ptr % 32 == 0:
-            a.ensure_planes()
+            a.ensure_planes()           # (first use: allocates and splits the whole arena once)
             return Planes(a.planes, a.planes.data_ptr() + 2 * off, a.planes_stride, w2d.stride(0), w2d.shape[0], w2d.shape[1])
     if ptr % 16 or w2d.stride(0) != w2d.shape[1]:
         return None
@@ -142,6 +157,8 @@ def weight(w2d: torch.Tensor) -> Optional[Planes]:
     # training outside an arena: parameters change through optimizers whose in-place updates bump the version, but raw
     # kernels do not - only trust the cache under no_grad (decode / eval), else split afresh
     pl = alloc(w2d.shape[0], w2d.shape[1], w2d.device)
+    if _DEBUG:
+        print("split_planes weight", tuple(w2d.shape), flush=True)
     hip.call("oe_split_planes", w2d, w2d.stride(0), w2d.shape[0], w2d.shape[1], pl.t, pl.ld, pl.stride)
     if not torch.is_grad_enabled():
         if len(_WCACHE) >= _WCACHE_MAX:
