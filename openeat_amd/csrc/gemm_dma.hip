@@ -265,9 +265,12 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     // ... and, with six MFMA terms per product (precision 6), every output at least 512 wide: the register-staged kernel's
     // exposed K-tile round trip costs more once the matrix work per tile doubles (7936 x 1024 x 256: 32.4 against 43.8 us,
     // x 768: 29.7 / 41.9, x 512: 21.0 / 27.8, dY W 7936 x 1024 x 256: 36.2 / 52.1; N = 256 outputs measured equal or slower)
-    const bool six = terms == 6 && !a_kmajor && N >= 512;
+    // ... and narrower outputs once 128 x 128 tiles still make more than a round of the chip (the 64 x 16 s batch, 25472 rows:
+    // x 256 x 1024 135 against 200 us, x 256 x 256 30 / 63, dY W 25472 x 256 x 1024 121 / 141 with 64 x 64 tiles)
+    const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk;
+    const bool six = terms == 6 && !a_kmajor && M >= 128 && N >= 128 && (N >= 512 || b22 >= 300);
     if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small && !wide && !six) return 1;
-    if (six && tile != 22 && M >= 128 && (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk >= 200) tile = 22;
+    if (six && tile != 22 && b22 >= (N >= 512 ? 200 : 300)) tile = 22;
     if (tile == 12) tile = 11;
     const int bm = 64 * (tile / 10), bn = 64 * (tile % 10);
     // pieces are 16 bytes: K a multiple of the K-tile; a k-major operand's row length (M resp. N) a multiple of 4.

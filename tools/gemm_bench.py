@@ -9,7 +9,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from openeat_amd import hip  # noqa: E402
 
-M = 7936
+M = int(os.environ.get("GEMM_BENCH_M", "7936"))          # B=32 x T'=248 rows (25472 = the 64 x 16 s batch)
 SHAPES = [
     # name, kind, (m, n, k)   kinds: nt = x W^T, nn = dy W, tn = dy^T x
     ("ffn.w1 fwd", "nt", (M, 1024, 256)),
