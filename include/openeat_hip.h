@@ -298,7 +298,7 @@ typedef struct oe_attn_args {
     float* delta;
     /* matrix-core arithmetic of the score / context products, as oe_gemm_args.precision:
      * 0 = fp32 MFMA (exact products), 1 = bf16 inputs, 3 = three-term bf16 split (2^-17 per product),
-     * 6 = six terms on three exact bf16 pieces (fp32-MFMA-grade; dK / dV then run on the fp32 kernel) */
+     * 6 = six terms on three exact bf16 pieces (fp32-MFMA-grade) */
     int precision;
     /* hint, forward: the (B, T1, T2) mask is zero above the diagonal (a decoder's self-attention): key blocks that lie wholly
      * above it are not visited.  Results are identical with or without the hint; ignored unless a full mask is given. */

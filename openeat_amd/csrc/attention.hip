@@ -21,6 +21,7 @@
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); algorithmic flops
 // fwd = 4*B*H*T1*T2*D, bwd = 14*B*H*T1*T2*D (S recomputed in both kernels).
+#include <stdlib.h>
 #include "attn_common.h"
 
 // Diagnostic build only (-DOE_GEMM_STAMPS, tools/attn_stamps.py): s_memtime sums per phase of the forward kernel.
@@ -728,8 +729,18 @@ extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
             else hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, TT, 1>), gk, dim3(ATT_GROUP), 0, st, p);   \
         }                                                                                                 \
     } while (0)
-    // precision 6: dQ on three planes where it fits; everything else of this call on exact fp32 products
-    if (a->precision == 3) ATT_BWD(3); else if (a->precision == 1) ATT_BWD(1); else ATT_BWD(0);
+    // precision 6: dQ and dK/dV on three planes where they fit (attention_bf16.hip); what does not fit on exact fp32 products
+    static const bool dkdv6 = !(getenv("OE_ATTN_DKDV6") && atoi(getenv("OE_ATTN_DKDV6")) == 0);      // 0: A/B against the fp32 kernel
+    if (a->precision == 6) {
+        if (!q_done) {
+            if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 1, 0, 1>), gq, dim3(ATT_GROUP), 0, st, p);
+            else hipLaunchKernelGGL((attn_qtile_kernel<64, 1, 0, 1>), gq, dim3(ATT_GROUP), 0, st, p);
+        }
+        if (!(dkdv6 && oe_attn_planes_dkdv_try(p, 6, st) == 0)) {
+            if (p.D <= 32) hipLaunchKernelGGL((attn_ktile_bwd_kernel<32, 0, 1>), gk, dim3(ATT_GROUP), 0, st, p);
+            else hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, 0, 1>), gk, dim3(ATT_GROUP), 0, st, p);
+        }
+    } else if (a->precision == 3) ATT_BWD(3); else if (a->precision == 1) ATT_BWD(1); else ATT_BWD(0);
 #undef ATT_BWD
     OE_LAUNCH_CHECK("oe_attention_bwd");
     return 0;

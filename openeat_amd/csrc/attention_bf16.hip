@@ -1,8 +1,10 @@
 // Fused multi-head attention on the bf16 matrix cores with the streamed operand kept in LDS as bf16 PLANES
 // (attention.py:65-97,112-117,189-209 and their autograd; precision 1 = hi plane only, precision 3 = hi + lo planes and
 // the three-term product hi*hi + hi*lo + lo*hi, precision 6 = three planes and the six-term product of oe_common.h for
-// the forward and dQ kernels - as oe_gemm_args.precision; the dK/dV kernel keeps four resident and four streamed images,
-// which at three planes each is more than a CU's LDS: precision 6 takes the exact-fp32 kernel of attention.hip there).
+// all three kernels - as oe_gemm_args.precision; the dK/dV kernel keeps four resident and four streamed images, which at
+// three planes each is more than a CU's LDS: there precision 6 single-buffers the streamed pair and packs the resident
+// images (ResImage) - 151 KiB; measured 77 against 121 us per layer's backward with the exact-fp32 dK/dV kernel at B = 32,
+// T = 248, 406 / 614 us at B = 64, T = 398).
 //
 // What changed against the first generation of bf16 kernels (attention.hip, still used for small problems and for the
 // exact-fp32 mode): those kept fp32 tiles in LDS and split every fragment to bf16 on EVERY use (each of the waves that
@@ -161,6 +163,46 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs<DPAD>& t, __bf16* im
         for (int n = 0; n < P::NPL; ++n) *reinterpret_cast<bf16x4*>(d + n * P::PLANE_ELEMS) = pl[n];
     }
 }
+
+// The dK/dV kernel's RESIDENT images (the block's own 128 keys: K' * scale and V, read as row fragments only).  At three
+// planes and DPAD = 64 the padded pitch does not fit beside the streamed images, so that case packs rows to 128 bytes and
+// permutes the 16-byte chunks of a row instead: chunk c of row r sits at c ^ ((r >> 1) & 7) - the 16 lanes of a b128 read
+// group (rows {0-3, 12-15, 20-27} + 32 k of one chunk index) then cover the 16 slots of the 256-byte bank row exactly once.
+template <int DPAD, int TERMS>
+struct ResImage {
+    static constexpr bool SWZ = (TERMS == 6 && DPAD == 64);
+    static constexpr int PITCH = SWZ ? DPAD : DPAD + 8;
+    static constexpr int NPL = oe_npl<TERMS>::N;
+    static constexpr int PLANE_ELEMS = PL_ROWS * PITCH;
+    static constexpr int ELEMS = PLANE_ELEMS * NPL;
+    static __device__ __forceinline__ int chunk_pos(int row, int c) { return SWZ ? (c ^ ((row >> 1) & 7)) : c; }
+    static __device__ __forceinline__ void row_frag(const __bf16* img, int row, int s, int g, PFrag<TERMS>& f) {
+        const __bf16* p = img + row * PITCH + 8 * chunk_pos(row, 2 * s + g);
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(p + n * PLANE_ELEMS);
+    }
+    static __device__ __forceinline__ void store(const ChunkRegs<DPAD>& t, __bf16* img, int r0, int nrows_total, int D, float mul) {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int i = 0; i < ChunkRegs<DPAD>::N; ++i) {
+            const int e = threadIdx.x + i * PL_THREADS;
+            const int row = e / (DPAD / 4), c4 = (e % (DPAD / 4)) * 4;
+            const bool live = (r0 + row < nrows_total) && (c4 < D);
+            const float x[4] = {live ? t.v[i].x * mul : 0.f, live ? t.v[i].y * mul : 0.f, live ? t.v[i].z * mul : 0.f, live ? t.v[i].w * mul : 0.f};
+            bf16x4 pl[NPL];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __bf16 q[NPL];
+                oe_split_bf16<NPL>(x[k], q);
+#pragma unroll
+                for (int n = 0; n < NPL; ++n) pl[n][k] = q[n];
+            }
+            __bf16* d = img + row * PITCH + 8 * chunk_pos(row, c4 >> 3) + (c4 & 4);
+#pragma unroll
+            for (int n = 0; n < NPL; ++n) *reinterpret_cast<bf16x4*>(d + n * PLANE_ELEMS) = pl[n];
+        }
+    }
+};
 
 // eight consecutive features of one row -> registers (two float4 when aligned); zeros past D or when !ok
 __device__ __forceinline__ void load8f(const float* row, int d0, int D, bool vec, bool ok, float (&out)[8]) {
@@ -499,15 +541,21 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_q_kernel(AttnParams
 template <int DPAD, int TERMS>
 __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_k_kernel(AttnParams p) {
     using P = Plane<DPAD, TERMS>;
+    using R = ResImage<DPAD, TERMS>;
     constexpr int DT = DPAD / 32, KS = DPAD / 16;
-    constexpr int IMG = P::ELEMS;
+    constexpr int IMG = P::ELEMS, RIMG = R::ELEMS;
     constexpr int MERGE_FLOATS = 2 * DPAD * 32 + 32;                // per resident tile: dK^T, dV^T [DPAD][32] + bias gradient [32]
     constexpr int PATCH_FLOATS = 32 * (DPAD + 1);
     constexpr int TAIL_BYTES = 4 * (MERGE_FLOATS + PATCH_FLOATS) * 4;
     // streamed images [buffer][Q | dO], then the block's own 128 keys, resident: [K' * scale | V][64-row half] - their row
     // fragments are re-read per query tile (2 x KS b128 reads per plane) instead of living in 64 registers per lane, which
-    // is what lets two waves share a SIMD without spilling
-    constexpr int IMG_BYTES = (2 * 2 + 2 * 2) * IMG * 2;
+    // is what lets two waves share a SIMD without spilling.  Three planes at DPAD = 64 (precision 6): the streamed pair is
+    // single-buffered (the next chunk waits in registers until every wave has left the current one: a second barrier per
+    // chunk) and the resident images are packed (ResImage) - 2 x 27 + 4 x 24 KiB = 150 KiB.
+    constexpr bool SB = (TERMS == 6 && DPAD == 64);
+    constexpr int NBUF = SB ? 1 : 2;
+    constexpr int IMG_BYTES = (NBUF * 2 * IMG + 2 * 2 * RIMG) * 2;
+    static_assert(IMG_BYTES + 2 * 2 * PL_ROWS * 4 <= 160 * 1024, "attention dK/dV: LDS image does not fit");
     __shared__ __attribute__((aligned(16))) char lds_raw[(IMG_BYTES > TAIL_BYTES ? IMG_BYTES : TAIL_BYTES)];
     __shared__ __attribute__((aligned(16))) float ld_s[2][2][PL_ROWS];   // [buffer][lse | delta]
     __bf16* imgs = reinterpret_cast<__bf16*>(lds_raw);
@@ -525,7 +573,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_k_kernel(AttnParams
     const long bh = (long)b * p.H + h;
     const bool vq = (p.D % 4 == 0) && (p.q_rs % 4 == 0) && ((((uintptr_t)qb) & 15) == 0);
     const bool vo = (p.D % 4 == 0) && (p.o_rs % 4 == 0) && ((((uintptr_t)dob) & 15) == 0);
-    __bf16* res = imgs + 4 * IMG;                                   // [(K', V)][half] resident images
+    __bf16* res = imgs + NBUF * 2 * IMG;                            // [(K', V)][half] resident images
     {
         const float* kbp = p.k + (long)b * p.k_bs + h * p.D;
         const float* vbp = p.v + (long)b * p.v_bs + h * p.D;
@@ -537,13 +585,13 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_k_kernel(AttnParams
         chunk_load<DPAD>(rb, kbp, p.k_rs, kb0 + 64, p.T2, p.D, vk);
         chunk_load<DPAD>(rc, vbp, p.v_rs, kb0, p.T2, p.D, vv);
         chunk_load<DPAD>(rd, vbp, p.v_rs, kb0 + 64, p.T2, p.D, vv);
-        chunk_store<DPAD, TERMS>(ra, res + 0 * IMG, kb0, p.T2, p.D, p.scale);
-        chunk_store<DPAD, TERMS>(rb, res + 1 * IMG, kb0 + 64, p.T2, p.D, p.scale);
-        chunk_store<DPAD, TERMS>(rc, res + 2 * IMG, kb0, p.T2, p.D);
-        chunk_store<DPAD, TERMS>(rd, res + 3 * IMG, kb0 + 64, p.T2, p.D);
+        R::store(ra, res + 0 * RIMG, kb0, p.T2, p.D, p.scale);
+        R::store(rb, res + 1 * RIMG, kb0 + 64, p.T2, p.D, p.scale);
+        R::store(rc, res + 2 * RIMG, kb0, p.T2, p.D, 1.f);
+        R::store(rd, res + 3 * RIMG, kb0 + 64, p.T2, p.D, 1.f);
     }
-    const __bf16* Kres = res + (tile >> 1) * IMG;
-    const __bf16* Vres = res + (2 + (tile >> 1)) * IMG;
+    const __bf16* Kres = res + (tile >> 1) * RIMG;
+    const __bf16* Vres = res + (2 + (tile >> 1)) * RIMG;
     const int rrow = (tile & 1) * 32 + lj;                          // this lane's key in its resident image
     const float kbiasL = ((p.keybias && k_ok) ? p.keybias[bh * p.T2 + kj] : 0.f) * 1.4426950408889634f;
     f32x16 dkacc[DT], dvacc[DT];
@@ -577,7 +625,7 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_k_kernel(AttnParams
     commit(0, 0);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
+        const int buf = SB ? 0 : (c & 1);
         if (c + 1 < nchunks) prefetch((c + 1) * PL_ROWS);
         const __bf16* Qi = imgs + (buf * 2 + 0) * IMG;
         const __bf16* Oi = imgs + (buf * 2 + 1) * IMG;
@@ -606,10 +654,10 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_k_kernel(AttnParams
             for (int s = 0; s < KS; ++s) {
                 PFrag<TERMS> a, bk;
                 P::row_frag(Qi, it * 32 + lj, s, lk, a);
-                P::row_frag(Kres, rrow, s, lk, bk);
+                R::row_frag(Kres, rrow, s, lk, bk);
                 sacc = pmma<TERMS>(a, bk, sacc);
                 P::row_frag(Oi, it * 32 + lj, s, lk, a);
-                P::row_frag(Vres, rrow, s, lk, bk);
+                R::row_frag(Vres, rrow, s, lk, bk);
                 dpacc = pmma<TERMS>(a, bk, dpacc);
             }
             float pd[16], ds[16], dsc[16];
@@ -643,7 +691,8 @@ __global__ __launch_bounds__(PL_THREADS, 2) void attn_planes_k_kernel(AttnParams
                 }
             }
         }
-        if (c + 1 < nchunks) commit(buf ^ 1, (c + 1) * PL_ROWS);
+        if (SB) __syncthreads();                        // every wave has left the only streamed buffer
+        if (c + 1 < nchunks) commit(SB ? 0 : (buf ^ 1), (c + 1) * PL_ROWS);
         __syncthreads();
     }
     dbias = xhalf_sum(dbias);
@@ -721,8 +770,13 @@ int oe_attn_planes_dq_try(const AttnParams& p, int terms, hipStream_t st) {
     return 0;
 }
 int oe_attn_planes_dkdv_try(const AttnParams& p, int terms, hipStream_t st) {
-    if (!planes_fit(p.T2) || (terms != 1 && terms != 3)) return 1;
+    if (!planes_fit(p.T2) || (terms != 1 && terms != 3 && terms != 6)) return 1;
     dim3 grid(oe_cdiv(p.T2, 128), p.H, p.B);
+    if (terms == 6) {
+        if (p.D <= 32) hipLaunchKernelGGL((attn_planes_k_kernel<32, 6>), grid, dim3(PL_THREADS), 0, st, p);
+        else hipLaunchKernelGGL((attn_planes_k_kernel<64, 6>), grid, dim3(PL_THREADS), 0, st, p);
+        return 0;
+    }
     if (p.D <= 32) {
         if (terms == 3) hipLaunchKernelGGL((attn_planes_k_kernel<32, 3>), grid, dim3(PL_THREADS), 0, st, p);
         else hipLaunchKernelGGL((attn_planes_k_kernel<32, 1>), grid, dim3(PL_THREADS), 0, st, p);
