@@ -273,8 +273,9 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
     // 45.8 us x W^T, 45.2 / 49.1 dY W; x 768: 33.3 / 36.0)
     const bool six_tall = terms == 6 && !a_kmajor && !six && M >= 128 && N >= 64 && K >= 512 && (long)oe_cdiv(M, 128) * oe_cdiv(N, 64) * sk >= 200;
     if (mode == 1 && !(a_kmajor && b_kmajor) && !(b_kmajor && K >= 512) && !small && !wide && !six && !six_tall) return 1;
-    if (six && tile != 22 && b22 >= (N >= 512 ? 200 : 300)) tile = 22;
-    if (mode == 1 && six_tall) tile = 21;
+    static const bool tile_forced = getenv("OE_GEMM_TILE") && atoi(getenv("OE_GEMM_TILE")) != 0;     // tuning (tools/gemm_bench.py)
+    if (!tile_forced && six && b22 >= (N >= 512 ? 200 : 300)) tile = 22;
+    if (!tile_forced && mode == 1 && six_tall) tile = 21;
     if (tile == 12) tile = 11;
     const int bm = 64 * (tile / 10), bn = 64 * (tile % 10);
     // pieces are 16 bytes: K a multiple of the K-tile; a k-major operand's row length (M resp. N) a multiple of 4.
@@ -310,6 +311,7 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
 #define OE_DMA_T(AK, BKM, T)                                                                                         \
     do {                                                                                                             \
         if (tile == 42) return launch_dma<4, 2, AK, BKM, T, 3>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
+        if (tile == 24) return launch_dma<2, 4, AK, BKM, T, 3>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \
         if (tile == 22 && nst == 2) return launch_dma<2, 2, AK, BKM, T, 2>(A, B, C, ldc, M, N, K, kc, nz, ep, st);   \
         if (tile == 22 && nst == 3) return launch_dma<2, 2, AK, BKM, T, 3>(A, B, C, ldc, M, N, K, kc, nz, ep, st);   \
         if (tile == 22) return launch_dma<2, 2, AK, BKM, T, 4>(A, B, C, ldc, M, N, K, kc, nz, ep, st);               \

@@ -27,24 +27,33 @@ CONF = dict(encoder_num_blocks=12, decoder_num_blocks=3, r_decoder_num_blocks=3,
 SECONDS = [10.0, 9.4, 8.7, 7.5, 6.2, 5.6, 10.0, 1.5]            # ragged; the last one is the short utterance
 TLENS = [30, 27, 25, 22, 18, 16, 30, 4]
 
-_CACHE = {}
+# bench.py's own batch size: 32 utterances, 7936 encoder rows once the eight 10 s ones pad the rest - the row count at which the
+# dispatch picks the tiles / kernels the benchmark times (128 x 128 ring tiles for the wide outputs, 128 x 64 for the long narrow
+# reductions, the grouped weight gradients, the conv front end's pre-split GEMMs with their full-size grids)
+SECONDS32 = [10.0] * 8 + [9.9 - 0.23 * i for i in range(23)] + [1.5]
+TLENS32 = [30] * 8 + [29 - i for i in range(23)] + [4]
+
+_CACHES = {}
 
 
-def _setup():
+def _setup(seconds=None, tlens=None):
+    seconds, tlens = seconds or SECONDS, tlens or TLENS
+    _CACHE = _CACHES.setdefault(len(seconds), {})
     if _CACHE:
         return _CACHE
+    SECONDS_, TLENS_ = seconds, tlens
     torch.manual_seed(777)
     model = ASRModel(80, V, **CONF)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
     g = torch.Generator().manual_seed(0)
-    B = len(SECONDS)
-    ns = torch.tensor([int(16000 * s) for s in SECONDS])
+    B = len(SECONDS_)
+    ns = torch.tensor([int(16000 * s) for s in SECONDS_])
     wav = torch.rand(B, int(ns.max()), generator=g) - 0.5       # bench.py::synth_batch
-    tgt = torch.full((B, max(TLENS)), -1, dtype=torch.int32)
+    tgt = torch.full((B, max(TLENS_)), -1, dtype=torch.int32)
     for b in range(B):
         wav[b, int(ns[b]):] = 0.0
-        tgt[b, : TLENS[b]] = torch.randint(2, V - 1, (TLENS[b],), generator=g, dtype=torch.int32)
-    tlen = torch.tensor(TLENS, dtype=torch.int32)
+        tgt[b, : TLENS_[b]] = torch.randint(2, V - 1, (TLENS_[b],), generator=g, dtype=torch.int32)
+    tlen = torch.tensor(TLENS_, dtype=torch.int32)
     feats, nfr = Fbank(80, device=DEV)(wav.to(DEV), ns.to(DEV))
     utt_normalize_(feats, nfr)
     torch.cuda.synchronize()
@@ -62,13 +71,17 @@ def _setup():
     return _CACHE
 
 
-@pytest.mark.parametrize("prec,fused_ffn", [(0, False), (6, False), (60, False), (3, False), (3, True)],
-                         ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x3-mfma", "bf16x3-mfma-fused-ffn"])
-def test_config2_width_model_matches_oracle(prec, fused_ffn):
+@pytest.mark.parametrize("prec,fused_ffn,full", [(0, False, False), (6, False, False), (60, False, False), (3, False, False), (3, True, False),
+                                                  (6, False, True), (61, False, True)],
+                         ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x3-mfma", "bf16x3-mfma-fused-ffn",
+                              "bf16x6-mfma-B32", "bf16x6-planes-ln-B32"])
+def test_config2_width_model_matches_oracle(prec, fused_ffn, full):
     """fused_ffn: the one-kernel feed forward (csrc/ffn.hip) forced on at this batch's 1984 rows (by default it takes over from
-    4096 rows on, i.e. at bench.py's batch) - the same tolerances end to end."""
+    4096 rows on, i.e. at bench.py's batch) - the same tolerances end to end.  full: bench.py's batch size (32 utterances, 7936
+    encoder rows) in the headline arithmetic, so that exactly the kernels / tiles the benchmark times are the ones checked;
+    61 = precision 6 with the "ln" pre-split policy (LayerNorm outputs + arena-free weight planes)."""
     from openeat_amd import hip, ops
-    c = _setup()
+    c = _setup(SECONDS32, TLENS32) if full else _setup()
     old_min, ops.FUSED_FFN_MIN_ROWS = ops.FUSED_FFN_MIN_ROWS, (0 if fused_ffn else 1 << 30)
     old_bwd, ops.FUSED_FFN_BWD = ops.FUSED_FFN_BWD, bool(fused_ffn)          # the one-launch input gradient rides along when forced
     model = ASRModel(80, V, **CONF)
@@ -76,10 +89,12 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
     model = model.to(DEV).eval()
     from openeat_amd import planes
     old, old_pmin, old_pol = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY
-    hip.GEMM_PRECISION = 6 if prec == 60 else prec
+    hip.GEMM_PRECISION = 6 if prec in (60, 61) else prec
     if prec == 60:
         planes.MIN_SPLIT_ELEMS, planes.POLICY = 0, "all"   # every operand pre-split: gemm_pl.hip wherever the shapes qualify
         hip.lib().oe_gemm_pl_config(0, -1, -1, -1)
+    if prec == 61:
+        planes.POLICY = "ln"
     try:
         loss, acc = model(c["feats"], c["nfr"], c["tgt"].to(DEV), c["tlen"].to(DEV))
         loss.backward()
@@ -105,7 +120,7 @@ def test_config2_width_model_matches_oracle(prec, fused_ffn):
     for key, ref in (("ctc.ctc_lo.weight", c["gctc"]), ("encoder.embed.conv.0.weight", c["gemb"])):
         got = dict(model.named_parameters())[key].grad.cpu()
         assert float((got - ref).abs().max()) <= 3e-3 * float(ref.abs().max()), key
-    assert greedy == c["greedy"]                                   # bit-exact CTC-greedy ids on all 8 utterances
+    assert greedy == c["greedy"]                                   # bit-exact CTC-greedy ids on every utterance
     assert sum(len(h) for h in greedy) > 0
 
 
