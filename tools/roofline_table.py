@@ -55,7 +55,7 @@ print(f"# Roofline by kernel class, config 2 (B=32 x 10 s), precision {PREC}\n")
 print("Kernel time: rocprofv3 `--kernel-trace --stats` of `bench.py --no-graph --single-stream` (every kernel alone on one stream), "
       f"per optimizer step; all kernels {tot:.2f} ms/step.  Work: algorithmic bytes / flops (DESIGN section 4).  Peaks: HBM 8 TB/s, "
       f"dense bf16 MFMA 2.5 PFLOP/s / {TERMS} = {2500 / TERMS:.0f} TFLOP/s of algorithmic flops (precision {PREC} issues {TERMS} MFMAs per product; "
-      "the attention class's dK/dV and short-axis kernels run on the fp32-input MFMA in this mode and are priced against the same figure).\n")
+      "the attention class's short-axis (decoder) kernels run on the fp32-input MFMA in this mode and are priced against the same figure).\n")
 print("| class | bound | algorithmic work / step | kernel ms / step | achieved | % of peak | work counted |\n|---|---|---|---|---|---|---|")
 seen = 0.0
 for name, bound, work, pred, note in classes:
