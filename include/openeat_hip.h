@@ -253,6 +253,16 @@ size_t oe_ctc_workspace_floats(int B, int T, int Lmax);
  * the dense passes' traffic (ordinary stream events; capturable; measured SLOWER on MI355X: each cross-stream edge costs
  * more than the chain time it hides); 2 = pipelined whatever the size. */
 int oe_ctc_config(int pipe_mode, int chunks);
+/* pipe_mode 3 / 4 (round 3): the OVERLAPPED form for large batches / always - row statistics first (a read-only pass over the
+ * logits, or oe_ctc_loss_fused_stats' row_stats), then two launches of mixed blocks: [one block per utterance runs the
+ * recursion | dense gradient rows of the first half of the frames] and [label fix-up of all frames | dense rows of the second
+ * half], then a small launch that zeroes infeasible utterances and sums the loss.  No block waits for another. */
+/* As oe_ctc_loss_fused; row_stats (optional): for every row of the logits and every group of 32 columns the pair (max, sum exp(x -
+ * max)) over the group's valid columns, [B*T][stats_groups = ceil(V/32)] float2 - what oe_gemm_f32 leaves in
+ * oe_gemm_args.row_stats when it produced the logits: the overlapped form then needs no statistics pass over the logits. */
+int oe_ctc_loss_fused_stats(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
+                            int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll, float* loss_sum,
+                            float* dlogits, float* workspace, const float* row_stats, int stats_groups, void* stream);
 int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
                       int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll, float* loss_sum,
                       float* dlogits, float* workspace, void* stream);

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* logits, long
                                                         const int* __restrict__ hlens, const int* __restrict__ targets,
                                                         int Lmax, const int* __restrict__ tlens, int Sp, float scale,
                                                         const float* __restrict__ utt_weight, float* __restrict__ lp_out,
-                                                        float* dlogits, int t0, int Tc) {
+                                                        float* dlogits, int t0, int Tc, float2* __restrict__ rowstat) {
     // frames t0 .. t0 + Tc - 1 of every utterance (`rows` = B * Tc of them; the whole batch: t0 = 0, Tc = T)
+    // rowstat (optional): (row maximum, 1 / sum exp(x - max)) of every live row, for ctc_dense_row
     const int lane = threadIdx.x & 63;
     const long rloc = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rloc >= rows) return;
@@ -121,6 +122,126 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* logits, long
         const int st = lane + 64 * q;
         if (st < S) lp_out[row * Sp + st] = (lv[q] - m) * 1.4426950408889634f - l2s;
     }
+    if (rowstat && lane == 0) rowstat[row] = make_float2(m, __builtin_amdgcn_exp2f(-l2s));
+}
+
+// ---- the overlapped form (oe_ctc_loss_fused, ctc_pipe_mode 3 / 4) ---------------------------------------------------------
+// One after the other the three passes cost rows + chain + labels (116 + 60 + 30 us at B = 64 x 16 s): the recursion is a serial
+// chain on 64 waves and the label fix-up a latency-bound scatter, both with the chip idle around them.  Here the row statistics
+// come first (from the logits: ctc_rows_kernel<.., false> with `rowstat`, a read-only pass; or from the per-32-column partials
+// the projection GEMM's epilogue left: ctc_lp_kernel, a few microseconds), and then TWO launches of mixed blocks follow:
+//   launch 2: one block per utterance runs alpha / beta / the label chains  +  dense-gradient blocks for frames [0, T/2)
+//   launch 3: the label fix-up blocks of all frames                         +  dense-gradient blocks for frames [T/2, T)
+// The special blocks come first in the grid (dispatched first), the dense blocks - pure streaming - fill the chip around them.
+// No block waits for another: the dense blocks write every column EXCEPT the blank and the utterance's labels (a per-wave bitmask
+// in LDS), the fix-up blocks write exactly those, so the two kinds never touch the same word and need no order between them
+// (in place too: a dense wave may read a label column the fix-up has already overwritten, but it never uses or writes it).
+// Rows of infeasible utterances are zeroed by a last small launch (ctc_final_kernel), which also sums the loss.
+template <int NV4>
+__device__ __forceinline__ void ctc_dense_row(const float* logits, long ldv, long rows, int T, int V, const int* __restrict__ hlens,
+                                              const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens, float scale,
+                                              const float* __restrict__ utt_weight, const float2* __restrict__ rowstat, float* dlogits,
+                                              int t0, int Tc, long rloc, unsigned* maskw) {
+    constexpr int MW = NV4 * 8;                        // bitmask dwords: 256 * NV4 columns
+    const int lane = threadIdx.x & 63;
+    if (rloc >= rows) return;
+    const int b = (int)(rloc / Tc), t = t0 + (int)(rloc % Tc);
+    const long row = (long)b * T + t;
+    const float* p = logits + row * ldv;
+    float* g = dlogits + row * ldv;
+    const int nv = (V + 3) >> 2;
+    if (t >= hlens[b]) {                               // padded frame: exact zeros in every column
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = lane; i < nv; i += 64) reinterpret_cast<float4*>(g)[i] = z;
+        return;
+    }
+    float4 v[NV4];
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nv) v[j] = p4[i];
+    }
+    const float2 st = rowstat[row];
+    if (utt_weight) scale *= utt_weight[b];
+    // the columns the fix-up owns: blank and the utterance's labels
+#pragma unroll
+    for (int i = lane; i < MW; i += 64) maskw[i] = (i == 0) ? 1u : 0u;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int L = min(tlens[b], Lmax);
+    for (int i = lane; i < L; i += 64) {
+        const int c = targets[(long)b * Lmax + i];
+        if (c >= 0 && c < V) atomicOr(&maskw[c >> 5], 1u << (c & 31));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const float f = scale * st.y;
+#pragma unroll
+    for (int j = 0; j < NV4; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nv) {
+            const int e = 4 * i;
+            const unsigned bits = (maskw[e >> 5] >> (e & 31)) & 0xfu;
+            const float4 o = make_float4(__expf(v[j].x - st.x) * f, __expf(v[j].y - st.x) * f, __expf(v[j].z - st.x) * f, __expf(v[j].w - st.x) * f);
+            if (bits == 0u) {
+                reinterpret_cast<float4*>(g)[i] = o;      // (columns past V inside the row padding get a value nobody reads, as in ctc_rows_kernel)
+            } else {
+                if (!(bits & 1u)) g[e] = o.x;
+                if (!(bits & 2u)) g[e + 1] = o.y;
+                if (!(bits & 4u)) g[e + 2] = o.z;
+                if (!(bits & 8u)) g[e + 3] = o.w;
+            }
+        }
+    }
+}
+
+// Row statistics from the projection GEMM's epilogue (oe_gemm_args.row_stats: per row and per group of 32 columns the pair
+// (max, sum exp(x - max))) -> lp at the states and (row maximum, 1 / sum): one wave per frame, no pass over the logits.
+__global__ __launch_bounds__(256) void ctc_lp_kernel(const float* __restrict__ logits, long ldv, long rows, int T, int V,
+                                                      const int* __restrict__ hlens, const int* __restrict__ targets, int Lmax,
+                                                      const int* __restrict__ tlens, int Sp, const float2* __restrict__ part, int groups,
+                                                      float* __restrict__ lp_out, float2* __restrict__ rowstat) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int b = (int)(row / T), t = (int)(row % T);
+    if (t >= hlens[b]) return;
+    const float* p = logits + row * ldv;
+    const int L = min(tlens[b], Lmax);
+    const int S = 2 * L + 1;
+    float lv[CTC_MAXQ];
+#pragma unroll
+    for (int q = 0; q < CTC_MAXQ; ++q) {
+        const int st = lane + 64 * q;
+        lv[q] = 0.f;
+        if (st < S) lv[q] = p[(st & 1) ? targets[(long)b * Lmax + (st >> 1)] : 0];
+    }
+    float m = NEG_INF;
+    const float2* pr = part + row * groups;
+    float2 mine[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gidx = lane + 64 * k;
+        mine[k] = make_float2(NEG_INF, 0.f);
+        if (gidx < groups) mine[k] = pr[gidx];
+        m = fmaxf(m, mine[k].x);
+    }
+    for (int gidx = lane + 256; gidx < groups; gidx += 64) m = fmaxf(m, pr[gidx].x);
+    m = wave_max(m);
+    float ssum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (mine[k].y > 0.f) ssum += mine[k].y * __expf(mine[k].x - m);
+    for (int gidx = lane + 256; gidx < groups; gidx += 64) { const float2 q2 = pr[gidx]; if (q2.y > 0.f) ssum += q2.y * __expf(q2.x - m); }
+    ssum = wave_sum(ssum);
+    const float l2s = __builtin_amdgcn_logf(ssum);
+#pragma unroll
+    for (int q = 0; q < CTC_MAXQ; ++q) {
+        const int st = lane + 64 * q;
+        if (st < S) lp_out[row * Sp + st] = (lv[q] - m) * 1.4426950408889634f - l2s;
+    }
+    if (lane == 0) rowstat[row] = make_float2(m, 1.f / ssum);
 }
 
 // ------------------------------------------------------------------ k2 ------
@@ -275,14 +396,12 @@ __device__ __forceinline__ void ctc_recurse(int lane, int Tb, int S, int Sp, con
 // label, + 1; 0 = none) | (first of its label ? 1 << 16 : 0).  k3 follows these chains per frame instead of comparing
 // labels (that comparison was O(S^2) per frame).
 template <int NS, int CH>
-__global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __restrict__ hlens, const int* __restrict__ targets,
-                                                            int Lmax, const int* __restrict__ tlens, int Sp,
-                                                            const float* __restrict__ lp, float* __restrict__ alpha,
-                                                            float* __restrict__ beta, float* __restrict__ ll_out,
-                                                            float* __restrict__ nll_out, int* __restrict__ chain,
-                                                            float* __restrict__ dump) {
-    __shared__ float fin[2];
-    const int b = blockIdx.x;
+__device__ __forceinline__ void ctc_alphabeta_block(int b, float* fin, int T, const int* __restrict__ hlens, const int* __restrict__ targets,
+                                                    int Lmax, const int* __restrict__ tlens, int Sp,
+                                                    const float* __restrict__ lp, float* __restrict__ alpha,
+                                                    float* __restrict__ beta, float* __restrict__ ll_out,
+                                                    float* __restrict__ nll_out, int* __restrict__ chain,
+                                                    float* __restrict__ dump) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Tb = min(hlens[b], T);
@@ -299,7 +418,7 @@ __global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __
             for (int q = s + 2; q < S; q += 2) if (tg[q >> 1] == c) { nx = q + 1; break; }
             chain[(long)b * Sp + s] = nx | (head << 16);
         }
-    } else if (Tb > 0) {
+    } else if (Tb > 0 && wv < 2) {       // (a fourth wave - the mixed launch's 256-thread blocks - only keeps the barriers company)
         float a[NS];
         if (wv == 0) {
             ctc_recurse<true, NS, CH>(lane, Tb, S, Sp, tg, lp + base, alpha + base, dump, a, 0, Tb);
@@ -325,6 +444,35 @@ __global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __
         ll_out[b] = ll;                                        // base 2, for k3
         nll_out[b] = (ll == NEG_INF) ? 0.f : -ll * CTC_LN2;
     }
+}
+template <int NS, int CH>
+__global__ __launch_bounds__(192) void ctc_alphabeta_kernel(int T, const int* __restrict__ hlens, const int* __restrict__ targets,
+                                                            int Lmax, const int* __restrict__ tlens, int Sp,
+                                                            const float* __restrict__ lp, float* __restrict__ alpha,
+                                                            float* __restrict__ beta, float* __restrict__ ll_out,
+                                                            float* __restrict__ nll_out, int* __restrict__ chain,
+                                                            float* __restrict__ dump) {
+    __shared__ float fin[2];
+    ctc_alphabeta_block<NS, CH>(blockIdx.x, fin, T, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll_out, nll_out, chain, dump);
+}
+// overlapped form, launch 2: blocks 0 .. B-1 = the recursion of one utterance each (waves 0 - 2 of four), the rest = dense rows
+template <int NV4, int NS, int CH>
+__global__ __launch_bounds__(256) void ctc_chain_dense_kernel(int B, const float* logits, long ldv, int T, int V, const int* __restrict__ hlens,
+                                                              const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens,
+                                                              int Sp, const float* __restrict__ lp, float* __restrict__ alpha,
+                                                              float* __restrict__ beta, float* __restrict__ ll_out, float* __restrict__ nll_out,
+                                                              int* __restrict__ chain, float* __restrict__ dump, float scale,
+                                                              const float* __restrict__ utt_weight, const float2* __restrict__ rowstat,
+                                                              float* dlogits, int t0, int Tc) {
+    __shared__ float fin[2];
+    __shared__ unsigned maskw[4][NV4 * 8];
+    if ((int)blockIdx.x < B) {
+        ctc_alphabeta_block<NS, CH>(blockIdx.x, fin, T, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll_out, nll_out, chain, dump);
+        return;
+    }
+    const int wv = threadIdx.x >> 6;
+    ctc_dense_row<NV4>(logits, ldv, (long)B * Tc, T, V, hlens, targets, Lmax, tlens, scale, utt_weight, rowstat, dlogits, t0, Tc,
+                       ((long)blockIdx.x - B) * 4 + wv, maskw[wv]);
 }
 
 // ---- the pipelined form (oe_ctc_loss_fused with T >= CTC_PIPE_MIN_T): the recursion in time chunks, one direction per launch.
@@ -387,30 +535,32 @@ __global__ __launch_bounds__(64) void ctc_chain_kernel(const int* __restrict__ t
 // One wave per frame (four per block).  k1 has written softmax * scale everywhere; the classes of the target get their
 // occupation term here, and frames of an infeasible utterance (ll = -inf) are zeroed.  Block 0 also sums the loss.
 // Sums run in a fixed order (blank: per-lane partials + shuffle tree; a label: along its chain): deterministic.
-__global__ __launch_bounds__(256) void ctc_labels_kernel(long rows, int B, int T, int V, long ldv, const int* __restrict__ hlens,
-                                                          const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens,
-                                                          int Sp, const float* __restrict__ lp, const float* __restrict__ alpha,
-                                                          const float* __restrict__ beta, const float* __restrict__ ll_in,
-                                                          const int* __restrict__ chain, const float* __restrict__ nll,
-                                                          float scale, const float* __restrict__ utt_weight,
-                                                          float* __restrict__ dlogits, float* __restrict__ loss_sum, int t0, int Tc) {
-    // frames t0 .. t0 + Tc - 1 of every utterance (`rows` = B * Tc; the whole batch: t0 = 0, Tc = T)
-    extern __shared__ __attribute__((aligned(16))) float sh[];   // per wave: gam[Sp]
+// ZERO_INF: rows of infeasible utterances are zeroed here (the three-launch form; the overlapped form leaves that to
+// ctc_final_kernel, because its dense blocks write those rows at the same time)
+template <bool ZERO_INF>
+__device__ __forceinline__ void ctc_labels_block(float* sh, long blk, long rows, int B, int T, int V, long ldv, const int* __restrict__ hlens,
+                                                 const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens,
+                                                 int Sp, const float* __restrict__ lp, const float* __restrict__ alpha,
+                                                 const float* __restrict__ beta, const float* __restrict__ ll_in,
+                                                 const int* __restrict__ chain, const float* __restrict__ nll,
+                                                 float scale, const float* __restrict__ utt_weight,
+                                                 float* __restrict__ dlogits, float* __restrict__ loss_sum, int t0, int Tc) {
+    // frames t0 .. t0 + Tc - 1 of every utterance (`rows` = B * Tc; the whole batch: t0 = 0, Tc = T); sh: per wave gam[Sp]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (loss_sum && blockIdx.x == 0 && wv == 0) {
+    if (loss_sum && blk == 0 && wv == 0) {
         float s = 0.f;
         for (int i = lane; i < B; i += 64) s += utt_weight ? nll[i] * utt_weight[i] : nll[i];
         s = wave_sum(s);
         if (lane == 0) loss_sum[0] = s;
     }
-    const long rloc = (long)blockIdx.x * 4 + wv;
+    const long rloc = blk * 4 + wv;
     const bool inrange = rloc < rows;
     const int b = inrange ? (int)(rloc / Tc) : 0, t = inrange ? t0 + (int)(rloc % Tc) : 0;
     const long row = (long)b * T + t;
     const bool frame = inrange && t < hlens[b];
     const float ll = ll_in[b];
     float* g = dlogits + row * ldv;
-    if (frame && ll == NEG_INF) {
+    if (ZERO_INF && frame && ll == NEG_INF) {
         for (int i = lane; i < V; i += 64) g[i] = 0.f;
     }
     const bool live = frame && ll != NEG_INF;
@@ -448,6 +598,55 @@ __global__ __launch_bounds__(256) void ctc_labels_kernel(long rows, int B, int T
         }
     }
 }
+__global__ __launch_bounds__(256) void ctc_labels_kernel(long rows, int B, int T, int V, long ldv, const int* __restrict__ hlens,
+                                                          const int* __restrict__ targets, int Lmax, const int* __restrict__ tlens,
+                                                          int Sp, const float* __restrict__ lp, const float* __restrict__ alpha,
+                                                          const float* __restrict__ beta, const float* __restrict__ ll_in,
+                                                          const int* __restrict__ chain, const float* __restrict__ nll,
+                                                          float scale, const float* __restrict__ utt_weight,
+                                                          float* __restrict__ dlogits, float* __restrict__ loss_sum, int t0, int Tc) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // per wave: gam[Sp]
+    ctc_labels_block<true>(sh, blockIdx.x, rows, B, T, V, ldv, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll_in, chain, nll, scale,
+                           utt_weight, dlogits, loss_sum, t0, Tc);
+}
+// overlapped form, launch 3: blocks 0 .. nlab-1 = the label fix-up of four frames each (all frames), the rest = dense rows
+template <int NV4>
+__global__ __launch_bounds__(256) void ctc_labels_dense_kernel(long nlab, const float* logits, int B, int T, int V, long ldv,
+                                                               const int* __restrict__ hlens, const int* __restrict__ targets, int Lmax,
+                                                               const int* __restrict__ tlens, int Sp, const float* __restrict__ lp,
+                                                               const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                               const float* __restrict__ ll_in, const int* __restrict__ chain,
+                                                               const float* __restrict__ nll, float scale, const float* __restrict__ utt_weight,
+                                                               const float2* __restrict__ rowstat, float* dlogits, int t0, int Tc) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // per wave: gam[Sp] (label blocks)
+    __shared__ unsigned maskw[4][NV4 * 8];
+    if ((long)blockIdx.x < nlab) {
+        ctc_labels_block<false>(sh, blockIdx.x, (long)B * T, B, T, V, ldv, hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll_in, chain, nll,
+                                scale, utt_weight, dlogits, nullptr, 0, T);
+        return;
+    }
+    const int wv = threadIdx.x >> 6;
+    ctc_dense_row<NV4>(logits, ldv, (long)B * Tc, T, V, hlens, targets, Lmax, tlens, scale, utt_weight, rowstat, dlogits, t0, Tc,
+                       ((long)blockIdx.x - nlab) * 4 + wv, maskw[wv]);
+}
+// overlapped form, last launch: one block per utterance zeroes the rows of an infeasible utterance (zero_infinity; the live frames
+// only - padded frames are zero already); block 0 also sums the loss
+__global__ __launch_bounds__(256) void ctc_final_kernel(int B, int T, int V, long ldv, const int* __restrict__ hlens, const float* __restrict__ ll_in,
+                                                         const float* __restrict__ nll, const float* __restrict__ utt_weight,
+                                                         float* __restrict__ dlogits, float* __restrict__ loss_sum) {
+    const int b = blockIdx.x;
+    if (loss_sum && b == 0 && threadIdx.x < 64) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < B; i += 64) s += utt_weight ? nll[i] * utt_weight[i] : nll[i];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) loss_sum[0] = s;
+    }
+    if (ll_in[b] != NEG_INF) return;
+    const int Tb = min(hlens[b], T);
+    float* g = dlogits + (long)b * T * ldv;
+    for (int t = 0; t < Tb; ++t)
+        for (int i = threadIdx.x; i < V; i += 256) g[(long)t * ldv + i] = 0.f;
+}
 
 __global__ void ctc_sum_kernel(const float* __restrict__ nll, const float* __restrict__ utt_weight, int B, float* __restrict__ out) {
     float s = 0.f;
@@ -483,7 +682,13 @@ static CtcPipe* ctc_pipe() {
     return &p;
 }
 
-// OE_CTC_PIPE: 0 = never pipeline (default), 1 = where the batch is large enough, 2 = always (tests); OE_CTC_CHUNKS: time chunks.
+// OE_CTC_PIPE: 0 = rows, alpha/beta, labels one after the other (default); 1 / 2 = chunk pipeline on two streams where the batch
+// is large enough / always; 3 / 4 = the overlapped form (mixed launches, ctc_dense_row) for large batches / always;
+// OE_CTC_CHUNKS: time chunks of the chunk pipeline.  Both alternatives are bit-for-bit / tolerance-equal (tests run them) and both
+// measured SLOWER than the default on MI355X (profiles/r03_experiments.md) - overlapped form at B = 64 x 16 s: statistics pass 86 us
+// (a read-only sweep of the logits runs at 3.8 TB/s where the read + write `rows` pass moves 6.0), recursion beside dense rows 100 us
+// (59 alone), fix-up beside dense rows 101 us: 294 us against 208; the streaming blocks take the memory system's latency up and the
+// latency-bound blocks (the recursion's prefetch, the fix-up's dependent loads) stretch by what the overlap was to hide.
 // Measured on MI355X (tools/ctc_graph_bench.py, profiles/r03_experiments.md): every cross-stream edge of the pipelined form
 // costs more than the chain time it hides - from a HIP graph 216 us sequential against 335 / 352 / 384 / 436 us with 2 / 3 /
 // 4 / 6 chunks at the north-star shape (eager launches: 209 against 310 with 4) - so it is not the default.
@@ -497,12 +702,28 @@ extern "C" int oe_ctc_config(int pipe_mode, int chunks) {
 
 extern "C" size_t oe_ctc_workspace_floats(int B, int T, int Lmax) {
     size_t Sp = 2 * (size_t)Lmax + 1;
-    return (size_t)B + 3 * (size_t)B * T * Sp + (size_t)B * Sp + 16;
+    return (size_t)B + 3 * (size_t)B * T * Sp + (size_t)B * Sp + 16 + 2 * (size_t)B * T + 2;      // .. + row statistics of the overlapped form
 }
 
+static int ctc_loss_impl(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
+                         int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll,
+                         float* loss_sum, float* dlogits, float* workspace, const float* row_stats, int stats_groups, void* stream);
 extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
                                  int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll,
                                  float* loss_sum, float* dlogits, float* workspace, void* stream) {
+    return ctc_loss_impl(logits, ldv, B, T, V, hlens, targets, Lmax, tlens, grad_scale, utt_weight, nll, loss_sum, dlogits, workspace, nullptr, 0, stream);
+}
+extern "C" int oe_ctc_loss_fused_stats(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
+                                       int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll,
+                                       float* loss_sum, float* dlogits, float* workspace, const float* row_stats, int stats_groups, void* stream) {
+    OE_REQUIRE(!row_stats || (stats_groups == (V + 31) / 32 && (((uintptr_t)row_stats) & 7) == 0),
+               "oe_ctc_loss_fused_stats: row_stats must hold ceil(V / 32) = %d (max, sum) pairs per row, 8-byte aligned (got %d groups)", (V + 31) / 32, stats_groups);
+    return ctc_loss_impl(logits, ldv, B, T, V, hlens, targets, Lmax, tlens, grad_scale, utt_weight, nll, loss_sum, dlogits, workspace, row_stats, stats_groups, stream);
+}
+
+static int ctc_loss_impl(const float* logits, long ldv, int B, int T, int V, const int* hlens, const int* targets,
+                         int Lmax, const int* tlens, float grad_scale, const float* utt_weight, float* nll,
+                         float* loss_sum, float* dlogits, float* workspace, const float* row_stats, int stats_groups, void* stream) {
     OE_REQUIRE(logits && hlens && tlens && nll && workspace, "oe_ctc_loss_fused: null pointer");
     OE_REQUIRE(targets || Lmax == 0, "oe_ctc_loss_fused: null targets");
     OE_REQUIRE(B > 0 && T > 0 && V > 1 && Lmax >= 0 && ldv >= V, "oe_ctc_loss_fused: bad shape B=%d T=%d V=%d Lmax=%d ldv=%ld",
@@ -521,9 +742,41 @@ extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, in
     const bool vec = (((uintptr_t)logits & 15) == 0) && (!dlogits || ((uintptr_t)dlogits & 15) == 0) && (ldv % 4 == 0) &&
                      (ldv >= (((long)V + 3) & ~3L)) && V <= 256 * 32;
     const int nv4 = !vec ? 0 : V <= 256 * 4 ? 4 : V <= 256 * 8 ? 8 : V <= 256 * 16 ? 16 : 32;
+    float2* rowstat = reinterpret_cast<float2*>((reinterpret_cast<uintptr_t>(dump + 16) + 7) & ~(uintptr_t)7);
+    // ---- overlapped form (see ctc_dense_row): statistics, chains + first half of the dense rows, fix-up + second half, final
+    const int pipe_mode0 = ctc_pipe_mode;
+    if (dlogits && nv4 > 0 && (pipe_mode0 == 4 || (pipe_mode0 == 3 && (double)rows * V >= 2.0e7))) {
+        if (row_stats) {
+            hipLaunchKernelGGL(ctc_lp_kernel, dim3(oe_cdiv(rows, 4)), dim3(256), 0, st, logits, ldv, rows, T, V, hlens, targets, Lmax, tlens, Sp,
+                               reinterpret_cast<const float2*>(row_stats), stats_groups, lp, rowstat);
+        } else {
+#define STATS(NV4) hipLaunchKernelGGL((ctc_rows_kernel<NV4, false>), dim3(oe_cdiv(rows, 4)), dim3(256), 0, st, logits, ldv, rows, T, V, hlens, targets, \
+                                      Lmax, tlens, Sp, grad_scale, utt_weight, lp, nullptr, 0, T, rowstat)
+            if (nv4 == 4) STATS(4); else if (nv4 == 8) STATS(8); else if (nv4 == 16) STATS(16); else STATS(32);
+#undef STATS
+        }
+        OE_LAUNCH_CHECK("ctc_stats");
+        const int T1 = T / 2;
+        const long nd1 = oe_cdiv((long)B * T1, 4), nd2 = oe_cdiv((long)B * (T - T1), 4), nlab = oe_cdiv(rows, 4);
+#define K2(NV4, NS, CH) hipLaunchKernelGGL((ctc_chain_dense_kernel<NV4, NS, CH>), dim3(B + nd1), dim3(256), 0, st, B, logits, ldv, T, V, hlens, targets, Lmax, \
+                                           tlens, Sp, lp, alpha, beta, ll, nll, chain, dump, grad_scale, utt_weight, rowstat, dlogits, 0, T1)
+#define K2S(NV4) do { if (Sp <= 64) K2(NV4, 1, 32); else if (Sp <= 128) K2(NV4, 2, 16); else if (Sp <= 256) K2(NV4, 4, 8); else K2(NV4, 8, 4); } while (0)
+        if (nv4 == 4) K2S(4); else if (nv4 == 8) K2S(8); else if (nv4 == 16) K2S(16); else K2S(32);
+#undef K2S
+#undef K2
+        OE_LAUNCH_CHECK("ctc_chain_dense");
+#define K3(NV4) hipLaunchKernelGGL((ctc_labels_dense_kernel<NV4>), dim3(nlab + nd2), dim3(256), (size_t)4 * Sp * sizeof(float), st, nlab, logits, B, T, V, ldv, \
+                                   hlens, targets, Lmax, tlens, Sp, lp, alpha, beta, ll, chain, nll, grad_scale, utt_weight, rowstat, dlogits, T1, T - T1)
+        if (nv4 == 4) K3(4); else if (nv4 == 8) K3(8); else if (nv4 == 16) K3(16); else K3(32);
+#undef K3
+        OE_LAUNCH_CHECK("ctc_labels_dense");
+        hipLaunchKernelGGL(ctc_final_kernel, dim3(B), dim3(256), 0, st, B, T, V, ldv, hlens, ll, nll, utt_weight, dlogits, loss_sum);
+        OE_LAUNCH_CHECK("ctc_final");
+        return 0;
+    }
 #define ROWS(NV4, WR, T0, TC)                                                                                                  \
     hipLaunchKernelGGL((ctc_rows_kernel<NV4, WR>), dim3(oe_cdiv((long)B * (TC), 4)), dim3(256), 0, st, logits, ldv, (long)B * (TC), T, V, \
-                       hlens, targets, Lmax, tlens, Sp, grad_scale, utt_weight, lp, dlogits, T0, TC)
+                       hlens, targets, Lmax, tlens, Sp, grad_scale, utt_weight, lp, dlogits, T0, TC, nullptr)
 #define ROWS_W(NV4, T0, TC) do { if (dlogits) ROWS(NV4, true, T0, TC); else ROWS(NV4, false, T0, TC); } while (0)
     auto launch_rows = [&](int t0, int tc) {
         switch (nv4) {
@@ -543,7 +796,7 @@ extern "C" int oe_ctc_loss_fused(const float* logits, long ldv, int B, int T, in
     const int pipe_mode = ctc_pipe_mode, pipe_chunks = ctc_pipe_chunks;
     CtcPipe* pp = nullptr;
     const int NC = min(max(pipe_chunks, 2), CTC_MAX_CHUNKS);
-    if (pipe_mode && dlogits && (pipe_mode == 2 ? T >= 2 * NC : (T >= 32 * NC && (double)rows * V >= 1.5e7))) pp = ctc_pipe();
+    if ((pipe_mode == 1 || pipe_mode == 2) && dlogits && (pipe_mode == 2 ? T >= 2 * NC : (T >= 32 * NC && (double)rows * V >= 1.5e7))) pp = ctc_pipe();
     if (pp) {
         const int Tq = oe_cdiv(T, NC);
         auto c0 = [&](int c) { return c * Tq; };

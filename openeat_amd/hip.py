@@ -149,6 +149,7 @@ _SIGNATURES = {
     "oe_ctc_workspace_floats": (SZ, [I, I, I]),
     "oe_ctc_config": (I, [I, I]),
     "oe_ctc_loss_fused": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P]),
+    "oe_ctc_loss_fused_stats": (I, [P, L, I, I, I, P, P, I, P, F, P, P, P, P, P, P, I, P]),
     "oe_ctc_greedy": (I, [P, L, I, I, I, P, I, P, P, P, P]),
     "oe_attention_fwd": (I, [C.POINTER(AttnArgs), P]),
     "oe_attention_bwd": (I, [C.POINTER(AttnArgs), P]),

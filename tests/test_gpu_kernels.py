@@ -245,11 +245,13 @@ def test_layernorm_backward_second_output_is_dropout_scale_of_dx(rows, d, p, alp
 
 
 # -------------------------------------------------------------------- CTC ----
-@pytest.fixture(params=[(0, 4), (2, 4), (2, 3), (2, 8)], ids=["default-form", "pipelined-4-chunks", "pipelined-3-chunks", "pipelined-8-chunks"])
+@pytest.fixture(params=[(0, 4), (4, 4), (2, 4), (2, 3), (2, 8)],
+                ids=["three-launch-form", "overlapped-form", "pipelined-4-chunks", "pipelined-3-chunks", "pipelined-8-chunks"])
 def ctc_form(request):
-    """The CTC tests run in the launch form the size picks (small problems: rows, alpha/beta, labels one after the other) and
-    with the pipelined form forced (the recursion in time chunks on two internal streams, resumed from the columns the
-    previous chunk left: oe_ctc_config) - same numbers either way."""
+    """The CTC tests run in the three-launch form (rows, alpha/beta, labels one after the other), with the overlapped form forced
+    (row statistics, then mixed launches: recursion blocks beside dense-gradient blocks, fix-up blocks beside the rest of the dense
+    blocks; ctc.hip) and with the pipelined form forced (the recursion in time chunks on two internal streams, resumed from the
+    columns the previous chunk left: oe_ctc_config) - same numbers every way."""
     mode, chunks = request.param
     hip.lib().oe_ctc_config(mode, chunks)
     yield request.param
