@@ -404,6 +404,10 @@ int oe_global_cmvn(const float* x, const float* mean, const float* istd, long n,
  * x (B,T,F) -> y (B,T1,F1,C) NHWC, w (C,1,3,3).  wgrad: dy must already be
  * masked by y>0; dw/db accumulated atomically. */
 int oe_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y, void* stream);
+/* the same, also writing y as three bf16 planes (oe_split_planes' layout: plane n at y_planes + n * plane_stride elements, rows of C)
+ * for a precision-6 conv2 on pre-split operands; y_planes NULL = oe_conv1_fwd */
+int oe_conv1_fwd_pl(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
+                    void* y_planes, long plane_stride, void* stream);
 int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int F, int C, float* dw, float* db, void* stream);
 
 /* Input gradient of Conv2d(C,C,3,stride 2) in gather form, fused with the

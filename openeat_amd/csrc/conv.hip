@@ -11,7 +11,8 @@
 // thread = 4 consecutive channels of one output position; weights live in registers.
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          const float* __restrict__ bias, int B, int T, int F, int T1, int F1,
-                                                         int C, int pos_per_block, float* __restrict__ y) {
+                                                         int C, int pos_per_block, float* __restrict__ y,
+                                                         __bf16* __restrict__ y_planes, long plane_stride) {
     const int cpt = C >> 2;                        // threads per position
     const int grp = threadIdx.x / cpt;             // position slot inside the block
     const int c4 = (threadIdx.x % cpt) * 4;
@@ -43,7 +44,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             for (int k = 0; k < 9; ++k) s += wr[e][k] * xv[k];
             o[e] = fmaxf(s, 0.f);
         }
-        *reinterpret_cast<float4*>(y + pos * C + c4) = make_float4(o[0], o[1], o[2], o[3]);
+        const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(y + pos * C + c4) = o4;
+        // precision 6: the activation also leaves as three bf16 planes (oe_common.h) - conv2's gather reads those, and a split
+        // pass of its own would read these 636 MB back (config 2) to write them
+        if (y_planes) store_planes4(y_planes + pos * C + c4, plane_stride, o4);
     }
 }
 
@@ -106,15 +111,22 @@ static int conv1_block(int C) {
     return cpt * (256 / cpt > 0 ? 256 / cpt : 1);
 }
 
+extern "C" int oe_conv1_fwd_pl(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
+                               void* y_planes, long plane_stride, void* stream);
 extern "C" int oe_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
                             void* stream) {
+    return oe_conv1_fwd_pl(x, w, bias, B, T, F, C, y, nullptr, 0, stream);
+}
+extern "C" int oe_conv1_fwd_pl(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
+                               void* y_planes, long plane_stride, void* stream) {
     OE_REQUIRE(x && w && bias && y, "oe_conv1_fwd: null pointer");
+    OE_REQUIRE(!y_planes || ((((uintptr_t)y_planes) & 7) == 0 && plane_stride % 4 == 0), "oe_conv1_fwd_pl: planes must be 8-byte aligned");
     OE_REQUIRE(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 4 == 0 && C <= 1024, "oe_conv1_fwd: bad shape (C %% 4 == 0, C <= 1024)");
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const long npos = (long)B * T1 * F1;
     const int ppb = 64;
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3(oe_cdiv(npos, ppb)), dim3(conv1_block(C)), 0, (hipStream_t)stream, x, w, bias, B, T,
-                       F, T1, F1, C, ppb, y);
+                       F, T1, F1, C, ppb, y, (__bf16*)y_planes, plane_stride);
     OE_LAUNCH_CHECK("conv1_fwd");
     return 0;
 }

@@ -174,6 +174,7 @@ _SIGNATURES = {
     "oe_masked_softmax_bwd": (I, [P, P, L, I, F, U64, P, P, P]),
     "oe_global_cmvn": (I, [P, P, P, L, I, P, P]),
     "oe_conv1_fwd": (I, [P, P, P, I, I, I, I, P, P]),
+    "oe_conv1_fwd_pl": (I, [P, P, P, I, I, I, I, P, P, L, P]),
     "oe_conv1_wgrad": (I, [P, P, I, I, I, I, P, P, P]),
     "oe_col2im_relu": (I, [P, P, I, I, I, I, P, P]),
     "oe_col2im_relu_ks": (I, [P, P, I, I, I, I, I, I, P, P]),

@@ -1314,7 +1314,11 @@ class ConvSubsamplingFn(torch.autograd.Function):
         assert len(geoms) == n
         dims = [((T - 3) // 2 + 1, (Fd - 3) // 2 + 1)]
         y = _new(B, dims[0][0], dims[0][1], C, like=x)
-        hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y)
+        y_pl = _planes.new_output(y.view(-1, C)) if (_planes.available() and n > 0) else None     # conv2 reads it pre-split
+        if y_pl is not None:
+            hip.call("oe_conv1_fwd_pl", x, w1, b1, B, T, Fd, C, y, y_pl.t, y_pl.stride)
+        else:
+            hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y)
         acts, wgs = [y], []
         for k in range(n):
             wk, bk = stage_params[2 * k], stage_params[2 * k + 1]
