@@ -105,6 +105,12 @@ typedef struct oe_gemm_args {
     const void* a_planes; long a_plane_stride;
     const void* b_planes; long b_plane_stride;
     void* c_planes; long c_plane_stride; long ldcp;
+    /* conv_gather == OE_GATHER_A on pre-split operands only: order of the reduction index.  0 = (kh, kw, ci) as everywhere
+     * else; 1 = channel-chunk major, k = ((ci / 32) * KH * KW + kh * KW + kw) * 32 + ci % 32 (C % 32 == 0; the caller lays B's
+     * columns out in the same order): the K-loop then visits the KH * KW taps of one 32-channel chunk back to back, so the
+     * overlapping windows of neighbouring output positions are re-read from L2 instead of HBM (conv2 forward at config 2:
+     * 2.2 GB -> 1.0 GB fetched).  The launch fails if the pre-split kernel does not take the problem. */
+    int conv_korder;
 } oe_gemm_args;
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);

@@ -236,10 +236,14 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     const int M = g->m, N = g->n, K = g->k, sk = g->split_k;
     OE_REQUIRE(g->precision == 0 || g->precision == 1 || g->precision == 3 || g->precision == 6,
                "oe_gemm_f32: precision must be 0 (fp32), 1 (bf16), 3 (bf16x3) or 6 (bf16x6)");
+    OE_REQUIRE(g->conv_korder == 0 || (g->conv_korder == 1 && ga && g->precision == 6 && g->a_planes && g->b_planes && sk <= 1 && A.C % 32 == 0),
+               "oe_gemm_f32: conv_korder 1 needs a gather on A, precision 6, pre-split operands, no split of the reduction and C %% 32 == 0");
     if (g->precision == 6 && g->a_planes && g->b_planes) {       // pre-split operands: tiles by LDS-DMA, no conversion in the loop
         const int r = oe_gemm_pl_try(A, B, g->a_planes, g->a_plane_stride, g->b_planes, g->b_plane_stride, g->c, g->ldc, M, N, K, sk, ep,
-                                     g->a_kmajor, g->b_kmajor, ga, gb, st);
+                                     g->a_kmajor, g->b_kmajor, ga, gb, st, g->conv_korder);
         if (r != 1) return r;
+        OE_REQUIRE(g->conv_korder == 0, "oe_gemm_f32: conv_korder 1, but the pre-split kernel does not take this problem (M=%d N=%d K=%d) - "
+                                        "B is laid out for it alone", M, N, K);
     }
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;

@@ -141,7 +141,7 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
                     bool a_kmajor, bool b_kmajor, bool gather_b, int terms, int tile, hipStream_t st);
 // pre-split operands (gemm_pl.hip): returns 1 when the problem does not qualify
 int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
-                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st);
+                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder = 0);
 
 // One output value: x = acc*alpha + bias -> (pre-activation kept) -> act fwd, or times act'(aux) in a
 // backward GEMM -> dropout mask -> dead-row zeroing -> res + beta*x.

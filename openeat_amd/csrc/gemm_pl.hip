@@ -35,6 +35,7 @@ struct PlOperand {
     int rows_total;        // row-major: rows of the logical operand (M or N); k-major: columns (M or N)
     // im2col gather (row-major A of a conv forward / parity-class input gradient, k-major B of a conv weight gradient)
     int T1, F1, T2, F2, C, KS, S;
+    int korder, KH;        // gathered A: order of the reduction index (oe_gemm_args.conv_korder), window height
 };
 
 __device__ __forceinline__ void pl_dma16(const __bf16* src, unsigned dst) {
@@ -199,14 +200,20 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
             step[j] = (long)BK * X.ld;
         }
     }
-    // running K position of a gathered A: kernel row kh and offset inside it (k = kh * KS * C + rem), wave-uniform
-    int ga_kh = 0, ga_rem = 0;
-    if (GA) { const int seg = A.KS * A.C; ga_kh = k_begin / seg; ga_rem = k_begin - ga_kh * seg; }
+    // running K position of a gathered A: kernel row kh and offset inside it (k = kh * KS * C + rem), wave-uniform.
+    // Channel-chunk-major order (A.korder, k_begin = 0): 32 channels at a time, all KH x KS taps of them back to back -
+    // ga_rem is then the column kw, ga_c the channel offset (chunk * 32 + the K-tile's half of the chunk when BK is 16)
+    int ga_kh = 0, ga_rem = 0, ga_c = 0;
+    if (GA && !A.korder) { const int seg = A.KS * A.C; ga_kh = k_begin / seg; ga_rem = k_begin - ga_kh * seg; }
     const unsigned lds_base = (unsigned)(uintptr_t)lds;
     int tiles_issued = 0;           // tiles whose pieces have been issued so far (wave-uniform); the last one is re-issued past the end
     unsigned stage_off = 0;         // stage the next issue writes
     long ga_off = 0;
-    auto begin_issue = [&]() { ga_off = GA ? (long)ga_kh * A.F1 * A.C + ga_rem : 0; };
+    auto begin_issue = [&]() {
+        if (!GA) ga_off = 0;
+        else if (!A.korder) ga_off = (long)ga_kh * A.F1 * A.C + ga_rem;
+        else ga_off = ((long)ga_kh * A.F1 + ga_rem) * A.C + ga_c;
+    };
     auto issue_piece = [&](int j) {
         const unsigned sb = lds_base + stage_off;
         const bool advance = tiles_issued + 1 < nk;                  // wave-uniform: a select, not a branch
@@ -225,7 +232,14 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
     };
     auto end_issue = [&]() {
         const bool advance = tiles_issued + 1 < nk;
-        if (GA && advance) { ga_rem += BK; if (ga_rem >= A.KS * A.C) { ga_rem -= A.KS * A.C; ++ga_kh; } }
+        if (GA && advance) {
+            if (!A.korder) { ga_rem += BK; if (ga_rem >= A.KS * A.C) { ga_rem -= A.KS * A.C; ++ga_kh; } }
+            else if (BK < 32 && (ga_c & 31) + BK < 32) ga_c += BK;                    // the next part of the same chunk and tap
+            else {
+                ga_c &= ~31;                                                          // next tap of the chunk, or the next chunk
+                if (++ga_rem == A.KS) { ga_rem = 0; if (++ga_kh == A.KH) { ga_kh = 0; ga_c += 32; } }
+            }
+        }
         ++tiles_issued;
         stage_off += STAGE;
         if (stage_off == NST * STAGE) stage_off = 0;
@@ -343,7 +357,7 @@ static int launch_pl(const PlOperand& A, const PlOperand& B, float* C, long ldc,
 // 0 on a launch.  Ap / Bp: plane 0 of the operands' pre-split copies (plane strides in elements), same logical layout and
 // leading dimensions as the fp32 operands they mirror.
 int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
-                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st) {
+                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder) {
     static const int mode = getenv("OE_GEMM_PL") ? atoi(getenv("OE_GEMM_PL")) : 1;            // 0 = never (A/B comparisons)
     if (!mode || !Ap || !Bp) return 1;
     if (a_kmajor && !b_kmajor) return 1;
@@ -352,7 +366,8 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     a.p = (const __bf16*)Ap; a.ld = A.ld; a.plane_stride = a_pstride; a.rows_total = M;
     b.p = (const __bf16*)Bp; b.ld = B.ld; b.plane_stride = b_pstride; b.rows_total = N;
     auto aligned = [](const void* p, long ld, long ps) { return (((uintptr_t)p) & 15) == 0 && ld % 8 == 0 && ps % 8 == 0; };
-    if (ga) { a.T1 = A.T1; a.F1 = A.F1; a.T2 = A.T2; a.F2 = A.F2; a.C = A.C; a.KS = A.KS; a.S = A.S; a.ld = 0; }
+    if (ga) { a.T1 = A.T1; a.F1 = A.F1; a.T2 = A.T2; a.F2 = A.F2; a.C = A.C; a.KS = A.KS; a.S = A.S; a.ld = 0; a.korder = korder; a.KH = K / (A.KS * A.C); }
+    if (korder && (!ga || sk > 1 || A.C % 32 || K != a.KH * A.KS * A.C)) return 1;
     if (gb) { b.T1 = B.T1; b.F1 = B.F1; b.T2 = B.T2; b.F2 = B.F2; b.C = B.C; b.KS = B.KS; b.S = B.S; b.ld = 0; }
     if (!aligned(Ap, ga ? 8 : A.ld, a_pstride) || !aligned(Bp, gb ? 8 : B.ld, b_pstride)) return 1;
     if ((a_kmajor && (M % 8 || M < 8)) || (b_kmajor && (N % 8 || N < 8))) return 1;

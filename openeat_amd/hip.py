@@ -55,6 +55,7 @@ class GemmArgs(C.Structure):
         ("out_scatter", C.c_int), ("sc_t1", C.c_int), ("sc_f1", C.c_int), ("sc_t2", C.c_int), ("sc_f2", C.c_int), ("sc_s", C.c_int),
         ("a_planes", c_fp), ("a_plane_stride", C.c_long), ("b_planes", c_fp), ("b_plane_stride", C.c_long),
         ("c_planes", c_fp), ("c_plane_stride", C.c_long), ("ldcp", C.c_long),
+        ("conv_korder", C.c_int),
     ]
 
 
@@ -243,7 +244,7 @@ def _dev_f32(t: torch.Tensor, name: str):
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
          bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, seed_dev=None, rowmask=None,
          residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None, a_colsum=None,
-         conv_kh=0, scatter=None, a_planes=None, b_planes=None, c_planes=None):
+         conv_kh=0, scatter=None, a_planes=None, b_planes=None, c_planes=None, conv_korder=0):
     """a_planes / b_planes / c_planes: Planes (openeat_amd.planes) of A / B (pre-split copies, precision 6) and for the output."""
     g = GemmArgs()
     g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
@@ -267,6 +268,7 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.precision = GEMM_PRECISION if precision is None else precision
     g.a_colsum = None if (a_colsum is None or g.precision == 0) else a_colsum.data_ptr()
     g.conv_kh = conv_kh
+    g.conv_korder = conv_korder
     if g.precision == 6:
         if a_planes is not None and b_planes is not None:
             g.a_planes, g.a_plane_stride = a_planes.ptr, a_planes.stride

@@ -1254,6 +1254,16 @@ def conv_module(x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residu
 # Conv2d subsampling (1/4) + output Linear + positional scaling
 # --------------------------------------------------------------------------- #
 CONV_DGRAD_IMPLICIT = os.environ.get("OE_CONV_DGRAD", "implicit") != "col2im"
+# pre-split conv GEMMs walk the reduction channel-chunk major (oe_gemm_args.conv_korder): the taps of one 32-channel chunk back to
+# back, so the overlapping windows of neighbouring output positions hit L2.  Only for problems the pre-split kernel surely takes.
+CONV_KORDER = os.environ.get("OE_CONV_KORDER", "1") == "1"
+CONV_KORDER_MIN_ROWS = 32768
+
+
+def _korder_cols(w2d, taps, C):
+    """(rows, taps * C) with columns (tap, c) -> columns (c // 32, tap, c % 32)."""
+    r = w2d.shape[0]
+    return w2d.view(r, taps, C // 32, 32).permute(0, 2, 1, 3).contiguous().view(r, taps * C)
 # the conv weight gradient on pre-split operands too (dy leaves the Linear's input-gradient GEMM with planes): 256 x 256 tiles
 # with the kernel's own split of the 150784-deep reduction, 1454 -> 817 us at config 2 (same-box A/B, step 21.9 -> 21.55 ms)
 CONV_WGRAD_PLANES = os.environ.get("OE_CONV_WGRAD_PLANES", "1") == "1"
@@ -1286,13 +1296,17 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
             a_off = (pt * (Fo + 2) + pf) * C           # odd classes start one padded row / column further
             o_off = (pt * Fi + pf) * C
             ap = bp = None
+            korder = 0
             if dyp_pl is not None:
-                bp = _planes.of(wsel, force=True)
+                korder = int(CONV_KORDER and C % 32 == 0 and B * ni * nj >= CONV_KORDER_MIN_ROWS)
+                bp = _planes.of(_korder_cols(wsel, KH * KW, C) if korder else wsel, force=True)
                 if bp is not None:             # the class's window into the padded dy: the same planes, a_off elements in
                     ap = _planes.Planes(dyp_pl.t, dyp_pl.ptr + 2 * a_off, dyp_pl.stride, C, dyp_pl.rows, C)
+                else:
+                    korder = 0
             hip.gemm(flat_in[a_off:], wsel, flat_out[o_off:], B * ni * nj, C, KH * KW * C, lda=0, ldb=KH * KW * C, ldc=C,
                      act=ACT_RELU, actgrad_in=flat_y[o_off:], ld_aux=C, conv=(To + 2, Fo + 2, ni, nj, C, KW, 1), conv_gather=hip.GATHER_A,
-                     conv_kh=KH, scatter=(Ti, Fi, ni, nj, 2), a_planes=ap, b_planes=bp)
+                     conv_kh=KH, scatter=(Ti, Fi, ni, nj, 2), a_planes=ap, b_planes=bp, conv_korder=korder)
     return dyin
 
 
@@ -1331,14 +1345,16 @@ class ConvSubsamplingFn(torch.autograd.Function):
             hip.call("oe_swap_last2", wk, C, C, kk, wg, 0)
             yo = _new(B * To * Fo, C, like=x)
             ap = bp = cp = None
+            korder = 0
             if _planes.available():            # pre-split mode: the NHWC activation and the re-laid weights as bf16 planes
                 ap = _planes.of(acts[-1].view(-1, C))
-                bp = _planes.of(wg, force=True) if ap is not None else None
+                korder = int(ap is not None and CONV_KORDER and C % 32 == 0 and B * To * Fo >= CONV_KORDER_MIN_ROWS)
+                bp = _planes.of(_korder_cols(wg, kk, C) if korder else wg, force=True) if ap is not None else None
                 if bp is None:
-                    ap = None
+                    ap, korder = None, 0
                 cp = _planes.new_output(yo) if (k + 1 < n or _planes.split_activations()) else None    # a next conv stage reads it as an operand
             hip.gemm(acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
-                     conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A, a_planes=ap, b_planes=bp, c_planes=cp)
+                     conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A, a_planes=ap, b_planes=bp, c_planes=cp, conv_korder=korder)
             dims.append((To, Fo))
             acts.append(yo.view(B, To, Fo, C))
             wgs.append(wg)

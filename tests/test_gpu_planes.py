@@ -178,11 +178,32 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
     assert hip.lib().oe_gemm_pl_launches() - n0 == 1
     got = out.cpu().view(B_, T2, F2, Cc).permute(0, 3, 1, 2)
     assert float((got.double() - ref).abs().max()) / math.sqrt(9 * Cc) < 1.5e-6
+    if Cc % 32 == 0:
+        # the same product with the reduction walked channel-chunk major (oe_gemm_args.conv_korder = 1; B's columns laid out to
+        # match): the taps of 32 channels back to back - and a non-square window (2 x 3: the input gradient's parity classes)
+        from openeat_amd.ops import _korder_cols
+        out2 = torch.empty(Mc, Cc, device=DEV)
+        hip.gemm(x_nhwc, w_g, out2, Mc, Cc, 9 * Cc, lda=0, ldb=9 * Cc, ldc=Cc, conv=conv, conv_gather=hip.GATHER_A, a_planes=xp,
+                 b_planes=split(_korder_cols(w_g, 9, Cc)), conv_korder=1)
+        sync()
+        got2 = out2.cpu().view(B_, T2, F2, Cc).permute(0, 3, 1, 2)
+        assert float((got2.double() - ref).abs().max()) / math.sqrt(9 * Cc) < 1.5e-6
+        w23 = torch.randn(Cc, Cc, 2, 3) * 0.1
+        T3, F3 = (T1 - 2) // 2 + 1, (F1 - 3) // 2 + 1
+        ref23 = F.conv2d(xc.double(), w23.double(), None, stride=2)
+        w23g = cu(w23.permute(0, 2, 3, 1).reshape(Cc, 6 * Cc))
+        out3 = torch.empty(B_ * T3 * F3, Cc, device=DEV)
+        hip.gemm(x_nhwc, w23g, out3, B_ * T3 * F3, Cc, 6 * Cc, lda=0, ldb=6 * Cc, ldc=Cc, conv=(T1, F1, T3, F3, Cc), conv_gather=hip.GATHER_A,
+                 conv_kh=2, a_planes=xp, b_planes=split(_korder_cols(w23g, 6, Cc)), conv_korder=1)
+        sync()
+        got3 = out3.cpu().view(B_, T3, F3, Cc).permute(0, 3, 1, 2)
+        assert float((got3.double() - ref23).abs().max()) / math.sqrt(6 * Cc) < 1.5e-6
     if Cc % 128 == 0 or (9 * Cc) % 128 == 0:
         dyc = torch.randn(Mc, Cc)
         dycd = cu(dyc)
         dwg = torch.zeros(Cc, 9 * Cc, device=DEV)
         hip.lib().oe_gemm_pl_config(-1, 44 if (tile == 44 and Cc % 256 == 0) else 0, -1, -1)    # k-major operands: 128 x 128 or 256 x 256 tiles
+        n0 = hip.lib().oe_gemm_pl_launches() - 1
         hip.gemm(dycd, x_nhwc, dwg, Cc, 9 * Cc, Mc, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True, split_k=2, atomic_out=True,
                  conv=conv, conv_gather=hip.GATHER_B, a_planes=split(dycd), b_planes=xp)
         sync()
