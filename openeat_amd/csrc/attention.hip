@@ -11,7 +11,7 @@
 // prepares K' and the bias (oe_relpos_prepare), so one kernel serves both forms.
 //
 // Matrix cores: v_mfma_f32_32x32x2_f32 (exact fp32, args->precision 0) or v_mfma_f32_32x32x16_bf16 with the
-// operands split to bf16 in registers (precision 1: plain bf16 products, 3: three-term split, fp32-grade; same
+// operands split to bf16 in registers (precision 1: plain bf16 products, 3: three-term split, 2^-17 per product, 6: six terms on three exact pieces; same
 // meaning as oe_gemm_args.precision).  Layout trick: the forward
 // and dQ kernels compute the TRANSPOSED score tile S^T = K Q^T, so the query
 // sits on the lane (softmax statistics are per-lane scalars) and the key on
@@ -43,7 +43,7 @@ extern "C" int oe_debug_set_attn_stamp_buffer(void* p) {
 #define ATT_ACC(slot, t0) do { } while (0)
 #endif
 
-// ---- bf16 matrix-core variants (TERMS = 1: bf16 products; TERMS = 3: hi*hi + hi*lo + lo*hi, fp32-grade) ----
+// ---- bf16 matrix-core variants (TERMS = 1: bf16 products; TERMS = 3: hi*hi + hi*lo + lo*hi, 2^-17 per product) ----
 // v_mfma_f32_32x32x16_bf16: lane (i = lane&31, g = lane>>5) supplies 8 consecutive k-slots 8g..8g+7 of row i (A) /
 // column i (B).  The k-slot -> (feature | key | query) assignment is free as long as A and B agree, so
 //   * products over features take slots = 8 consecutive features (row fragment, A from an LDS tile row);
@@ -51,23 +51,24 @@ extern "C" int oe_debug_set_attn_stamp_buffer(void* p) {
 //     B operand is then simply registers 8s..8s+7 of the score tile this lane already holds (P never leaves
 //     registers, as in the fp32 kernels), and A is read from LDS at those rows (column fragment).
 // The tiles stay fp32 in LDS; fragments are split to bf16 hi (+ lo) in registers.
-template <int TERMS> struct BFrag { bf16x8 hi, lo; };
+// (TERMS = 6: three exact pieces and six products, oe_common.h - the arithmetic of precision 6 where the planes kernels of
+// attention_bf16.hip do not fit: the decoders' 31-query self- and source attention)
+template <int TERMS> struct BFrag { bf16x8 p[oe_npl<TERMS>::N]; };
 
 template <int TERMS>
 __device__ __forceinline__ void bsplit(const float (&x)[8], BFrag<TERMS>& f) {
+    constexpr int NPL = oe_npl<TERMS>::N;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        f.hi[e] = (__bf16)x[e];
-        if (TERMS == 3) f.lo[e] = (__bf16)(x[e] - (float)f.hi[e]);
+        __bf16 q[NPL];
+        oe_split_bf16<NPL>(x[e], q);
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) f.p[n][e] = q[n];
     }
 }
 template <int TERMS>
 __device__ __forceinline__ f32x16 bmma(const BFrag<TERMS>& a, const BFrag<TERMS>& b, f32x16 c) {
-    if (TERMS == 3) {
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.lo, b.hi, c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.lo, c, 0, 0, 0);
-    }
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.hi, b.hi, c, 0, 0, 0);
+    return oe_mma_terms<TERMS>(a, b, c);
 }
 // A[row][16s + 8g + e] of an LDS tile with row stride LD
 template <int TERMS, int LD>
@@ -154,7 +155,7 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* src, long rs
 // (second launch bound = waves per SIMD the register allocation must leave room for: the split forward needs two
 // of its four-wave blocks per CU to have all 512 blocks of config 2 resident at once)
 template <int DPAD, int MODE, int TERMS, int SPLIT>
-__global__ __launch_bounds__(ATT_GROUP * SPLIT, SPLIT) void attn_qtile_kernel(AttnParams p) {
+__global__ __launch_bounds__(ATT_GROUP * SPLIT, (MODE == 1 && TERMS == 6) ? 1 : SPLIT) void attn_qtile_kernel(AttnParams p) {
     constexpr int LD = DPAD + 4;             // pitch: rows stay 16-byte aligned (b128 LDS accesses) and 4 banks apart
     constexpr int DT = DPAD / 32;
     constexpr int KS = DPAD / 16;            // bf16 k-steps over the features
@@ -701,8 +702,8 @@ extern "C" int oe_attention_fwd(const oe_attn_args* a, void* stream) {
         if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 0, TT, 2>), grid, dim3(ATT_GROUP * 2), 0, st, p); \
         else hipLaunchKernelGGL((attn_qtile_kernel<64, 0, TT, 2>), grid, dim3(ATT_GROUP * 2), 0, st, p);        \
     } while (0)
-    // precision 6 where the planes kernel does not fit (short query axes: the decoders): exact fp32 products
-    if (a->precision == 3) ATT_FWD(3); else if (a->precision == 1) ATT_FWD(1); else ATT_FWD(0);
+    // precision 6 where the planes kernel does not fit (short query axes: the decoders): the six-term product on fragments split in registers
+    if (a->precision == 3) ATT_FWD(3); else if (a->precision == 1) ATT_FWD(1); else if (a->precision == 6) ATT_FWD(6); else ATT_FWD(0);
 #undef ATT_FWD
     OE_LAUNCH_CHECK("oe_attention_fwd");
     return 0;
@@ -733,12 +734,20 @@ extern "C" int oe_attention_bwd(const oe_attn_args* a, void* stream) {
     static const bool dkdv6 = !(getenv("OE_ATTN_DKDV6") && atoi(getenv("OE_ATTN_DKDV6")) == 0);      // 0: A/B against the fp32 kernel
     if (a->precision == 6) {
         if (!q_done) {
-            if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 1, 0, 1>), gq, dim3(ATT_GROUP), 0, st, p);
-            else hipLaunchKernelGGL((attn_qtile_kernel<64, 1, 0, 1>), gq, dim3(ATT_GROUP), 0, st, p);
+            // few query tiles against a long key axis (the decoders' source attention: 31 queries, 248 keys, one block per (b, h)):
+            // two wave groups split the keys, as the forward does
+            const bool split = (long)gq.x * gq.y * gq.z <= 512 && p.T2 >= 128;
+            if (split) {
+                if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 1, 6, 2>), gq, dim3(ATT_GROUP * 2), 0, st, p);
+                else hipLaunchKernelGGL((attn_qtile_kernel<64, 1, 6, 2>), gq, dim3(ATT_GROUP * 2), 0, st, p);
+            } else {
+                if (p.D <= 32) hipLaunchKernelGGL((attn_qtile_kernel<32, 1, 6, 1>), gq, dim3(ATT_GROUP), 0, st, p);
+                else hipLaunchKernelGGL((attn_qtile_kernel<64, 1, 6, 1>), gq, dim3(ATT_GROUP), 0, st, p);
+            }
         }
         if (!(dkdv6 && oe_attn_planes_dkdv_try(p, 6, st) == 0)) {
-            if (p.D <= 32) hipLaunchKernelGGL((attn_ktile_bwd_kernel<32, 0, 1>), gk, dim3(ATT_GROUP), 0, st, p);
-            else hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, 0, 1>), gk, dim3(ATT_GROUP), 0, st, p);
+            if (p.D <= 32) hipLaunchKernelGGL((attn_ktile_bwd_kernel<32, 6, 1>), gk, dim3(ATT_GROUP), 0, st, p);
+            else hipLaunchKernelGGL((attn_ktile_bwd_kernel<64, 6, 1>), gk, dim3(ATT_GROUP), 0, st, p);
         }
     } else if (a->precision == 3) ATT_BWD(3); else if (a->precision == 1) ATT_BWD(1); else ATT_BWD(0);
 #undef ATT_BWD
