@@ -211,6 +211,19 @@ size_t oe_layernorm_bwd_workspace_floats(int rows, int d);
 int oe_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* beta, int act,
                      const float* stats, int rows, int d, const unsigned char* rowmask, const float* add,
                      float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
+/* Two LayerNorms back to back in one pass, y2 = LN2(LN1(x)): the norms at an encoder layer boundary
+ * (/root/reference/openeat/modules/encoder_layer.py:109-110 `x = norm_final(x)` followed by the next layer's :79-80
+ * `x = norm_ff_macaron(x)`, or encoder.py's after_norm behind the last layer).  y1 (LN1's output, the next block's residual) may be
+ * NULL when nothing else reads it; stats1 / stats2 = (mean, rstd) per row of each norm.  The backward takes dy2 (gradient of
+ * y2) and `add` (the gradient reaching y1 on its other path, NULL: none), recomputes y1 from x, and writes dx (plus the optional
+ * dropped copy gout of oe_layernorm_bwd_dx_drop) and the partial parameter-gradient rows of LN1 / LN2 into workspace1 / workspace2
+ * (oe_layernorm_bwd_workspace_floats(rows, d) floats each; summed by oe_layernorm_param_reduce[_table]). */
+int oe_layernorm_pair_fwd(const float* x, const float* gamma1, const float* beta1, float eps1, const float* gamma2, const float* beta2,
+                          float eps2, int rows, int d, float* y1, float* stats1, float* y2, float* stats2, void* stream);
+int oe_layernorm_pair_bwd_dx_drop(const float* dy2, const float* x, const float* gamma1, const float* beta1, const float* stats1,
+                                  const float* gamma2, const float* stats2, int rows, int d, const float* add, float* dx, float* gout,
+                                  float g_alpha, float g_p, unsigned long long g_seed, const unsigned long long* g_seed_dev,
+                                  const unsigned char* g_rowmask, float* workspace1, float* workspace2, void* stream);
 /* The same split in two: oe_layernorm_bwd_dx writes dx and the per-block partial sums of the parameter gradients into
  * `workspace`; oe_layernorm_param_reduce_table reduces the partials of n such calls with ONE launch.  table (device
  * memory) holds 5 int64 words per call: { workspace pointer, rows, d, dgamma pointer, dbeta pointer } (a null workspace
@@ -367,6 +380,16 @@ int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out, int accum
 int oe_pad1_nhwc(const float* dy, int B, int To, int Fo, int C, float* out, void* stream);
 int oe_conv_dgrad_k3s2_weights(const float* w, int C, float* out, void* stream);
 
+/* The joint loss of /root/reference/openeat/models/asr_model.py:150-157 and :196-198 as one launch on device scalars:
+ *   att = loss_att * (1 - reverse_weight) + loss_att_r * reverse_weight   (loss_att_r NULL: att = loss_att)
+ *   out = (ctc_weight * loss_ctc + (1 - ctc_weight) * att) * inv_accum    (loss_ctc NULL: out = att * inv_accum)
+ * each product and sum rounded on its own in that order (the value torch's scalar ops produce); oe_loss_combine_bwd writes
+ * the three gradients for an incoming scalar gradient g (d_ctc / d_att_r NULL where the term is absent). */
+int oe_loss_combine(const float* loss_ctc, const float* loss_att, const float* loss_att_r, float ctc_weight, float reverse_weight,
+                    float inv_accum, float* out, void* stream);
+int oe_loss_combine_bwd(const float* g, float ctc_weight, float reverse_weight, float inv_accum, float* d_ctc, float* d_att,
+                        float* d_att_r, void* stream);
+
 /* out = a*(*a_dev)*x + b*y (y, a_dev may be NULL). */
 int oe_axpby(const float* x, const float* y, long n, float a, float b, const float* a_dev, float* out, void* stream);
 
@@ -432,6 +455,12 @@ int oe_col2im_relu_ks(const float* dcol, const float* y1, int B, int T1, int F1,
  * gradient.  backward: da (B,T,2d) written, dw/db accumulated atomically. */
 int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
                       int K, int causal, float* y, void* stream);
+/* oe_dwconv_glu_fwd plus the LayerNorm + activation that follows it in the Conformer convolution module
+ * (/root/reference/openeat/modules/convolution.py:107-111) from the same launch: z (optional) = act(LN(y)), ln_stats = (mean, rstd)
+ * per row as oe_layernorm_fwd writes them; bit-identical to oe_dwconv_glu_fwd followed by oe_layernorm_fwd. */
+int oe_dwconv_glu_ln_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d, int K, int causal,
+                         float* y, const float* ln_gamma, const float* ln_beta, float ln_eps, int ln_act, float* z, float* ln_stats,
+                         void* stream);
 size_t oe_dwconv_glu_bwd_workspace_floats(int B, int T, int d, int K);
 int oe_dwconv_glu_bwd(const float* a, const float* dy, const float* w, const float* gpad, int B, int T, int d, int K,
                       int causal, float* da, float* dw, float* db, float* dgpad, float* workspace, void* stream);

@@ -215,11 +215,17 @@ extern "C" int oe_debug_set_dw_stamp_buffer(void* p) { return (int)hipMemcpyToSy
 // its input BEFORE the pointwise conv (convolution.py:92-93), so those frames carry GLU(pointwise bias).
 // KT = compile-time bound of the kernel size; EXACT: K == KT, so the per-tap loops carry no runtime test (with a test
 // every tap became a scalar branch and every LDS read its own wait)
+// LN (z != nullptr): the LayerNorm + activation that follows the depthwise convolution (convolution.py:107-111) in the same
+// launch - a block owns DW_TT whole rows of y, so it parks them in LDS and each wave normalises four of them exactly as
+// layernorm_fwd_kernel does (same per-lane float4 order, same two-pass statistics: the same bits), writing z = act(LN(y)) and
+// the (mean, rstd) pairs its backward reads.
 template <int KT, bool EXACT>
 __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __restrict__ a, const float* __restrict__ w,
                                                               const float* __restrict__ bias, const float* __restrict__ gpad,
-                                                              int T, int d, int K, int pad_left, float* __restrict__ y) {
-    extern __shared__ __attribute__((aligned(16))) float win[];       // [(DW_TT + K - 1)][d]
+                                                              int T, int d, int K, int pad_left, float* __restrict__ y,
+                                                              const float* __restrict__ ln_gamma, const float* __restrict__ ln_beta, float ln_eps,
+                                                              int ln_act, float* __restrict__ z, float* __restrict__ ln_stats) {
+    extern __shared__ __attribute__((aligned(16))) float win[];       // [(DW_TT + K - 1)][d] (+ [DW_TT][d] with the fused LayerNorm)
     const int b = blockIdx.y;
     const int t0 = blockIdx.x * DW_TT;
     const int rows = DW_TT + K - 1;
@@ -273,6 +279,35 @@ __global__ __launch_bounds__(256) void dwconv_glu_fwd_kernel(const float* __rest
 #pragma unroll
             for (int k = 0; k < KT; ++k) if (EXACT || k < K) s += wk[k] * win[(tt + k) * d + c];
             if (t < T) y[((long)b * T + t) * d + c] = s;
+            if (z) win[(rows + tt) * d + c] = s;
+        }
+    }
+    if (z == nullptr) return;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float4* g4 = reinterpret_cast<const float4*>(ln_gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(ln_beta);
+    for (int tt = wave; tt < DW_TT; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= T) break;                                           // wave-uniform
+        const float4* yr = reinterpret_cast<const float4*>(win + (rows + tt) * d);
+        float sum = 0.f;
+        for (int i = lane; i < dv; i += 64) { const float4 v = yr[i]; sum += v.x + v.y + v.z + v.w; }
+        const float mean = wave_sum(sum) / d;
+        float q = 0.f;
+        for (int i = lane; i < dv; i += 64) {
+            const float4 v = yr[i];
+            const float p0 = v.x - mean, p1 = v.y - mean, p2 = v.z - mean, p3 = v.w - mean;
+            q += p0 * p0 + p1 * p1 + p2 * p2 + p3 * p3;
+        }
+        const float rstd = rsqrtf(wave_sum(q) / d + ln_eps);
+        const long row = (long)b * T + t;
+        if (lane == 0) { ln_stats[row * 2] = mean; ln_stats[row * 2 + 1] = rstd; }
+        float4* zr = reinterpret_cast<float4*>(z + row * d);
+        for (int i = lane; i < dv; i += 64) {
+            const float4 v = yr[i], g = g4[i], bb = b4[i];
+            zr[i] = make_float4(act_fwd(ln_act, (v.x - mean) * rstd * g.x + bb.x), act_fwd(ln_act, (v.y - mean) * rstd * g.y + bb.y),
+                                act_fwd(ln_act, (v.z - mean) * rstd * g.z + bb.z), act_fwd(ln_act, (v.w - mean) * rstd * g.w + bb.w));
         }
     }
 }
@@ -424,19 +459,29 @@ extern "C" size_t oe_dwconv_glu_bwd_workspace_floats(int B, int T, int d, int K)
     return (size_t)B * oe_cdiv(T, DW_TT) * (K + 1) * d;
 }
 
+extern "C" int oe_dwconv_glu_ln_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
+                                    int K, int causal, float* y, const float* ln_gamma, const float* ln_beta, float ln_eps, int ln_act,
+                                    float* z, float* ln_stats, void* stream);
 extern "C" int oe_dwconv_glu_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
                                  int K, int causal, float* y, void* stream) {
+    return oe_dwconv_glu_ln_fwd(a, w, bias, gpad, B, T, d, K, causal, y, nullptr, nullptr, 0.f, 0, nullptr, nullptr, stream);
+}
+// z (optional) = act(LayerNorm(y; ln_gamma, ln_beta, ln_eps)) and ln_stats = (mean, rstd) per row, from the same launch
+extern "C" int oe_dwconv_glu_ln_fwd(const float* a, const float* w, const float* bias, const float* gpad, int B, int T, int d,
+                                    int K, int causal, float* y, const float* ln_gamma, const float* ln_beta, float ln_eps, int ln_act,
+                                    float* z, float* ln_stats, void* stream) {
     OE_REQUIRE(a && w && bias && y, "oe_dwconv_glu_fwd: null pointer");
+    OE_REQUIRE(!z || (ln_gamma && ln_beta && ln_stats), "oe_dwconv_glu_ln_fwd: the fused LayerNorm needs gamma, beta and a statistics buffer");
     OE_REQUIRE(B > 0 && T > 0 && d > 0 && d % 4 == 0 && K >= 1 && K <= DW_MAXK, "oe_dwconv_glu_fwd: bad shape (d %% 4, K <= %d)", DW_MAXK);
     OE_REQUIRE(causal || (K % 2 == 1), "oe_dwconv_glu_fwd: kernel size must be odd for the symmetric convolution");
     const int pad_left = causal ? K - 1 : (K - 1) / 2;
-    const size_t lds = (size_t)(DW_TT + K - 1) * d * sizeof(float);
+    const size_t lds = (size_t)(DW_TT + K - 1 + (z ? DW_TT : 0)) * d * sizeof(float);
     OE_REQUIRE(lds <= 160 * 1024, "oe_dwconv_glu_fwd: window does not fit LDS (d=%d)", d);
 #define DW_FWD(KT, EX)                                                                                                           \
     do {                                                                                                                     \
         if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)dwconv_glu_fwd_kernel<KT, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((dwconv_glu_fwd_kernel<KT, EX>), dim3(oe_cdiv(T, DW_TT), B), dim3(256), lds, (hipStream_t)stream, a, w, bias, gpad, T, d, \
-                           K, pad_left, y);                                                                                  \
+                           K, pad_left, y, ln_gamma, ln_beta, ln_eps, ln_act, z, ln_stats);                                  \
     } while (0)
     if (K == 15) DW_FWD(15, true); else if (K == 7) DW_FWD(7, true); else if (K == 31) DW_FWD(31, true);
     else if (K < 7) DW_FWD(7, false); else if (K < 15) DW_FWD(15, false); else DW_FWD(31, false);

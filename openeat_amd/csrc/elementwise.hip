@@ -311,6 +311,44 @@ extern "C" int oe_axpby(const float* x, const float* y, long n, float a, float b
     return 0;
 }
 
+// Joint loss of asr_model.py:150-157 / :196-198 in ONE launch (was ~8 scalar launches forward, ~7 backward):
+//   att = la * (1 - r) + lr * r ;  loss = wc * lc + (1 - wc) * att      (lr, lc may be NULL: term absent)
+// Every product / sum is rounded on its own, in the reference's order, so the value is the one torch computes.
+__global__ void loss_combine_kernel(const float* __restrict__ lc, const float* __restrict__ la, const float* __restrict__ lr, float wc, float r,
+                                    float inv_accum, float* __restrict__ out) {
+    float att = la[0];
+    if (lr) att = __fadd_rn(__fmul_rn(att, 1.f - r), __fmul_rn(lr[0], r));
+    float loss = att;
+    if (lc) loss = __fadd_rn(__fmul_rn(wc, lc[0]), __fmul_rn(1.f - wc, att));
+    if (inv_accum != 1.f) loss = __fmul_rn(loss, inv_accum);
+    out[0] = loss;
+}
+// gradients of the three losses from the incoming scalar g: d_lc = g wc, d_att = g (1 - wc), d_la = d_att (1 - r), d_lr = d_att r
+__global__ void loss_combine_bwd_kernel(const float* __restrict__ g, float wc, float r, float inv_accum, int has_lc, int has_lr,
+                                        float* __restrict__ d_lc, float* __restrict__ d_la, float* __restrict__ d_lr) {
+    float gg = g[0];
+    if (inv_accum != 1.f) gg = __fmul_rn(gg, inv_accum);
+    const float d_att = has_lc ? __fmul_rn(gg, 1.f - wc) : gg;
+    if (has_lc) d_lc[0] = __fmul_rn(gg, wc);
+    d_la[0] = has_lr ? __fmul_rn(d_att, 1.f - r) : d_att;
+    if (has_lr) d_lr[0] = __fmul_rn(d_att, r);
+}
+extern "C" int oe_loss_combine(const float* loss_ctc, const float* loss_att, const float* loss_att_r, float ctc_weight, float reverse_weight,
+                               float inv_accum, float* out, void* stream) {
+    OE_REQUIRE(loss_att && out, "oe_loss_combine: null pointer");
+    hipLaunchKernelGGL(loss_combine_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, loss_ctc, loss_att, loss_att_r, ctc_weight, reverse_weight, inv_accum, out);
+    OE_LAUNCH_CHECK("loss_combine");
+    return 0;
+}
+extern "C" int oe_loss_combine_bwd(const float* g, float ctc_weight, float reverse_weight, float inv_accum, float* d_ctc, float* d_att,
+                                   float* d_att_r, void* stream) {
+    OE_REQUIRE(g && d_att, "oe_loss_combine_bwd: null pointer");
+    hipLaunchKernelGGL(loss_combine_bwd_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, g, ctc_weight, reverse_weight, inv_accum, d_ctc != nullptr,
+                       d_att_r != nullptr, d_ctc, d_att, d_att_r);
+    OE_LAUNCH_CHECK("loss_combine_bwd");
+    return 0;
+}
+
 // global CMVN (modules/cmvn.py:43-45): y = (x - mean[f]) * istd[f]
 __global__ void cmvn_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ istd, long n, int F,
                             float* __restrict__ y) {

@@ -332,7 +332,7 @@ extern "C" long oe_gemm_pl_launches(void) { return pl_launches; }
 // forced tile (22 / 11, 0 = automatic), bk = forced K-tile of the 128 x 128 tiles (16 / 32, 0 = automatic), waves = 8 or 4
 static int pl_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static int pl_min_blocks = pl_env("OE_PL_MIN_BLOCKS", 96), pl_forced_tile = pl_env("OE_PL_TILE", 0), pl_forced_bk = pl_env("OE_PL_BK", 0),
-           pl_waves = pl_env("OE_PL_WAVES", 8);
+           pl_waves = pl_env("OE_PL_WAVES", 8), pl_t44_min = pl_env("OE_PL_T44_MIN", 1024);
 extern "C" int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves) {
     if (min_blocks >= 0) pl_min_blocks = min_blocks;
     if (tile >= 0) pl_forced_tile = tile;
@@ -392,7 +392,7 @@ int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, l
     // wide problems whose grid still fills the chip: conv2 (forward, input and weight gradients), the 16 s batches.
     const long b44 = (long)oe_cdiv(M, 256) * oe_cdiv(N, 256);
     if (M >= 256 && N >= 256 && N % 256 == 0 && (!a_kmajor || M % 256 == 0) && K % 16 == 0 &&
-        (ep.atomic ? b44 * (K / 2048) >= 200 : b44 >= 1024)) tile = 44;     // (conv2 forward, 589 such tiles = 2.3 rounds: 128 x 256 is faster)
+        (ep.atomic ? b44 * (K / 2048) >= 200 : b44 >= pl_t44_min)) tile = 44;     // (conv2 forward, 589 such tiles = 2.3 rounds: 128 x 256 is faster)
     if (forced_tile) tile = forced_tile;
     if ((a_kmajor || b_kmajor) && tile != 22 && tile != 44) return 1;
     if (ga && tile != 22 && tile != 24 && tile != 44) return 1;

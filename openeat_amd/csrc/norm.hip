@@ -6,12 +6,18 @@
 
 #define LN_MAXV 8   // float4 per lane -> d <= 2048
 
-template <int NV>
+// PAIR: a second LayerNorm (gamma2, beta2, eps2) applied to the first one's output in the same pass - the back-to-back
+// norms at an encoder layer boundary (encoder_layer.py:109-110 `x = norm_final(x)`, then the next layer's :79-80
+// `x = norm_ff_macaron(x)`, or encoder.py's after_norm behind the last layer): y2 = LN2(LN1(x)), stats2 = LN2's
+// (mean, rstd); y (the first norm's output, the next block's residual) is optional then.
+template <int NV, bool PAIR>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps, int rows, int d,
                                                              const unsigned char* __restrict__ rowmask, int act,
                                                              float* __restrict__ y, float* __restrict__ stats,
-                                                             __bf16* __restrict__ ypl, long pstride) {
+                                                             __bf16* __restrict__ ypl, long pstride,
+                                                             const float* __restrict__ gamma2, const float* __restrict__ beta2, float eps2,
+                                                             float* __restrict__ y2, float* __restrict__ stats2) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -52,8 +58,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
                 o.z = act_fwd(act, (v[j].z - mean) * rstd * g.z + bb.z);
                 o.w = act_fwd(act, (v[j].w - mean) * rstd * g.w + bb.w);
             }
-            yr[i] = o;
+            if (!PAIR || y) yr[i] = o;
             if (ypl) store_planes4(ypl + row * d + 4 * i, pstride, o);       // the output as bf16 planes too (gemm_pl.hip operand)
+            if (PAIR) v[j] = o;
+        }
+    }
+    if (PAIR) {
+        float s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) s2 += v[j].x + v[j].y + v[j].z + v[j].w;
+        }
+        const float mean2 = wave_sum(s2) / d;
+        float q2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                float a = v[j].x - mean2, b = v[j].y - mean2, c = v[j].z - mean2, e = v[j].w - mean2;
+                q2 += a * a + b * b + c * c + e * e;
+            }
+        }
+        const float rstd2 = rsqrtf(wave_sum(q2) / d + eps2);
+        if (lane == 0) { stats2[row * 2] = mean2; stats2[row * 2 + 1] = rstd2; }
+        float4* y2r = reinterpret_cast<float4*>(y2 + row * d);
+        const float4* g24 = reinterpret_cast<const float4*>(gamma2);
+        const float4* b24 = reinterpret_cast<const float4*>(beta2);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) {
+                const float4 g = g24[i], bb = b24[i];
+                y2r[i] = make_float4((v[j].x - mean2) * rstd2 * g.x + bb.x, (v[j].y - mean2) * rstd2 * g.y + bb.y,
+                                     (v[j].z - mean2) * rstd2 * g.z + bb.z, (v[j].w - mean2) * rstd2 * g.w + bb.w);
+            }
         }
     }
 }
@@ -63,7 +102,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 // Backward is a latency chain per row (load dy/x -> two wave reductions -> store); with one row in flight per
 // wave the 3*rows*d*4 bytes move at a fraction of the HBM rate.  Each wave therefore issues the loads of its
 // RB rows back to back and only then reduces them one by one.
-template <int NV, int RB>
+// PAIR: backward of y2 = LN2(u), u = LN1(x) in one pass (the forward's PAIR): dy is the gradient of y2, `add` the gradient
+// that reaches u on its other path (the next block's residual), u is recomputed from x and LN1's statistics; the row first
+// goes through LN2's backward (partials of its parameter gradients to partial2), the result through LN1's (act = 0, no mask).
+template <int NV, int RB, bool PAIR>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta, int act,
                                                              const float* __restrict__ stats,
@@ -73,7 +115,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              float g_p, unsigned long long g_seed,
                                                              const unsigned long long* __restrict__ g_seed_dev,
                                                              const unsigned char* __restrict__ g_rowmask,
-                                                             __bf16* __restrict__ opl, long opl_stride) {
+                                                             __bf16* __restrict__ opl, long opl_stride,
+                                                             const float* __restrict__ gamma2, const float* __restrict__ stats2,
+                                                             float* __restrict__ partial2) {
     extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][d]
     // optional second output gout = g_alpha * dropout_mask(g_seed) * dx (oe_dropout_scale's definition: element idx belongs
     // to Philox call idx >> 3): the gradient the PREVIOUS block's backward starts from, i.e. its `residual + dropout(.)`
@@ -85,13 +129,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
     float4 gam[NV], bet[NV], dg[NV], db[NV];
+    float4 gam2[PAIR ? NV : 1], dg2[PAIR ? NV : 1], db2[PAIR ? NV : 1];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int i = lane + 64 * j;
         gam[j] = (i < nv) ? g4[i] : make_float4(0, 0, 0, 0);
-        bet[j] = (i < nv && act) ? b4[i] : make_float4(0, 0, 0, 0);
+        bet[j] = (i < nv && (act || PAIR)) ? b4[i] : make_float4(0, 0, 0, 0);
         dg[j] = make_float4(0, 0, 0, 0);
         db[j] = make_float4(0, 0, 0, 0);
+        if (PAIR) {
+            gam2[j] = (i < nv) ? reinterpret_cast<const float4*>(gamma2)[i] : make_float4(0, 0, 0, 0);
+            dg2[j] = make_float4(0, 0, 0, 0);
+            db2[j] = make_float4(0, 0, 0, 0);
+        }
     }
     const long w0 = (long)blockIdx.x * LNB_ROWS + wave * (LNB_ROWS / 4);
     for (int rb = 0; rb < LNB_ROWS / 4; rb += RB) {
@@ -121,6 +171,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         // ---- one row at a time: reductions, dx, parameter-gradient partials
 #pragma unroll
         for (int k = 0; k < RB; ++k) {
+            if (PAIR) {
+                // LN2's backward on this row first: u = LN1(x) recomputed, dyv <- add + LN2'(dy); `add` is used up
+                const long rc = min(w0 + rb + k, (long)rows - 1);
+                const float mean2 = stats2[rc * 2], rstd2 = stats2[rc * 2 + 1];
+                float4 g2[NV], xh2[NV];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const int i = lane + 64 * j;
+                    const bool on = live[k] && i < nv;
+                    const float4 v = xv[k][j];
+                    const float4 u = make_float4((v.x - mean[k]) * rstd[k] * gam[j].x + bet[j].x, (v.y - mean[k]) * rstd[k] * gam[j].y + bet[j].y,
+                                                 (v.z - mean[k]) * rstd[k] * gam[j].z + bet[j].z, (v.w - mean[k]) * rstd[k] * gam[j].w + bet[j].w);
+                    xh2[j] = make_float4((u.x - mean2) * rstd2, (u.y - mean2) * rstd2, (u.z - mean2) * rstd2, (u.w - mean2) * rstd2);
+                    float4 t = dyv[k][j];
+                    if (!on) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh2[j] = t; }
+                    g2[j] = make_float4(t.x * gam2[j].x, t.y * gam2[j].y, t.z * gam2[j].z, t.w * gam2[j].w);
+                    s1 += g2[j].x + g2[j].y + g2[j].z + g2[j].w;
+                    s2 += g2[j].x * xh2[j].x + g2[j].y * xh2[j].y + g2[j].z * xh2[j].z + g2[j].w * xh2[j].w;
+                    dg2[j].x += t.x * xh2[j].x; dg2[j].y += t.y * xh2[j].y; dg2[j].z += t.z * xh2[j].z; dg2[j].w += t.w * xh2[j].w;
+                    db2[j].x += t.x; db2[j].y += t.y; db2[j].z += t.z; db2[j].w += t.w;
+                }
+                const float c1 = wave_sum(s1) / d, c2 = wave_sum(s2) / d;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    float4 o = av[k][j];
+                    o.x += rstd2 * (g2[j].x - c1 - xh2[j].x * c2);
+                    o.y += rstd2 * (g2[j].y - c1 - xh2[j].y * c2);
+                    o.z += rstd2 * (g2[j].z - c1 - xh2[j].z * c2);
+                    o.w += rstd2 * (g2[j].w - c1 - xh2[j].w * c2);
+                    dyv[k][j] = o;
+                    av[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
             float4* dxr = reinterpret_cast<float4*>(dx + (w0 + rb + k) * d);
             float4 g[NV], xh[NV];
             float s1 = 0.f, s2 = 0.f;
@@ -189,6 +273,17 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     // one partial row [dgamma | dbeta] per block; summed in fixed order by ln_param_reduce_kernel
     for (int c = threadIdx.x; c < 2 * d; c += 256)
         partial[(long)blockIdx.x * 2 * d + c] = sh[c] + sh[2 * d + c] + sh[4 * d + c] + sh[6 * d + c];
+    if (PAIR) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nv) { shg[i] = dg2[j]; shg[nv + i] = db2[j]; }
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 2 * d; c += 256)
+            partial2[(long)blockIdx.x * 2 * d + c] = sh[c] + sh[2 * d + c] + sh[4 * d + c] + sh[6 * d + c];
+    }
 }
 
 // second stage: 64 columns x 16 partial rows per block, LDS reduce, one atomic per column per block
@@ -222,8 +317,8 @@ extern "C" int oe_layernorm_fwd_pl(const float* x, const float* gamma, const flo
     OE_REQUIRE(x && gamma && beta && y, "oe_layernorm_fwd: null pointer");
     OE_REQUIRE(!y_planes || ((((uintptr_t)y_planes) & 7) == 0 && plane_stride % 4 == 0), "oe_layernorm_fwd_pl: planes must be 8-byte aligned");
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_fwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
-#define LN_FWD(NVV) hipLaunchKernelGGL(layernorm_fwd_kernel<NVV>, dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, \
-                                       beta, eps, rows, d, rowmask, act, y, stats, (__bf16*)y_planes, plane_stride)
+#define LN_FWD(NVV) hipLaunchKernelGGL((layernorm_fwd_kernel<NVV, false>), dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, \
+                                       beta, eps, rows, d, rowmask, act, y, stats, (__bf16*)y_planes, plane_stride, nullptr, nullptr, 0.f, nullptr, nullptr)
     if (d <= 256) LN_FWD(1); else if (d <= 512) LN_FWD(2); else if (d <= 1024) LN_FWD(4); else LN_FWD(8);
 #undef LN_FWD
     OE_LAUNCH_CHECK("layernorm_fwd");
@@ -260,12 +355,47 @@ extern "C" int oe_layernorm_bwd_dx_drop_pl(const float* dy, const float* x, cons
     OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
     OE_REQUIRE(workspace, "oe_layernorm_bwd: null workspace");
     const int nb = oe_cdiv(rows, LNB_ROWS);
-#define LN_BWD(NVV, RBB) hipLaunchKernelGGL((layernorm_bwd_kernel<NVV, RBB>), dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
+#define LN_BWD(NVV, RBB) hipLaunchKernelGGL((layernorm_bwd_kernel<NVV, RBB, false>), dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
                                             dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, workspace, gout, g_alpha, g_p,  \
-                                            g_seed, g_seed_dev, g_rowmask, (__bf16*)out_planes, plane_stride)
+                                            g_seed, g_seed_dev, g_rowmask, (__bf16*)out_planes, plane_stride, nullptr, nullptr, nullptr)
     if (d <= 256) LN_BWD(1, 4); else if (d <= 512) LN_BWD(2, 2); else if (d <= 1024) LN_BWD(4, 1); else LN_BWD(8, 1);
 #undef LN_BWD
     OE_LAUNCH_CHECK("layernorm_bwd");
+    return 0;
+}
+
+// y2 = LN2(LN1(x)) in one pass (layernorm_fwd_kernel<.., PAIR>): y1 (LN1's output, optional), stats1 / stats2 as oe_layernorm_fwd's.
+extern "C" int oe_layernorm_pair_fwd(const float* x, const float* gamma1, const float* beta1, float eps1, const float* gamma2,
+                                     const float* beta2, float eps2, int rows, int d, float* y1, float* stats1, float* y2, float* stats2,
+                                     void* stream) {
+    OE_REQUIRE(x && gamma1 && beta1 && gamma2 && beta2 && stats1 && y2 && stats2, "oe_layernorm_pair_fwd: null pointer");
+    OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_pair_fwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
+#define LN_PFWD(NVV) hipLaunchKernelGGL((layernorm_fwd_kernel<NVV, true>), dim3(oe_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma1, \
+                                        beta1, eps1, rows, d, nullptr, 0, y1, stats1, nullptr, 0L, gamma2, beta2, eps2, y2, stats2)
+    if (d <= 256) LN_PFWD(1); else if (d <= 512) LN_PFWD(2); else if (d <= 1024) LN_PFWD(4); else LN_PFWD(8);
+#undef LN_PFWD
+    OE_LAUNCH_CHECK("layernorm_pair_fwd");
+    return 0;
+}
+
+// Backward of the pair: dy2 = gradient of y2, add = the gradient reaching y1 on its other path (NULL: none), dx as
+// oe_layernorm_bwd_dx_drop's (with its optional dropped copy gout); workspace1 / workspace2 (oe_layernorm_bwd_workspace_floats each)
+// receive the partials of LN1's / LN2's parameter gradients (oe_layernorm_param_reduce[_table] sums them).
+extern "C" int oe_layernorm_pair_bwd_dx_drop(const float* dy2, const float* x, const float* gamma1, const float* beta1, const float* stats1,
+                                             const float* gamma2, const float* stats2, int rows, int d, const float* add, float* dx,
+                                             float* gout, float g_alpha, float g_p, unsigned long long g_seed,
+                                             const unsigned long long* g_seed_dev, const unsigned char* g_rowmask, float* workspace1,
+                                             float* workspace2, void* stream) {
+    OE_REQUIRE(dy2 && x && gamma1 && beta1 && stats1 && gamma2 && stats2 && dx && workspace1 && workspace2, "oe_layernorm_pair_bwd: null pointer");
+    OE_REQUIRE(!gout || (d % 8 == 0 && g_p >= 0.f && g_p < 1.f && gout != dx), "oe_layernorm_pair_bwd: the dropped output needs d %% 8 == 0, 0 <= p < 1");
+    OE_REQUIRE(rows > 0 && d > 0 && d % 4 == 0 && d <= 256 * LN_MAXV, "oe_layernorm_pair_bwd: d=%d must be a multiple of 4 and <= %d", d, 256 * LN_MAXV);
+    const int nb = oe_cdiv(rows, LNB_ROWS);
+#define LN_PBWD(NVV, RBB) hipLaunchKernelGGL((layernorm_bwd_kernel<NVV, RBB, true>), dim3(nb), dim3(256), (size_t)8 * d * sizeof(float), (hipStream_t)stream, \
+                                             dy2, x, gamma1, beta1, 0, stats1, rows, d, nullptr, add, dx, workspace1, gout, g_alpha, g_p,  \
+                                             g_seed, g_seed_dev, g_rowmask, nullptr, 0L, gamma2, stats2, workspace2)
+    if (d <= 256) LN_PBWD(1, 4); else if (d <= 512) LN_PBWD(2, 2); else if (d <= 1024) LN_PBWD(4, 1); else LN_PBWD(8, 1);
+#undef LN_PBWD
+    OE_LAUNCH_CHECK("layernorm_pair_bwd");
     return 0;
 }
 

@@ -141,6 +141,8 @@ _SIGNATURES = {
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_fwd_pl": (I, [P, P, P, F, I, I, P, I, P, P, P, L, P]),
     "oe_layernorm_bwd_workspace_floats": (SZ, [I, I]),
+    "oe_layernorm_pair_fwd": (I, [P, P, P, F, P, P, F, I, I, P, P, P, P, P]),
+    "oe_layernorm_pair_bwd_dx_drop": (I, [P, P, P, P, P, P, P, I, I, P, P, P, F, F, U64, P, P, P, P, P]),
     "oe_layernorm_bwd": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P, P, P]),
     "oe_layernorm_bwd_dx": (I, [P, P, P, P, I, P, I, I, P, P, P, P, P]),
     "oe_layernorm_param_reduce": (I, [P, I, I, P, P, P]),
@@ -165,6 +167,8 @@ _SIGNATURES = {
     "oe_pad1_nhwc": (I, [P, I, I, I, I, P, P]),
     "oe_conv_dgrad_k3s2_weights": (I, [P, I, P, P]),
     "oe_axpby": (I, [P, P, L, F, F, P, P, P]),
+    "oe_loss_combine": (I, [P, P, P, F, F, F, P, P]),
+    "oe_loss_combine_bwd": (I, [P, F, F, F, P, P, P, P]),
     "oe_act_fwd": (I, [P, L, I, P, P]),
     "oe_act_grad": (I, [P, P, L, I, P, P]),
     "oe_log_softmax": (I, [P, L, I, P, P]),
@@ -180,6 +184,7 @@ _SIGNATURES = {
     "oe_col2im_relu": (I, [P, P, I, I, I, I, P, P]),
     "oe_col2im_relu_ks": (I, [P, P, I, I, I, I, I, I, P, P]),
     "oe_dwconv_glu_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P]),
+    "oe_dwconv_glu_ln_fwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, F, I, P, P, P]),
     "oe_dwconv_glu_bwd_workspace_floats": (SZ, [I, I, I, I]),
     "oe_dwconv_glu_bwd": (I, [P, P, P, P, I, I, I, I, I, P, P, P, P, P, P]),
     "oe_lsm_workspace_bytes": (SZ, [L]),

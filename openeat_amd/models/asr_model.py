@@ -134,15 +134,22 @@ class ASRModel(torch.nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
-            loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length, prep)
+            l_loss, r_loss, acc = self._att_losses(encoder_out, encoder_mask, targets, targets_length, prep)
             main.wait_stream(side)
             loss_ctc.record_stream(main)
-            return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att, acc
+            return self._joint_loss(loss_ctc, l_loss, r_loss), acc
         loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
         if self.ctc_weight < 1:
-            loss_att, acc = self._calc_att_loss(encoder_out, encoder_mask, targets, targets_length)
-            return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att, acc
+            l_loss, r_loss, acc = self._att_losses(encoder_out, encoder_mask, targets, targets_length)
+            return self._joint_loss(loss_ctc, l_loss, r_loss), acc
         return loss_ctc, None
+
+    def _joint_loss(self, loss_ctc, l_loss, r_loss):
+        """asr_model.py:150-157 with :196-198 folded in: ctc_weight * ctc + (1 - ctc_weight) * (l * (1 - rw) + r * rw)."""
+        if l_loss.is_cuda and l_loss.dtype == torch.float32:
+            return ops.combine_losses(l_loss, r_loss, loss_ctc, self.ctc_weight, self.reverse_weight)
+        loss_att = l_loss if r_loss is None else l_loss * (1 - self.reverse_weight) + r_loss * self.reverse_weight
+        return self.ctc_weight * loss_ctc + (1 - self.ctc_weight) * loss_att
 
     def _att_inputs(self, ys_pad, ys_pad_lens):
         """asr_model.py:162-176: decoder inputs / targets of both directions and the target mask (token bookkeeping only)."""
@@ -171,6 +178,15 @@ class ASRModel(torch.nn.Module):
 
     def _calc_att_loss(self, encoder_out, encoder_mask, ys_pad, ys_pad_lens, prep=None):
         """asr_model.py:159-203; the output layers are fused with the loss."""
+        l_loss, r_loss, acc = self._att_losses(encoder_out, encoder_mask, ys_pad, ys_pad_lens, prep)
+        if r_loss is None:
+            return l_loss, acc
+        if l_loss.is_cuda and l_loss.dtype == torch.float32:
+            return ops.combine_losses(l_loss, r_loss, None, 0.0, self.reverse_weight), acc
+        return l_loss * (1 - self.reverse_weight) + r_loss * self.reverse_weight, acc
+
+    def _att_losses(self, encoder_out, encoder_mask, ys_pad, ys_pad_lens, prep=None):
+        """The two decoders' losses of asr_model.py:159-203 before they are mixed: (left, right or None, accuracy)."""
         ys_in_pad, ys_out_pad, tgt_mask, r_ys_in_pad, r_ys_out_pad = prep if prep is not None else self._att_inputs(ys_pad, ys_pad_lens)
         dec = self.decoder
 
@@ -181,7 +197,7 @@ class ASRModel(torch.nn.Module):
 
         if not self.reverse_weight > 0:
             loss_att, n_ok, n_valid = left()
-            return loss_att, torch.true_divide(n_ok, n_valid)
+            return loss_att, None, torch.true_divide(n_ok, n_valid)
 
         def right():
             r_hid = dec.right_decoder.hidden(r_ys_in_pad, tgt_mask, encoder_out, encoder_mask)
@@ -200,8 +216,7 @@ class ASRModel(torch.nn.Module):
         else:
             loss_att, n_ok, n_valid = left()
             r_loss = right()
-        loss_att = loss_att * (1 - self.reverse_weight) + r_loss * self.reverse_weight
-        return loss_att, torch.true_divide(n_ok, n_valid)
+        return loss_att, r_loss, torch.true_divide(n_ok, n_valid)
 
     # ----------------------------------------------------------------- decode --
     def ctc_greedy_search(self, features: torch.Tensor, features_length: torch.Tensor) -> List[List[int]]:

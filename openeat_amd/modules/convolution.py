@@ -45,8 +45,7 @@ class ConvolutionModule(nn.Module):
             return y[:, cache.size(2):]
         rowmask = None
         if mask_pad is not None and mask_pad.numel() > 0:
-            m = mask_pad if mask_pad.dtype == torch.uint8 else mask_pad.to(torch.uint8)
-            rowmask = m.contiguous().view(-1)
+            rowmask = ops.mask_bytes(mask_pad).view(-1)
         dw = self.depthwise_conv
         return ops.conv_module(x, rowmask, self.pointwise_conv1.weight, self.pointwise_conv1.bias,
                                dw.weight.view(dw.weight.shape[0], -1), dw.bias, self.norm.weight, self.norm.bias,

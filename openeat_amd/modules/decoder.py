@@ -43,8 +43,8 @@ class Decoder(torch.nn.Module):
         """decoder.py:76-108: one decoding step of the embedding-free stack; cache = each block application's previous
         output (B, L-1, d); returns (x (B, L, d), new_cache)."""
         x = tgt
-        tm = tgt_mask.to(torch.uint8).contiguous() if tgt_mask.dtype != torch.uint8 else tgt_mask
-        mm = memory_mask.to(torch.uint8).contiguous() if memory_mask.dtype != torch.uint8 else memory_mask
+        tm = ops.mask_bytes(tgt_mask)
+        mm = ops.mask_bytes(memory_mask)
         new_cache = []
         for i, layer in enumerate(self.decoders):
             for j in range(self.num_blocks_share):
@@ -76,8 +76,8 @@ class TransformerDecoder(torch.nn.Module):
     def hidden(self, tgt, tgt_mask, memory, memory_mask) -> torch.Tensor:
         """Everything up to (and including) after_norm: the input of the output layer."""
         x = self._embed(tgt)
-        tm = tgt_mask.to(torch.uint8).contiguous() if tgt_mask.dtype != torch.uint8 else tgt_mask
-        mm = memory_mask.to(torch.uint8).contiguous() if memory_mask.dtype != torch.uint8 else memory_mask
+        tm = ops.mask_bytes(tgt_mask)
+        mm = ops.mask_bytes(memory_mask)
         for layer in self.decoders:
             for _ in range(self.num_blocks_share):
                 x = layer(x, tm, memory, mm)
@@ -92,8 +92,8 @@ class TransformerDecoder(torch.nn.Module):
     def forward_one_step(self, tgt, tgt_mask, memory, memory_mask, cache: Optional[List[torch.Tensor]] = None):
         """decoder.py:196-232: incremental decoding with the per-layer output cache."""
         x = self._embed(tgt)
-        tm = tgt_mask.to(torch.uint8).contiguous()
-        mm = memory_mask.to(torch.uint8).contiguous()
+        tm = ops.mask_bytes(tgt_mask)
+        mm = ops.mask_bytes(memory_mask)
         new_cache = []
         for i, layer in enumerate(self.decoders):
             for j in range(self.num_blocks_share):

@@ -48,7 +48,7 @@ class Encoder(torch.nn.Module):
         return self._output_size
 
     def forward(self, xs: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor):
-        m8 = masks.to(torch.uint8) if masks.dtype != torch.uint8 else masks
+        m8 = ops.mask_bytes(masks)
         for layer in self.encoders:
             for _ in range(self.num_blocks_share):
                 xs, _ = layer(xs, m8, pos_emb)
@@ -91,7 +91,7 @@ class TransformerEncoder(torch.nn.Module):
         if self.global_cmvn is not None:
             xs = self.global_cmvn(xs)
         xs, masks, pos_emb = self.embed(xs, masks)
-        m8 = masks.to(torch.uint8).contiguous()
+        m8 = ops.mask_bytes(masks)
         hooks = getattr(self, "grad_ready_hooks", None)           # {layer index: callback}, set by TrainEngine (multi-GPU)
         ahead = []
         if ops.POS_PROJ_AHEAD and xs.is_cuda:
@@ -109,6 +109,7 @@ class TransformerEncoder(torch.nn.Module):
                         ahead.append(att)
         try:
             ops.stamp("fwd: input layer done")
+            pre, normed_out = None, False
             for i, layer in enumerate(self.encoders):
                 if i % 3 == 0:
                     ops.stamp(f"fwd: encoder layer {i} starts")
@@ -116,12 +117,33 @@ class TransformerEncoder(torch.nn.Module):
                 if hooks and i in hooks and xs.requires_grad:
                     xs.register_hook(lambda g, cb=hooks[i]: cb())     # gradient of layer i's input ready = layers >= i done
                     xs = ops.cut(xs, f"enc{i}")                       # segmented capture: the tape ends here (identity otherwise)
-                for _ in range(self.num_blocks_share):
-                    xs, _ = layer(xs, m8, pos_emb)
+                # a layer's norm_final and the norm that follows it (the next layer's first pre-norm, or after_norm behind the
+                # last layer) as one launch: the layer hands back its un-normalised output, the pair is applied here.  Not across
+                # a boundary that carries a gradient hook / tape cut (the multi-rank overlap points): those need the tensor between.
+                nxt = self.encoders[i + 1] if i + 1 < len(self.encoders) else None
+                boundary_hooked = bool(hooks) and (i + 1) in hooks
+                fuse = (self.num_blocks_share == 1 and ops.ln_pair_ok(xs) and getattr(layer, "conv_module", None) is not None
+                        and not boundary_hooked and (nxt is None or getattr(nxt, "feed_forward_macaron", None) is not None))
+                if not fuse:
+                    for _ in range(self.num_blocks_share):
+                        xs, _ = layer(xs, m8, pos_emb, pre=pre)
+                        pre = None
+                    continue
+                xs, _ = layer(xs, m8, pos_emb, pre=pre, defer_final=True)
+                nf = layer.norm_final
+                if nxt is None:
+                    an = self.after_norm
+                    xs = ops.layer_norm_pair(xs, nf.weight, nf.bias, nf.eps, an.weight, an.bias, an.eps, want_first=False, sole_consumer=True)
+                    normed_out = True
+                else:
+                    nm = nxt.norm_ff_macaron
+                    pre = ops.layer_norm_pair(xs, nf.weight, nf.bias, nf.eps, nm.weight, nm.bias, nm.eps, want_first=True, sole_consumer=True)
+                    xs = pre[0]
         finally:
             for att in ahead:
                 att._pp_ahead = None
             if ahead:
                 torch.cuda.current_stream().wait_stream(ops.decoder_stream())
-        xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps, sole_consumer=True)
+        if not normed_out:
+            xs = ops.layer_norm(xs, self.after_norm.weight, self.after_norm.bias, self.after_norm.eps, sole_consumer=True)
         return xs, masks, pos_emb

@@ -42,16 +42,21 @@ class EncoderLayer(nn.Module):
         sole: x feeds nothing but this fork (true everywhere in this layer except where the adapter also reads x)."""
         return ops.pre_norm(x, norm.weight, norm.bias, norm.eps, rowmask, sole_consumer=sole)
 
-    def forward(self, x: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor):
+    def forward(self, x: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor, pre=None, defer_final: bool = False):
+        """pre: (residual, norm_ff_macaron(residual)) already computed by the caller - the previous layer's norm_final and this
+        layer's first norm as one launch (ops.layer_norm_pair); defer_final: return x BEFORE norm_final (the caller applies
+        it together with whatever norm follows).  Both default to the plain reference flow."""
         p = self.dropout.p
         if self.feed_forward_macaron is not None:
-            r, y = self._fork(self.norm_ff_macaron, x)
+            r, y = pre if pre is not None else self._fork(self.norm_ff_macaron, x)
             x = self.feed_forward_macaron(y, residual=r, out_scale=self.ff_scale, out_dropout=p)
+        else:
+            assert pre is None
         r, y = self._fork(self.norm_mha, x)
         x = self.self_attn(y, y, y, masks, pos_emb, residual=r, out_dropout=p)
         if self.conv_module is not None:
-            m8 = masks if masks.dtype == torch.uint8 else masks.to(torch.uint8)
-            rowmask = m8.contiguous().view(-1)
+            m8 = ops.mask_bytes(masks)
+            rowmask = m8.view(-1)
             # the reference zeroes padded frames of norm_conv's output in place (convolution.py:88-89):
             # fused into the LayerNorm kernel, so the module skips its own input-mask pass.
             r, y = self._fork(self.norm_conv, x, rowmask)
@@ -61,6 +66,6 @@ class EncoderLayer(nn.Module):
         x = self.feed_forward(y, residual=r, out_scale=self.ff_scale, out_dropout=p)
         if adapt_x is not None:
             x = ops.add(x, adapt_x)                                           # encoder_layer.py:108
-        if self.conv_module is not None:
+        if self.conv_module is not None and not defer_final:
             x = self._ln(self.norm_final, x)
         return x, masks

@@ -690,6 +690,73 @@ def pre_norm(x, gamma, beta, eps, rowmask=None, sole_consumer=False):
     return PreNormFn.apply(x, gamma, beta, eps, rowmask, sole_consumer)
 
 
+# Two LayerNorms back to back - an encoder layer's norm_final followed by the next layer's first pre-norm fork, or by the
+# encoder's after_norm (encoder_layer.py:109-110 -> :79-80; encoder.py after the last layer) - as ONE launch each way:
+# 12 forward and 12 backward launches and a round trip of the (rows, d) activation each less per step at config 2.
+LN_PAIR = os.environ.get("OE_LN_PAIR", "1") == "1"
+
+
+def ln_pair_ok(x):
+    return LN_PAIR and x.is_cuda and x.dtype == torch.float32 and not _planes.active()
+
+
+class NormPairFn(torch.autograd.Function):
+    """x -> (u, y) with u = LN1(x), y = LN2(u); u is also an output when the caller needs it (the next block's residual).
+    Backward: d x = LN1'(d u + LN2'(d y)) in one kernel, u recomputed from x."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, eps1, g2, b2, eps2, want_first, sole_consumer):
+        x = _chk(x, "layer_norm_pair")
+        d = x.shape[-1]
+        rows = x.numel() // d
+        u = torch.empty_like(x) if want_first else None
+        y = torch.empty_like(x)
+        st1, st2 = _new(rows, 2, like=x), _new(rows, 2, like=x)
+        hip.call("oe_layernorm_pair_fwd", x, g1, b1, eps1, g2, b2, eps2, rows, d, u, st1, y, st2)
+        ctx.save_for_backward(x, g1, b1, st1, g2, b2, st2)
+        ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
+        ctx.want_first = want_first
+        if want_first:
+            return u, y
+        return y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        du, dy = grads if ctx.want_first else (None, grads[0])
+        x, g1, b1, st1, g2, b2, st2 = ctx.saved_tensors
+        d = x.shape[-1]
+        rows = x.numel() // d
+        if dy is None:
+            dy = torch.zeros_like(x)
+        dy = dy.contiguous()
+        add = None if du is None else du.contiguous()
+        dx = torch.empty_like(x)
+        (dg1, rg1), (db1, rb1) = grad_sink(g1), grad_sink(b1)
+        (dg2, rg2), (db2, rb2) = grad_sink(g2), grad_sink(b2)
+        ws1, ws2 = _ln_ws(x, rows, d), _ln_ws(x, rows, d)
+        gout, alpha, p, seed, gmask = None, 1.0, 0.0, 0, None
+        if ctx.prev_drop is not None and FUSE_OUT_DROP and d % 8 == 0:
+            gout = torch.empty_like(dx)
+            alpha, p, seed, gmask = ctx.prev_drop
+        hip.call("oe_layernorm_pair_bwd_dx_drop", dy, x, g1, b1, st1, g2, st2, rows, d, add, dx, gout, alpha, p, seed, _seed_dev, gmask, ws1, ws2)
+        if gout is not None:
+            _PREDROP[dx.data_ptr()] = (gout, ctx.prev_drop, dx, dx._version)
+        t = LN_TABLE
+        for ws, dg, db, to_arena in ((ws1, dg1, db1, rg1 is None and rb1 is None), (ws2, dg2, db2, rg2 is None and rb2 is None)):
+            if t is None or not to_arena:
+                hip.call("oe_layernorm_param_reduce", ws, rows, d, dg, db)
+            else:
+                t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
+                t["keep"].append(ws)
+                t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
+        return dx, rg1, rb1, None, rg2, rb2, None, None, None
+
+
+def layer_norm_pair(x, g1, b1, eps1, g2, b2, eps2, want_first=True, sole_consumer=False):
+    """(LN1(x), LN2(LN1(x))) - or only the second with want_first=False.  sole_consumer: as layer_norm's."""
+    return NormPairFn.apply(x, g1, b1, eps1, g2, b2, eps2, want_first, sole_consumer)
+
+
 # --------------------------------------------------------------------------- #
 # Linear (single GEMM with bias / activation)
 # --------------------------------------------------------------------------- #
@@ -794,6 +861,32 @@ class AddFn(torch.autograd.Function):
 
 def add(x, y):
     return AddFn.apply(x, y)
+
+
+class LossCombineFn(torch.autograd.Function):
+    """asr_model.py:150-157 + :196-198 on device scalars, one launch each way:
+    att = l * (1 - r) + lr * r;  loss = wc * ctc + (1 - wc) * att  (absent terms: None)."""
+
+    @staticmethod
+    def forward(ctx, loss_att, loss_att_r, loss_ctc, ctc_weight, reverse_weight):
+        f = lambda t: None if t is None else _chk(t.reshape(1), "loss")
+        la, lr, lc = f(loss_att), f(loss_att_r), f(loss_ctc)
+        out = _new(1, like=la)
+        hip.call("oe_loss_combine", lc, la, lr, float(ctc_weight), float(reverse_weight), 1.0, out)
+        ctx.cfg = (float(ctc_weight), float(reverse_weight), lr is not None, lc is not None)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        wc, r, has_r, has_c = ctx.cfg
+        g = g.contiguous().reshape(1)
+        d = _new(3, like=g)
+        hip.call("oe_loss_combine_bwd", g, wc, r, 1.0, d[0:1] if has_c else None, d[1:2], d[2:3] if has_r else None)
+        return d[1].view(()), (d[2].view(()) if has_r else None), (d[0].view(()) if has_c else None), None, None
+
+
+def combine_losses(loss_att, loss_att_r=None, loss_ctc=None, ctc_weight=0.0, reverse_weight=0.0):
+    return LossCombineFn.apply(loss_att, loss_att_r, loss_ctc, ctc_weight, reverse_weight)
 
 
 class CmvnFn(torch.autograd.Function):
@@ -930,11 +1023,17 @@ def feed_forward(x, w1, b1, w2, b2, act, p_in=0.0, residual=None, out_scale=1.0,
 # --------------------------------------------------------------------------- #
 # Multi-head attention (plain and relative-position)
 # --------------------------------------------------------------------------- #
+def mask_bytes(mask: torch.Tensor) -> torch.Tensor:
+    """A boolean / integer mask as contiguous uint8; a bool tensor is reinterpreted in place (no launch)."""
+    if mask.dtype == torch.bool:
+        return mask.contiguous().view(torch.uint8)
+    return (mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)).contiguous()
+
+
 def _mask_u8(mask: Optional[torch.Tensor]):
     if mask is None:
         return None, (0, 0)
-    m = mask if mask.dtype == torch.uint8 else mask.to(torch.uint8)
-    m = m.contiguous()
+    m = mask_bytes(mask)
     assert m.dim() == 3, "mask must be (B, 1|T1, T2)"
     return m, (m.shape[1] * m.shape[2], 0 if m.shape[1] == 1 else m.shape[2])
 
@@ -1182,6 +1281,9 @@ def pos_proj(pos_emb, wpos):
 # --------------------------------------------------------------------------- #
 # Conformer convolution module
 # --------------------------------------------------------------------------- #
+DWCONV_LN_FUSED = os.environ.get("OE_DWCONV_LN", "1") == "1"
+
+
 class ConvModuleFn(torch.autograd.Function):
     """convolution.py:72-120: mask -> pw1 -> GLU -> depthwise -> LayerNorm -> act -> pw2 -> mask
     (+ optional fused `residual + dropout(.)`, encoder_layer.py:95)."""
@@ -1199,10 +1301,14 @@ class ConvModuleFn(torch.autograd.Function):
         if causal:   # the reference pads before pointwise_conv1: padded frames hold GLU(bias)
             gpad = _new(d, like=x)
             hip.call("oe_glu_fwd", b1, 1, d, gpad)
-        hip.call("oe_dwconv_glu_fwd", a, wd, bd, gpad, B, T, d, K, int(causal), yc)
         z = torch.empty_like(yc)
         stats = _new(B * T, 2, like=x)
-        _ln_fwd(yc, g, b, 1e-5, B * T, d, None, act, z, stats)
+        if DWCONV_LN_FUSED and not _planes.active():
+            # the depthwise convolution normalises its own rows: one launch and one pass over (B*T, d) less per layer
+            hip.call("oe_dwconv_glu_ln_fwd", a, wd, bd, gpad, B, T, d, K, int(causal), yc, g, b, 1e-5, act, z, stats)
+        else:
+            hip.call("oe_dwconv_glu_fwd", a, wd, bd, gpad, B, T, d, K, int(causal), yc)
+            _ln_fwd(yc, g, b, 1e-5, B * T, d, None, act, z, stats)
         s_out = next_seed() if p_out > 0 else 0
         res2 = None if residual is None else _chk(residual, "residual").view(-1, d)
         y = gemm_nt(z, w2m, b2, drop_p=p_out, seed=s_out, seed_dev=_seed_dev, rowmask=rowmask, residual=res2,
