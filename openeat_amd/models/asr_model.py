@@ -133,7 +133,9 @@ class ASRModel(torch.nn.Module):
             main, side = torch.cuda.current_stream(), ops.ctc_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                ops.stamp("fwd: ctc head starts (its stream)")
                 loss_ctc = self.ctc(encoder_out, encoder_out_lens, targets, targets_length)
+                ops.stamp("fwd: ctc head done (its stream)")
             l_loss, r_loss, acc = self._att_losses(encoder_out, encoder_mask, targets, targets_length, prep)
             main.wait_stream(side)
             loss_ctc.record_stream(main)
@@ -209,8 +211,12 @@ class ASRModel(torch.nn.Module):
             main, side = torch.cuda.current_stream(), ops.decoder_stream()
             side.wait_stream(main)
             with torch.cuda.stream(side):
+                ops.stamp("fwd: right decoder starts (its stream)")
                 r_loss = right()
+                ops.stamp("fwd: right decoder done (its stream)")
+            ops.stamp("fwd: left decoder starts")
             loss_att, n_ok, n_valid = left()
+            ops.stamp("fwd: left decoder done")
             main.wait_stream(side)
             r_loss.record_stream(main)
         else:

@@ -1577,6 +1577,7 @@ class CTCHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        stamp("bwd: ctc head backward starts")
         hs2, w, dlogits = ctx.saved_tensors
         B, T, d, V = ctx.shape
         g = g.contiguous().view(1)
@@ -1618,6 +1619,7 @@ class LSMHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _g1, _g2):
+        stamp("bwd: a decoder's backward starts")
         x2, w, dlogits = ctx.saved_tensors
         shape, V = ctx.shape
         g = g.contiguous().view(1)
@@ -1683,6 +1685,7 @@ class EmbedFn(torch.autograd.Function):
         dout = dout.contiguous()
         dt, rt = grad_sink(ctx.table_ref)
         hip.call("oe_embed_bwd", tok, dout, tok.numel(), d, V, xscale, dt)
+        stamp("bwd: a decoder's backward done")
         return None, rt, None, None
 
 
