@@ -3,6 +3,7 @@
 //   col2im  gather form of the Conv2d(C,C,3,2) input gradient + ReLU mask
 //   dwconv  GLU + depthwise Conv1d(K) of the Conformer conv module (convolution.py:104-107)
 // All HBM-bound (a handful of MACs per byte); windows are staged in LDS.
+#include <stdlib.h>
 #include "oe_common.h"
 #include "../../include/openeat_hip.h"
 
@@ -54,11 +55,16 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 
 // dw[c][k] += sum_pos dy[pos,c] * x[.., 2t+kh, 2f+kw] ; db[c] += sum_pos dy[pos,c]
 // (dy is the gradient w.r.t. the pre-ReLU output, i.e. already masked by y>0.)
-__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int T,
+// The kernel streams dy once (636 MB at config 2) against 40 FMAs per float4: it is bound by how many loads a wave keeps in
+// flight.  UB positions go through the loop together - their UB float4 loads of dy and 9 UB window taps are issued before
+// the first FMA - and, with UNIFORM (C == 256: a wave is exactly one position group), the taps are wave-uniform scalar
+// loads instead of nine vector loads of one address each (they cost as much issue time as the FMAs did).
+template <int UB, bool UNIFORM>
+__global__ __launch_bounds__(UNIFORM ? 512 : 256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int B, int T,
                                                            int F, int T1, int F1, int C, int pos_per_block,
                                                            float* __restrict__ dw, float* __restrict__ db) {
     const int cpt = C >> 2;
-    const int grp = threadIdx.x / cpt;
+    const int grp = UNIFORM ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : threadIdx.x / cpt;
     const int c4 = (threadIdx.x % cpt) * 4;
     const int ngrp = blockDim.x / cpt;
     float acc[4][10];
@@ -72,27 +78,50 @@ __global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restric
     const long pstart = p0 + grp, pend = min(npos, p0 + pos_per_block);
     int f = (int)(pstart % F1), t = (int)((pstart / F1) % T1);
     long b = pstart / ((long)F1 * T1);
-#pragma unroll 2
-    for (long pos = pstart; pos < pend; pos += ngrp) {
-        const float* xp = x + (b * T + 2 * t) * F + 2 * f;
-        float xv[9];
+    for (long pos = pstart; pos < pend; pos += (long)UB * ngrp) {
+        float xv[UB][9];
+        float4 g4[UB];
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
+        for (int u = 0; u < UB; ++u) {
+            const long pu = pos + (long)u * ngrp;
+            const bool ok = pu < pend;                                  // (wave-uniform with UNIFORM)
+            const float* xp = x + (b * T + 2 * t) * F + 2 * f;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) xv[kh * 3 + kw] = xp[kh * F + kw];
-        const float4 g4 = *reinterpret_cast<const float4*>(dy + pos * C + c4);
-        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+            for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[e][k] += g[e] * xv[k];
-            acc[e][9] += g[e];
+                for (int kw = 0; kw < 3; ++kw) xv[u][kh * 3 + kw] = ok ? xp[kh * F + kw] : 0.f;
+            g4[u] = ok ? *reinterpret_cast<const float4*>(dy + pu * C + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            f += ngrp;
+            while (f >= F1) { f -= F1; if (++t == T1) { t = 0; ++b; } }
+            if (b >= B) { b = B - 1; t = 0; f = 0; }                    // past the end: any valid address (the values are not used)
         }
-        f += ngrp;
-        while (f >= F1) { f -= F1; if (++t == T1) { t = 0; ++b; } }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const float g[4] = {g4[u].x, g4[u].y, g4[u].z, g4[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) acc[e][k] += g[e] * xv[u][k];
+                acc[e][9] += g[e];
+            }
+        }
     }
     // reduce the position slots of this block through LDS, then one atomic per output per block
-    extern __shared__ float sh[];                  // [ngrp][C][10]
+    extern __shared__ float sh[];                  // [ngrp][C][10]; UNIFORM: [C][10], the waves add into it (ds_add_f32)
+    if (UNIFORM) {
+        for (int i = threadIdx.x; i < C * 10; i += blockDim.x) sh[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < 10; ++k) atomicAdd(&sh[(c4 + e) * 10 + k], acc[e][k]);
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * 10; i += blockDim.x) {
+            const int c = i / 10, k = i % 10;
+            if (k < 9) atomicAdd(dw + c * 9 + k, sh[i]); else atomicAdd(db + c, sh[i]);
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -136,11 +165,24 @@ extern "C" int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int
     OE_REQUIRE(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 4 == 0 && C <= 1024, "oe_conv1_wgrad: bad shape");
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
     const long npos = (long)B * T1 * F1;
-    const int ppb = 512;
-    const int threads = conv1_block(C);
+    // C == 256: blocks of eight waves (a wave = one position group; the taps are scalar loads), 1024 positions per block - half
+    // the block-end reductions and atomics of 256-thread blocks at the same number of waves (cold operands at config 2:
+    // 252 us at 1024 positions per 256-thread block, 282 at 512, 423 at 128)
+    static const int ppb_env = getenv("OE_CONV1_WGRAD_PPB") ? atoi(getenv("OE_CONV1_WGRAD_PPB")) : 0;     // tuning
+    static const int variant = getenv("OE_CONV1_WGRAD") ? atoi(getenv("OE_CONV1_WGRAD")) : 0;             // tuning: 1 = the plain form
+    const bool uni = (C == 256) && variant != 1;
+    // ... and exactly two blocks per CU (512 blocks: 240 us; 607 blocks of 1024 positions: 257 us; the plain form: 300 us)
+    const int ppb = ppb_env > 0 ? ppb_env : (uni ? (int)max(256L, (npos + 511) / 512) : 512);
+    const int threads = uni ? 512 : conv1_block(C);
     const int ngrp = threads / (C / 4);
-    hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(oe_cdiv(npos, ppb)), dim3(threads), (size_t)ngrp * C * 10 * sizeof(float),
-                       (hipStream_t)stream, x, dy, B, T, F, T1, F1, C, ppb, dw, db);
+    const size_t lds = uni ? (size_t)C * 10 * sizeof(float) : (size_t)ngrp * C * 10 * sizeof(float);
+#define C1W(UBB, UNI) hipLaunchKernelGGL((conv1_wgrad_kernel<UBB, UNI>), dim3(oe_cdiv(npos, ppb)), dim3(threads), lds, (hipStream_t)stream, x, dy, B, T, F, T1,  \
+                                         F1, C, ppb, dw, db)
+    if (uni && variant == 8) C1W(8, true);
+    else if (uni) C1W(4, true);
+    else if (variant == 1) C1W(1, false);
+    else C1W(4, false);
+#undef C1W
     OE_LAUNCH_CHECK("conv1_wgrad");
     return 0;
 }
