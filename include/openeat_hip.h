@@ -111,6 +111,10 @@ typedef struct oe_gemm_args {
      * overlapping windows of neighbouring output positions are re-read from L2 instead of HBM (conv2 forward at config 2:
      * 2.2 GB -> 1.0 GB fetched).  The launch fails if the pre-split kernel does not take the problem. */
     int conv_korder;
+    /* actgrad_in points at bf16 values (ld_aux counts elements) instead of fp32 - with act = relu only, where nothing but the
+     * sign of the source is read: plane 0 of an activation that exists as bf16 planes alone (the conv1 output of the
+     * subsampling front end, whose fp32 copy - 636 MB at config 2 - is then never written or read). */
+    int actgrad_bf16;
 } oe_gemm_args;
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);
@@ -378,6 +382,10 @@ int oe_swap_last2(const float* in, long A, int Bd, int Cd, float* out, int accum
  * oe_conv_dgrad_k3s2_weights: OIHW weight w[C][C][3][3] -> the four classes' B operands [ci][(window row, window col, co)]
  * back to back in out (9 C^2 floats; class (t1%2, f1%2) at offsets 0, 4C^2, 6C^2, 8C^2). */
 int oe_pad1_nhwc(const float* dy, int B, int To, int Fo, int C, float* out, void* stream);
+/* oe_pad1_nhwc straight into three bf16 planes of the padded tensor (plane n at planes + n * plane_stride elements, rows of C;
+ * oe_split_planes' definition); out (the padded fp32 tensor) is optional - the parity-class GEMMs on pre-split operands read
+ * the planes only. */
+int oe_pad1_nhwc_planes(const float* dy, int B, int To, int Fo, int C, float* out, void* planes, long plane_stride, void* stream);
 int oe_conv_dgrad_k3s2_weights(const float* w, int C, float* out, void* stream);
 
 /* The joint loss of /root/reference/openeat/models/asr_model.py:150-157 and :196-198 as one launch on device scalars:
@@ -434,7 +442,8 @@ int oe_global_cmvn(const float* x, const float* mean, const float* istd, long n,
  * masked by y>0; dw/db accumulated atomically. */
 int oe_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y, void* stream);
 /* the same, also writing y as three bf16 planes (oe_split_planes' layout: plane n at y_planes + n * plane_stride elements, rows of C)
- * for a precision-6 conv2 on pre-split operands; y_planes NULL = oe_conv1_fwd */
+ * for a precision-6 conv2 on pre-split operands; y_planes NULL = oe_conv1_fwd; y NULL (with y_planes): the planes are the only
+ * copy written (oe_gemm_args.actgrad_bf16 reads the ReLU mask from plane 0) */
 int oe_conv1_fwd_pl(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
                     void* y_planes, long plane_stride, void* stream);
 int oe_conv1_wgrad(const float* x, const float* dy, int B, int T, int F, int C, float* dw, float* db, void* stream);

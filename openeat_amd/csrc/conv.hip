@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             o[e] = fmaxf(s, 0.f);
         }
         const float4 o4 = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(y + pos * C + c4) = o4;
+        if (y) *reinterpret_cast<float4*>(y + pos * C + c4) = o4;
         // precision 6: the activation also leaves as three bf16 planes (oe_common.h) - conv2's gather reads those, and a split
         // pass of its own would read these 636 MB back (config 2) to write them
         if (y_planes) store_planes4(y_planes + pos * C + c4, plane_stride, o4);
@@ -148,7 +148,7 @@ extern "C" int oe_conv1_fwd(const float* x, const float* w, const float* bias, i
 }
 extern "C" int oe_conv1_fwd_pl(const float* x, const float* w, const float* bias, int B, int T, int F, int C, float* y,
                                void* y_planes, long plane_stride, void* stream) {
-    OE_REQUIRE(x && w && bias && y, "oe_conv1_fwd: null pointer");
+    OE_REQUIRE(x && w && bias && (y || y_planes), "oe_conv1_fwd: null pointer");     // y may be NULL when the planes are the only copy wanted
     OE_REQUIRE(!y_planes || ((((uintptr_t)y_planes) & 7) == 0 && plane_stride % 4 == 0), "oe_conv1_fwd_pl: planes must be 8-byte aligned");
     OE_REQUIRE(B > 0 && T >= 3 && F >= 3 && C > 0 && C % 4 == 0 && C <= 1024, "oe_conv1_fwd: bad shape (C %% 4 == 0, C <= 1024)");
     const int T1 = (T - 3) / 2 + 1, F1 = (F - 3) / 2 + 1;
@@ -581,6 +581,35 @@ extern "C" int oe_pad1_nhwc(const float* dy, int B, int To, int Fo, int C, float
     hipLaunchKernelGGL(pad1_nhwc_kernel, dim3((unsigned)min((long)oe_cdiv(n, 256), 65536L)), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)dy, B, To, Fo, C / 4, (float4*)out);
     OE_LAUNCH_CHECK("pad1_nhwc");
+    return 0;
+}
+// (1') the same padding straight into three bf16 planes (oe_common.h: p0 + p1 + p2 = x), `out` optional: with the four
+//      parity-class GEMMs on pre-split operands nothing reads the padded fp32 tensor, and one pass (read dy, write planes)
+//      replaces the pad pass and the split pass over it (config 2: 63 + 68 us, 172 MB less written and read back)
+__global__ __launch_bounds__(256) void pad1_nhwc_planes_kernel(const float4* __restrict__ dy, int B, int To, int Fo, int C4, float4* __restrict__ out,
+                                                                __bf16* __restrict__ planes, long pstride) {
+    const long n = (long)B * (To + 2) * (Fo + 2) * C4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C4);
+        long q = i / C4;
+        const int f = (int)(q % (Fo + 2)) - 1;
+        q /= (Fo + 2);
+        const int t = (int)(q % (To + 2)) - 1;
+        const long b = q / (To + 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t >= 0 && t < To && f >= 0 && f < Fo) v = dy[((b * To + t) * Fo + f) * C4 + c];
+        if (out) out[i] = v;
+        store_planes4(planes + 4 * i, pstride, v);
+    }
+}
+extern "C" int oe_pad1_nhwc_planes(const float* dy, int B, int To, int Fo, int C, float* out, void* planes, long plane_stride, void* stream) {
+    OE_REQUIRE(dy && planes && B > 0 && To > 0 && Fo > 0 && C > 0 && C % 4 == 0, "oe_pad1_nhwc_planes: bad arguments (C must be a multiple of 4)");
+    OE_REQUIRE((((uintptr_t)dy | (uintptr_t)out) & 15) == 0 && (((uintptr_t)planes) & 7) == 0 && plane_stride % 4 == 0,
+               "oe_pad1_nhwc_planes: dy / out must be 16-byte, the planes 8-byte aligned");
+    const long n = (long)B * (To + 2) * (Fo + 2) * (C / 4);
+    hipLaunchKernelGGL(pad1_nhwc_planes_kernel, dim3((unsigned)min((long)oe_cdiv(n, 256), 65536L)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)dy, B, To, Fo, C / 4, (float4*)out, (__bf16*)planes, plane_stride);
+    OE_LAUNCH_CHECK("pad1_nhwc_planes");
     return 0;
 }
 // (2) the B operands of the four parity classes (t1 % 2, f1 % 2) from the OIHW weight w[co][ci][3][3], back to back:

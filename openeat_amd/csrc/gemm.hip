@@ -186,7 +186,10 @@ static int launch(const OperandDesc& A, const OperandDesc& B, float* C, long ldc
 static bool vec_ok(const void* p, long ld) { return ((uintptr_t)p % 16 == 0) && (ld % 4 == 0); }
 
 extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
-    OE_REQUIRE(g && g->a && g->b && g->c, "oe_gemm_f32: null operand");
+    // an operand may exist as pre-split planes ALONE (a / b NULL with a_planes / b_planes given, precision 6): the launch then fails
+    // if the pre-split kernel does not take the problem - no other kernel could read it
+    OE_REQUIRE(g && g->c && (g->a || (g->a_planes && g->b_planes && g->precision == 6)) && (g->b || (g->a_planes && g->b_planes && g->precision == 6)),
+               "oe_gemm_f32: null operand");
     OE_REQUIRE(g->m > 0 && g->n > 0 && g->k >= 0, "oe_gemm_f32: bad shape m=%d n=%d k=%d", g->m, g->n, g->k);
     OE_REQUIRE(g->split_k >= 1, "oe_gemm_f32: split_k must be >= 1");
     OE_REQUIRE(!(g->split_k > 1 && !g->atomic_out), "oe_gemm_f32: split_k > 1 needs atomic_out");
@@ -218,6 +221,9 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
     EpiParams ep{};
     ep.alpha = g->alpha; ep.alpha_dev = g->alpha_dev; ep.bias = g->bias; ep.act = g->act;
     ep.preact_out = g->preact_out; ep.actgrad_in = g->actgrad_in; ep.ld_aux = g->ld_aux ? g->ld_aux : g->ldc;
+    ep.actgrad_bf16 = g->actgrad_bf16;
+    OE_REQUIRE(!g->actgrad_bf16 || (g->actgrad_in && g->act == OE_ACT_RELU && !g->preact_out),
+               "oe_gemm_f32: actgrad_bf16 is for the ReLU mask (only the sign of the source is read), without preact_out");
     ep.drop_p = g->drop_p; ep.seed = g->seed; ep.seed_dev = g->seed_dev; ep.rowmask = g->rowmask;
     ep.residual = g->residual; ep.ldr = g->ldr ? g->ldr : g->ldc; ep.beta = g->beta; ep.res_row_mod = g->res_row_mod;
     ep.accumulate = g->accumulate; ep.atomic = g->atomic_out; ep.a_colsum = g->a_colsum;
@@ -245,6 +251,8 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
         OE_REQUIRE(g->conv_korder == 0, "oe_gemm_f32: conv_korder 1, but the pre-split kernel does not take this problem (M=%d N=%d K=%d) - "
                                         "B is laid out for it alone", M, N, K);
     }
+    OE_REQUIRE(g->a && g->b, "oe_gemm_f32: an operand exists as bf16 planes only, but the pre-split kernel does not take this problem "
+                             "(M=%d N=%d K=%d, a_kmajor=%d b_kmajor=%d gather=%d)", M, N, K, g->a_kmajor, g->b_kmajor, g->conv_gather);
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);
     const long b22 = (long)oe_cdiv(M, 128) * oe_cdiv(N, 128) * sk, b12 = (long)oe_cdiv(M, 64) * oe_cdiv(N, 128) * sk;
     const int tile = (b22 >= 200 && M >= 128 && N >= 128) ? 22 : (b12 >= 160 && N >= 128) ? 12 : 11;

@@ -94,6 +94,7 @@ struct EpiParams {
     int atomic;
     float* a_colsum;   // optional: out[m] += alpha * sum_k A(m,k) for a k-major A (bias gradient fused into wgrad)
     int scatter, sc_t1, sc_f1, sc_t2, sc_f2, sc_s;   // output row scatter (oe_gemm_args.out_scatter)
+    int actgrad_bf16;  // actgrad_in points at bf16 values (plane 0 of the activation: its sign is the activation's), ld_aux in elements
     __bf16* c_planes;  // optional: the output ALSO as three bf16 planes (oe_common.h), for a consumer on gemm_pl.hip
     long c_pstride;    // elements between planes
     long ld_cp;        // row stride of a plane
@@ -167,6 +168,15 @@ __device__ __forceinline__ float epi_value(const EpiParams& ep, float v, float a
 // once a branch separates load and use.  So the paths below keep their loads out of branches that also
 // hold stores: blocks that are interior and 16-byte aligned take straight-line code with every auxiliary
 // load of a 32x32 tile issued ahead of the tile's stores; only ragged-edge blocks take the bounds-checked path.
+// four consecutive values of the act-grad source at element offset `off`: fp32, or bf16 (ep.actgrad_bf16: one 8-byte load)
+__device__ __forceinline__ float4 load_aux4(const EpiParams& ep, long off) {
+    if (!ep.actgrad_bf16) return *reinterpret_cast<const float4*>(ep.actgrad_in + off);
+    const oe_bf16x4 h = *reinterpret_cast<const oe_bf16x4*>(reinterpret_cast<const __bf16*>(ep.actgrad_in) + off);
+    return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ float load_aux1(const EpiParams& ep, long off) {
+    return ep.actgrad_bf16 ? (float)reinterpret_cast<const __bf16*>(ep.actgrad_in)[off] : ep.actgrad_in[off];
+}
 // WM = waves along M (2: the 256-thread kernels; 4: gemm_pl.hip's 512-thread blocks, whose lds must then hold 8 patches);
 // two waves along N always: the block tile is (32 TM WM) x (64 TN).
 template <int TM, int TN, int WM = 2>
@@ -264,7 +274,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 long ro[4];
                 pass_rows(ep, row0, ro);
 #pragma unroll
-                for (int p = 0; p < 4; ++p) aux[p] = *reinterpret_cast<const float4*>(ep.actgrad_in + ro[p] * ep.ld_aux + col);
+                for (int p = 0; p < 4; ++p) aux[p] = load_aux4(ep, ro[p] * ep.ld_aux + col);
             }
             if (ep.residual) {
 #pragma unroll
@@ -421,9 +431,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], float* lds,
                 float aux[4] = {0.f, 0.f, 0.f, 0.f}, res[4] = {0.f, 0.f, 0.f, 0.f};
                 const long orow = ep.scatter ? scatter_row(ep, row) : row;      // where this row lives in C / the act-grad source
                 if (ep.actgrad_in) {
-                    const float* ap = ep.actgrad_in + orow * ep.ld_aux + col;
-                    if (full && aux_vec) { float4 a4 = *reinterpret_cast<const float4*>(ap); aux[0] = a4.x; aux[1] = a4.y; aux[2] = a4.z; aux[3] = a4.w; }
-                    else for (int e = 0; e < ncol; ++e) aux[e] = ap[e];
+                    const long aoff = orow * ep.ld_aux + col;
+                    if (full && aux_vec) { float4 a4 = load_aux4(ep, aoff); aux[0] = a4.x; aux[1] = a4.y; aux[2] = a4.z; aux[3] = a4.w; }
+                    else for (int e = 0; e < ncol; ++e) aux[e] = load_aux1(ep, aoff + e);
                 }
                 if (ep.residual) {
                     const float* rp = ep.residual + (ep.res_row_mod > 0 ? row % ep.res_row_mod : row) * ep.ldr + col;

@@ -56,6 +56,7 @@ class GemmArgs(C.Structure):
         ("a_planes", c_fp), ("a_plane_stride", C.c_long), ("b_planes", c_fp), ("b_plane_stride", C.c_long),
         ("c_planes", c_fp), ("c_plane_stride", C.c_long), ("ldcp", C.c_long),
         ("conv_korder", C.c_int),
+        ("actgrad_bf16", C.c_int),
     ]
 
 
@@ -165,6 +166,7 @@ _SIGNATURES = {
     "oe_embed_bwd": (I, [P, P, L, I, I, F, P, P]),
     "oe_swap_last2": (I, [P, L, I, I, P, I, P]),
     "oe_pad1_nhwc": (I, [P, I, I, I, I, P, P]),
+    "oe_pad1_nhwc_planes": (I, [P, I, I, I, I, P, P, L, P]),
     "oe_conv_dgrad_k3s2_weights": (I, [P, I, P, P]),
     "oe_axpby": (I, [P, P, L, F, F, P, P, P]),
     "oe_loss_combine": (I, [P, P, P, F, F, F, P, P]),
@@ -249,11 +251,12 @@ def _dev_f32(t: torch.Tensor, name: str):
 def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, split_k=1, alpha=1.0, alpha_dev=None,
          bias=None, act=0, preact_out=None, actgrad_in=None, ld_aux=0, drop_p=0.0, seed=0, seed_dev=None, rowmask=None,
          residual=None, ldr=0, res_row_mod=0, beta=1.0, accumulate=False, atomic_out=False, conv=None, conv_gather=GATHER_NONE, precision=None, a_colsum=None,
-         conv_kh=0, scatter=None, a_planes=None, b_planes=None, c_planes=None, conv_korder=0):
+         conv_kh=0, scatter=None, a_planes=None, b_planes=None, c_planes=None, conv_korder=0, actgrad_bf16=False):
     """a_planes / b_planes / c_planes: Planes (openeat_amd.planes) of A / B (pre-split copies, precision 6) and for the output."""
     g = GemmArgs()
-    g.a, g.lda, g.a_kmajor = a.data_ptr(), lda, int(a_kmajor)
-    g.b, g.ldb, g.b_kmajor = b.data_ptr(), ldb, int(b_kmajor)
+    # a / b None: the operand exists as pre-split planes only (a_planes / b_planes); the launch fails if gemm_pl.hip declines
+    g.a, g.lda, g.a_kmajor = (None if a is None else a.data_ptr()), lda, int(a_kmajor)
+    g.b, g.ldb, g.b_kmajor = (None if b is None else b.data_ptr()), ldb, int(b_kmajor)
     g.c, g.ldc = c.data_ptr(), ldc
     g.m, g.n, g.k, g.split_k = m, n, k, split_k
     g.alpha = alpha
@@ -262,6 +265,7 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
     g.act = act
     g.preact_out = None if preact_out is None else preact_out.data_ptr()
     g.actgrad_in = None if actgrad_in is None else actgrad_in.data_ptr()
+    g.actgrad_bf16 = int(actgrad_bf16)
     g.ld_aux = ld_aux
     g.drop_p, g.seed = drop_p, seed
     g.seed_dev = None if seed_dev is None else seed_dev.data_ptr()

@@ -1373,9 +1373,13 @@ def _korder_cols(w2d, taps, C):
 # the conv weight gradient on pre-split operands too (dy leaves the Linear's input-gradient GEMM with planes): 256 x 256 tiles
 # with the kernel's own split of the 150784-deep reduction, 1454 -> 817 us at config 2 (same-box A/B, step 21.9 -> 21.55 ms)
 CONV_WGRAD_PLANES = os.environ.get("OE_CONV_WGRAD_PLANES", "1") == "1"
+# the conv1 activation as bf16 planes only, its ReLU mask read from plane 0 (ConvSubsamplingFn.forward)
+CONV1_PLANES_ONLY = os.environ.get("OE_CONV1_PLANES_ONLY", "1") == "1"
+# the zero-padded dy of the stride-2 input gradient written as bf16 planes directly (_conv_dgrad_k3s2)
+CONV_PAD_PLANES = os.environ.get("OE_CONV_PAD_PLANES", "1") == "1"
 
 
-def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
+def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C, yin_planes=None):
     """Input gradient of Conv2d(C, C, 3, stride 2) (+ the ReLU mask of its input) without a column buffer.
     dx[b, t1, f1, ci] = sum over the taps (kh, kw) with t1 - kh and f1 - kw even of dy[b, (t1-kh)/2, (f1-kw)/2, :] . W[:, ci, kh, kw]:
     per parity class (t1 % 2, f1 % 2) that is a stride-1 convolution of dy with a 2x2 / 1x2 / 2x1 / 1x1 kernel, i.e. an
@@ -1383,13 +1387,26 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
     bounds and the gather needs no predicate) and whose epilogue scatters the rows to dx[:, t1 % 2 :: 2, f1 % 2 :: 2]
     and applies the mask.  The same 2*M*N*K flops as the column-buffer form, 1.4 GB less written and 2.7 GB less gathered
     at config 2."""
-    dyp = _new(B, To + 2, Fo + 2, C, like=dy)
-    hip.call("oe_pad1_nhwc", dy, B, To, Fo, C, dyp)
+    # every class on pre-split operands in channel-chunk order (the launch fails rather than fall back): the padded dy is made
+    # as bf16 planes directly - no padded fp32 tensor, no split pass over it
+    ni_min, nj_min = Ti // 2, Fi // 2
+    direct = bool(_planes.available() and CONV_PAD_PLANES and CONV_KORDER and C % 32 == 0 and B * ni_min * nj_min >= CONV_KORDER_MIN_ROWS)
+    dyp_pl = None
+    if direct:
+        dyp = None
+        dyp_pl = _planes.alloc(B * (To + 2) * (Fo + 2), C, dy.device)
+        hip.call("oe_pad1_nhwc_planes", dy, B, To, Fo, C, None, dyp_pl.t, dyp_pl.stride)
+    else:
+        dyp = _new(B, To + 2, Fo + 2, C, like=dy)
+        hip.call("oe_pad1_nhwc", dy, B, To, Fo, C, dyp)
     wcls = _new(9 * C * C, like=dy)                    # the four classes' B operands [ci][(window row, window col, co)], one launch
     hip.call("oe_conv_dgrad_k3s2_weights", wk, C, wcls)
-    dyin = torch.empty_like(yin)
-    flat_in, flat_out, flat_y = dyp.view(-1), dyin.view(-1), yin.reshape(-1)
-    dyp_pl = _planes.of(dyp.view(-1, C)) if _planes.available() else None       # pre-split mode: one pass over the padded dy
+    # yin_planes: the stage's input exists as bf16 planes only - the ReLU mask is read from plane 0 (same sign, half the bytes)
+    dyin = torch.empty_like(yin) if yin_planes is None else _new(B, Ti, Fi, C, like=dy)
+    flat_in, flat_out = (None if dyp is None else dyp.view(-1)), dyin.view(-1)
+    flat_y = yin.reshape(-1) if yin_planes is None else yin_planes.t[0].reshape(-1)
+    if dyp_pl is None:
+        dyp_pl = _planes.of(dyp.view(-1, C)) if _planes.available() else None   # pre-split mode: one pass over the padded dy
     w_off = 0
     for pt in (0, 1):
         KH = 2 if pt == 0 else 1                       # window row 0 is dy row i - 1 (tap 2), row 1 is dy row i (tap 0); odd t1: tap 1
@@ -1410,9 +1427,10 @@ def _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C):
                     ap = _planes.Planes(dyp_pl.t, dyp_pl.ptr + 2 * a_off, dyp_pl.stride, C, dyp_pl.rows, C)
                 else:
                     korder = 0
-            hip.gemm(flat_in[a_off:], wsel, flat_out[o_off:], B * ni * nj, C, KH * KW * C, lda=0, ldb=KH * KW * C, ldc=C,
+            assert flat_in is not None or (korder and ap is not None)
+            hip.gemm(None if flat_in is None else flat_in[a_off:], wsel, flat_out[o_off:], B * ni * nj, C, KH * KW * C, lda=0, ldb=KH * KW * C, ldc=C,
                      act=ACT_RELU, actgrad_in=flat_y[o_off:], ld_aux=C, conv=(To + 2, Fo + 2, ni, nj, C, KW, 1), conv_gather=hip.GATHER_A,
-                     conv_kh=KH, scatter=(Ti, Fi, ni, nj, 2), a_planes=ap, b_planes=bp, conv_korder=korder)
+                     conv_kh=KH, scatter=(Ti, Fi, ni, nj, 2), a_planes=ap, b_planes=bp, conv_korder=korder, actgrad_bf16=yin_planes is not None)
     return dyin
 
 
@@ -1433,13 +1451,32 @@ class ConvSubsamplingFn(torch.autograd.Function):
         n = len(stage_params) // 2
         assert len(geoms) == n
         dims = [((T - 3) // 2 + 1, (Fd - 3) // 2 + 1)]
-        y = _new(B, dims[0][0], dims[0][1], C, like=x)
-        y_pl = _planes.new_output(y.view(-1, C)) if (_planes.available() and n > 0) else None     # conv2 reads it pre-split
-        if y_pl is not None:
-            hip.call("oe_conv1_fwd_pl", x, w1, b1, B, T, Fd, C, y, y_pl.t, y_pl.stride)
+        T1, F1 = dims[0]
+        # The conv1 activation as bf16 planes ONLY (no fp32 copy: 636 MB less written here and 318 MB less read by the input
+        # gradient's ReLU mask at config 2) when every reader is sure to take the pre-split kernel: the first C -> C stage is the
+        # 3x3 stride-2 one in channel-chunk order forward and in all four parity classes backward (oe_gemm_f32 fails loudly
+        # otherwise), and its weight gradient runs on planes too.
+        planes_only = False
+        if _planes.available() and n > 0 and CONV1_PLANES_ONLY and geoms[0] == (3, 2) and CONV_DGRAD_IMPLICIT and CONV_WGRAD_PLANES \
+                and CONV_KORDER and C % 32 == 0 and C % 128 == 0 and T1 >= 3 and F1 >= 3:
+            To0, Fo0 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+            # (rows a multiple of the K-tile: the weight gradient reduces over them and has no other kernel to fall back to)
+            planes_only = (B * To0 * Fo0 >= CONV_KORDER_MIN_ROWS and B * (T1 // 2) * (F1 // 2) >= CONV_KORDER_MIN_ROWS and
+                           (B * To0 * Fo0) % 32 == 0)
+        if planes_only:
+            y = None
+            y_pl = _planes.alloc(B * T1 * F1, C, x.device)
+            hip.call("oe_conv1_fwd_pl", x, w1, b1, B, T, Fd, C, None, y_pl.t, y_pl.stride)
+            acts = [y_pl.t]
         else:
-            hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y)
-        acts, wgs = [y], []
+            y = _new(B, T1, F1, C, like=x)
+            y_pl = _planes.new_output(y.view(-1, C)) if (_planes.available() and n > 0) else None     # conv2 reads it pre-split
+            if y_pl is not None:
+                hip.call("oe_conv1_fwd_pl", x, w1, b1, B, T, Fd, C, y, y_pl.t, y_pl.stride)
+            else:
+                hip.call("oe_conv1_fwd", x, w1, b1, B, T, Fd, C, y)
+            acts = [y]
+        wgs = []
         for k in range(n):
             wk, bk = stage_params[2 * k], stage_params[2 * k + 1]
             Ti, Fi = dims[-1]
@@ -1453,13 +1490,14 @@ class ConvSubsamplingFn(torch.autograd.Function):
             ap = bp = cp = None
             korder = 0
             if _planes.available():            # pre-split mode: the NHWC activation and the re-laid weights as bf16 planes
-                ap = _planes.of(acts[-1].view(-1, C))
+                ap = y_pl if (k == 0 and planes_only) else _planes.of(acts[-1].view(-1, C))
                 korder = int(ap is not None and CONV_KORDER and C % 32 == 0 and B * To * Fo >= CONV_KORDER_MIN_ROWS)
                 bp = _planes.of(_korder_cols(wg, kk, C) if korder else wg, force=True) if ap is not None else None
                 if bp is None:
                     ap, korder = None, 0
                 cp = _planes.new_output(yo) if (k + 1 < n or _planes.split_activations()) else None    # a next conv stage reads it as an operand
-            hip.gemm(acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
+            assert not (k == 0 and planes_only) or (korder and bp is not None)
+            hip.gemm(None if (k == 0 and planes_only) else acts[-1], wg, yo, B * To * Fo, C, kk * C, lda=0, ldb=kk * C, ldc=C, bias=bk, act=ACT_RELU,
                      conv=(Ti, Fi, To, Fo, C, ks, st), conv_gather=hip.GATHER_A, a_planes=ap, b_planes=bp, c_planes=cp, conv_korder=korder)
             dims.append((To, Fo))
             acts.append(yo.view(B, To, Fo, C))
@@ -1474,6 +1512,7 @@ class ConvSubsamplingFn(torch.autograd.Function):
         ctx.save_for_backward(x, wlg, *acts, *wgs)
         ctx.params = (w1, b1, wl, bl, stage_params)
         ctx.cfg = (B, T, Fd, C, d, xscale, n, dims, geoms)
+        ctx.planes_only = planes_only
         return out.view(B, TL, d)
 
     @staticmethod
@@ -1504,14 +1543,23 @@ class ConvSubsamplingFn(torch.autograd.Function):
             yin = acts[k]
             dwg = _new(C, kk * C, like=do2, zero=True)
             (dbk_buf, dbk) = grad_sink(bk)
-            ap, bp = wgrad_planes(dy, yin.view(-1, C), always=CONV_WGRAD_PLANES)
+            yin_pl = None
+            if k == 0 and ctx.planes_only:          # acts[0] is the (3, rows, C) bf16 planes tensor: there is no fp32 copy
+                yin_pl = _planes.Planes(yin, yin.data_ptr(), yin.shape[1] * C, C, yin.shape[1], C)
+                ap, bp = _planes.of(dy, make=True, force=True), yin_pl
+                assert ap is not None, "the conv stage's output gradient must be dense, 16-byte aligned fp32"
+                yin = None
+            else:
+                ap, bp = wgrad_planes(dy, yin.view(-1, C), always=CONV_WGRAD_PLANES)
             hip.gemm(dy, yin, dwg, C, kk * C, Mo, lda=C, ldb=0, ldc=kk * C, a_kmajor=True, b_kmajor=True,
                      split_k=_split_k(C, kk * C, Mo), atomic_out=True, conv=conv, conv_gather=hip.GATHER_B,
                      a_colsum=dbk_buf if fused else None, a_planes=ap, b_planes=bp)
             if not fused:
                 colsum(dy, out=dbk_buf)
             stage_grads[2 * k], stage_grads[2 * k + 1] = _sink_swapped(wk, dwg, C, kk, C), dbk
-            if (ks, st) == (3, 2) and CONV_DGRAD_IMPLICIT:
+            if yin_pl is not None:
+                dyin = _conv_dgrad_k3s2(dy, wk, None, B, Ti, Fi, To, Fo, C, yin_planes=yin_pl)
+            elif (ks, st) == (3, 2) and CONV_DGRAD_IMPLICIT:
                 dyin = _conv_dgrad_k3s2(dy, wk, yin, B, Ti, Fi, To, Fo, C)
             else:
                 dcol = gemm_nn(dy, wgs[k])                           # (Mo, k*k*C)

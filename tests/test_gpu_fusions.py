@@ -131,3 +131,35 @@ def test_dwconv_with_its_layernorm_equals_the_two_launches(B, T, d, K, causal, a
     assert torch.equal(y0, y1)
     assert float((st0 - st1).abs().max()) <= 1e-6 * float(st0.abs().max())
     assert float((z0 - z1).abs().max()) <= 1e-6 * float(z0.abs().max())
+
+
+def test_conv1_activation_as_planes_only_equals_the_fp32_copy_path():
+    """Conv2dSubsampling4 at a size where the conv1 output is kept as bf16 planes alone (no fp32 copy; the ReLU mask of the
+    input gradient read from plane 0): same output, same gradients as with the fp32 copy (subsampling.py:110-116)."""
+    from openeat_amd import hip, planes
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = 6
+    try:
+        B, T, Fd, C, d = 8, 998, 80, 256, 256
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(B, T, Fd, generator=g).to(DEV)
+        ps = [torch.randn(C, 1, 3, 3, generator=g) * 0.3, torch.randn(C, generator=g) * 0.1, torch.randn(d, C * 19, generator=g) * 0.02,
+              torch.randn(d, generator=g) * 0.1, torch.randn(C, C, 3, 3, generator=g) * 0.03, torch.randn(C, generator=g) * 0.1]
+        dout = torch.randn(B, 248, d, generator=g).to(DEV)
+        res = {}
+        for mode in (True, False):
+            ops.CONV1_PLANES_ONLY = mode
+            planes.clear()
+            leaves = [p.to(DEV).requires_grad_(True) for p in ps]
+            w1, b1, wl, bl, w2, b2 = leaves
+            out = ops.ConvSubsamplingFn.apply(x, w1, b1, wl, bl, None, 16.0, ((3, 2),), w2, b2)
+            assert bool(out.grad_fn.planes_only) == mode                      # the size qualifies: the switch alone decides
+            (out * dout).sum().backward()
+            res[mode] = [out.detach()] + [p.grad.clone() for p in leaves]
+        assert torch.equal(res[True][0], res[False][0])
+        for a, b, name in zip(res[True][1:], res[False][1:], ("dw1", "db1", "dwl", "dbl", "dw2", "db2")):
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), name       # (atomic accumulation orders differ run to run)
+    finally:
+        ops.CONV1_PLANES_ONLY = True
+        hip.GEMM_PRECISION = old
+        planes.clear()
