@@ -30,6 +30,11 @@ y1 = B * T1 * F1 * C * f4        # conv1 output: 636 MB
 attn_enc = 12 * (4 + 14) * B * H * Tp * Tp * (d // H)                    # fwd 4 + bwd 14 flops per (q, k, feature)
 attn_dec = 6 * (4 + 14) * B * H * (L1 * L1 + L1 * Tp) * (d // H)         # self + source attention of 2 x 3 decoder layers
 ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 block norms + conv-module norm per layer, after_norm
+# round 3, second session: a layer's norm_final + the norm behind it are ONE launch (11 pairs that write both outputs, one - in
+# front of after_norm - that writes the second only), the conv module's norm rides in the depthwise-conv forward
+ln_single = 12 * 3 + 1                                                  # norm_mha, norm_conv, norm_ff per layer + layer 0's macaron norm
+ln_fwd_bytes = (ln_single * 2 + 11 * 3 + 1 * 2) * act + ln_dec * 2 * actd
+ln_bwd_bytes = (ln_single * 4 + 12 * 3 + 11 * 4 + 1 * 3) * act + ln_dec * 4 * actd
 classes = [
     ("GEMM kernels (`gemm_pl_kernel`, `gemm_dma_kernel`, `gemm_bf16_kernel`, `gemm_tn_*`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n,   # gemm_tn_grouped_kernel included
      f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
@@ -37,12 +42,12 @@ classes = [
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
     ("CTC (`ctc_rows`, `ctc_alphabeta`, `ctc_labels`)", "hbm", 2 * M * V * f4 + 4 * M * (2 * 30 + 1) * f4, lambda n: "ctc_" in n and "greedy" not in n,
      "logits read once + gradient written once + alpha/beta"),
-    ("LayerNorm forward", "hbm", (ln_enc * act + ln_dec * actd) * 2, lambda n: "layernorm_fwd" in n, "read x + write y"),
-    ("LayerNorm backward (+ parameter reduce)", "hbm", (ln_enc * act + ln_dec * actd) * 4, lambda n: "layernorm_bwd" in n or "ln_param_reduce" in n,
+    ("LayerNorm forward (single norms and norm pairs)", "hbm", ln_fwd_bytes, lambda n: "layernorm_fwd" in n, "read x + write y (a pair: + its first norm's output)"),
+    ("LayerNorm backward (+ parameter reduce)", "hbm", ln_bwd_bytes, lambda n: "layernorm_bwd" in n or "ln_param_reduce" in n,
      "read dy, x, residual gradient + write dx"),
-    ("depthwise conv + GLU forward", "hbm", 12 * 3 * act, lambda n: "dwconv_glu_fwd" in n, "read (B*T', 2d) + write (B*T', d)"),
+    ("depthwise conv + GLU + its LayerNorm, forward", "hbm", 12 * 4 * act, lambda n: "dwconv_glu_fwd" in n, "read (B*T', 2d) + write (B*T', d) twice (conv output, normalised + activated)"),
     ("depthwise conv + GLU backward (+ reduce)", "hbm", 12 * 5 * act, lambda n: "dwconv_glu_bwd" in n or "dwconv_param_reduce" in n, "read a, dy + write da"),
-    ("conv1 forward (`conv1_fwd`)", "hbm", y1 + B * T * 80 * f4, lambda n: "conv1_fwd" in n, "write the NHWC activation"),
+    ("conv1 forward (`conv1_fwd`)", "hbm", y1 * 3 // 2 + B * T * 80 * f4, lambda n: "conv1_fwd" in n, "write the NHWC activation as three bf16 planes (6 bytes per element; no fp32 copy)"),
     ("conv1 weight gradient", "hbm", y1 + B * T * 80 * f4, lambda n: "conv1_wgrad" in n, "read dy1 + x"),
     ("fbank + per-utterance norm", "hbm", B * 160000 * f4 + 3 * B * T * 80 * f4, lambda n: "fbank_kernel" in n or "utt_norm" in n, "read wav, write/normalise features"),
     ("label-smoothing loss rows", "hbm", 2 * 2 * Md * V * f4, lambda n: "lsm_" in n, "logits read + gradient written, two decoders"),
