@@ -194,6 +194,7 @@ def main():
     ap.add_argument("--no-graph-multi", dest="graph_multi", action="store_false",
                     help="N > 1: do not try the HIP-graph replay of forward+backward, time eager steps only")
     ap.add_argument("--force-graph", action="store_true", help="time the HIP-graph replay even if the eager step calibrated faster")
+    ap.add_argument("--no-single-graph", action="store_true", help="N > 1: do not try the one-graph + one-all-reduce form beside the chain of five graphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-table", action="store_true", help="log the per-problem GEMM timing table of one step to stderr")
     ap.add_argument("--dropout", type=float, default=None, help="tuning aid: override the config's dropout 0.1 (the reported line is only valid at the default)")
@@ -208,6 +209,11 @@ def main():
     ap.add_argument("--cpu-decode-utts", type=int, default=16, help="utterances of the decode workload the CPU baseline rescoring times (the first warms up)")
     ap.add_argument("--no-other-modes", action="store_true", help="skip the extra ms/step measurements in arithmetic modes 0 (fp32) and 1 (bf16)")
     args = ap.parse_args()
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner at its first collective):
+    # keep the real stdout for the line alone and send everything else that reaches descriptor 1 to stderr.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     from openeat_amd import ddp, hip
     hip.GEMM_PRECISION = int(os.environ.get("OE_GEMM_PRECISION", "6"))      # default: the reference-precision 6-term bf16 split
@@ -288,7 +294,7 @@ def main():
         torch.cuda.synchronize()
         return agree((time.perf_counter() - t) / n * 1e3)
 
-    use_graph = False
+    use_graph, graph_form = False, None
     # N > 1: the step is captured as a chain of five graphs cut at the encoder output and the quarter points of the encoder
     # stack (TrainEngine._capture_segments); the all-reduce of the arena tail that a graph has finished is issued right
     # after its replay and runs beside the next graph, clip + Adam follow the last collective - against an eager step that
@@ -306,7 +312,45 @@ def main():
         except Exception as e:                        # capture trouble must never cost the run: stay eager
             log(f"graph capture/replay failed ({type(e).__name__}: {e}); staying eager")
             t_graph = float("inf")
-        use_graph = args.force_graph or t_graph <= t_eager
+        graph_form = "one graph" if not engine.reducer.active else "five graphs, all-reduces of the finished arena tails between the replays"
+        # Several ranks: two more forms of the captured step are tried beside the chain of five graphs, and the fastest is timed.
+        # The chain hides the collectives but loses ~0.35 ms of overlap at each of its four cuts (one rank over RCCL: 20.4 against
+        # 19.05 ms/step for one graph); over xGMI the 125 MB all-reduce may be cheaper than that - measured here, not assumed:
+        #   two graphs: one cut below the first quarter of the encoder; the all-reduce of everything above it (~80 % of the arena)
+        #               runs beside the second graph, a small one follows it;
+        #   one graph:  the whole step, then ONE all-reduce of the gradient arena, clip + Adam.
+        if engine.reducer.active and engine.segmented and t_graph != float("inf") and not args.no_single_graph:
+            n_enc = len(model.encoder.encoders)
+            forms = {"five": (None, True, True, graph_form),
+                     "two": ([max(1, n_enc // 4)], False, True, "two graphs cut below encoder layer %d, the all-reduce of the upper arena beside the second" % max(1, n_enc // 4)),
+                     "one": (None, True, False, "one graph, then one all-reduce of the gradient arena, clip + Adam")}
+
+            def capture_form(name):
+                cuts, heads, seg, _ = forms[name]
+                engine.set_overlap_cuts(cuts, heads)           # (drops the current graph and its pool)
+                engine.segmented = seg
+                engine.capture(batch, warmup=1)
+
+            times = {"five": t_graph}
+            current = "five"
+            for name in ("two", "one"):
+                try:
+                    capture_form(name)
+                    current = name
+                    times[name] = trial(engine.replay, n_trial, give_up_ms=3.0 * t_eager)
+                except Exception as e:
+                    log(f"capture/replay of the '{name}' form failed ({type(e).__name__}: {e})")
+                    times[name] = float("inf")
+            best = min(times, key=times.get)
+            log("warm-up calibration of the captured forms: " + ", ".join(f"{k} {v:.2f}" for k, v in times.items()) + f" ms/step -> {best}")
+            if best != current:
+                try:
+                    capture_form(best)
+                except Exception as e:
+                    log(f"re-capture of the '{best}' form failed ({type(e).__name__}: {e}); staying eager")
+                    times[best] = float("inf")
+            t_graph, graph_form = times[best], forms[best][3]
+        use_graph = (args.force_graph and t_graph != float("inf")) or t_graph <= t_eager
         log(f"warm-up calibration: eager {t_eager:.2f} ms/step, graph replay {t_graph:.2f} ms/step -> timing {'graph' if use_graph else 'eager'}")
         if not use_graph:
             engine.drop_graph()
@@ -469,11 +513,13 @@ def main():
                                        f"B={args.batch}/GPU x {args.seconds:g} s 16 kHz wav (T={T} frames), L={args.target_len}, "
                                        "CTC+attention joint loss, fbank+fwd+bwd+clip+Adam, dropout 0.1",
                            "global_batch": world * args.batch, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                           **({"graph_form": graph_form} if use_graph and engine.reducer.active else {}),
                            **({"ddp_forced_with_one_rank": "OE_DDP_FORCE=1: RCCL process group, hooks and all-reduces (over a group of one) "
                                                            "inside the timed step"} if ddp.forced() else {})},
                 **({"invalid": f"dropout overridden to {args.dropout}"} if args.dropout is not None else {}),
                 "loss": loss, "roofline": roof, "cpu_baseline": cpu, **other, "decode": dec}
-        print(json.dumps(line))
+        real_stdout.write(json.dumps(line) + "\n")
+        real_stdout.flush()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

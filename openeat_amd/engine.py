@@ -51,12 +51,16 @@ class TrainEngine:
         self.cache_hits = self.cache_misses = 0
         self.cache_uncapturable = 0              # shapes whose capture was refused: they run eagerly (step_cached warns once per shape)
 
-    def _install_overlap_hooks(self):
+    def _install_overlap_hooks(self, layer_cuts=None, heads: bool = True):
         """Start the gradient all-reduce of the arena tail whose gradients are final while backward is still running:
         after the heads (gradient of the encoder output ready) and at the quarter points of the encoder stack; what is
-        left after backward is the first quarter of the encoder and the input layer."""
+        left after backward is the first quarter of the encoder and the input layer.
+        layer_cuts / heads: other cut sets (set_overlap_cuts) - encoder layer indices whose input gradient marks a cut, and
+        whether the encoder output is one."""
         us = self.arena.unit_start
-        enc = getattr(self.model, "encoder", None)
+        if getattr(self, "_hook_model", None) is None:
+            self._hook_model = self.model            # (callers may wrap engine.model later: the hooks stay on this one)
+        enc = getattr(self._hook_model, "encoder", None)
         if enc is None or "heads" not in us:
             return
 
@@ -68,10 +72,17 @@ class TrainEngine:
                 self.reducer.reduce_tail(us[unit])
             return cb
 
-        self.model.grad_ready_hooks = {"encoder_out": tail_from("heads")}
+        self._hook_model.grad_ready_hooks = {"encoder_out": tail_from("heads")} if heads else {}
         n = len(enc.encoders)
-        cuts = sorted({(n * q) // 4 for q in (1, 2, 3)} - {0})      # quarter points of the encoder stack
-        enc.grad_ready_hooks = {i: tail_from(f"enc{i}") for i in cuts if f"enc{i}" in us}
+        cuts = sorted({(n * q) // 4 for q in (1, 2, 3)} - {0}) if layer_cuts is None else sorted(set(int(c) for c in layer_cuts) - {0})
+        enc.grad_ready_hooks = {i: tail_from(f"enc{i}") for i in cuts if f"enc{i}" in us}      # default: quarter points of the stack
+
+    def set_overlap_cuts(self, layer_cuts=None, heads: bool = True):
+        """Choose where the multi-rank step is cut (eager: where backward hands finished arena tails to the collective; captured in
+        segments: where one graph ends and the next begins).  None / True = the default (encoder output + quarter points: five
+        graphs); e.g. ([n // 4], False) = two graphs, one all-reduce beside the second.  Drops any captured graph."""
+        self.drop_graph()
+        self._install_overlap_hooks(layer_cuts, heads)
 
     # one micro-step: loss (already divided by accum_grad) and its backward
     def _fwd_bwd(self, batch):
