@@ -409,6 +409,47 @@ def test_segmented_capture_equals_eager_steps(parallel):
     check_updates(m2.state_dict(), m1.state_dict(), None, steps=4)
 
 
+def test_two_graph_form_of_the_segmented_capture_equals_eager_steps():
+    """TrainEngine.set_overlap_cuts([k], heads=False): the multi-rank step as TWO graphs cut at encoder layer k's input (bench.py
+    tries this form, the chain of five and the single graph at N > 1 and times the fastest).  The one tail handed to the collective
+    between the replays starts where that layer's arena unit does; losses and parameters equal eager steps; the default cut set
+    comes back with set_overlap_cuts()."""
+    from openeat_amd.models.asr_model import ASRModel
+
+    def four_layers():
+        torch.manual_seed(17)
+        return ASRModel(80, 40, encoder_num_blocks=4, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+                        linear_units=64, dropout_rate=0.0, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3).to(DEV).train()
+    m1, m2 = four_layers(), four_layers()
+    b = batch_of(seed=6)
+    e1 = TrainEngine(m1, lr=1e-3, grad_clip=5.0, static_shapes=True)
+    for _ in range(4):
+        l_eager, _ = e1.step(b)
+    torch.cuda.synchronize()
+    e1.arena.deactivate()
+    e2 = TrainEngine(m2, lr=1e-3, grad_clip=5.0, static_shapes=True, parallel_decoders=True, segmented=True)
+    try:
+        sent = []
+        e2.reducer.reduce_tail = lambda start: sent.append(start)
+        e2.set_overlap_cuts([1], heads=False)
+        e2.capture(b, warmup=1)
+        us = e2.arena.unit_start
+        assert [f for _, f in e2._segments] == [us["enc1"], None]
+        for _ in range(3):
+            l_graph, _ = e2.replay()
+        torch.cuda.synchronize()
+        assert sent == [us["enc1"]] * 3
+        e2.set_overlap_cuts()                      # the default again: encoder output + quarter points (graph dropped)
+        assert e2._graph is None and sorted(m2.encoder.grad_ready_hooks) == [1, 2, 3] and "encoder_out" in m2.grad_ready_hooks
+    finally:
+        e2.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        ops.PARALLEL_DECODERS = False
+        ops.POS_PROJ_AHEAD = False
+    torch.testing.assert_close(l_graph, l_eager, rtol=1e-4, atol=1e-5)
+    check_updates(m2.state_dict(), m1.state_dict(), None, steps=4)
+
+
 def test_dropout_training_step_runs_and_is_seed_dependent():
     m = tiny(seed=9, dropout=0.1).to(DEV).train()
     b = batch_of(seed=4)
