@@ -1,6 +1,7 @@
 // Small memory-bound kernels of the path: relative-position key preparation,
 // GLU, dropout scaling, token embedding, weight layout swaps, axpby.
 // All HBM-bound: bytes moved = inputs read once + outputs written once.
+#include <stdlib.h>
 #include "oe_common.h"
 #include "../../include/openeat_hip.h"
 
@@ -96,6 +97,67 @@ __global__ void relpos_backward_kernel(const float* __restrict__ dkp, const floa
     atomicAdd(dv + h * D + d, dvs);
 }
 
+// The same, one block per time step: lane = four consecutive features of the (H, D) row, wave w = a quarter of the batch - every
+// wave's loads (eight utterances' dkp / k float4s and key-bias gradients) go out in ONE round trip (the kernel above makes
+// ceil(B / 8) dependent ones per thread: 16 us per call at config 2, 12 calls per step), the four partial sums of dp / du / dv meet in
+// LDS and are added in wave order (dp stays deterministic; du / dv are atomics across the time steps as before).
+__global__ __launch_bounds__(256) void relpos_backward_rows_kernel(const float* __restrict__ dkp, const float* __restrict__ dkeybias,
+                                                                    const float* __restrict__ k, long k_bs, long k_rs, const float* __restrict__ p,
+                                                                    long p_rs, const float* __restrict__ u, const float* __restrict__ v, int B, int T,
+                                                                    int H, int D, float scale, float* __restrict__ dk, float* __restrict__ dp, long dp_rs,
+                                                                    float* __restrict__ du, float* __restrict__ dv) {
+    extern __shared__ float4 rp_sh[];                    // [3 (dp, du, dv)][4 waves][dq]
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int dq = (H * D) >> 2;
+    const int bpw = (B + 3) >> 2;
+    const int b_lo = wave * bpw, b_hi = min(B, b_lo + bpw);
+    for (int c = lane; c < dq; c += 64) {
+        const int h = (4 * c) / D;
+        const float4 uu = reinterpret_cast<const float4*>(u)[c], vv = reinterpret_cast<const float4*>(v)[c];
+        const float4 pv = *reinterpret_cast<const float4*>(p + (long)t * p_rs + 4 * c);
+        float4 dps = make_float4(0.f, 0.f, 0.f, 0.f), dus = dps, dvs = dps;
+        for (int b0 = b_lo; b0 < b_hi; b0 += 8) {
+            float4 g[8], kv[8];
+            float gb[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int b = min(b0 + i, b_hi - 1);
+                g[i] = *reinterpret_cast<const float4*>(dkp + ((long)b * T + t) * H * D + 4 * c);
+                gb[i] = dkeybias[((long)b * H + h) * T + t] * scale;
+                kv[i] = *reinterpret_cast<const float4*>(k + (long)b * k_bs + (long)t * k_rs + 4 * c);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (b0 + i < b_hi) {
+                    dus.x += gb[i] * kv[i].x; dus.y += gb[i] * kv[i].y; dus.z += gb[i] * kv[i].z; dus.w += gb[i] * kv[i].w;
+                    *reinterpret_cast<float4*>(dk + (long)(b0 + i) * k_bs + (long)t * k_rs + 4 * c) =
+                        make_float4(g[i].x + gb[i] * uu.x, g[i].y + gb[i] * uu.y, g[i].z + gb[i] * uu.z, g[i].w + gb[i] * uu.w);
+                    dps.x += g[i].x + gb[i] * vv.x; dps.y += g[i].y + gb[i] * vv.y; dps.z += g[i].z + gb[i] * vv.z; dps.w += g[i].w + gb[i] * vv.w;
+                    dvs.x += gb[i] * pv.x; dvs.y += gb[i] * pv.y; dvs.z += gb[i] * pv.z; dvs.w += gb[i] * pv.w;
+                }
+            }
+        }
+        rp_sh[(0 * 4 + wave) * dq + c] = dps;
+        rp_sh[(1 * 4 + wave) * dq + c] = dus;
+        rp_sh[(2 * 4 + wave) * dq + c] = dvs;
+    }
+    __syncthreads();
+    // final sums in SCALAR layout, all four waves, consecutive lanes on consecutive floats: an atomic instruction then touches two
+    // cache lines of du / dv, not eight (every block adds into the same 2 KB: with float4-strided lanes this tail alone cost 15 us)
+    const float* shf = reinterpret_cast<const float*>(rp_sh);
+    const int dfl = H * D;
+    for (int i = threadIdx.x; i < dfl; i += 256) {
+        float s3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            s3[q] = ((shf[(q * 4 + 0) * dfl + i] + shf[(q * 4 + 1) * dfl + i]) + shf[(q * 4 + 2) * dfl + i]) + shf[(q * 4 + 3) * dfl + i];
+        dp[(long)t * dp_rs + i] = s3[0];
+        atomicAdd(du + i, s3[1]);
+        atomicAdd(dv + i, s3[2]);
+    }
+}
+
 extern "C" int oe_relpos_prepare(const float* k, long k_bstride, long k_rstride, const float* p, long p_rstride,
                                  const float* u, const float* v, int B, int T, int H, int D, float scale, float* kp,
                                  float* keybias, void* stream) {
@@ -121,6 +183,16 @@ extern "C" int oe_relpos_backward(const float* dkp, const float* dkeybias, const
                                   float scale, float* dk, float* dp, long dp_rstride, float* du, float* dv, void* stream) {
     OE_REQUIRE(dkp && dkeybias && k && p && u && v && dk && dp && du && dv, "oe_relpos_backward: null pointer");
     const long n = (long)T * H * D;
+    const bool rows_ok = (D % 4 == 0) && (k_bstride % 4 == 0) && (k_rstride % 4 == 0) && (p_rstride % 4 == 0) && (dp_rstride % 4 == 0) &&
+                         (((uintptr_t)dkp | (uintptr_t)k | (uintptr_t)p | (uintptr_t)u | (uintptr_t)v | (uintptr_t)dk | (uintptr_t)dp) & 15) == 0 &&
+                         (size_t)3 * 4 * (H * D / 4) * sizeof(float4) <= 64 * 1024;
+    static const bool rows_on = !(getenv("OE_RELPOS_BWD_ROWS") && atoi(getenv("OE_RELPOS_BWD_ROWS")) == 0);      // 0: the per-element form (A/B)
+    if (rows_ok && rows_on) {
+        hipLaunchKernelGGL(relpos_backward_rows_kernel, dim3(T), dim3(256), (size_t)3 * 4 * (H * D / 4) * sizeof(float4), (hipStream_t)stream, dkp,
+                           dkeybias, k, k_bstride, k_rstride, p, p_rstride, u, v, B, T, H, D, scale, dk, dp, dp_rstride, du, dv);
+        OE_LAUNCH_CHECK("relpos_backward");
+        return 0;
+    }
     hipLaunchKernelGGL(relpos_backward_kernel, dim3(oe_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dkp, dkeybias, k,
                        k_bstride, k_rstride, p, p_rstride, u, v, B, T, H, D, scale, dk, dp, dp_rstride, du, dv);
     OE_LAUNCH_CHECK("relpos_backward");
