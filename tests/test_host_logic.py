@@ -245,3 +245,17 @@ def test_get_subsample_matches_reference_table():
     import pytest
     with pytest.raises(AssertionError):
         get_subsample({"encoder_conf": {"input_layer": "linear"}})
+
+
+def test_mask_bytes_views_a_bool_mask_and_converts_the_rest():
+    """ops.mask_bytes: the masks of encoder_layer.py:86-95 / decoder.py:167-194 as uint8 without a conversion launch."""
+    from openeat_amd import ops
+    m = torch.tensor([[[True, False, True, True]], [[False, False, True, True]]])
+    b = ops.mask_bytes(m)
+    assert b.dtype == torch.uint8 and b.data_ptr() == m.data_ptr() and b.tolist() == m.int().tolist()
+    t = m.transpose(0, 2)                                   # not contiguous: copied, then viewed
+    assert ops.mask_bytes(t).is_contiguous() and ops.mask_bytes(t).tolist() == t.int().tolist()
+    i = m.to(torch.int64)
+    assert ops.mask_bytes(i).dtype == torch.uint8 and ops.mask_bytes(i).tolist() == i.tolist()
+    u = m.to(torch.uint8)
+    assert ops.mask_bytes(u).data_ptr() == u.data_ptr()
