@@ -100,8 +100,10 @@ typedef struct oe_gemm_args {
      * as three bf16 planes p0 + p1 + p2 = x (oe_split_planes, or a producer's planes output), same logical layout and
      * leading dimensions as a / b, plane n at + n * plane_stride ELEMENTS; when both are given and the problem qualifies
      * (16-byte alignment, leading dimensions and K multiples of 8 / the K-tile) the product runs on gemm_pl.hip - tiles
-     * by LDS-DMA, no conversion in the loop.  c_planes: ALSO write the output as planes (row stride ldcp): the next GEMM's
-     * operand without a pass over it. */
+     * by LDS-DMA, no conversion in the loop.  b_planes ALONE (a_planes NULL; a row-major A, no gather, no split of the reduction):
+     * the weight operand of a Linear taken from its pre-split copy, the activation split on the fragment (gemm_hyb.hip) - half the
+     * conversion work of the all-fp32 kernels for nothing but the weights' one split per optimizer step.  c_planes: ALSO write the
+     * output as planes (row stride ldcp): the next GEMM's operand without a pass over it. */
     const void* a_planes; long a_plane_stride;
     const void* b_planes; long b_plane_stride;
     void* c_planes; long c_plane_stride; long ldcp;

@@ -123,7 +123,7 @@ class ParamArena:
     def refresh_planes(self):
         """fp32 arena -> bf16 planes (one launch over all parameters; capturable)."""
         from . import hip, planes as _planes
-        if not _planes.active():          # only the general Linear plumbing reads weight planes (the conv path splits its re-laid copies)
+        if not _planes.weights_presplit():          # (the conv path splits its re-laid copies itself)
             return
         if self.planes is None:
             self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)

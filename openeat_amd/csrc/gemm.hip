@@ -251,6 +251,10 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
         OE_REQUIRE(g->conv_korder == 0, "oe_gemm_f32: conv_korder 1, but the pre-split kernel does not take this problem (M=%d N=%d K=%d) - "
                                         "B is laid out for it alone", M, N, K);
     }
+    if (g->precision == 6 && g->b_planes && !g->a_planes && g->a && !ga && !gb && !g->a_kmajor) {     // the weight operand pre-split, the activation fp32
+        const int r = oe_gemm_hyb_try(A, B, g->b_planes, g->b_plane_stride, g->c, g->ldc, M, N, K, sk, ep, g->b_kmajor, st);
+        if (r != 1) return r;
+    }
     OE_REQUIRE(g->a && g->b, "oe_gemm_f32: an operand exists as bf16 planes only, but the pre-split kernel does not take this problem "
                              "(M=%d N=%d K=%d, a_kmajor=%d b_kmajor=%d gather=%d)", M, N, K, g->a_kmajor, g->b_kmajor, g->conv_gather);
     if (g->precision) return oe_gemm_bf16_dispatch(A, B, g->c, g->ldc, M, N, K, sk, ep, g->a_kmajor, g->b_kmajor, ga, gb, g->precision, st);

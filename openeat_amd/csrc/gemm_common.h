@@ -141,6 +141,8 @@ int oe_gemm_tn_planes_try(const OperandDesc& A, const OperandDesc& B, float* C, 
 int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep,
                     bool a_kmajor, bool b_kmajor, bool gather_b, int terms, int tile, hipStream_t st);
 // pre-split operands (gemm_pl.hip): returns 1 when the problem does not qualify
+int oe_gemm_hyb_try(const OperandDesc& A, const OperandDesc& B, const void* Bp, long b_pstride, float* C, long ldc, int M, int N, int K, int sk,
+                    const EpiParams& ep, bool b_kmajor, hipStream_t st);
 int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
                    int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder = 0);
 

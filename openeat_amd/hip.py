@@ -282,6 +282,8 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
         if a_planes is not None and b_planes is not None:
             g.a_planes, g.a_plane_stride = a_planes.ptr, a_planes.stride
             g.b_planes, g.b_plane_stride = b_planes.ptr, b_planes.stride
+        elif b_planes is not None and a is not None:             # the weight operand alone (gemm_hyb.hip)
+            g.b_planes, g.b_plane_stride = b_planes.ptr, b_planes.stride
         if c_planes is not None:
             g.c_planes, g.c_plane_stride, g.ldcp = c_planes.ptr, c_planes.stride, c_planes.ld
     if scatter is not None:                      # (T1, F1, T2, F2, S): output rows (b, t, f) -> (b*T1 + S*t)*F1 + S*f

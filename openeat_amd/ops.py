@@ -81,7 +81,8 @@ def _split_k(out_rows: int, out_cols: int, k: int) -> int:
 def _operand_planes(act2d, w2d):
     """Pre-split copies (planes.py) of an activation operand and a weight operand of one GEMM - both or neither."""
     if not _planes.active():
-        return None, None
+        # the weight alone, from the arena's planes (gemm_hyb.hip splits the activation on the fragment)
+        return None, (_planes.arena_weight(w2d) if _planes.weights_presplit() else None)
     ap = _planes.of(act2d, make=_planes.split_activations())
     if ap is None:
         return None, None

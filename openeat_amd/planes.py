@@ -49,6 +49,32 @@ def active() -> bool:
     return POLICY in ("all", "ln") and hip.GEMM_PRECISION == 6
 
 
+# The weights of the parameter arena as planes under EVERY policy (one split pass over the arena per optimizer step): csrc/gemm_hyb.hip
+# takes a Linear's weight operand pre-split and splits only the activation on the fragment - half the ring kernel's vector work.
+WEIGHT_PLANES = os.environ.get("OE_WEIGHT_PLANES", "1") == "1"
+
+
+def weights_presplit() -> bool:
+    """The arena keeps bf16 planes of the weights (ParamArena.refresh_planes after every optimizer step)."""
+    return hip.GEMM_PRECISION == 6 and (POLICY in ("all", "ln") or (WEIGHT_PLANES and POLICY != "0"))
+
+
+def arena_weight(w2d: torch.Tensor) -> Optional[Planes]:
+    """Planes of a weight matrix that lives in the parameter arena (a window of the arena's planes), else None - never a split pass."""
+    if not weights_presplit() or w2d.dim() != 2 or w2d.stride(1) != 1 or w2d.stride(0) % 8 or w2d.shape[1] % 8:
+        return None
+    from . import arena as _arena
+    a = _arena.active()
+    if a is None:
+        return None
+    ptr = w2d.data_ptr()
+    off = (ptr - a.flat.data_ptr()) // 4
+    if not (0 <= off < a.numel) or ptr % 32:
+        return None
+    a.ensure_planes()
+    return Planes(a.planes, a.planes.data_ptr() + 2 * off, a.planes_stride, w2d.stride(0), w2d.shape[0], w2d.shape[1])
+
+
 def split_activations() -> bool:
     """Activations whose producer wrote no planes get a split pass of their own / GEMM epilogues write planes of their
     outputs ("all"); under "ln" only what LayerNorm forward / backward wrote on its way (and the weights) is pre-split."""

@@ -211,3 +211,60 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
         col = F.unfold(xc.double(), 3, stride=2).transpose(1, 2).reshape(Mc, Cc, 9)
         ref_dw = torch.einsum("mo,mck->okc", dyc.double(), col).reshape(Cc, 9 * Cc)
         assert float((dwg.cpu().double() - ref_dw).abs().max()) / math.sqrt(Mc) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(7936, 1024, 256), (7936, 256, 1024), (7930, 768, 256), (3072, 3246, 256), (25472, 512, 512)])
+def test_weight_planes_gemm_vs_float64_and_fp32_kernel(M, N, K):
+    """csrc/gemm_hyb.hip: x W^T and dy W with ONLY the weight operand pre-split (the activation is split on the fragment): error
+    against float64 not above 1.5 x the exact-fp32 kernel's on the same problem, ragged M / N edges included; the launches counted."""
+    import ctypes
+    lib = hip.lib()
+    lib.oe_gemm_hyb_launches.restype = ctypes.c_long
+    torch.manual_seed(5)
+    x, w, dy, b = torch.randn(M, K), torch.randn(N, K), torch.randn(M, N), torch.randn(N)
+    xd, wd, dyd, bd = cu(x), cu(w), cu(dy), cu(b)
+    ref_y = x.double() @ w.double().T + b.double()
+    ref_dx = dy.double() @ w.double()
+    res = {}
+    n0 = lib.oe_gemm_hyb_launches()
+    for prec, use_pl in ((0, False), (6, True)):
+        wp = split(wd) if use_pl else None
+        y = torch.empty(M, N, device=DEV)
+        hip.gemm(xd, wd, y, M, N, K, lda=K, ldb=K, ldc=N, bias=bd, precision=prec, b_planes=wp)
+        dx = torch.empty(M, K, device=DEV)
+        hip.gemm(dyd, wd, dx, M, K, N, lda=N, ldb=K, ldc=K, b_kmajor=True, precision=prec, b_planes=wp)
+        sync()
+        res[prec] = (_err(y, ref_y, K), _err(dx, ref_dx, N))
+    ran = lib.oe_gemm_hyb_launches() - n0
+    print(f"M={M} N={N} K={K}: fp32 {res[0]}  weight planes {res[6]}  ({ran} of 2 on gemm_hyb.hip)")
+    assert ran >= 1, "x W^T with a pre-split weight at these sizes is meant for gemm_hyb.hip"
+    for e0, e6 in zip(res[0], res[6]):
+        assert e6 <= 1.5 * e0 + 2e-7, (res[0], res[6])
+
+
+def test_weight_planes_gemm_epilogues_match_the_plain_kernels():
+    """Every epilogue feature through gemm_hyb.hip equals the same call without planes (same dropout bits) to fp32 rounding."""
+    import ctypes
+    lib = hip.lib()
+    lib.oe_gemm_hyb_launches.restype = ctypes.c_long
+    torch.manual_seed(3)
+    M, N, K = 7936, 1024, 256
+    x, w, b, res = cu(torch.randn(M, K)), cu(torch.randn(N, K) * 0.1), cu(torch.randn(N)), cu(torch.randn(M, N))
+    rowmask = cu((torch.rand(M) > 0.2).to(torch.uint8))
+    outs = {}
+    n0 = lib.oe_gemm_hyb_launches()
+    for use_pl in (False, True):
+        wp = split(w) if use_pl else None
+        pre = torch.empty(M, N, device=DEV)
+        a = torch.empty(M, N, device=DEV)
+        hip.gemm(x, w, a, M, N, K, lda=K, ldb=K, ldc=N, bias=b, act=2, preact_out=pre, ld_aux=N, drop_p=0.1, seed=77, b_planes=wp)
+        y = torch.empty(M, N, device=DEV)
+        hip.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, residual=res, ldr=N, beta=0.5, rowmask=rowmask, drop_p=0.1, seed=78, b_planes=wp)
+        g = torch.empty(M, N, device=DEV)
+        hip.gemm(x, w, g, M, N, K, lda=K, ldb=K, ldc=N, act=2, actgrad_in=pre, ld_aux=N, b_planes=wp)
+        sync()
+        outs[use_pl] = (pre.cpu(), a.cpu(), y.cpu(), g.cpu())
+    assert lib.oe_gemm_hyb_launches() - n0 == 3
+    for t0, t1 in zip(outs[False], outs[True]):
+        torch.testing.assert_close(t1, t0, rtol=1e-5, atol=1e-5)
+        assert torch.equal(t0 == 0, t1 == 0)
