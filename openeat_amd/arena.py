@@ -120,15 +120,31 @@ class ParamArena:
         _ACTIVE = self
         return self
 
-    def refresh_planes(self):
-        """fp32 arena -> bf16 planes (one launch over all parameters; capturable)."""
+    def refresh_planes(self, after_optimizer: bool = False):
+        """fp32 arena -> bf16 planes (one launch over all parameters; capturable).
+        after_optimizer: the engine's call behind every optimizer step - only under the policies whose Linears all read weight
+        planes ("all" / "ln"); the weight-operand-only kernel (gemm_hyb.hip) refreshes on a step's first use instead (step_planes)."""
         from . import hip, planes as _planes
-        if not _planes.weights_presplit():          # (the conv path splits its re-laid copies itself)
+        if not _planes.weights_presplit() or (after_optimizer and not _planes.active()):
             return
         if self.planes is None:
             self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)
         hip.call("oe_split_planes", self.flat, self.numel, 1, self.numel, self.planes, self.numel, self.planes_stride)
         self._planes_version = self.flat._version
+        self._planes_fresh = True
+
+    _planes_fresh = False
+
+    def mark_step(self):
+        """A new forward pass starts (ops.predrop_clear): planes made during the previous one may be stale - raw kernels (Adam) do
+        not bump the arena's version, and a captured graph replays no Python - so the first reader of this pass splits again, and
+        that launch is part of whatever graph the pass is captured into."""
+        self._planes_fresh = False
+
+    def step_planes(self):
+        """Planes valid for the current pass: split on the pass's first use (49 us for 31 M parameters), reused until mark_step()."""
+        if not self._planes_fresh or self.planes is None or self._planes_version != self.flat._version:
+            self.refresh_planes()
 
     def ensure_planes(self):
         """Refresh if torch wrote the arena since the last refresh (load_state_dict, broadcast, init); raw kernels (Adam)

@@ -82,10 +82,11 @@ __device__ __forceinline__ void hy_b_col_frag(const unsigned char* tile, int pla
     }
 }
 
-// Block = 2 x 2 waves, each TM x TN accumulator tiles of 32 x 32: block tile (64 TM) x (64 TN).  BKM: B is k-major (64 TN must
-// then be a multiple of 128).
-template <int TM, int TN, bool BKM, int NST>
-__global__ __launch_bounds__(256, (NST * (64 * TM * HBK * 4 + 3 * 64 * TN * HBK * 2) <= 80 * 1024) ? 2 : 1)
+// Block = WM x 2 waves, each TM x TN accumulator tiles of 32 x 32: block tile (32 TM WM) x (64 TN).  BKM: B is k-major (64 TN must
+// then be a multiple of 128).  WM = 4, TM = 1, TN = 4 (128 x 256, eight waves of 32 x 128): an activation element is split by two
+// waves for 2 x 4 x 6 MFMAs each - a third of the 2 x 2 arrangement's split work per MFMA.
+template <int TM, int TN, bool BKM, int NST, int WM = 2>
+__global__ __launch_bounds__(WM * 128, (NST * (32 * TM * WM * HBK * 4 + 3 * 64 * TN * HBK * 2) <= 80 * 1024) ? 2 : 1)
 void gemm_hyb_kernel(const float* __restrict__ Ap, long lda, const __bf16* __restrict__ Bp, long ldb, long b_pstride, float* __restrict__ C, long ldc,
                      int M, int N, int K, int gx, int gy, EpiParams ep) {
     int tile_x, tile_y;
@@ -96,14 +97,15 @@ void gemm_hyb_kernel(const float* __restrict__ Ap, long lda, const __bf16* __res
         tile_x = swz % gx;
         tile_y = swz / gx;
     }
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int NW = WM * 2;
+    constexpr int BM = 32 * TM * WM, BN = 64 * TN;
     static_assert(!BKM || BN % 128 == 0, "k-major tiles are made of 128-column sub-tiles");
     constexpr int A_BYTES = BM * HBK * 4, B_T = BN * HBK * 2;         // fp32 A tile; one B plane tile
     constexpr int STAGE = A_BYTES + 3 * B_T;
     constexpr int PA = A_BYTES / 1024, PB = 3 * B_T / 1024;           // 1 KiB pieces per stage
-    constexpr int PPW = (PA + PB) / 4;                                // per wave
-    static_assert((PA + PB) % 4 == 0, "piece count must split over the four waves");
-    constexpr int EPI_BYTES = 4 * 32 * 36 * 4;
+    constexpr int PPW = (PA + PB) / NW;                               // per wave
+    static_assert((PA + PB) % NW == 0, "piece count must split over the waves");
+    constexpr int EPI_BYTES = NW * 32 * 36 * 4;
     constexpr int LDS_BYTES = (NST * STAGE > EPI_BYTES) ? NST * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[LDS_BYTES];
 
@@ -203,18 +205,18 @@ void gemm_hyb_kernel(const float* __restrict__ Ap, long lda, const __bf16* __res
     }
     // the surplus pieces (issued past the end of the range) must have landed before the epilogue reuses the LDS
     hy_wait_and_barrier<0>();
-    gemm_epilogue<TM, TN>(acc, reinterpret_cast<float*>(lds), C, ldc, M, N, m0, n0, ep, 0);
+    gemm_epilogue<TM, TN, WM>(acc, reinterpret_cast<float*>(lds), C, ldc, M, N, m0, n0, ep, 0);
 }
 
 static long hyb_launches = 0;
 extern "C" long oe_gemm_hyb_launches(void) { return hyb_launches; }
 
-template <int TM, int TN, bool BKM, int NST>
+template <int TM, int TN, bool BKM, int NST, int WM = 2>
 static int launch_hyb(const OperandDesc& A, const void* Bp, long ldb, long b_pstride, float* C, long ldc, int M, int N, int K, const EpiParams& ep,
                       hipStream_t st) {
-    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 64 * TM);
-    hipLaunchKernelGGL((gemm_hyb_kernel<TM, TN, BKM, NST>), dim3(gx * gy), dim3(256), 0, st, A.p, A.ld, (const __bf16*)Bp, ldb, b_pstride, C, ldc, M, N, K,
-                       gx, gy, ep);
+    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 32 * TM * WM);
+    hipLaunchKernelGGL((gemm_hyb_kernel<TM, TN, BKM, NST, WM>), dim3(gx * gy), dim3(WM * 128), 0, st, A.p, A.ld, (const __bf16*)Bp, ldb, b_pstride, C, ldc,
+                       M, N, K, gx, gy, ep);
     OE_LAUNCH_CHECK("oe_gemm (bf16x6, weight planes)");
     ++hyb_launches;
     return 0;
@@ -239,7 +241,15 @@ int oe_gemm_hyb_try(const OperandDesc& A, const OperandDesc& B, const void* Bp, 
     else if (!b_kmajor && K >= 512 && b21 >= 200) tile = 21;
     // (k-major B tiles are 128 columns wide: the long reductions into 256-wide outputs - 124 such tiles at config 2 - stay on the
     // ring kernel's 128 x 64 tiles)
+    // 128 x 256 (eight waves) wherever the grid of such tiles is about one round of the chip or more - whole 256-wide rows at the
+    // 16 s batches too (25472 x 256 x 1024: 83.5 us against 94.7 on 128 x 128 tiles and 111 on the ring; x W of the same: 79 / 91 / 114)
+    const long b24 = (N % 256 == 0) ? (long)oe_cdiv(M, 128) * (N / 256) : 0;
+    if (b24 >= 160 && (tile == 22 || tile == 21 || (b_kmajor && K >= 512))) tile = 24;
     if (forced) tile = forced;
+    if (tile == 24 && N >= 256) {
+        if (b_kmajor) return launch_hyb<1, 4, true, 2, 4>(A, Bp, B.ld, b_pstride, C, ldc, M, N, K, ep, st);
+        return launch_hyb<1, 4, false, 2, 4>(A, Bp, B.ld, b_pstride, C, ldc, M, N, K, ep, st);
+    }
     if (tile == 22) {
         if (b_kmajor) return launch_hyb<2, 2, true, 2>(A, Bp, B.ld, b_pstride, C, ldc, M, N, K, ep, st);
         return launch_hyb<2, 2, false, 2>(A, Bp, B.ld, b_pstride, C, ldc, M, N, K, ep, st);

@@ -103,7 +103,8 @@ class TrainEngine:
         # inside a capture the learning rate is whatever replay() puts into lr_dev; everywhere else (eager steps, also
         # those taken beside a captured graph) it is the optimizer's current param_groups value
         self.optimizer.step(lr_from_device=self._capturing or self._replaying)
-        self.arena.refresh_planes()            # precision 6: the new weights as bf16 planes, once per step (planes.py)
+        self.arena.refresh_planes(after_optimizer=True)            # precision 6, policies "all" / "ln": the new weights as bf16 planes
+        self.arena.mark_step()                 # (the weight-operand-only kernel's planes are stale now: its next reader splits again)
         self.seed_counter.add_(1)
         ops.stamp("optimizer done")
 
@@ -257,7 +258,8 @@ class TrainEngine:
             go = torch.cuda.CUDAGraph()
             with torch.cuda.graph(go, pool=pool, capture_error_mode=mode):
                 self.optimizer.step(lr_from_device=True)
-                self.arena.refresh_planes()
+                self.arena.refresh_planes(after_optimizer=True)
+            self.arena.mark_step()
             self._opt_graph = go
         return g, unjoined
 
@@ -388,6 +390,7 @@ class TrainEngine:
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
         assert self._graph is not None
+        self.arena.mark_step()                 # the replayed optimizer moves the weights: eager readers of their planes split again
         if batch is not None:
             for k, v in batch.items():
                 self._static[k].copy_(v)

@@ -95,6 +95,8 @@ class ASRModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ train --
     def _encode(self, features, features_length):
+        from openeat_amd import planes as _planes
+        _planes.new_pass()                      # (decode entry points come through here without forward()'s predrop_clear)
         masks = ~make_pad_mask(features_length, features.size(1)).unsqueeze(1)      # (B,1,T)
         return self.encoder(features, masks)
 

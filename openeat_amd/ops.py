@@ -82,7 +82,7 @@ def _operand_planes(act2d, w2d):
     """Pre-split copies (planes.py) of an activation operand and a weight operand of one GEMM - both or neither."""
     if not _planes.active():
         # the weight alone, from the arena's planes (gemm_hyb.hip splits the activation on the fragment)
-        return None, (_planes.arena_weight(w2d) if _planes.weights_presplit() else None)
+        return None, (_planes.arena_weight(w2d) if (_planes.weights_presplit() and act2d.shape[0] >= _planes.HYB_MIN_ROWS) else None)
     ap = _planes.of(act2d, make=_planes.split_activations())
     if ap is None:
         return None, None

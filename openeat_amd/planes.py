@@ -52,6 +52,9 @@ def active() -> bool:
 # The weights of the parameter arena as planes under EVERY policy (one split pass over the arena per optimizer step): csrc/gemm_hyb.hip
 # takes a Linear's weight operand pre-split and splits only the activation on the fragment - half the ring kernel's vector work.
 WEIGHT_PLANES = os.environ.get("OE_WEIGHT_PLANES", "1") == "1"
+# ... from this many activation rows on (measured, same-box A/B of the whole step: 25472 rows 51.3 -> 49.8 ms/step, 7936 rows
+# 18.51 -> 18.67: there the launches are bound by what they write and by cold operands, and the arena's split pass costs 50 us)
+HYB_MIN_ROWS = int(os.environ.get("OE_HYB_MIN_ROWS", "12288"))
 
 
 def weights_presplit() -> bool:
@@ -71,7 +74,10 @@ def arena_weight(w2d: torch.Tensor) -> Optional[Planes]:
     off = (ptr - a.flat.data_ptr()) // 4
     if not (0 <= off < a.numel) or ptr % 32:
         return None
-    a.ensure_planes()
+    if active():
+        a.ensure_planes()                # "all" / "ln": refreshed behind every optimizer step
+    else:
+        a.step_planes()                  # split on this pass's first use
     return Planes(a.planes, a.planes.data_ptr() + 2 * off, a.planes_stride, w2d.stride(0), w2d.shape[0], w2d.shape[1])
 
 
@@ -106,6 +112,16 @@ _NO_GRAD_KEEP = 64     # inference: a tensor's planes are consumed right after t
 
 def clear():
     _REG.clear()
+    new_pass()
+
+
+def new_pass():
+    """A forward pass starts (training step, decode, LM scoring): the arena's weight planes are split again by their first reader
+    (whatever wrote the weights since - Adam's raw kernel, load_state_dict, a broadcast - is picked up)."""
+    from . import arena as _arena
+    a = _arena.active()
+    if a is not None:
+        a.mark_step()
 
 
 def _dense2d(t: torch.Tensor) -> bool:

@@ -632,3 +632,44 @@ def test_eager_step_beside_a_captured_graph_uses_the_current_learning_rate():
     finally:
         e.arena.deactivate()
         ops.set_seed_device_counter(None)
+
+
+def test_arena_weight_planes_are_never_stale():
+    """planes.arena_weight (the weight operand of csrc/gemm_hyb.hip): the arena's bf16 planes are split again by the first reader of
+    every forward pass and after every optimizer step - eager, captured and replayed - because Adam moves the weights through a raw
+    kernel no tensor version counter sees.  p0 + p1 + p2 must equal the CURRENT weight exactly at every point a GEMM could read it."""
+    from openeat_amd import hip, planes
+    old = (hip.GEMM_PRECISION, planes.HYB_MIN_ROWS)
+    hip.GEMM_PRECISION, planes.HYB_MIN_ROWS = 6, 0
+    m = tiny(seed=21).to(DEV).train()
+    e = TrainEngine(m, lr=1e-2, grad_clip=5.0, static_shapes=True)
+    b = batch_of(seed=8)
+    w = m.encoder.encoders[0].feed_forward.w_1.weight
+
+    def planes_equal_weight():
+        pl = planes.arena_weight(w)
+        assert pl is not None and pl.rows == w.shape[0] and pl.cols == w.shape[1]
+        off = (pl.ptr - e.arena.planes.data_ptr()) // 2
+        p = torch.stack([e.arena.planes[n, off:off + w.numel()].view_as(w).float() for n in range(3)])
+        torch.cuda.synchronize()
+        return torch.equal(p[0] + p[1] + p[2], w.detach())
+    try:
+        assert planes.weights_presplit()
+        e.step(b)
+        w0 = w.detach().clone()
+        assert planes_equal_weight()                      # right after an eager optimizer step (first reader splits)
+        e.step(b)
+        assert not torch.equal(w.detach(), w0) and planes_equal_weight()
+        e.capture(b, warmup=1)
+        for _ in range(3):
+            e.replay()
+        assert planes_equal_weight()                      # after replays (their Adam ran without any Python)
+        with torch.no_grad():
+            w.mul_(1.5)                                   # a torch write (a loaded checkpoint, an average): seen by the next pass
+        planes.new_pass()                                 # ... which every forward / decode entry point announces
+        assert planes_equal_weight()
+    finally:
+        hip.GEMM_PRECISION, planes.HYB_MIN_ROWS = old
+        e.arena.deactivate()
+        ops.set_seed_device_counter(None)
+        planes.clear()
