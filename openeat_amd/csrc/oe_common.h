@@ -183,7 +183,9 @@ enum { OE_ACT_NONE = 0, OE_ACT_RELU = 1, OE_ACT_SWISH = 2, OE_ACT_TANH = 3, OE_A
 #define OE_SELU_ALPHA 1.6732632423543772848170429916717f
 #define OE_SELU_SCALE 1.0507009873554804934193349852946f
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// 1 / (1 + e^-x) on the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division (~10 instructions: scale, Newton steps,
+// fix-up): the sigmoid runs on every element of the feed-forward / GLU / swish epilogues with the matrix pipe idle (tools/epi_cost.py)
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float act_fwd(int act, float x) {
     if (act == OE_ACT_RELU) return fmaxf(x, 0.f);
     if (act == OE_ACT_SWISH) return x * sigmoidf_(x);
