@@ -129,6 +129,8 @@ int oe_split_planes(const float* x, long ld, long rows, long cols, void* planes,
 /* how many oe_gemm_f32 calls of this process ran on the pre-split kernel (gemm_pl.hip) so far: tests and tools check that a
  * problem they meant for it did not silently take the splitting kernels */
 long oe_gemm_pl_launches(void);
+/* launches of the weight-operand-only kernel (gemm_hyb.hip: b_planes alone) so far - tests assert a problem meant for it took it */
+long oe_gemm_hyb_launches(void);
 /* dispatch knobs of the pre-split kernel, for tests and tuning tools (-1 keeps a value): the smallest grid it accepts
  * (default 96 blocks: below that the splitting kernels' smaller tiles / split-K fill the chip better), a forced tile (22 =
  * 128 x 128, 11 = 64 x 64, 0 = automatic), a forced K-tile (16 / 32, 0 = automatic), waves per 128 x 128 block (8 / 4) */

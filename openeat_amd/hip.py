@@ -129,6 +129,7 @@ _SIGNATURES = {
     "oe_gemm_f32": (I, [C.POINTER(GemmArgs), P]),
     "oe_split_planes": (I, [P, L, L, L, P, L, L, P]),
     "oe_gemm_pl_launches": (L, []),
+    "oe_gemm_hyb_launches": (L, []),
     "oe_gemm_pl_config": (I, [I, I, I, I]),
     "oe_gemm_tn_grouped_plan": (I, [C.POINTER(TnProblem), I, I]),
     "oe_gemm_tn_grouped": (I, [P, I, I, I, P]),

@@ -217,9 +217,7 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
 def test_weight_planes_gemm_vs_float64_and_fp32_kernel(M, N, K):
     """csrc/gemm_hyb.hip: x W^T and dy W with ONLY the weight operand pre-split (the activation is split on the fragment): error
     against float64 not above 1.5 x the exact-fp32 kernel's on the same problem, ragged M / N edges included; the launches counted."""
-    import ctypes
     lib = hip.lib()
-    lib.oe_gemm_hyb_launches.restype = ctypes.c_long
     torch.manual_seed(5)
     x, w, dy, b = torch.randn(M, K), torch.randn(N, K), torch.randn(M, N), torch.randn(N)
     xd, wd, dyd, bd = cu(x), cu(w), cu(dy), cu(b)
@@ -244,9 +242,7 @@ def test_weight_planes_gemm_vs_float64_and_fp32_kernel(M, N, K):
 
 def test_weight_planes_gemm_epilogues_match_the_plain_kernels():
     """Every epilogue feature through gemm_hyb.hip equals the same call without planes (same dropout bits) to fp32 rounding."""
-    import ctypes
     lib = hip.lib()
-    lib.oe_gemm_hyb_launches.restype = ctypes.c_long
     torch.manual_seed(3)
     M, N, K = 7936, 1024, 256
     x, w, b, res = cu(torch.randn(M, K)), cu(torch.randn(N, K) * 0.1), cu(torch.randn(N)), cu(torch.randn(M, N))
