@@ -4,7 +4,7 @@
 set -o pipefail
 OUT=gpurun_out/gemm_pmc; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-CMD="python3 bench.py --no-cpu-baseline --no-decode --no-other-modes --no-graph --single-stream --steps 2 --warmup 1"
+CMD="python3 bench.py --no-cpu-baseline --no-decode --no-other-modes --no-graph --single-stream --steps 2 --warmup 1 ${BENCH_ARGS:-}"     # BENCH_ARGS: e.g. the north-star shape
 rm -rf $OUT/sq $OUT/sq2 $OUT/tcc
 timeout -k 10 500 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq -o sq --output-format csv -- $CMD > $OUT/sq.log 2>&1 || { tail -5 $OUT/sq.log; exit 1; }
 timeout -k 10 500 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace -d $OUT/sq2 -o sq2 --output-format csv -- $CMD > $OUT/sq2.log 2>&1 || { tail -5 $OUT/sq2.log; echo "(second SQ pass failed: counter names?)"; }
@@ -24,7 +24,8 @@ for d in ("sq", "sq2", "tcc"):
             seen[k].add(r["Dispatch_Id"])
         for k, v in seen.items():
             disp[(k, d)] = v
-print("# Where the wave cycles of the step's GEMM / attention / LayerNorm kernels go (precision 6, config 2, eager single-stream step)\n")
+import os
+print("# Where the wave cycles of the step's GEMM / attention / LayerNorm kernels go (precision 6, " + (os.environ.get("BENCH_ARGS") or "config 2") + ", eager single-stream step)\n")
 print("Per-kernel sums over the dispatches of 4 optimizer steps, as fractions: wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES (parked on s_waitcnt / barrier), "
       "stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES (issue stalls, of which LDS = SQ_WAIT_INST_LDS), issue = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES, "
       "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), co-exec = SQ_VALU_MFMA_COEXEC_CYCLES / SQ_VALU_MFMA_BUSY_CYCLES, "
