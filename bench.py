@@ -334,6 +334,7 @@ def main():
             times = {"five": t_graph}
             current = "five"
             for name in ("two", "one"):
+                current = None                                # (capture_form drops whatever graph the engine held)
                 try:
                     capture_form(name)
                     current = name
@@ -349,11 +350,14 @@ def main():
                 except Exception as e:
                     log(f"re-capture of the '{best}' form failed ({type(e).__name__}: {e}); staying eager")
                     times[best] = float("inf")
+                    engine.drop_graph()
             t_graph, graph_form = times[best], forms[best][3]
         use_graph = (args.force_graph and t_graph != float("inf")) or t_graph <= t_eager
         log(f"warm-up calibration: eager {t_eager:.2f} ms/step, graph replay {t_graph:.2f} ms/step -> timing {'graph' if use_graph else 'eager'}")
         if not use_graph:
             engine.drop_graph()
+            if engine.reducer.active:
+                engine.set_overlap_cuts()             # the eager step's hooks at their default places again
     run = (lambda: engine.replay()) if use_graph else eager
     if not use_graph:
         for _ in range(args.warmup):
