@@ -56,7 +56,7 @@ def _pair_inputs(rows, d, seed):
     return x, ps, du, dy
 
 
-@pytest.mark.parametrize("rows,d", [(100, 256), (7936, 256), (37, 512), (19, 1024), (5, 144)])
+@pytest.mark.parametrize("rows,d", [(100, 256), (7936, 256), (37, 512), (19, 1024), (5, 144), (9, 2048)])
 def test_layer_norm_pair_equals_the_two_norms(rows, d):
     x, ps, du, dy = _pair_inputs(rows, d, rows + d)
     leaves = lambda: [t.detach().clone().requires_grad_(True) for t in [x] + ps]
