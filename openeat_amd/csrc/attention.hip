@@ -57,14 +57,7 @@ template <int TERMS> struct BFrag { bf16x8 p[oe_npl<TERMS>::N]; };
 
 template <int TERMS>
 __device__ __forceinline__ void bsplit(const float (&x)[8], BFrag<TERMS>& f) {
-    constexpr int NPL = oe_npl<TERMS>::N;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 q[NPL];
-        oe_split_bf16<NPL>(x[e], q);
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) f.p[n][e] = q[n];
-    }
+    oe_split8<oe_npl<TERMS>::N>(x, f.p);
 }
 template <int TERMS>
 __device__ __forceinline__ f32x16 bmma(const BFrag<TERMS>& a, const BFrag<TERMS>& b, f32x16 c) {

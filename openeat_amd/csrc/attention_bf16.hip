@@ -65,14 +65,7 @@ __device__ __forceinline__ f32x16 pmma(const PFrag<TERMS>& a, const PFrag<TERMS>
 }
 template <int TERMS>
 __device__ __forceinline__ void psplit(const float (&x)[8], PFrag<TERMS>& f) {
-    constexpr int NPL = oe_npl<TERMS>::N;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 q[NPL];
-        oe_split_bf16<NPL>(x[e], q);
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) f.p[n][e] = q[n];
-    }
+    oe_split8<oe_npl<TERMS>::N>(x, f.p);
 }
 
 // One streamed tensor's image in LDS: `planes` consecutive [PL_ROWS][PITCH] bf16 arrays (hi, then lo).
@@ -151,13 +144,7 @@ __device__ __forceinline__ void chunk_store(const ChunkRegs<DPAD>& t, __bf16* im
         const bool live = (r0 + row < nrows_total) && (c4 < D);          // zero what chunk_load's fast path over-read
         const float x[4] = {live ? t.v[i].x * mul : 0.f, live ? t.v[i].y * mul : 0.f, live ? t.v[i].z * mul : 0.f, live ? t.v[i].w * mul : 0.f};
         bf16x4 pl[P::NPL];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            __bf16 q[P::NPL];
-            oe_split_bf16<P::NPL>(x[k], q);
-#pragma unroll
-            for (int n = 0; n < P::NPL; ++n) pl[n][k] = q[n];
-        }
+        oe_split4<P::NPL>(x, pl);
         __bf16* d = img + row * P::PITCH + c4;
 #pragma unroll
         for (int n = 0; n < P::NPL; ++n) *reinterpret_cast<bf16x4*>(d + n * P::PLANE_ELEMS) = pl[n];
@@ -190,13 +177,7 @@ struct ResImage {
             const bool live = (r0 + row < nrows_total) && (c4 < D);
             const float x[4] = {live ? t.v[i].x * mul : 0.f, live ? t.v[i].y * mul : 0.f, live ? t.v[i].z * mul : 0.f, live ? t.v[i].w * mul : 0.f};
             bf16x4 pl[NPL];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                __bf16 q[NPL];
-                oe_split_bf16<NPL>(x[k], q);
-#pragma unroll
-                for (int n = 0; n < NPL; ++n) pl[n][k] = q[n];
-            }
+            oe_split4<NPL>(x, pl);
             __bf16* d = img + row * PITCH + 8 * chunk_pos(row, c4 >> 3) + (c4 & 4);
 #pragma unroll
             for (int n = 0; n < NPL; ++n) *reinterpret_cast<bf16x4*>(d + n * PLANE_ELEMS) = pl[n];

@@ -292,12 +292,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     const float4 a = *reinterpret_cast<const float4*>(x + r * ld + c), b = *reinterpret_cast<const float4*>(x + r * ld + c + 4);
     const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     oe_bf16x8 o[3];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 q[3];
-        oe_split_bf16<3>(v[e], q);
-        o[0][e] = q[0]; o[1][e] = q[1]; o[2][e] = q[2];
-    }
+    oe_split8<3>(v, o);
 #pragma unroll
     for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x8*>(pl + n * pstride + r * ldp + c) = o[n];
 }

@@ -46,15 +46,7 @@ __device__ __forceinline__ void wait_dma_and_barrier() {
 
 template <int NPL> struct DFrag { bf16x8 p[NPL]; };
 template <int NPL>
-__device__ __forceinline__ void split8(const float (&x)[8], DFrag<NPL>& f) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 q[NPL];
-        oe_split_bf16<NPL>(x[e], q);
-#pragma unroll
-        for (int n = 0; n < NPL; ++n) f.p[n][e] = q[n];
-    }
-}
+__device__ __forceinline__ void split8(const float (&x)[8], DFrag<NPL>& f) { oe_split8<NPL>(x, f.p); }
 
 // fragment (32 rows x 16 k) of one operand tile: lane -> row (lane & 31), k half (lane >> 5)
 template <bool KMAJOR, int ROWS>

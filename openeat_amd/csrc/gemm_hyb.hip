@@ -38,14 +38,7 @@ __device__ __forceinline__ void hy_wait_and_barrier() {
 
 struct HFrag { bf16x8 p[3]; };
 
-__device__ __forceinline__ void hy_split8(const float (&x)[8], HFrag& f) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 q[3];
-        oe_split_bf16<3>(x[e], q);
-        f.p[0][e] = q[0]; f.p[1][e] = q[1]; f.p[2][e] = q[2];
-    }
-}
+__device__ __forceinline__ void hy_split8(const float (&x)[8], HFrag& f) { oe_split8<3>(x, f.p); }
 // A fragment (32 rows x 16 k) of the fp32 tile [rows][32] with 16-byte chunk c of row r at slot c ^ ((r >> 1) & 7) (gemm_dma.hip)
 __device__ __forceinline__ void hy_a_frag(const float* tile, int row, int half, int ks, HFrag& f) {
     const int slot = (4 * ks + 2 * half) ^ ((row >> 1) & 7);

@@ -142,6 +142,54 @@ __device__ __forceinline__ void oe_split_bf16(float x, __bf16 (&p)[NPL]) {
         if constexpr (NPL > 2) p[2] = (__bf16)(r1 - (float)p[1]);   // exact, and representable: at most 8 significant bits are left
     }
 }
+// Eight values -> their NPL pieces as MFMA fragments (bf16x8 each), two values at a time on the packed conversions
+// (v_cvt_pk_bf16_f32, v_pk_add_f32): the same round-to-nearest pieces as oe_split_bf16, bit for bit, without the per-element
+// inserts the scalar form leaves the compiler to assemble into registers (ring kernel: 11.7 vector instructions per MFMA).
+typedef float oe_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 oe_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 oe_bf16x8 __attribute__((ext_vector_type(8)));
+template <int NPL>
+__device__ __forceinline__ void oe_split8(const float (&x)[8], oe_bf16x8 (&p)[NPL]) {
+    oe_bf16x2 a[4], b[4], c[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        oe_f32x2 v;
+        v[0] = x[2 * i]; v[1] = x[2 * i + 1];
+        a[i] = __builtin_convertvector(v, oe_bf16x2);
+        if constexpr (NPL > 1) {
+            const oe_f32x2 r1 = v - __builtin_convertvector(a[i], oe_f32x2);           // exact
+            b[i] = __builtin_convertvector(r1, oe_bf16x2);
+            if constexpr (NPL > 2) c[i] = __builtin_convertvector(r1 - __builtin_convertvector(b[i], oe_f32x2), oe_bf16x2);
+        }
+    }
+    auto join = [](const oe_bf16x2 (&q)[4]) {
+        const auto lo = __builtin_shufflevector(q[0], q[1], 0, 1, 2, 3), hi = __builtin_shufflevector(q[2], q[3], 0, 1, 2, 3);
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    };
+    p[0] = join(a);
+    if constexpr (NPL > 1) p[1] = join(b);
+    if constexpr (NPL > 2) p[2] = join(c);
+}
+// ... and four values -> bf16x4 per piece (staging stores of the kernels that keep bf16 planes in LDS / HBM)
+typedef __bf16 oe_bf16x4v __attribute__((ext_vector_type(4)));
+template <int NPL>
+__device__ __forceinline__ void oe_split4(const float (&x)[4], oe_bf16x4v (&p)[NPL]) {
+    oe_bf16x2 a[2], b[2], c[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        oe_f32x2 v;
+        v[0] = x[2 * i]; v[1] = x[2 * i + 1];
+        a[i] = __builtin_convertvector(v, oe_bf16x2);
+        if constexpr (NPL > 1) {
+            const oe_f32x2 r1 = v - __builtin_convertvector(a[i], oe_f32x2);
+            b[i] = __builtin_convertvector(r1, oe_bf16x2);
+            if constexpr (NPL > 2) c[i] = __builtin_convertvector(r1 - __builtin_convertvector(b[i], oe_f32x2), oe_bf16x2);
+        }
+    }
+    p[0] = __builtin_shufflevector(a[0], a[1], 0, 1, 2, 3);
+    if constexpr (NPL > 1) p[1] = __builtin_shufflevector(b[0], b[1], 0, 1, 2, 3);
+    if constexpr (NPL > 2) p[2] = __builtin_shufflevector(c[0], c[1], 0, 1, 2, 3);
+}
 // the TERMS products of one fragment pair, smallest first; F holds NPL fragments f.p[0..NPL)
 template <int TERMS, class F, class ACC>
 __device__ __forceinline__ ACC oe_mma_terms(const F& a, const F& b, ACC c) {
@@ -162,12 +210,7 @@ typedef __bf16 oe_bf16x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_planes4(__bf16* dst, long pstride, const float4& v) {
     const float x[4] = {v.x, v.y, v.z, v.w};
     oe_bf16x4 pl[3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        __bf16 q[3];
-        oe_split_bf16<3>(x[e], q);
-        pl[0][e] = q[0]; pl[1][e] = q[1]; pl[2][e] = q[2];
-    }
+    oe_split4<3>(x, pl);
 #pragma unroll
     for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4*>(dst + n * pstride) = pl[n];
 }
