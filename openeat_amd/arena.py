@@ -101,8 +101,8 @@ class ParamArena:
             self.unit_start.setdefault(u, o)
         self.by_ptr: Dict[int, torch.Tensor] = {}
         self.enabled = True
-        # the weights as three bf16 planes (precision 6 GEMM operands, planes.py): allocated on first use, refreshed by
-        # refresh_planes() after every optimizer step (TrainEngine) and whenever the fp32 arena was written through torch
+        # the weights as three bf16 planes (precision 6 GEMM operands, planes.py): allocated on first use, split again by the
+        # first reader of every pass (step_planes) - after an optimizer step, a graph replay, a torch write
         self.planes: Optional[torch.Tensor] = None
         self.planes_stride = total
         self._planes_version = -1
@@ -120,37 +120,42 @@ class ParamArena:
         _ACTIVE = self
         return self
 
-    def refresh_planes(self, after_optimizer: bool = False):
-        """fp32 arena -> bf16 planes (one launch over all parameters; capturable).
-        after_optimizer: the engine's call behind every optimizer step - only under the policies whose Linears all read weight
-        planes ("all" / "ln"); the weight-operand-only kernel (gemm_hyb.hip) refreshes on a step's first use instead (step_planes)."""
+    def refresh_planes(self):
+        """fp32 arena -> bf16 planes (one launch over all parameters, 49 us for 31 M; capturable)."""
         from . import hip, planes as _planes
-        if not _planes.weights_presplit() or (after_optimizer and not _planes.active()):
+        if not _planes.weights_presplit():
             return
-        if self.planes is None:
-            self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)
+        self.alloc_planes()
         hip.call("oe_split_planes", self.flat, self.numel, 1, self.numel, self.planes, self.numel, self.planes_stride)
         self._planes_version = self.flat._version
         self._planes_fresh = True
 
     _planes_fresh = False
 
+    def alloc_planes(self):
+        """The planes buffer outlives every graph that reads it: never allocate it from a capture's private pool
+        (planes.capture_scope allocates it ahead of the capture)."""
+        if self.planes is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ParamArena: the weights' bf16 planes must be allocated before a graph capture "
+                                   "(wrap the capture in openeat_amd.planes.capture_scope())")
+            self.planes = torch.empty(3, self.numel, dtype=torch.bfloat16, device=self.flat.device)
+
     def mark_step(self):
-        """A new forward pass starts (ops.predrop_clear): planes made during the previous one may be stale - raw kernels (Adam) do
-        not bump the arena's version, and a captured graph replays no Python - so the first reader of this pass splits again, and
-        that launch is part of whatever graph the pass is captured into."""
+        """The weights may have moved without torch noticing - a raw kernel wrote them (FusedAdam.step calls this), a graph
+        replay ran its Adam without any Python (TrainEngine.replay), or a new forward pass starts and nobody can vouch for what
+        happened since the last one (planes.new_pass: ASRModel.forward, the decode entry points, LanguageModel.forward) - so the
+        next reader splits again, under EVERY policy, and that launch is part of whatever graph the pass is captured into.
+        planes.capture_scope() calls this on exit: a split that was only RECORDED has refreshed nothing."""
         self._planes_fresh = False
 
     def step_planes(self):
-        """Planes valid for the current pass: split on the pass's first use (49 us for 31 M parameters), reused until mark_step()."""
+        """Planes valid for the current pass: split on the pass's first use, reused until mark_step() or a torch write."""
         if not self._planes_fresh or self.planes is None or self._planes_version != self.flat._version:
             self.refresh_planes()
 
-    def ensure_planes(self):
-        """Refresh if torch wrote the arena since the last refresh (load_state_dict, broadcast, init); raw kernels (Adam)
-        do not bump the version - their caller refreshes."""
-        if self.planes is None or self._planes_version != self.flat._version:
-            self.refresh_planes()
+    ensure_planes = step_planes      # (round 3 had a second form that trusted the tensor version alone: stale after any
+    #                                   optimizer step taken outside TrainEngine, ADVICE r03)
 
     def deactivate(self):
         global _ACTIVE

@@ -9,6 +9,7 @@ from typing import Dict, Optional
 import torch
 
 from openeat_amd import ops
+from openeat_amd import planes as _planes
 from openeat_amd.arena import ParamArena
 from openeat_amd.ddp import GradAllReduce
 from openeat_amd.optim import FusedAdam
@@ -102,9 +103,7 @@ class TrainEngine:
         self.reducer()
         # inside a capture the learning rate is whatever replay() puts into lr_dev; everywhere else (eager steps, also
         # those taken beside a captured graph) it is the optimizer's current param_groups value
-        self.optimizer.step(lr_from_device=self._capturing or self._replaying)
-        self.arena.refresh_planes(after_optimizer=True)            # precision 6, policies "all" / "ln": the new weights as bf16 planes
-        self.arena.mark_step()                 # (the weight-operand-only kernel's planes are stale now: its next reader splits again)
+        self.optimizer.step(lr_from_device=self._capturing or self._replaying)      # (marks the weights' bf16 planes stale)
         self.seed_counter.add_(1)
         ops.stamp("optimizer done")
 
@@ -215,19 +214,21 @@ class TrainEngine:
                 mode = "thread_local" if self.reducer.active else "global"
                 ops.ln_table_begin(self.arena.flat.device)
                 try:
-                    if self._accum_capture:
-                        g, unjoined = self._capture_accum(pool, mode)
-                    elif self.segmented:
-                        g, unjoined = self._capture_segments(pool, mode)
-                    else:
-                        with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
-                            try:
-                                self.arena.grad.zero_()
-                                self._out = self._fwd_bwd(self._static)
-                                if not self._split:
-                                    self._finish()
-                            finally:
-                                unjoined = self._lead_forks_back()      # also when the step raised: capture_end comes next
+                    # no pre-split operand crosses the capture's boundary in either direction (planes.capture_scope)
+                    with _planes.capture_scope():
+                        if self._accum_capture:
+                            g, unjoined = self._capture_accum(pool, mode)
+                        elif self.segmented:
+                            g, unjoined = self._capture_segments(pool, mode)
+                        else:
+                            with torch.cuda.graph(g, pool=pool, capture_error_mode=mode):
+                                try:
+                                    self.arena.grad.zero_()
+                                    self._out = self._fwd_bwd(self._static)
+                                    if not self._split:
+                                        self._finish()
+                                finally:
+                                    unjoined = self._lead_forks_back()      # also when the step raised: capture_end comes next
                 finally:
                     self._ln_table = ops.ln_table_end()        # the graph's launch reads this tensor: keep it alive
             finally:
@@ -258,8 +259,6 @@ class TrainEngine:
             go = torch.cuda.CUDAGraph()
             with torch.cuda.graph(go, pool=pool, capture_error_mode=mode):
                 self.optimizer.step(lr_from_device=True)
-                self.arena.refresh_planes(after_optimizer=True)
-            self.arena.mark_step()
             self._opt_graph = go
         return g, unjoined
 
@@ -335,48 +334,37 @@ class TrainEngine:
         torch.cuda.empty_cache()
 
     # ---- ragged training: one graph per batch shape ------------------------------------------------
-    def step_cached(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, max_graphs: int = 64):
+    def step_cached(self, batch: Dict[str, torch.Tensor], lr: Optional[float] = None, max_graphs: int = 64, agree_shapes: bool = True):
         """A training step on a batch of any shape, replayed from a captured graph when this shape has been seen before
         (/root/reference/openeat/dataset/dataset.py:337-364 forms length buckets: a handful of (B, T) shapes recur all
         epoch).  First sight of a shape: the step runs eagerly - a real step - and is then captured for the next time
         (the capture executes nothing).  At most `max_graphs` graphs are kept, least recently used dropped first; all of
         them allocate from one memory pool, so the activation memory held is that of the largest shape, not the sum.
         Callers bound the number of distinct shapes by padding to multiples (frames: the bucket's length_multiple;
-        targets: pad_targets below)."""
+        targets: pad_targets below).  agree_shapes=False: the caller guarantees that every rank sees the same shape
+        sequence (synthetic benchmarks) - no per-call handshake."""
         key = tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in batch.items()))
         rec = self._cache.get(key, False)
+        # Several ranks: ragged data gives the ranks different shape sequences, so one rank may hold a graph for its batch
+        # while another sees its shape for the first time.  The launch mode decides which collectives a rank issues (a
+        # replayed accumulation sends the whole arena once, an eager boundary step sends hook tails and a remainder) and a
+        # cross-rank handshake inside a capture on SOME ranks would pair with the others' next loop handshake (ADVICE r03):
+        # the ranks agree hit / miss first - one host-side integer MIN per call - and replay only if every rank can;
+        # otherwise all of them take the eager step, and those that missed capture LOCALLY afterwards, no collective.
+        multi = self.reducer.active and agree_shapes
+        if multi and self.reducer.agree_min(1 if isinstance(rec, tuple) else 0) == 0:
+            self.static_shapes = True
+            out = self.step(batch, lr)
+            if rec is not False:
+                self._cache.move_to_end(key)
+                return out
+            self.cache_misses += 1
+            return self._capture_for_cache(key, batch, out, max_graphs, local=True)
         if rec is False:
             self.cache_misses += 1
             self.static_shapes = True
             out = self.step(batch, lr)
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            micro = self._micro                       # an accumulation may be under way: the capture executes nothing and must not disturb it
-            try:
-                self._micro = 0
-                self.capture(batch, pool=self._pool, _warm=True)
-                rec = (self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep)
-            except Exception as e:               # noqa: BLE001 - capture() has cleaned up after itself
-                # A shape that does not capture keeps running eagerly (~1.7x slower at config 2) - never silently: warn once
-                # per shape and count it.  What is NOT a property of the shape is re-raised: a fork that never rejoined is a
-                # bug in the step's stream handling, a HIP / launch error is a broken device state.
-                msg = f"{type(e).__name__}: {e}"
-                if ("had not rejoined" in msg or "HIP error" in msg or "hipError" in msg or "CUDA error" in msg or "launch failed" in msg
-                        or isinstance(e, (torch.cuda.OutOfMemoryError, MemoryError))):
-                    self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
-                    raise
-                import warnings
-                self.cache_uncapturable += 1
-                warnings.warn(f"TrainEngine.step_cached: batch shape {[tuple(v.shape) for v in batch.values()]} does not capture "
-                              f"({msg}); it will run eagerly every time", RuntimeWarning, stacklevel=2)
-                rec = None
-            finally:
-                self._micro = micro
-            self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
-            self._cache[key] = rec
-            while len(self._cache) > max(1, max_graphs):
-                self._cache.popitem(last=False)
-            return out
+            return self._capture_for_cache(key, batch, out, max_graphs, local=False)
         self._cache.move_to_end(key)
         if rec is None:
             return self.step(batch, lr)
@@ -387,6 +375,37 @@ class TrainEngine:
         finally:
             self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
 
+    def _capture_for_cache(self, key, batch, out, max_graphs: int, local: bool):
+        """step_cached: the shape's first (eager) step has just run - capture it for the next time.  local: no cross-rank
+        agreement about the outcome (the ranks agree per call instead; a rank whose capture fails keeps reporting a miss)."""
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        micro = self._micro                       # an accumulation may be under way: the capture executes nothing and must not disturb it
+        try:
+            self._micro = 0
+            (self._capture_impl if local else self.capture)(batch, pool=self._pool, _warm=True)
+            rec = (self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep)
+        except Exception as e:               # noqa: BLE001 - capture() has cleaned up after itself
+            # A shape that does not capture keeps running eagerly (~1.7x slower at config 2) - never silently: warn once
+            # per shape and count it.  What is NOT a property of the shape is re-raised: a fork that never rejoined is a
+            # bug in the step's stream handling, a HIP / launch error is a broken device state.
+            msg = f"{type(e).__name__}: {e}"
+            if ("had not rejoined" in msg or "HIP error" in msg or "hipError" in msg or "CUDA error" in msg or "launch failed" in msg
+                    or isinstance(e, (torch.cuda.OutOfMemoryError, MemoryError))):
+                self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
+                raise
+            import warnings
+            self.cache_uncapturable += 1
+            warnings.warn(f"TrainEngine.step_cached: batch shape {[tuple(v.shape) for v in batch.values()]} does not capture "
+                          f"({msg}); it will run eagerly every time", RuntimeWarning, stacklevel=2)
+            rec = None
+        finally:
+            self._micro = micro
+        self._graph, self._static, self._out, self._ln_table, self._segments, self._seg_keep = None, {}, None, None, None, None
+        self._cache[key] = rec
+        while len(self._cache) > max(1, max_graphs):
+            self._cache.popitem(last=False)
+        return out
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
         assert self._graph is not None

@@ -10,6 +10,7 @@ from typing import List, Optional, Tuple
 import torch
 
 from openeat_amd import ops
+from openeat_amd import planes as _planes
 from openeat_amd.modules.cmvn import GlobalCMVN
 from openeat_amd.modules.ctc import CTC
 from openeat_amd.modules.decoder import BiTransformerDecoder
@@ -41,7 +42,9 @@ def _graph_call(cache, key, fn, args):
         g = torch.cuda.CUDAGraph()
         try:
             torch.cuda.synchronize()
-            with torch.cuda.graph(g):
+            # the capture neither reads pre-split operands that eager code made (the registry's FIFO would free them under the
+            # graph: the position table's planes, round 3's red replay) nor leaves its own - unwritten until the first replay - behind
+            with _planes.capture_scope(), torch.cuda.graph(g):
                 sout = fn(*static)
             cache[key] = (g, static, sout)
         except Exception as e:                                     # noqa: BLE001 - whatever the capture objected to: stay eager
@@ -95,7 +98,6 @@ class ASRModel(torch.nn.Module):
 
     # ------------------------------------------------------------------ train --
     def _encode(self, features, features_length):
-        from openeat_amd import planes as _planes
         _planes.new_pass()                      # (decode entry points come through here without forward()'s predrop_clear)
         masks = ~make_pad_mask(features_length, features.size(1)).unsqueeze(1)      # (B,1,T)
         return self.encoder(features, masks)

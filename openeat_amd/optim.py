@@ -39,6 +39,7 @@ class FusedAdam(torch.optim.Optimizer):
         b1, b2 = g["betas"]
         hip.call("oe_adam_step", self.arena.flat, self.arena.grad, self.exp_avg, self.exp_avg_sq, self.arena.numel,
                  self.lr_dev, 0.0, b1, b2, g["eps"], float(self.max_grad_norm), self.total_norm, self.step_state)
+        self.arena.mark_step()          # the raw kernel bumps no version counter: the weights' bf16 planes are stale (any training loop)
         return None
 
     def zero_grad(self, set_to_none: bool = False):

@@ -6,8 +6,8 @@ matrix work itself, so tensors that feed GEMMs carry a second copy, three bf16 P
 
 * activations / gradients: by the kernel that produces them (LayerNorm forward / backward, GEMM epilogues:
   ``c_planes``) or by one pass of ``oe_split_planes``;
-* weights: the whole parameter arena is split once per optimizer step (``ParamArena.refresh_planes``); weights outside
-  an arena are split on first use and cached by (address, version).
+* weights: the whole parameter arena is split by the first reader of every pass (``ParamArena.step_planes``); weights
+  outside an arena are split on first use and cached by (address, version) under no_grad.
 
 ``csrc/gemm_pl.hip`` then moves tiles global -> LDS by LDS-DMA and its loop is DMA issue, LDS reads and MFMAs only.
 Everything here is optional: an operand without planes sends the GEMM to the kernels that split in the loop.
@@ -58,7 +58,7 @@ HYB_MIN_ROWS = int(os.environ.get("OE_HYB_MIN_ROWS", "12288"))
 
 
 def weights_presplit() -> bool:
-    """The arena keeps bf16 planes of the weights (ParamArena.refresh_planes after every optimizer step)."""
+    """The arena keeps bf16 planes of the weights (ParamArena.step_planes: split by the first reader of every pass)."""
     return hip.GEMM_PRECISION == 6 and (POLICY in ("all", "ln") or (WEIGHT_PLANES and POLICY != "0"))
 
 
@@ -74,10 +74,7 @@ def arena_weight(w2d: torch.Tensor) -> Optional[Planes]:
     off = (ptr - a.flat.data_ptr()) // 4
     if not (0 <= off < a.numel) or ptr % 32:
         return None
-    if active():
-        a.ensure_planes()                # "all" / "ln": refreshed behind every optimizer step
-    else:
-        a.step_planes()                  # split on this pass's first use
+    a.step_planes()                      # split on this pass's first use
     return Planes(a.planes, a.planes.data_ptr() + 2 * off, a.planes_stride, w2d.stride(0), w2d.shape[0], w2d.shape[1])
 
 
@@ -104,15 +101,62 @@ def alloc(rows: int, cols: int, device) -> Planes:
 # An entry keeps its source tensor alive, so the address cannot be handed to another tensor while the entry exists; the
 # registry is emptied when a new step starts (ops.predrop_clear's call sites).  Planes that backward needs are kept by the
 # autograd functions themselves (ctx), not looked up again.
+import contextlib
 from collections import OrderedDict
 
 _REG: "OrderedDict[int, tuple]" = OrderedDict()
 _NO_GRAD_KEEP = 64     # inference: a tensor's planes are consumed right after they are made - keep a short FIFO only
+_CAPTURE_DEPTH = 0     # > 0 inside capture_scope(): no planes made outside the capture may be handed to a captured launch
+ISOLATE_CAPTURES = True   # tools/capture_probe.py switches this off to show what round 3's red test was
 
 
 def clear():
     _REG.clear()
     new_pass()
+
+
+def clear_all():
+    """Everything keyed by a device address: the activation registry AND the cached weight splits (test teardown; a model
+    that goes away must not leave planes of its weights behind under an address the next model may be given)."""
+    _WCACHE.clear()
+    clear()
+
+
+@contextlib.contextmanager
+def capture_scope():
+    """Around the capture of a HIP graph.  A capture executes nothing and bakes device addresses into its launches, so it
+    must neither READ planes that eager code owns nor leave its own behind for eager code to find:
+
+    * the registry is a FIFO under no_grad (_NO_GRAD_KEEP) and is emptied at every step: an entry that a captured GEMM
+      picked up - e.g. the planes of the position table slice, whose address is the same at every call - is evicted a few
+      registrations later, its memory goes back to the allocator, and the replay reads whatever was put there since
+      (GPUTEST_r03: first replay of the decode stage-1 graph under OE_PLANES=all returned empty hypotheses);
+    * a cached weight split (_WCACHE) handed to a capture would be read by every replay even after the weights changed;
+    * an entry registered DURING the capture points into the graph's private pool, which holds nothing before the first
+      replay: an eager reader would multiply garbage.
+
+    Inside the scope the registry starts empty and weights outside an arena are split by a captured launch (the replay
+    then follows the weights); on exit the capture's entries are dropped and the outer registry is back.  Planes made and
+    freed INSIDE one capture need no owner: their blocks are only ever reused by later allocations of the same capture,
+    i.e. by launches that the replay orders behind their last reader.  The arena's planes buffer is allocated BEFORE the
+    capture so that it never lives in a graph's pool."""
+    global _REG, _CAPTURE_DEPTH
+    if not ISOLATE_CAPTURES:
+        yield
+        return
+    from . import arena as _arena
+    a = _arena.active()
+    if a is not None and weights_presplit():
+        a.alloc_planes()
+    outer, _REG = _REG, OrderedDict()
+    _CAPTURE_DEPTH += 1
+    try:
+        yield
+    finally:
+        _CAPTURE_DEPTH -= 1
+        _REG = outer
+        if a is not None:
+            a.mark_step()                # a split that was only recorded has refreshed nothing
 
 
 def new_pass():
@@ -189,12 +233,13 @@ def weight(w2d: torch.Tensor) -> Optional[Planes]:
     if a is not None and (a.planes is not None or active()):
         off = (ptr - a.flat.data_ptr()) // 4
         if 0 <= off < a.numel and ptr % 32 == 0:
-            a.ensure_planes()           # (first use: allocates and splits the whole arena once)
+            a.step_planes()             # split on this pass's first use
             return Planes(a.planes, a.planes.data_ptr() + 2 * off, a.planes_stride, w2d.stride(0), w2d.shape[0], w2d.shape[1])
     if ptr % 16 or w2d.stride(0) != w2d.shape[1]:
         return None
+    cacheable = not torch.is_grad_enabled() and not _CAPTURE_DEPTH      # capture_scope(): a captured launch splits, every replay
     e = _WCACHE.get(ptr)
-    if e is not None and e[2] == w2d._version and e[0].rows == w2d.shape[0] and e[0].cols == w2d.shape[1] and not torch.is_grad_enabled():
+    if e is not None and e[2] == w2d._version and e[0].rows == w2d.shape[0] and e[0].cols == w2d.shape[1] and cacheable:
         return e[0]
     # training outside an arena: parameters change through optimizers whose in-place updates bump the version, but raw
     # kernels do not - only trust the cache under no_grad (decode / eval), else split afresh
@@ -202,8 +247,8 @@ def weight(w2d: torch.Tensor) -> Optional[Planes]:
     if _DEBUG:
         print("split_planes weight", tuple(w2d.shape), flush=True)
     hip.call("oe_split_planes", w2d, w2d.stride(0), w2d.shape[0], w2d.shape[1], pl.t, pl.ld, pl.stride)
-    if not torch.is_grad_enabled():
-        if len(_WCACHE) >= _WCACHE_MAX:
-            _WCACHE.clear()
+    if cacheable:
+        while len(_WCACHE) >= _WCACHE_MAX:           # oldest first (no capture holds a cached split: capture_scope)
+            _WCACHE.pop(next(iter(_WCACHE)))
         _WCACHE[ptr] = (pl, w2d, w2d._version)
     return pl

@@ -248,9 +248,86 @@ def test_rccl_collectives_run_with_one_rank(tmp_path):
         assert abs(got[tag][1] - float(loss)) < 1e-3 * abs(float(loss)), tag
 
 
+def _batch_shape(seed, dev, T, L):
+    g = torch.Generator().manual_seed(seed)
+    B = 3
+    feats = torch.randn(B, T, 80, generator=g)
+    flen = torch.tensor([T, T - 11, T - 30], dtype=torch.int32)
+    tgt = torch.randint(2, V - 1, (B, L), generator=g, dtype=torch.int32)
+    tlen = torch.tensor([L, L - 1, L - 2], dtype=torch.int32)
+    for b in range(B):
+        tgt[b, int(tlen[b]):] = -1
+    return dict(features=feats.to(dev), features_length=flen.to(dev), targets=tgt.to(dev), targets_length=tlen.to(dev))
+
+
+def worker_cached_ragged():
+    """step_cached with DIFFERENT shape orders per rank (ragged buckets, dataset.py:337-364): at some calls one rank holds a
+    graph for its batch and the other sees its shape for the first time.  The ranks must agree the launch mode per call
+    (round 3's step_cached let the missing rank run a capture-time handshake the other rank never answered) - with and
+    without gradient accumulation, where the replayed and the eager boundary step issue different collectives."""
+    sys.path.insert(0, ROOT)
+    from openeat_amd import ddp, ops
+    from openeat_amd.engine import TrainEngine
+    rank, _, world = ddp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    shapes = {"a": (83, 6), "b": (67, 5)}
+    order = ["a", "b", "a", "a", "b", "a", "b", "b"] if rank == 0 else ["b", "b", "a", "b", "a", "a", "b", "a"]
+    out = {}
+    for accum in (1, 2):
+        model = _model(dev)
+        eng = TrainEngine(model, lr=1e-2, grad_clip=5.0, accum_grad=accum, static_shapes=True, parallel_decoders=True)
+        modes = []
+        for i, name in enumerate(order):
+            h0 = eng.cache_hits
+            loss, _ = eng.step_cached(_batch_shape(1000 * accum + 10 * i + rank, dev, *shapes[name]))
+            modes.append(eng.cache_hits - h0)
+            assert bool(torch.isfinite(loss))
+        torch.cuda.synchronize()
+        out[accum] = (eng.arena.flat.detach().cpu(), modes, eng.cache_misses)
+        eng.drop_graph()
+        eng.arena.deactivate()
+        ops.set_seed_device_counter(None)
+    torch.save(out, os.environ["OE_TEST_OUT"] + f".{rank}")
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_cached_with_different_shape_orders(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "ragged_out")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2",
+                   OE_TEST_OUT=out, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "worker_cached_ragged"], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:                    # ranks that disagree about a collective hang: kill exactly these two
+            for q in procs:
+                q.kill()
+            raise AssertionError("the ranks hung (mismatched collectives)")
+    for p, lg in zip(procs, logs):
+        assert p.returncode == 0, lg[-4000:]
+    got = [torch.load(out + f".{r}") for r in range(2)]
+    for accum in (1, 2):
+        assert torch.equal(got[0][accum][0], got[1][accum][0]), accum             # the ranks never diverged
+        assert got[0][accum][1] == got[1][accum][1], (accum, got[0][accum][1], got[1][accum][1])   # same launch mode at every call
+        assert sum(got[0][accum][1]) >= 2                                         # and graphs were replayed once both ranks held them
+        assert got[0][accum][2] == 2 and got[1][accum][2] == 2                    # each shape captured once per rank
+
+
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker_rccl_one_rank":
     worker_rccl_one_rank()
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker":
     worker()
 if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker_segmented":
     worker_segmented()
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker_cached_ragged":
+    worker_cached_ragged()

@@ -673,3 +673,47 @@ def test_arena_weight_planes_are_never_stale():
         e.arena.deactivate()
         ops.set_seed_device_counter(None)
         planes.clear()
+
+
+@pytest.mark.parametrize("policy", ["ln", "all", "conv"])
+def test_weight_planes_follow_an_optimizer_loop_outside_the_engine(policy):
+    """The reference-shaped loop of utils/executor.py:42-63 - model(**batch), loss.backward(), optimizer.step() - steps FusedAdam
+    without TrainEngine._finish.  The raw Adam kernel bumps no tensor version, so the arena's bf16 planes must go stale by the
+    optimizer's own doing (FusedAdam.step -> ParamArena.mark_step) and be honoured by every reader under every planes policy
+    (round 3: under "ln" / "all" such a loop kept training on the weights of the first split).  Each step's loss
+    must equal the same loop's without any pre-split operand."""
+    from openeat_amd import hip, planes
+    from openeat_amd.optim import FusedAdam
+    old = (hip.GEMM_PRECISION, planes.POLICY, planes.MIN_SPLIT_ELEMS, planes.HYB_MIN_ROWS)
+    b = batch_of(seed=12)
+    losses = {}
+    try:
+        for pol in ("0", policy):
+            hip.GEMM_PRECISION, planes.POLICY, planes.MIN_SPLIT_ELEMS, planes.HYB_MIN_ROWS = 6, pol, 0, 0
+            planes.clear_all()
+            m = tiny(seed=23).to(DEV).train()
+            ar = A.ParamArena(m).activate()
+            opt = FusedAdam(ar, lr=2e-2, max_grad_norm=5.0)                  # a large rate: stale weights show in the next loss
+            out = []
+            for _ in range(4):
+                opt.zero_grad()
+                loss, _ = m(**b)
+                loss.backward()
+                ops.join_side_stream()
+                opt.step()
+                out.append(float(loss))
+            if pol != "0":
+                w = m.encoder.encoders[0].feed_forward.w_1.weight
+                pl = planes.arena_weight(w)                                   # a reader after the last step: split again
+                assert pl is not None
+                off = (pl.ptr - ar.planes.data_ptr()) // 2
+                p = torch.stack([ar.planes[n, off:off + w.numel()].view_as(w).float() for n in range(3)])
+                torch.cuda.synchronize()
+                assert torch.equal(p[0] + p[1] + p[2], w.detach())
+            losses[pol] = out
+            ar.deactivate()
+    finally:
+        hip.GEMM_PRECISION, planes.POLICY, planes.MIN_SPLIT_ELEMS, planes.HYB_MIN_ROWS = old
+        planes.clear_all()
+    assert losses["0"][0] > losses["0"][-1]                                   # the loop does train
+    np.testing.assert_allclose(losses[policy], losses["0"], rtol=5e-4)

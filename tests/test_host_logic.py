@@ -259,3 +259,41 @@ def test_mask_bytes_views_a_bool_mask_and_converts_the_rest():
     assert ops.mask_bytes(i).dtype == torch.uint8 and ops.mask_bytes(i).tolist() == i.tolist()
     u = m.to(torch.uint8)
     assert ops.mask_bytes(u).data_ptr() == u.data_ptr()
+
+
+def test_capture_scope_isolates_the_planes_registry_on_the_host():
+    """planes.capture_scope (host logic only, no device): inside the scope the registry starts empty and cached weight splits
+    are neither read nor written; on exit the capture's entries are gone and the outer registry object is back (round 3's red
+    GPU test: a capture baked in planes that the eager FIFO later freed)."""
+    from openeat_amd import planes
+    planes.clear_all()
+    src = torch.zeros(4, 8)
+    pl = planes.Planes(torch.zeros(3, 4, 8, dtype=torch.bfloat16), 0, 32, 8, 4, 8)
+    planes._REG[1234] = (pl, src, src._version)
+    outer = planes._REG
+    with planes.capture_scope():
+        assert planes._REG is not outer and len(planes._REG) == 0 and planes._CAPTURE_DEPTH == 1
+        planes._REG[99] = (pl, src, src._version)
+        with planes.capture_scope():                          # nests (a segmented capture inside an engine capture)
+            assert len(planes._REG) == 0 and planes._CAPTURE_DEPTH == 2
+        assert 99 in planes._REG
+    assert planes._REG is outer and list(outer) == [1234] and planes._CAPTURE_DEPTH == 0
+    try:
+        with planes.capture_scope():
+            raise KeyError("boom")
+    except KeyError:
+        pass
+    assert planes._REG is outer and planes._CAPTURE_DEPTH == 0
+    planes.clear_all()
+    assert len(planes._REG) == 0 and len(planes._WCACHE) == 0
+
+
+def test_gpu_files_are_collected_kernel_proofs_first():
+    """One failing integration test must not hide the kernel-level evidence under the driver's `pytest -x`."""
+    import conftest
+    order = conftest._GPU_FILE_ORDER
+    for early in ("test_gpu_kernels.py", "test_gpu_planes.py", "test_gpu_width.py"):
+        assert order.index(early) < order.index("test_gpu_model.py") < order.index("test_gpu_engine.py")
+    here = os.path.dirname(os.path.abspath(__file__))
+    present = sorted(f for f in os.listdir(here) if f.startswith("test_gpu_") and f.endswith(".py"))
+    assert set(present) <= set(order), f"add {set(present) - set(order)} to conftest._GPU_FILE_ORDER"
