@@ -468,11 +468,11 @@ def _e2e(name, kwargs, lens, tlens, V, seed, beam=4, store_sd=True, force_token=
     meta = {"kwargs": kwargs, "V": V, "beam": beam, "greedy": greedy, "grad_norm": gnorm, "seed": seed, "scale": 0.5,
             "param_order": [[k, list(p.shape)] for k, p in model.named_parameters()],
             "nbest": [[list(p), float(s)] for p, s in nbest], "rescored": list(hyp),
-            "recognize": rec.tolist(), "loss": float(loss), "acc": float(acc)}
+            "recognize": rec.tolist(), "loss": float(loss), "acc": None if acc is None else float(acc)}
     with open(os.path.join(HERE, name + ".json"), "w") as f:
         json.dump(meta, f)
     save(name, **{"in": {"feats": feats, "flen": flen, "tgt": tgt, "tlen": tlen}, "sd": sd_of(model) if store_sd else {},
-                  "out": {"loss": loss, "acc": acc, "enc": enc, "enc_mask": enc_mask, "ctc_logits": ctc_logits},
+                  "out": dict({"loss": loss, "enc": enc, "enc_mask": enc_mask, "ctc_logits": ctc_logits}, **({} if acc is None else {"acc": acc})),
                   "grad": grads})
 
 
@@ -517,6 +517,16 @@ def f23_e2e_nonzero_accuracy():
               linear_units=64, dropout_rate=0.0, activation_type="swish", macaron_style=True, use_cnn_module=True,
               cnn_module_kernel=15, pos_enc_layer_type="rel_pos", ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3),
          lens=[95, 70, 43, 88], tlens=[7, 5, 3, 6], V=40, seed=23, force_token=5)
+
+
+def f25_e2e_ctc_only():
+    """ctc_weight = 1.0: the branch of asr_model.py:148-157 that skips the decoder - loss = loss_ctc, acc = None, no gradient
+    reaches any decoder parameter (their entries are absent from `grad` / `grad_norm`)."""
+    _e2e("f25_tiny_conformer_ctc_only",
+         dict(encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=32, attention_heads=4,
+              linear_units=64, dropout_rate=0.0, activation_type="swish", macaron_style=True, use_cnn_module=True,
+              cnn_module_kernel=15, pos_enc_layer_type="rel_pos", ctc_weight=1.0, lsm_weight=0.1, reverse_weight=0.3),
+         lens=[95, 70, 43, 61], tlens=[7, 5, 3, 6], V=40, seed=25)
 
 
 def f22_api_signatures():
@@ -580,4 +590,4 @@ if __name__ == "__main__":
         f1_subsampling(); f2_relpos_mha(); f3_mha(); f4_conv_module(); f5_f6_encoder(); f7_ctc(); f8_lsm(); f9_decoder()
         f10_helpers(); f11_f12_e2e(); f13_misc(); f14_ctc_length_normalized(); f15_e2e_length_normalized()
         f16_encoder_linear_input(); f17_spec_augment(); f18_encoder_conv2d8(); f19_activations(); f20_e2e_adapters(); f21_encoder_conv2d6()
-        f22_api_signatures(); f23_e2e_nonzero_accuracy(); f24_conv_module_cache()
+        f22_api_signatures(); f23_e2e_nonzero_accuracy(); f24_conv_module_cache(); f25_e2e_ctc_only()

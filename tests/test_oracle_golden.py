@@ -299,7 +299,7 @@ def test_f10_helper_tables():
 
 
 E2E = {"f11_config1_transformer": True, "f12_tiny_conformer": False, "f15_tiny_conformer_lennorm": False,
-       "f20_tiny_conformer_adapters": False}
+       "f20_tiny_conformer_adapters": False, "f23_tiny_conformer_acc": False, "f25_tiny_conformer_ctc_only": False}
 
 
 @pytest.mark.parametrize("name", list(E2E))
@@ -312,7 +312,10 @@ def test_f11_f12_end_to_end(name):
     i = g["in"]
     loss, acc = O.forward(sdr, cfg, i["feats"], i["flen"], i["tgt"], i["tlen"])
     torch.testing.assert_close(loss, g["out"]["loss"], rtol=2e-4, atol=2e-4)
-    torch.testing.assert_close(acc, g["out"]["acc"])
+    if meta["acc"] is None:                                 # ctc_weight = 1.0: asr_model.py:148-157 skips the decoder
+        assert acc is None
+    else:
+        torch.testing.assert_close(acc, g["out"]["acc"])
     loss.backward()
     for k, n in meta["grad_norm"].items():
         got = float(sdr[k].grad.norm())

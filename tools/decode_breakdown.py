@@ -41,8 +41,9 @@ for it in range(3):
         nb2 = T("host prefix beam x64 (batch, threads)", lambda: hip.ctc_prefix_beam_host_batch(tpc, tic, lens, 10), acc)
         assert nb == nb2
         assert [[p for p, _ in u] for u in nb_dev] == [[p for p, _ in u] for u in nb2]
-        acc["mean n-best length"] = sum(len(p) for u in nb for p, _ in u) / 640.0
+        mean_len = sum(len(p) for u in nb for p, _ in u) / 640.0
         T("whole attention_rescoring_batch", lambda: model.attention_rescoring_batch(feats, nfr, 10, ctc_weight=0.5, reverse_weight=0.3), acc)
     if it == 2:
         for k, v in acc.items():
             print(f"{k:72s} {v:8.2f} ms")
+        print(f"{'mean n-best length (untrained weights: hypotheses of nearly every frame)':72s} {mean_len:8.2f} tokens")
