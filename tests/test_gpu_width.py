@@ -174,3 +174,72 @@ def test_config2_width_training_trajectory_matches_oracle():
     for i, (g, w) in enumerate(zip(got, want)):
         if g is not None:
             assert abs(g - w) <= 2e-4 * abs(w), (i, got, want)
+
+
+# ---- BASELINE.json configs[4]'s model: 24-layer Conformer d = 512 (h = 8, ff = 2048, K = 15; SURVEY 8d's assumed widths) ----------
+CONF5 = dict(CONF, encoder_num_blocks=24, d_model=512, attention_heads=8, linear_units=2048)
+SECONDS5 = [4.0, 3.1, 2.3, 1.5]
+TLENS5 = [14, 11, 8, 4]
+_C5 = {}
+
+
+def _setup5():
+    if _C5:
+        return _C5
+    torch.manual_seed(778)
+    model = ASRModel(80, V, **CONF5)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(5)
+    B = len(SECONDS5)
+    ns = torch.tensor([int(16000 * s) for s in SECONDS5])
+    wav = torch.rand(B, int(ns.max()), generator=g) - 0.5
+    tgt = torch.full((B, max(TLENS5)), -1, dtype=torch.int32)
+    for b in range(B):
+        wav[b, int(ns[b]):] = 0.0
+        tgt[b, : TLENS5[b]] = torch.randint(2, V - 1, (TLENS5[b],), generator=g, dtype=torch.int32)
+    tlen = torch.tensor(TLENS5, dtype=torch.int32)
+    feats, nfr = Fbank(80, device=DEV)(wav.to(DEV), ns.to(DEV))
+    utt_normalize_(feats, nfr)
+    torch.cuda.synchronize()
+    cfg = O.Config(input_size=80, vocab_size=V, **CONF5)
+    osd = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    loss, acc = O.forward(osd, cfg, feats.cpu(), nfr.cpu(), tgt, tlen)
+    loss.backward()
+    greedy = O.ctc_greedy_search({k: v.detach() for k, v in osd.items()}, cfg, feats.cpu(), nfr.cpu())
+    _C5.update(sd=sd, feats=feats, nfr=nfr, tgt=tgt, tlen=tlen, loss=float(loss), acc=float(acc), greedy=greedy,
+               gnorm={k: float(v.grad.norm()) for k, v in osd.items() if v.grad is not None})
+    return _C5
+
+
+@pytest.mark.parametrize("prec", [6, 0], ids=["bf16x6-mfma", "fp32-mfma"])
+def test_config5_width_model_matches_oracle(prec):
+    """The d = 512 dispatch (other tiles, K = 512 / 2048 reductions, eight heads of 64, 192.5 M parameters in one arena-less model)
+    against oracle/asr.py on four ragged utterances: loss rtol 2e-4, every parameter-gradient norm 3e-3, CTC-greedy ids identical
+    (asr_model.py:37-70 kwargs)."""
+    from openeat_amd import hip, planes
+    c = _setup5()
+    model = ASRModel(80, V, **CONF5)
+    model.load_state_dict(c["sd"])
+    model = model.to(DEV).eval()
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = prec
+    try:
+        loss, acc = model(c["feats"], c["nfr"], c["tgt"].to(DEV), c["tlen"].to(DEV))
+        loss.backward()
+        with torch.no_grad():
+            greedy = model.ctc_greedy_search(c["feats"], c["nfr"])
+        torch.cuda.synchronize()
+    finally:
+        hip.GEMM_PRECISION = old
+        planes.clear()
+    assert abs(float(loss) - c["loss"]) <= 2e-4 * abs(c["loss"]), (float(loss), c["loss"])
+    assert abs(float(acc) - c["acc"]) <= 1e-6
+    bad = []
+    for k, p in model.named_parameters():
+        want = c["gnorm"][k]
+        got = float(p.grad.norm())
+        if abs(got - want) > 3e-3 * abs(want) + 1e-6:
+            bad.append((k, got, want))
+    assert not bad, bad[:10]
+    assert greedy == c["greedy"] and sum(len(h) for h in greedy) > 0

@@ -139,9 +139,14 @@ torch.cuda.synchronize()
 pair_ms = sorted(a.elapsed_time(b) for a, b in pairs)[100]
 g_secs = sum(max(r[0].elapsed_time(r[1]) - pair_ms, 0.0) for r in recs) * 1e-3
 g_flops = sum(r[2] for r in recs)
+# bench.py's convention: the peak for ALGORITHMIC flops is the dense bf16 MFMA rate divided by the MFMAs a mode issues per product
+# (6 in the headline mode: 2500 / 6 = 416.7 TFLOP/s; 157.3 on the fp32-input MFMA), mfma_issue = algorithmic x that count
+_terms = {0: 1, 1: 1, 3: 3, 6: 6}[hip.GEMM_PRECISION]
+_peak = 157.3 if hip.GEMM_PRECISION == 0 else 2500.0 / _terms
 gemm_roof = {"batch": f"B={big[0].shape[0]} x {big[0].shape[1]} samples", "launches": len(recs), "gemm_ms": g_secs * 1e3,
-             "algorithmic_gflop": g_flops / 1e9, "achieved_tflops": g_flops / g_secs / 1e12, "peak_tflops_dense_bf16": 2500.0,
-             "frac": g_flops / g_secs / 1e12 / 2500.0, "mfma_issue_tflops": g_flops * (3 if hip.GEMM_PRECISION == 3 else 1) / g_secs / 1e12}
+             "algorithmic_gflop": g_flops / 1e9, "achieved_tflops": g_flops / g_secs / 1e12, "peak": _peak, "unit": "TFLOP/s",
+             "frac": g_flops / g_secs / 1e12 / _peak, "mfma_terms_per_product": _terms, "peak_dense_bf16_mfma": 2500.0,
+             "mfma_issue_tflops": g_flops * _terms / g_secs / 1e12}
 padded = sum(len(b) * max(fb.num_frames(int(sec * 16000 / s + 0.5)) for _, sec, _, s in b) for b in batches[args.warmup:])
 what = ("configs[4] on 1 GPU: 24L Conformer d=512 h=8 ff=2048 (192.5 M params)" if args.model == "24L512" else
         "configs[4]'s ragged data through configs[1]'s model: 12L Conformer d=256 h=4 ff=2048")
