@@ -174,6 +174,11 @@ int oe_ffn_fwd(const oe_ffn_args* args, void* stream);
  * gradient of W1 consumes it), y = dX (rows, d); b1, b2, residual unset, drop_out 0, beta 1. */
 int oe_ffn_pack_weights_bwd(const float* w1, const float* w2, int d, int ff, int precision, void* w2t_packed, void* w1t_packed, void* stream);
 int oe_ffn_bwd(const oe_ffn_args* a, void* stream);
+/* precision 6 (csrc/ffn6.hip; d in {128, 256, 512}, three planes, oe_ffn_packed_bytes = 6 bytes per weight): block shape of the
+ * fused kernel - 0 = automatic (32-row blocks of eight waves in two staggered groups wherever ff is a multiple of 256),
+ * 1 = 64 rows / four waves (d <= 256), 2 = 32 rows / four waves, 3 = two groups; -1 only reads.  Returns the mode in force.
+ * Tuning / tests only: results are identical in every mode up to the order of the fp32 sums over the ff axis. */
+int oe_ffn6_config(int mode);
 
 /* Several weight gradients  C_i (+)= alpha_i * A_i^T B_i  (A_i (k_i, m_i), B_i (k_i, n_i), both k-major, fp32) in ONE launch
  * of the bf16-planes kernel, accumulated atomically into C_i (ops.flush_wgrads: the deferred weight gradients of a captured

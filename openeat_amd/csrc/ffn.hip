@@ -81,14 +81,12 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
     } else {
         return;
     }
-    bf16x8 hi, lo;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        hi[e] = (__bf16)x[e];
-        lo[e] = (__bf16)(x[e] - (float)hi[e]);
-    }
-    *reinterpret_cast<bf16x8*>(dst) = hi;
-    if (planes == 2) *reinterpret_cast<bf16x8*>(dst + 512) = lo;
+    // planes 1 / 2: bf16(x), bf16(x - p0) (precision 1 / 3); planes 3: the three exact pieces of precision 6 (oe_common.h)
+    oe_bf16x8 pl[3];
+    oe_split8<3>(x, pl);
+    *reinterpret_cast<oe_bf16x8*>(dst) = pl[0];
+    if (planes >= 2) *reinterpret_cast<oe_bf16x8*>(dst + 512) = pl[1];
+    if (planes >= 3) *reinterpret_cast<oe_bf16x8*>(dst + 1024) = pl[2];
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------------------------------------
@@ -338,13 +336,19 @@ __global__ __launch_bounds__(FFN_THREADS) void ffn_fwd_kernel(FfnParams p) {
     }
 }
 
+// precision 6 (three planes, six terms): csrc/ffn6.hip
+int oe_ffn6_supported(int d, int ff);
+int oe_ffn6_run(const oe_ffn_args* a, bool bwd, void* stream);
+static int ffn_planes(int precision) { return precision == 6 ? 3 : precision == 3 ? 2 : 1; }
+
 extern "C" size_t oe_ffn_packed_bytes(int d, int ff, int precision) {
-    return (size_t)d * ff * 2 * (precision == 3 ? 2 : 1);
+    return (size_t)d * ff * 2 * ffn_planes(precision);
 }
 
 extern "C" int oe_ffn_supported(int d, int ff, int precision, int act) {
-    return (d == 128 || d == 256) && ff > 0 && ff % 128 == 0 && ff <= 8192 && (precision == 1 || precision == 3) &&
-           (act == OE_ACT_NONE || act == OE_ACT_RELU || act == OE_ACT_SWISH);
+    if (!(act == OE_ACT_NONE || act == OE_ACT_RELU || act == OE_ACT_SWISH)) return 0;
+    if (precision == 6) return oe_ffn6_supported(d, ff);
+    return (d == 128 || d == 256) && ff > 0 && ff % 128 == 0 && ff <= 8192 && (precision == 1 || precision == 3);
 }
 
 static int ffn_pack(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, bool transposed, void* stream) {
@@ -354,10 +358,10 @@ static int ffn_pack(const float* w1, const float* w2, int d, int ff, int precisi
     const long pieces = (long)(ff / 32) * (d / 16) + (long)(ff / 32) * (d / 32) * 2;
     if (transposed)
         hipLaunchKernelGGL(ffn_pack_kernel<true>, dim3(oe_cdiv(pieces, 4)), dim3(256), 0, (hipStream_t)stream, w1, w2, d, ff,
-                           precision == 3 ? 2 : 1, (__bf16*)w1p, (__bf16*)w2p);
+                           ffn_planes(precision), (__bf16*)w1p, (__bf16*)w2p);
     else
         hipLaunchKernelGGL(ffn_pack_kernel<false>, dim3(oe_cdiv(pieces, 4)), dim3(256), 0, (hipStream_t)stream, w1, w2, d, ff,
-                           precision == 3 ? 2 : 1, (__bf16*)w1p, (__bf16*)w2p);
+                           ffn_planes(precision), (__bf16*)w1p, (__bf16*)w2p);
     OE_LAUNCH_CHECK("oe_ffn_pack_weights");
     return 0;
 }
@@ -388,6 +392,7 @@ extern "C" int oe_ffn_fwd(const oe_ffn_args* a, void* stream) {
                  ((uintptr_t)a->w1p) | ((uintptr_t)a->w2p)) & 15) == 0, "oe_ffn_fwd: 16-byte alignment required");
     OE_REQUIRE(a->drop_in >= 0.f && a->drop_in < 1.f && a->drop_out >= 0.f && a->drop_out < 1.f, "oe_ffn_fwd: dropout rate out of range");
     OE_REQUIRE(!(a->act_out && !a->pre_out), "oe_ffn_fwd: act_out needs pre_out (the store count is a compile-time constant)");
+    if (a->precision == 6) return oe_ffn6_run(a, false, stream);
     FfnParams p{};
     p.x = a->x; p.ldx = a->ldx; p.w1p = (const __bf16*)a->w1p; p.b1 = a->b1; p.w2p = (const __bf16*)a->w2p; p.b2 = a->b2;
     p.pre = a->pre_out; p.act_out = a->act_out; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta; p.y = a->y; p.ldy = a->ldy;
@@ -413,6 +418,7 @@ extern "C" int oe_ffn_bwd(const oe_ffn_args* a, void* stream) {
     OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->pre_out) | ((uintptr_t)a->act_out) | ((uintptr_t)a->w1p) |
                  ((uintptr_t)a->w2p)) & 15) == 0, "oe_ffn_bwd: 16-byte alignment required");
     OE_REQUIRE(a->drop_in >= 0.f && a->drop_in < 1.f, "oe_ffn_bwd: dropout rate out of range");
+    if (a->precision == 6) return oe_ffn6_run(a, true, stream);
     FfnParams p{};
     p.x = a->x; p.ldx = a->ldx; p.w1p = (const __bf16*)a->w1p; p.w2p = (const __bf16*)a->w2p;
     p.pre = a->pre_out; p.act_out = a->act_out; p.beta = 1.f; p.y = a->y; p.ldy = a->ldy;

@@ -1,0 +1,467 @@
+// Position-wise feed forward as ONE kernel in the REFERENCE-PRECISION arithmetic (precision 6: three exact bf16 pieces per
+// operand, six MFMA terms per product - oe_common.h):   y = residual + beta * drop_out( W2 drop_in(act(W1 x + b1)) + b2 )
+// (/root/reference/openeat/modules/positionwise_feed_forward.py:36-43 inside encoder_layer.py:81-83,104-106) and, on the same
+// skeleton, its input gradient  dH = (dY W2) * mask * act'(pre),  dX = dH W1  (autograd of the same lines).
+//
+// Why a kernel of its own (ffn.hip is precision 1 / 3, d <= 256, everything in registers): with three planes the block's x
+// fragments alone would be 192 registers per lane and the partial y^T of a wave 128-256 more.  And why fuse at all: as two
+// GEMM launches the (rows, ff) pre-activation AND activation go to HBM and the activation comes back (config 2: 64 MB written,
+// 32 MB read per feed-forward, 24 of them per step), each launch pays its own ramp for 4 GFLOP, and in the step the pair takes
+// 100 us (47.5 + 52.6, profiles/r03_experiments.md) against 72 us alone.
+//
+// Design (everything transposed, as ffn.hip: weights are the MFMA A operand, activations the B operand with the row on the lane):
+//   * a block owns BM = 32 RT rows (RT = 2 at d <= 256: every weight fragment that leaves L2 feeds 12 MFMAs instead of 6 - the
+//     kernel is bound by that stream: 3 MB of weight planes per block at d = 256, ff = 1024);
+//   * the block's x rows are split ONCE into three bf16 planes in LDS ([plane][row][d + 8]: the 16-byte pad puts the 16 rows of
+//     a ds_read_b128 lane group on 16 different bank quads);
+//   * the ff axis is walked in chunks of 128 (four 32-wide tiles).  Per chunk, wave w (one per SIMD, the whole register file)
+//       GEMM 1:  h^T tile w = W1[tile] . x^T  for both row tiles  (A from the packed weight stream, B = x fragments from LDS)
+//       epilogue 1 on the accumulators: + b1, pre-activation out (through a wave-private LDS patch, 128-byte row segments),
+//                activation, dropout, split into three planes -> LDS, in the B-fragment order of GEMM 2 (lane-linear 16-byte
+//                pieces: the accumulator's registers 8s..8s+7 ARE k-slots 8 lk..8 lk + 7 of step s, ffn.hip's k-slot permutation)
+//       GEMM 2:  y^T[d tiles of wave w] += W2[those d tiles, chunk] . h^T   - the waves split the OUTPUT columns here, so every
+//                wave reads all four h tiles of the chunk from LDS and nobody holds a partial sum: no cross-wave reduction,
+//                64 accumulator registers instead of 256;
+//     two raw s_barriers per chunk (h written -> read; read -> rewritten), 384 MFMAs per wave between them;
+//   * the weight fragments come pre-split IN FRAGMENT ORDER (oe_ffn_pack_weights, 3 planes: one 3 KiB piece = the 64 lanes' 8
+//     elements of one MFMA operand, three planes) straight L2 -> registers, four rotating register sets of two fragments
+//     (18 KiB per wave in flight across both GEMMs, the barriers and the chunk boundaries; hipcc counts the vmcnt);
+//   * epilogue 2: each wave's own 64 output columns leave through its LDS patch as 128-byte row segments: + b2, dropout, scaled
+//     residual.
+// Supported: d in {128, 256} (64-row blocks) and 512 (32-row blocks: 96 KiB of x planes), ff a multiple of 128.
+#include <stdlib.h>
+#include "gemm_common.h"
+#include "../../include/openeat_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct Ffn6Params {
+    const float* x; long ldx;
+    const unsigned char* w1p; const float* b1;
+    const unsigned char* w2p; const float* b2;
+    float* pre; float* act_out;                  // (rows, ff): fwd outputs (either may be null); BWD: pre is an INPUT, act_out = dH
+    const float* residual; long ldr; float beta;
+    float* y; long ldy;
+    int rows, ff, act;
+    float p_in; unsigned long long seed_in;
+    float p_out; unsigned long long seed_out;
+    const unsigned long long* seed_dev;
+};
+
+// derivative of the three activations the kernel admits (oe_ffn_supported): none, relu, swish - act_bwd's full table (tanh, erf, ...)
+// is too much code for the unrolled epilogue: hipcc then keeps a loop and the tile's registers become a private array in LDS
+__device__ __forceinline__ float f6_act_bwd(int act, float x) {
+    const float s = sigmoidf_(x);
+    const float sw = s * (1.f + x * (1.f - s));
+    return act == OE_ACT_SWISH ? sw : (act == OE_ACT_RELU ? (x > 0.f ? 1.f : 0.f) : 1.f);
+}
+struct F6 { bf16x8 p[3]; };
+
+// Diagnostic build only (-DOE_GEMM_STAMPS, tools/ffn6_stamps.py): s_memtime stamps of block 0's waves at the phase boundaries,
+// written to a buffer nothing else reads.  No stamp exists in the shipped library.
+#ifdef OE_GEMM_STAMPS
+static __device__ unsigned long long* f6_stamp_buf = nullptr;
+extern "C" int oe_ffn6_set_stamps(void* buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(f6_stamp_buf), &buf, sizeof(buf));
+}
+#define F6_STAMP(slot)                                                                                                   \
+    do {                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        unsigned long long t_;                                                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                    \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (f6_stamp_buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (slot) < 128) f6_stamp_buf[(threadIdx.x >> 6) * 128 + (slot)] = t_; \
+    } while (0)
+#else
+#define F6_STAMP(slot) do { } while (0)
+#endif
+__device__ __forceinline__ int f6_acc_row(int r, int lk) { return (r & 3) + 8 * (r >> 2) + 4 * lk; }
+__device__ __forceinline__ void f6_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void f6_wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Epilogue 1 of one 32 x 32 h^T tile (fc on the accumulator rows, row m on the lane) - a function with BY-VALUE arguments, not a
+// lambda: captured by reference, the prefetched pre-activation rows were kept in memory (a private array promoted to LDS, each load
+// waited for with vmcnt(0) and parked there).  q0..q3: forward = the bias of the tile's columns 8 g + 4 lk .. + 3 (g = 0..3);
+// backward = rows 8 ps + (lane >> 3), columns 4 (lane & 7) .. + 3 of the forward's pre-activation tile (ps = 0..3).
+// hv: the finished tile (activation x mask / dH) in accumulator order, for f6_write_planes.
+template <bool BWD, int NOUT>
+__device__ __forceinline__ void f6_epilogue1(const Ffn6Params& p, const f32x16& hacc, float4 q0, float4 q1, float4 q2, float4 q3, long mrow, int ft,
+                                             int lane, float* patch, unsigned long long seed_in, const DropParams& dp_in, float (&hv)[16]) {
+    const int lq = lane & 31, lk = lane >> 5;
+    auto store_tile = [&](float* out) {                              // the tile's 32 x 32 block of a (rows, ff) tensor as 128-byte row segments
+        f6_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[lq * 36 + f6_acc_row(r, lk)] = hv[r];
+        f6_wave_sync();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            if (mrow + row < p.rows)
+                *reinterpret_cast<float4*>(out + (mrow + row) * p.ff + ft * 32 + c4) = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+        }
+    };
+    if (!BWD) {
+        hv[0] = hacc[0] + q0.x; hv[1] = hacc[1] + q0.y; hv[2] = hacc[2] + q0.z; hv[3] = hacc[3] + q0.w;
+        hv[4] = hacc[4] + q1.x; hv[5] = hacc[5] + q1.y; hv[6] = hacc[6] + q1.z; hv[7] = hacc[7] + q1.w;
+        hv[8] = hacc[8] + q2.x; hv[9] = hacc[9] + q2.y; hv[10] = hacc[10] + q2.z; hv[11] = hacc[11] + q2.w;
+        hv[12] = hacc[12] + q3.x; hv[13] = hacc[13] + q3.y; hv[14] = hacc[14] + q3.z; hv[15] = hacc[15] + q3.w;
+        if (NOUT >= 1 && p.pre) store_tile(p.pre);
+        if (p.act == OE_ACT_SWISH) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] *= sigmoidf_(hv[r]);
+        } else if (p.act == OE_ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hv[r] = fmaxf(hv[r], 0.f);
+        }
+    } else {
+        // the pre-activation tile, coalesced into the patch and read back transposed
+        f6_wave_sync();
+        float* pr = &patch[(lane >> 3) * 36 + (lane & 7) * 4];
+        *reinterpret_cast<float4*>(pr) = q0;
+        *reinterpret_cast<float4*>(pr + 8 * 36) = q1;
+        *reinterpret_cast<float4*>(pr + 16 * 36) = q2;
+        *reinterpret_cast<float4*>(pr + 24 * 36) = q3;
+        f6_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hv[r] = hacc[r] * f6_act_bwd(p.act, patch[lq * 36 + f6_acc_row(r, lk)]);
+    }
+    if (p.p_in > 0.f) {
+        const unsigned long long e0 = (unsigned long long)(mrow + lq) * p.ff + ft * 32 + 4 * lk;     // element (m, fc) of the (rows, ff) tensor
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const uint2 h = drop_hash4(seed_in, (e0 + 8 * g4) >> 2);
+            hv[4 * g4] *= drop_field(h.x, 0, dp_in); hv[4 * g4 + 1] *= drop_field(h.x, 1, dp_in);
+            hv[4 * g4 + 2] *= drop_field(h.y, 0, dp_in); hv[4 * g4 + 3] *= drop_field(h.y, 1, dp_in);
+        }
+    }
+    if ((BWD || NOUT == 2) && p.act_out) store_tile(p.act_out);
+}
+// three planes of a finished tile, as the two B fragments (k-steps s = 0, 1) of GEMM 2: lane-linear 16-byte pieces.  Only after
+// EVERY row tile's patch traffic is over: the patch lives in the same LDS region as these planes.
+__device__ __forceinline__ void f6_write_planes(const float (&hv)[16], unsigned char* hdst, int s_stride, int lane) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = hv[8 * s + e];
+        oe_bf16x8 pl[3];
+        oe_split8<3>(v, pl);
+#pragma unroll
+        for (int pn = 0; pn < 3; ++pn) *reinterpret_cast<oe_bf16x8*>(hdst + s * s_stride + pn * 1024 + lane * 16) = pl[pn];
+    }
+}
+
+// D = model width, RT = 32-row tiles per block, BWD = the input gradient, NOUT = (rows, ff) tensors written per tile (fwd: 0 / 1 / 2),
+// NG = wave groups.  NG = 2 (RT = 1): eight waves, two per SIMD; group g walks the chunks g, g + 2, ... with an h buffer of its own
+// and runs ONE BARRIER BEHIND the other group, so that in every interval between two barriers one group is in its matrix phase
+// (GEMM 2 of a chunk + GEMM 1 of its next) while the other is in its vector phase (epilogue 1): with one wave per SIMD the
+// epilogues (a quarter of the block's cycles, tools/ffn6_stamps.py) and every wait on the weight stream stand in front of the
+// matrix pipe; with two co-resident waves of opposite phase the hardware interleaves them.  The groups' partial y^T meet in LDS.
+template <int D, int RT, bool BWD, int NOUT, int NG>
+__global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 1) void ffn6_kernel(Ffn6Params p) {
+    static_assert(NG == 1 || (NG == 2 && RT == 1), "two wave groups: 32-row blocks");
+    constexpr int BM = 32 * RT;
+    constexpr int KS = D / 16, DT = D / 32, DPW = DT / 4;            // k-steps of GEMM 1, output tiles, output tiles per wave
+    constexpr int FR = 2, NSET = 4;
+    constexpr int NS1 = KS / FR, NS2 = DPW * 8 / FR, NSTG = NS1 + NS2;
+    static_assert(DT % 4 == 0 && KS % FR == 0 && NSTG % NSET == 0, "stage split");
+    constexpr int XP = D + 8;                                        // bf16 elements per x row in LDS
+    constexpr int X_BYTES = 3 * BM * XP * 2;
+    constexpr int H_WAVE = 2 * RT * 3 * 1024;                        // one wave's h tile: [s][rt][plane][lane][8] bf16
+    constexpr int H_BYTES = 4 * H_WAVE;
+    static_assert(H_WAVE >= 32 * 36 * 4, "the wave's h region doubles as its 32 x 36 fp32 patch");
+    constexpr int PIECE = 3 * 1024;                                  // one packed fragment: three planes
+    constexpr int NT = RT * DPW;                                     // output tiles (32 x 32) per wave
+    static_assert(NG == 1 || (NT % 2 == 0 && 8 * (NT / 2) * 4096 <= X_BYTES), "the groups' exchange buffer reuses the x planes");
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[X_BYTES + NG * H_BYTES];
+    unsigned char* xs = lds;
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = NG == 2 ? (wv >> 2) : 0;                         // wave group; `wave` = this wave's role inside it
+    const int wave = wv & 3;
+    unsigned char* hs = lds + X_BYTES + grp * H_BYTES;
+    const int lq = lane & 31, lk = lane >> 5;
+    const long m0 = (long)blockIdx.x * BM;
+    const int nchunks = p.ff / 128;
+    const int rot = blockIdx.x % nchunks;                            // blocks start their walk over the weights at different chunks
+
+    // ---- the block's rows -> three bf16 planes in LDS (rows past the end re-read the last one; never stored)
+    {
+        constexpr int C4 = D / 4;
+        for (int i = threadIdx.x; i < BM * C4; i += 256 * NG) {
+            const int row = i / C4, c4 = (i - row * C4) * 4;
+            const long gr = min(m0 + row, (long)p.rows - 1);
+            const float4 v = *reinterpret_cast<const float4*>(p.x + gr * p.ldx + c4);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            oe_bf16x4v pl[3];
+            oe_split4<3>(xv, pl);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + c4) * 2) = pl[n];
+        }
+    }
+
+    // ---- the weight stream.  Stage w (0 .. NSTG - 1) of a chunk: FR packed fragments - GEMM 1's first (k-steps FR w + j of this
+    // wave's ff tile), then GEMM 2's ([dtl][ftl][s] order).  Which fragments a stage holds is a COMPILE-TIME property of w, the
+    // chunk only moves two wave-uniform base pointers: no branch, no division in the loop (a runtime stage decode cost 50 branches
+    // per chunk and cut the loop into scheduling regions of a dozen MFMAs).
+    const unsigned char* w1l = p.w1p + lane * 16 + (long)wave * KS * PIECE;            // + chunk * 4 KS PIECE
+    const unsigned char* w2l = p.w2p + lane * 16 + (long)wave * DPW * 2 * PIECE;      // + chunk * 4 DT 2 PIECE
+    constexpr long W1_CHUNK = 4L * KS * PIECE, W2_CHUNK = 4L * DT * 2 * PIECE;
+    auto load_stage = [&](auto w_c, int c, F6 (&f)[FR]) {
+        constexpr int w = decltype(w_c)::value;
+        const unsigned char* b1p = w1l + c * W1_CHUNK;
+        const unsigned char* b2p = w2l + c * W2_CHUNK;
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+            const unsigned char* src;
+            if constexpr (w < NS1) {
+                src = b1p + (long)(w * FR + j) * PIECE;
+            } else {
+                const int fidx = (w - NS1) * FR + j;                                   // [dtl][ftl][s]
+                const int dtl = fidx >> 3, ftl = (fidx >> 1) & 3, s = fidx & 1;
+                src = b2p + (long)(((ftl * DT + dtl) * 2) + s) * PIECE;
+            }
+            f[j].p[0] = *reinterpret_cast<const bf16x8*>(src); f[j].p[1] = *reinterpret_cast<const bf16x8*>(src + 1024);
+            f[j].p[2] = *reinterpret_cast<const bf16x8*>(src + 2048);
+        }
+    };
+    auto chunk_at = [&](int ci) {                                    // the ci-th chunk of this block's walk (past the end: the last one again)
+        int c = min(ci, nchunks - 1) + rot;
+        return c >= nchunks ? c - nchunks : c;
+    };
+    F6 fr[NSET][FR];
+    {
+        const int c0 = chunk_at(grp);
+        static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, c0, fr[decltype(k_c)::value]); });
+    }
+
+    f32x16 yacc[RT][DPW];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int t = 0; t < DPW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) yacc[a][t][r] = 0.f;
+    const unsigned long long sd = p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull;
+    const unsigned long long seed_in = p.seed_in + sd, seed_out = p.seed_out + sd;
+    const DropParams dp_in = drop_params(p.p_in), dp_out = drop_params(p.p_out);
+    unsigned char* hmine = hs + wave * H_WAVE;
+    float* patch = reinterpret_cast<float*>(hmine);
+
+    // x fragment (B operand of GEMM 1): row 32 rt + lq, features 16 ks + 8 lk .. + 7
+    auto x_frag = [&](int rt, int ks, F6& f) {
+        const unsigned char* a = xs + ((size_t)(rt * 32 + lq) * XP + 16 * ks + 8 * lk) * 2;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(a + (size_t)n * BM * XP * 2);
+    };
+    F6_STAMP(0);
+    __syncthreads();                                                 // x planes (nothing else is in flight in LDS yet)
+    F6_STAMP(1);
+    if (NG == 2 && grp == 1) f6_lds_barrier();                       // the stagger: group 1 runs one barrier behind group 0
+
+    for (int ci = grp; ci < nchunks; ci += NG) {
+        const int c = chunk_at(ci), c_next = chunk_at(ci + NG);
+        const int ft = 4 * c + wave;
+        // ---- bias / pre-activation of this tile, issued ahead of the product (named registers: see f6_epilogue1)
+        float4 qa0, qa1, qa2, qa3, qb0, qb1, qb2, qb3;
+        qa0 = qa1 = qa2 = qa3 = qb0 = qb1 = qb2 = qb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!BWD) {
+            if (p.b1) {
+                const float* bp = p.b1 + ft * 32 + 4 * lk;
+                qa0 = *reinterpret_cast<const float4*>(bp); qa1 = *reinterpret_cast<const float4*>(bp + 8); qa2 = *reinterpret_cast<const float4*>(bp + 16); qa3 = *reinterpret_cast<const float4*>(bp + 24);
+            }
+        } else {
+            const long col = ft * 32 + (lane & 7) * 4;
+            const long last = (long)p.rows - 1;
+            const long r0 = m0 + (lane >> 3);
+            qa0 = *reinterpret_cast<const float4*>(p.pre + min(r0, last) * p.ff + col);
+            qa1 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 8, last) * p.ff + col);
+            qa2 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 16, last) * p.ff + col);
+            qa3 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 24, last) * p.ff + col);
+            if constexpr (RT > 1) {
+                qb0 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 32, last) * p.ff + col);
+                qb1 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 40, last) * p.ff + col);
+                qb2 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 48, last) * p.ff + col);
+                qb3 = *reinterpret_cast<const float4*>(p.pre + min(r0 + 56, last) * p.ff + col);
+            }
+        }
+        // ---- GEMM 1: h^T tile = W1[ft] . x^T, both row tiles
+        f32x16 hacc[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hacc[rt][r] = 0.f;
+        F6 xf[2][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) x_frag(rt, 0, xf[0][rt]);
+        static_for<0, NS1>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int cu = st % NSET, pf = (st + NSET - 1) % NSET;
+            constexpr int ahead = st + NSET - 1;                     // stage prefetched now: unconditional (a branch here makes hipcc wait vmcnt(0))
+            load_stage(std::integral_constant<int, ahead % NSTG>{}, ahead < NSTG ? c : c_next, fr[pf]);
+            __builtin_amdgcn_sched_barrier(0);                      // nothing crosses: left alone, hipcc sinks each prefetch load to its first use
+            //                                                         (shorter live range) and waits vmcnt(0) there - a load-use chain, not a ring
+            static_for<0, FR>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                constexpr int ks = st * FR + j;
+                if constexpr (ks + 1 < KS) {
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) x_frag(rt, ks + 1, xf[(ks + 1) & 1][rt]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) hacc[rt] = oe_mma_terms<6>(fr[cu][j], xf[ks & 1][rt], hacc[rt]);
+            });
+        });
+        F6_STAMP(2 + 5 * (ci / NG));                                 // GEMM 1 done
+        // every wave of the group has finished reading the previous chunk's h tiles (its GEMM 2) before anyone overwrites them
+        // (unconditional: with two groups every barrier is one group's "read" and the other's "written" barrier)
+        f6_lds_barrier();
+        F6_STAMP(3 + 5 * (ci / NG));
+        // ---- epilogue 1, per row tile: first everything that goes through the patch, then the planes (same LDS region)
+        float hv0[16], hv1[16];
+        f6_epilogue1<BWD, NOUT>(p, hacc[0], qa0, qa1, qa2, qa3, m0, ft, lane, patch, seed_in, dp_in, hv0);
+        if constexpr (RT > 1) {
+            if (BWD) f6_epilogue1<BWD, NOUT>(p, hacc[1], qb0, qb1, qb2, qb3, m0 + 32, ft, lane, patch, seed_in, dp_in, hv1);
+            else f6_epilogue1<BWD, NOUT>(p, hacc[1], qa0, qa1, qa2, qa3, m0 + 32, ft, lane, patch, seed_in, dp_in, hv1);
+        }
+        f6_wave_sync();
+        f6_write_planes(hv0, hmine, RT * 3 * 1024, lane);
+        if constexpr (RT > 1) f6_write_planes(hv1, hmine + 3 * 1024, RT * 3 * 1024, lane);
+        F6_STAMP(4 + 5 * (ci / NG));                                 // epilogue 1 done
+        f6_lds_barrier();                                            // the chunk's four h tiles are in LDS
+        F6_STAMP(5 + 5 * (ci / NG));
+        // ---- GEMM 2: y^T[this wave's d tiles] += W2[d tiles, chunk] . h^T
+        auto h_frag = [&](int ftl, int s, int rt, F6& f) {
+            const unsigned char* a = hs + ftl * H_WAVE + ((s * RT + rt) * 3) * 1024 + lane * 16;
+#pragma unroll
+            for (int pn = 0; pn < 3; ++pn) f.p[pn] = *reinterpret_cast<const bf16x8*>(a + pn * 1024);
+        };
+        F6 hf[2][RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) h_frag(0, 0, rt, hf[0][rt]);
+        static_for<0, NS2>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int cu = (NS1 + st) % NSET, pf = (NS1 + st + NSET - 1) % NSET;
+            constexpr int ahead = NS1 + st + NSET - 1;
+            load_stage(std::integral_constant<int, ahead % NSTG>{}, ahead < NSTG ? c : c_next, fr[pf]);
+            __builtin_amdgcn_sched_barrier(0);                      // nothing crosses: left alone, hipcc sinks each prefetch load to its first use
+            //                                                         (shorter live range) and waits vmcnt(0) there - a load-use chain, not a ring
+            static_for<0, FR>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                constexpr int fidx = st * FR + j;
+                constexpr int dtl = fidx >> 3;
+                if constexpr (fidx + 1 < DPW * 8) {
+                    constexpr int nx = fidx + 1;
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) h_frag((nx >> 1) & 3, nx & 1, rt, hf[nx & 1][rt]);
+                }
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) yacc[rt][dtl] = oe_mma_terms<6>(fr[cu][j], hf[fidx & 1][rt], yacc[rt][dtl]);
+            });
+        });
+        F6_STAMP(6 + 5 * (ci / NG));                                 // GEMM 2 done
+    }
+    F6_STAMP(2 + 5 * (nchunks / NG));                                // last GEMM 2 done
+    if (NG == 2 && grp == 0) f6_lds_barrier();                       // (group 1 made this one at its start)
+    f6_lds_barrier();                                                // the last chunk's h tiles have been read: the regions are patches now
+
+    // ---- two groups: each wave hands the tiles its partner (same role, other group) finishes to it through LDS (the x planes are
+    // dead by now) and adds the partner's share of its own: tile t belongs to group t % 2
+    if constexpr (NG == 2) {
+        float* ex = reinterpret_cast<float*>(xs);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if ((t & 1) != grp) {
+                float* dst = ex + (size_t)((grp * 4 + wave) * (NT / 2) + (t >> 1)) * 1024 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[r * 64] = yacc[t / DPW][t % DPW][r];
+            }
+        f6_lds_barrier();
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if ((t & 1) == grp) {
+                const float* src = ex + (size_t)(((1 - grp) * 4 + wave) * (NT / 2) + (t >> 1)) * 1024 + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) yacc[t / DPW][t % DPW][r] += src[r * 64];
+            }
+    }
+
+    // ---- epilogue 2: this wave's 32 DPW output columns of every row tile (two groups: the tiles of its own parity)
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int dtl = 0; dtl < DPW; ++dtl) {
+            if (NG == 2 && ((rt * DPW + dtl) & 1) != grp) continue;
+            const int dt = wave * DPW + dtl;
+            f6_wave_sync();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) patch[lq * 36 + f6_acc_row(r, lk)] = yacc[rt][dtl][r];
+            f6_wave_sync();
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+                const long gr = m0 + rt * 32 + row;
+                if (gr >= p.rows) continue;
+                const int col = dt * 32 + c4;
+                float4 v = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+                if (p.b2) { v.x += p.b2[col]; v.y += p.b2[col + 1]; v.z += p.b2[col + 2]; v.w += p.b2[col + 3]; }
+                if (p.p_out > 0.f) {
+                    const uint2 h = drop_hash4(seed_out, ((unsigned long long)gr * D + col) >> 2);
+                    v.x *= drop_field(h.x, 0, dp_out); v.y *= drop_field(h.x, 1, dp_out);
+                    v.z *= drop_field(h.y, 0, dp_out); v.w *= drop_field(h.y, 1, dp_out);
+                }
+                float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.residual) res = *reinterpret_cast<const float4*>(p.residual + gr * p.ldr + col);
+                v = make_float4(res.x + p.beta * v.x, res.y + p.beta * v.y, res.z + p.beta * v.z, res.w + p.beta * v.w);
+                *reinterpret_cast<float4*>(p.y + gr * p.ldy + col) = v;
+            }
+        }
+    F6_STAMP(3 + 5 * (nchunks / NG));
+}
+
+template <int D, int RT, int NG>
+static int ffn6_launch(const Ffn6Params& p, bool bwd, int nout, hipStream_t st) {
+    const dim3 grid(oe_cdiv(p.rows, 32 * RT)), block(256 * NG);
+    if (bwd) hipLaunchKernelGGL((ffn6_kernel<D, RT, true, 1, NG>), grid, block, 0, st, p);
+    else if (nout == 2) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 2, NG>), grid, block, 0, st, p);
+    else if (nout == 1) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 1, NG>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 0, NG>), grid, block, 0, st, p);
+    OE_LAUNCH_CHECK(bwd ? "oe_ffn_bwd (precision 6)" : "oe_ffn_fwd (precision 6)");
+    return 0;
+}
+
+int oe_ffn6_supported(int d, int ff) { return (d == 128 || d == 256 || d == 512) && ff > 0 && ff % 128 == 0 && ff <= 8192; }
+
+// Block shape (OE_FFN6_MODE forces one: 1 = 64 rows / 4 waves, 2 = 32 rows / 4 waves, 3 = 32 rows / 8 waves in two groups).
+// Measured on MI355X (tools/ffn6_bench.py, profiles/r04_ffn6.md): the kernel is bound by the weight stream (3 MB of planes per
+// block at d = 256) and by what one wave per SIMD cannot overlap; two staggered groups are the default wherever they exist.
+static int ffn6_mode_v = getenv("OE_FFN6_MODE") ? atoi(getenv("OE_FFN6_MODE")) : 0;
+static int ffn6_mode() { return ffn6_mode_v; }
+extern "C" int oe_ffn6_config(int mode) {
+    if (mode >= 0) ffn6_mode_v = mode;
+    return ffn6_mode_v;
+}
+
+// called by ffn.hip's oe_ffn_fwd / oe_ffn_bwd for precision 6 (arguments already validated there)
+int oe_ffn6_run(const oe_ffn_args* a, bool bwd, void* stream) {
+    Ffn6Params p{};
+    p.x = a->x; p.ldx = a->ldx; p.w1p = (const unsigned char*)a->w1p; p.b1 = a->b1; p.w2p = (const unsigned char*)a->w2p; p.b2 = a->b2;
+    p.pre = a->pre_out; p.act_out = a->act_out; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta; p.y = a->y; p.ldy = a->ldy;
+    p.rows = a->rows; p.ff = a->ff; p.act = a->act; p.p_in = a->drop_in; p.seed_in = a->seed_in; p.p_out = a->drop_out; p.seed_out = a->seed_out;
+    p.seed_dev = a->seed_dev;
+    const int nout = a->act_out ? 2 : a->pre_out ? 1 : 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int mode = ffn6_mode();
+    const bool two_groups = (a->ff % 256 == 0) && mode != 1 && mode != 2;
+    if (a->d == 512) return two_groups ? ffn6_launch<512, 1, 2>(p, bwd, nout, st) : ffn6_launch<512, 1, 1>(p, bwd, nout, st);
+    if (a->d == 256) {
+        if (two_groups) return ffn6_launch<256, 1, 2>(p, bwd, nout, st);
+        return mode == 2 ? ffn6_launch<256, 1, 1>(p, bwd, nout, st) : ffn6_launch<256, 2, 1>(p, bwd, nout, st);
+    }
+    return ffn6_launch<128, 2, 1>(p, bwd, nout, st);
+}

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "oe_ffn_pack_weights_bwd": (I, [P, P, I, I, I, P, P, P]),
     "oe_ffn_fwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_ffn_bwd": (I, [C.POINTER(FfnArgs), P]),
+    "oe_ffn6_config": (I, [I]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_fwd_pl": (I, [P, P, P, F, I, I, P, I, P, P, P, L, P]),

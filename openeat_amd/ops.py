@@ -918,7 +918,13 @@ FUSED_FFN = os.environ.get("OE_FUSED_FFN", "1") == "1"
 # chip (config 2: 7936 rows = 248 blocks, 71 us incl. the weight packing against 79 us for the two GEMMs); the decoders'
 # 992 rows are 31 blocks that each still take the full ~56 us, against 41 us for their two small GEMMs.
 FUSED_FFN_MIN_ROWS = int(os.environ.get("OE_FUSED_FFN_MIN_ROWS", "4096"))
-FUSED_FFN_BWD = os.environ.get("OE_FUSED_FFN_BWD", "0") == "1"         # the input gradient in one launch too: measured slower in the step (profiles/r02_experiments.md), off
+# the input gradient in one launch too (oe_ffn_bwd).  None = automatic: on in precision 6 (csrc/ffn6.hip: 61 us against 92 for the
+# two GEMMs at 7936 rows, profiles/r04_ffn6.md), off in precision 1 / 3 (measured slower in the step, profiles/r02_experiments.md)
+FUSED_FFN_BWD = {"1": True, "0": False}.get(os.environ.get("OE_FUSED_FFN_BWD", ""), None)
+
+
+def _ffn_bwd_fused() -> bool:
+    return (hip.GEMM_PRECISION == 6) if FUSED_FFN_BWD is None else bool(FUSED_FFN_BWD)
 
 
 def _ffn_fused_ok(x2, w1, w2, act, res2):
@@ -993,7 +999,7 @@ class FeedForwardFn(torch.autograd.Function):
         g2 = dy2 if (p_out == 0 and out_scale == 1.0) else _out_drop_grad(dy2, out_scale, p_out, s_out)
         b1, b2 = ctx.biases
         dw2, db2 = wgrad_bias(w2, b2, g2, a)
-        if ctx.fused and FUSED_FFN_BWD and g2.stride(0) % 4 == 0:
+        if ctx.fused and _ffn_bwd_fused() and g2.stride(0) % 4 == 0:
             # both input-gradient GEMMs in one launch (csrc/ffn.hip, oe_ffn_bwd): dH is written once and never re-read here
             M, d, ff = g2.shape[0], w2.shape[0], w1.shape[0]
             prec = hip.GEMM_PRECISION

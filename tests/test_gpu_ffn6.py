@@ -1,0 +1,200 @@
+"""GPU: the one-kernel feed forward in the headline arithmetic (precision 6, csrc/ffn6.hip) and its input gradient, through the
+C ABI (oe_ffn_pack_weights / oe_ffn_fwd / oe_ffn_pack_weights_bwd / oe_ffn_bwd), against float64 restatements of
+positionwise_feed_forward.py:36-43 with the caller's dropout / scaled residual (encoder_layer.py:81-83,104-106).
+
+Tolerance: precision 6 is held to what the exact-fp32-input GEMM path itself shows against float64 on the same problem (the
+two-GEMM path at oe_gemm_args.precision = 0), with a factor for the different summation order - not to a widened bf16 figure."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from openeat_amd import hip, ops  # noqa: E402
+
+DEV = "cuda"
+
+
+def cu(t):
+    return t.to(DEV).contiguous()
+
+
+def sync():
+    torch.cuda.synchronize()
+
+
+def test_precision6_shapes_are_supported():
+    L = hip.lib()
+    assert L.oe_ffn_supported(256, 1024, 6, 2) and L.oe_ffn_supported(512, 2048, 6, 2) and L.oe_ffn_supported(128, 512, 6, 1)
+    assert not L.oe_ffn_supported(384, 1024, 6, 2) and not L.oe_ffn_supported(256, 1000, 6, 2) and not L.oe_ffn_supported(256, 1024, 6, 3)
+    assert L.oe_ffn_packed_bytes(256, 1024, 6) == 256 * 1024 * 2 * 3
+
+
+def _unfused_fp32(x, w1, b1, w2, b2, res, act, beta, p_in, s_in, p_out, s_out, ctr):
+    """The same feed forward as two oe_gemm_f32 launches on the fp32-input MFMA (precision 0): the error yardstick."""
+    rows, d = x.shape
+    ff = w1.shape[0]
+    pre = torch.empty(rows, ff, device=DEV)
+    a = torch.empty(rows, ff, device=DEV)
+    hip.gemm(x, w1, a, rows, ff, d, lda=d, ldb=d, ldc=ff, bias=b1, act=act, preact_out=pre, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=ctr,
+             precision=0)
+    y = torch.empty(rows, d, device=DEV)
+    hip.gemm(a, w2, y, rows, d, ff, lda=ff, ldb=ff, ldc=d, bias=b2, drop_p=p_out, seed=s_out, seed_dev=ctr, residual=res, ldr=d, beta=beta,
+             precision=0)
+    return y, pre, a
+
+
+@pytest.mark.parametrize("rows,d,ff,act,p_in,p_out,nout", [
+    (7936, 256, 1024, 2, 0.1, 0.1, 2),            # the benchmark's encoder feed-forward (124 blocks of 64 rows)
+    (1000, 256, 1024, 2, 0.1, 0.1, 1),            # ragged last block (1000 = 15 * 64 + 40), pre-activation only
+    (77, 256, 512, 1, 0.0, 0.0, 0),               # relu, nothing saved, a second block of 13 rows
+    (333, 128, 512, 1, 0.0, 0.25, 2),             # d = 128 (configs[0] width): one output tile per wave
+    (64, 128, 128, 0, 0.0, 0.0, 2),               # one chunk, no activation
+    (1500, 512, 2048, 2, 0.1, 0.1, 2),            # configs[4] width: 32-row blocks, four output tiles per wave
+    (31, 512, 256, 2, 0.0, 0.0, 1),               # less than one block of rows
+])
+@pytest.mark.parametrize("mode", [0, 1, 2], ids=["auto", "64rows-4waves", "32rows-4waves"])
+def test_fused_feed_forward_precision6(rows, d, ff, act, p_in, p_out, nout, mode):
+    """mode: the block shape (oe_ffn6_config) - automatic = two staggered wave groups wherever ff % 256 == 0."""
+    if mode and d != 256:
+        pytest.skip("block shapes other than the automatic one exist at d = 256 only")
+    hip.lib().oe_ffn6_config(mode)
+    try:
+        _fwd_case(rows, d, ff, act, p_in, p_out, nout)
+    finally:
+        hip.lib().oe_ffn6_config(0)
+
+
+def _fwd_case(rows, d, ff, act, p_in, p_out, nout):
+    torch.manual_seed(66)
+    x = torch.randn(rows, d)
+    w1, b1 = torch.randn(ff, d) / math.sqrt(d), torch.randn(ff) * 0.1
+    w2, b2 = torch.randn(d, ff) / math.sqrt(ff), torch.randn(d) * 0.1
+    res = torch.randn(rows, d)
+    beta, s_in, s_out = 0.5, 0x1111, 0x2222
+    L = hip.lib()
+    assert L.oe_ffn_supported(d, ff, 6, act)
+    nb = L.oe_ffn_packed_bytes(d, ff, 6)
+    w1p, w2p = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    xd, w1d, w2d, b1d, b2d, resd = cu(x), cu(w1), cu(w2), cu(b1), cu(b2), cu(res)
+    hip.call("oe_ffn_pack_weights", w1d, w2d, d, ff, 6, w1p, w2p)
+    pre = torch.full((rows, ff), float("nan"), device=DEV) if nout >= 1 else None
+    aout = torch.full((rows, ff), float("nan"), device=DEV) if nout == 2 else None
+    y = torch.full((rows, d), float("nan"), device=DEV)
+    ctr = torch.tensor([3], dtype=torch.int64, device=DEV)
+    hip.ffn_fwd(xd, w1p, b1d, w2p, b2d, rows, d, ff, act, drop_in=p_in, seed_in=s_in, drop_out=p_out, seed_out=s_out, seed_dev=ctr,
+                pre_out=pre, act_out=aout, residual=resd, ldr=d, beta=beta, y=y, precision=6)
+    y0, pre0, a0 = _unfused_fp32(xd, w1d, b1d, w2d, b2d, resd, act, beta, p_in, s_in, p_out, s_out, ctr)
+    ones_in, ones_out = torch.ones(rows, ff, device=DEV), torch.ones(rows, d, device=DEV)
+    m_in, m_out = torch.empty_like(ones_in), torch.empty_like(ones_out)
+    hip.call("oe_dropout_scale", ones_in, ones_in.numel(), ff, 1.0, p_in, s_in, ctr, None, m_in)
+    hip.call("oe_dropout_scale", ones_out, ones_out.numel(), d, 1.0, p_out, s_out, ctr, None, m_out)
+    sync()
+    h = x.double() @ w1.double().t() + b1.double()
+    a = (h * torch.sigmoid(h) if act == 2 else h.clamp(min=0) if act == 1 else h) * m_in.cpu().double()
+    want = res.double() + beta * ((a @ w2.double().t() + b2.double()) * m_out.cpu().double())
+
+    def err(got, ref):
+        return float((got.cpu().double() - ref).abs().max())
+    e6, e0 = err(y, want), err(y0, want)
+    assert not torch.isnan(y).any()
+    assert e6 <= 2.5 * e0 + 1e-6 * float(want.abs().max()), (e6, e0)         # at the fp32-input kernel's own error
+    torch.testing.assert_close(y.cpu().double(), want, rtol=1e-4, atol=5e-5)  # mode 0's module tolerance
+    if nout >= 1:
+        assert err(pre, h) <= 2.5 * err(pre0, h) + 1e-6 * float(h.abs().max())
+    if nout == 2:
+        assert err(aout, a) <= 2.5 * err(a0, a) + 1e-6 * float(a.abs().max())
+        if p_in > 0:                                                          # bit-identical masks to oe_gemm_f32's epilogue
+            assert float(((aout == 0) != (m_in == 0)).float().mean()) < 1e-4  # (a itself can be exactly 0)
+
+
+@pytest.mark.parametrize("rows,d,ff,act,p_in", [(7936, 256, 1024, 2, 0.1), (333, 256, 512, 1, 0.0), (100, 128, 256, 2, 0.2), (64, 128, 128, 0, 0.0),
+                                                  (1100, 512, 2048, 2, 0.1)])
+@pytest.mark.parametrize("mode", [0, 1], ids=["auto", "64rows-4waves"])
+def test_fused_feed_forward_input_gradient_precision6(rows, d, ff, act, p_in, mode):
+    """oe_ffn_bwd in precision 6: dH = (dY W2) * mask * act'(pre), dX = dH W1 - against float64 and against the two
+    oe_gemm_f32 launches of the unfused backward on the fp32-input MFMA."""
+    if mode and d != 256:
+        pytest.skip("block shapes other than the automatic one exist at d = 256 only")
+    hip.lib().oe_ffn6_config(mode)
+    try:
+        _bwd_case(rows, d, ff, act, p_in)
+    finally:
+        hip.lib().oe_ffn6_config(0)
+
+
+def _bwd_case(rows, d, ff, act, p_in):
+    torch.manual_seed(67)
+    dy = torch.randn(rows, d)
+    w1, w2 = torch.randn(ff, d) / math.sqrt(d), torch.randn(d, ff) / math.sqrt(ff)
+    pre = torch.randn(rows, ff) * 1.5
+    s_in = 0x3333
+    L = hip.lib()
+    nb = L.oe_ffn_packed_bytes(d, ff, 6)
+    w2tp, w1tp = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    dyd, w1d, w2d, pred = cu(dy), cu(w1), cu(w2), cu(pre)
+    hip.call("oe_ffn_pack_weights_bwd", w1d, w2d, d, ff, 6, w2tp, w1tp)
+    dh = torch.full((rows, ff), float("nan"), device=DEV)
+    dx = torch.full((rows, d), float("nan"), device=DEV)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    hip.ffn_bwd(dyd, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pred, dh=dh, dx=dx, precision=6)
+    # the unfused backward in exact fp32 products
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = 0
+    try:
+        dh0 = ops.gemm_nn(dyd, w2d, act=act, actgrad_in=pred, ld_aux=ff, drop_p=p_in, seed=s_in, seed_dev=ctr)
+        dx0 = ops.gemm_nn(dh0, w1d)
+    finally:
+        hip.GEMM_PRECISION = old
+    ones = torch.ones(rows, ff, device=DEV)
+    m_in = torch.empty_like(ones)
+    hip.call("oe_dropout_scale", ones, ones.numel(), ff, 1.0, p_in, s_in, ctr, None, m_in)
+    sync()
+    h = pre.double()
+    sg = torch.sigmoid(h)
+    dact = sg * (1 + h * (1 - sg)) if act == 2 else (h > 0).double() if act == 1 else torch.ones_like(h)
+    want_dh = (dy.double() @ w2.double()) * m_in.cpu().double() * dact
+    want_dx = want_dh @ w1.double()
+
+    def err(got, ref):
+        return float((got.cpu().double() - ref).abs().max())
+    assert not torch.isnan(dh).any() and not torch.isnan(dx).any()
+    assert err(dh, want_dh) <= 2.5 * err(dh0, want_dh) + 1e-6 * float(want_dh.abs().max())
+    assert err(dx, want_dx) <= 2.5 * err(dx0, want_dx) + 1e-6 * float(want_dx.abs().max())
+    torch.testing.assert_close(dx.cpu().double(), want_dx, rtol=1e-4, atol=5e-5 * max(1.0, float(want_dx.abs().max())))
+
+
+def test_feed_forward_op_fused_equals_unfused_in_precision6():
+    """ops.feed_forward (the autograd function the encoder layers call) with the fused forward and the fused input gradient forced
+    on, against the same op on the two-GEMM path: output, input gradient, every parameter gradient."""
+    from openeat_amd import planes
+    old = (hip.GEMM_PRECISION, ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD, ops.FUSED_FFN)
+    hip.GEMM_PRECISION = 6
+    torch.manual_seed(68)
+    rows, d, ff = 700, 256, 1024
+    x0 = torch.randn(rows, d, device=DEV)
+    w1 = (torch.randn(ff, d, device=DEV) / 16).requires_grad_()
+    b1 = (torch.randn(ff, device=DEV) * 0.1).requires_grad_()
+    w2 = (torch.randn(d, ff, device=DEV) / 32).requires_grad_()
+    b2 = (torch.randn(d, device=DEV) * 0.1).requires_grad_()
+    wgt = torch.randn(rows, d, device=DEV)
+    out = {}
+    try:
+        for fused in (False, True):
+            ops.FUSED_FFN, ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD = fused, 0, fused
+            planes.clear_all()
+            ops.manual_seed(9)
+            x = x0.clone().requires_grad_()
+            for t in (w1, b1, w2, b2):
+                t.grad = None
+            y = ops.feed_forward(x, w1, b1, w2, b2, ops.ACT_SWISH, p_in=0.1, residual=x, out_scale=0.5, p_out=0.1)
+            (y * wgt).sum().backward()
+            ops.join_side_stream()
+            sync()
+            out[fused] = [y.detach().clone(), x.grad.clone()] + [t.grad.clone() for t in (w1, b1, w2, b2)]
+    finally:
+        hip.GEMM_PRECISION, ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD, ops.FUSED_FFN = old
+        planes.clear_all()
+    for a, b, name in zip(out[True], out[False], ("y", "dx", "dw1", "db1", "dw2", "db2")):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())), msg=lambda m, name=name: f"{name}: {m}")

@@ -27,7 +27,7 @@ from openeat_amd.modules.swish import Swish  # noqa: E402
 DEV = "cuda"
 
 
-@pytest.fixture(autouse=True, params=[0, 6, 60, 3], ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x3-mfma"])
+@pytest.fixture(autouse=True, params=[0, 6, 60, 62, 3], ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x6-fused-ffn", "bf16x3-mfma"])
 def gemm_precision(request):
     """Every test of this file runs three times: with exact-fp32 matrix products (oe_gemm_args.precision 0: gemm_f32_kernel
     and the fp32 attention variants), in the arithmetic bench.py's headline times (precision 6: three exact bf16 pieces per
@@ -36,15 +36,21 @@ def gemm_precision(request):
     close()) - same goldens, same bit-exact id checks."""
     # "planes-forced": precision 6 with every GEMM operand pre-split however small (planes.MIN_SPLIT_ELEMS = 0), so that the
     # goldens' tiny shapes go through oe_split_planes, the producers' planes outputs and gemm_pl.hip wherever they qualify
-    from openeat_amd import hip, planes
+    # "fused-ffn": precision 6 with the one-kernel feed forward and its one-kernel input gradient (csrc/ffn6.hip) forced on at
+    # the goldens' row counts (by default they take over from 4096 rows on): F05 / F06 / F19 and every end-to-end golden
+    from openeat_amd import hip, ops, planes
     old, old_min, old_pol = hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY
-    hip.GEMM_PRECISION = 6 if request.param == 60 else request.param
+    old_ffn = (ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD)
+    hip.GEMM_PRECISION = 6 if request.param in (60, 62) else request.param
     if request.param == 60:
         planes.MIN_SPLIT_ELEMS, planes.POLICY = 0, "all"
         hip.lib().oe_gemm_pl_config(0, -1, -1, -1)
+    if request.param == 62:
+        ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD = 0, True
     planes.clear()
     yield request.param
     hip.GEMM_PRECISION, planes.MIN_SPLIT_ELEMS, planes.POLICY = old, old_min, old_pol
+    ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD = old_ffn
     hip.lib().oe_gemm_pl_config(96, 0, 0, 8)
     planes.clear()
 

@@ -72,9 +72,9 @@ def _setup(seconds=None, tlens=None):
 
 
 @pytest.mark.parametrize("prec,fused_ffn,full", [(0, False, False), (6, False, False), (60, False, False), (3, False, False), (3, True, False),
-                                                  (6, False, True), (61, False, True)],
+                                                  (6, False, True), (61, False, True), (6, True, False), (6, True, True)],
                          ids=["fp32-mfma", "bf16x6-mfma", "bf16x6-planes-forced", "bf16x3-mfma", "bf16x3-mfma-fused-ffn",
-                              "bf16x6-mfma-B32", "bf16x6-planes-ln-B32"])
+                              "bf16x6-mfma-B32", "bf16x6-planes-ln-B32", "bf16x6-mfma-fused-ffn", "bf16x6-mfma-fused-ffn-B32"])
 def test_config2_width_model_matches_oracle(prec, fused_ffn, full):
     """fused_ffn: the one-kernel feed forward (csrc/ffn.hip) forced on at this batch's 1984 rows (by default it takes over from
     4096 rows on, i.e. at bench.py's batch) - the same tolerances end to end.  full: bench.py's batch size (32 utterances, 7936
@@ -212,18 +212,21 @@ def _setup5():
     return _C5
 
 
-@pytest.mark.parametrize("prec", [6, 0], ids=["bf16x6-mfma", "fp32-mfma"])
-def test_config5_width_model_matches_oracle(prec):
+@pytest.mark.parametrize("prec,fused_ffn", [(6, False), (0, False), (6, True)], ids=["bf16x6-mfma", "fp32-mfma", "bf16x6-mfma-fused-ffn"])
+def test_config5_width_model_matches_oracle(prec, fused_ffn):
     """The d = 512 dispatch (other tiles, K = 512 / 2048 reductions, eight heads of 64, 192.5 M parameters in one arena-less model)
     against oracle/asr.py on four ragged utterances: loss rtol 2e-4, every parameter-gradient norm 3e-3, CTC-greedy ids identical
     (asr_model.py:37-70 kwargs)."""
-    from openeat_amd import hip, planes
+    from openeat_amd import hip, ops, planes
     c = _setup5()
     model = ASRModel(80, V, **CONF5)
     model.load_state_dict(c["sd"])
     model = model.to(DEV).eval()
     old = hip.GEMM_PRECISION
     hip.GEMM_PRECISION = prec
+    old_ffn = (ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD)
+    if fused_ffn:                                    # csrc/ffn6.hip at d = 512, ff = 2048 (32-row blocks, two wave groups), forward and input gradient
+        ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD = 0, True
     try:
         loss, acc = model(c["feats"], c["nfr"], c["tgt"].to(DEV), c["tlen"].to(DEV))
         loss.backward()
@@ -232,6 +235,7 @@ def test_config5_width_model_matches_oracle(prec):
         torch.cuda.synchronize()
     finally:
         hip.GEMM_PRECISION = old
+        ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_BWD = old_ffn
         planes.clear()
     assert abs(float(loss) - c["loss"]) <= 2e-4 * abs(c["loss"]), (float(loss), c["loss"])
     assert abs(float(acc) - c["acc"]) <= 1e-6
