@@ -117,6 +117,12 @@ typedef struct oe_gemm_args {
      * sign of the source is read: plane 0 of an activation that exists as bf16 planes alone (the conv1 output of the
      * subsampling front end, whose fp32 copy - 636 MB at config 2 - is then never written or read). */
     int actgrad_bf16;
+    /* Weight gradients (a_kmajor && b_kmajor, atomic_out) on pre-split operands whose reduction length k is NOT a multiple of 16
+     * (ragged batches: k = valid rows of the step): set when BOTH planes buffers hold at least ceil(k / 16) * 16 rows and A's rows
+     * beyond k are ZERO (openeat_amd.planes.alloc pads every buffer that way); a gathered B is read at clamped positions there.
+     * The pre-split kernel then runs the padded length; without the flag such a k leaves it to the kernels that split in the loop
+     * (configs[4], 24L d = 512: the conv2 weight gradient over k = 222 547 positions took 57.9 ms there, a third of the step). */
+    int planes_k_padded;
 } oe_gemm_args;
 
 int oe_gemm_f32(const oe_gemm_args* args, void* stream);

@@ -246,7 +246,7 @@ extern "C" int oe_gemm_f32(const oe_gemm_args* g, void* stream) {
                "oe_gemm_f32: conv_korder 1 needs a gather on A, precision 6, pre-split operands, no split of the reduction and C %% 32 == 0");
     if (g->precision == 6 && g->a_planes && g->b_planes) {       // pre-split operands: tiles by LDS-DMA, no conversion in the loop
         const int r = oe_gemm_pl_try(A, B, g->a_planes, g->a_plane_stride, g->b_planes, g->b_plane_stride, g->c, g->ldc, M, N, K, sk, ep,
-                                     g->a_kmajor, g->b_kmajor, ga, gb, st, g->conv_korder);
+                                     g->a_kmajor, g->b_kmajor, ga, gb, st, g->conv_korder, g->planes_k_padded != 0);
         if (r != 1) return r;
         OE_REQUIRE(g->conv_korder == 0, "oe_gemm_f32: conv_korder 1, but the pre-split kernel does not take this problem (M=%d N=%d K=%d) - "
                                         "B is laid out for it alone", M, N, K);

@@ -144,7 +144,8 @@ int oe_gemm_dma_try(const OperandDesc& A, const OperandDesc& B, float* C, long l
 int oe_gemm_hyb_try(const OperandDesc& A, const OperandDesc& B, const void* Bp, long b_pstride, float* C, long ldc, int M, int N, int K, int sk,
                     const EpiParams& ep, bool b_kmajor, hipStream_t st);
 int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
-                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder = 0);
+                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder = 0,
+                   bool k_padded = false);
 
 // One output value: x = acc*alpha + bias -> (pre-activation kept) -> act fwd, or times act'(aux) in a
 // backward GEMM -> dropout mask -> dead-row zeroing -> res + beta*x.

@@ -114,7 +114,8 @@ __device__ __forceinline__ int pl_div_small(int k, int d, float rd, int& rem) { 
 // standing in front of the fragment reads).
 template <int TM, int TN, int WM, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
 __global__ __launch_bounds__(WM * 128, (WM == 2 && NST * 3 * (32 * TM * WM + 64 * TN) * BK * 2 <= 80 * 1024) ? 2 : (WM == 4 ? 2 : 1))
-void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep) {
+void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep,
+                    int k_valid) {
     int tile_x, tile_y, tile_z;
     {   // XCD-aware tile order (gemm_bf16.hip)
         const int nblk = gridDim.x, id = blockIdx.x;
@@ -221,7 +222,8 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
             pl_dma16(src[j] + ga_off, sb + dst[j]);
         } else if (is_gb[j]) {
             int f, t;
-            const int q = pl_div_small(kpos[j], B.F2, rF2, f);
+            // (reduction padded to the K-tile, oe_gemm_args.planes_k_padded: positions past the last one read the last one - A is zero there)
+            const int q = pl_div_small(min(kpos[j], k_valid - 1), B.F2, rF2, f);
             const int b = pl_div_small(q, B.T2, rT2, t);
             pl_dma16(src[j] + (((long)b * B.T1 + B.S * t) * B.F1 + B.S * f) * B.C, sb + dst[j]);
             kpos[j] += advance ? BK : 0;
@@ -341,13 +343,15 @@ extern "C" int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves) {
     return 0;
 }
 
+static int pl_k_valid = 0;          // set by oe_gemm_pl_try around a launch whose K was padded (host-side, same thread as the launch)
 template <int TM, int TN, int WM, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
 static int launch_pl(const PlOperand& A, const PlOperand& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep, hipStream_t st) {
     int kc = oe_cdiv(oe_cdiv(K, sk), BK) * BK;
     if (kc <= 0) kc = BK;
     const int nz = oe_cdiv(K, kc);
     const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 32 * TM * WM);
-    hipLaunchKernelGGL((gemm_pl_kernel<TM, TN, WM, AK, BKM, BK, NST, GA, GB>), dim3(gx * gy * nz), dim3(WM * 128), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep);
+    hipLaunchKernelGGL((gemm_pl_kernel<TM, TN, WM, AK, BKM, BK, NST, GA, GB>), dim3(gx * gy * nz), dim3(WM * 128), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep,
+                       pl_k_valid > 0 ? pl_k_valid : K);
     OE_LAUNCH_CHECK("oe_gemm (bf16x6 planes)");
     ++pl_launches;
     return 0;
@@ -356,8 +360,23 @@ static int launch_pl(const PlOperand& A, const PlOperand& B, float* C, long ldc,
 // Returns 1 when the problem does not qualify (the caller goes on to the kernels that split fp32 operands themselves),
 // 0 on a launch.  Ap / Bp: plane 0 of the operands' pre-split copies (plane strides in elements), same logical layout and
 // leading dimensions as the fp32 operands they mirror.
+static int pl_try_impl(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
+                       int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder);
 int oe_gemm_pl_try(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
-                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder) {
+                   int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder,
+                   bool k_padded) {
+    // a weight gradient over a reduction that is not a whole number of K-tiles: the caller vouches for zero rows of A (and readable
+    // rows of B) up to the next multiple of 16 - run the padded length, gathers clamp to the last valid position
+    if (k_padded && a_kmajor && b_kmajor && ep.atomic && K % 16 != 0 && K > 16) {
+        pl_k_valid = K;
+        const int r = pl_try_impl(A, B, Ap, a_pstride, Bp, b_pstride, C, ldc, M, N, (K + 15) / 16 * 16, sk, ep, a_kmajor, b_kmajor, ga, gb, st, korder);
+        pl_k_valid = 0;
+        return r;
+    }
+    return pl_try_impl(A, B, Ap, a_pstride, Bp, b_pstride, C, ldc, M, N, K, sk, ep, a_kmajor, b_kmajor, ga, gb, st, korder);
+}
+static int pl_try_impl(const OperandDesc& A, const OperandDesc& B, const void* Ap, long a_pstride, const void* Bp, long b_pstride, float* C, long ldc,
+                       int M, int N, int K, int sk, const EpiParams& ep, bool a_kmajor, bool b_kmajor, bool ga, bool gb, hipStream_t st, int korder) {
     static const int mode = getenv("OE_GEMM_PL") ? atoi(getenv("OE_GEMM_PL")) : 1;            // 0 = never (A/B comparisons)
     if (!mode || !Ap || !Bp) return 1;
     if (a_kmajor && !b_kmajor) return 1;

@@ -57,6 +57,7 @@ class GemmArgs(C.Structure):
         ("c_planes", c_fp), ("c_plane_stride", C.c_long), ("ldcp", C.c_long),
         ("conv_korder", C.c_int),
         ("actgrad_bf16", C.c_int),
+        ("planes_k_padded", C.c_int),
     ]
 
 
@@ -284,6 +285,8 @@ def gemm(a, b, c, m, n, k, *, lda, ldb, ldc, a_kmajor=False, b_kmajor=False, spl
         if a_planes is not None and b_planes is not None:
             g.a_planes, g.a_plane_stride = a_planes.ptr, a_planes.stride
             g.b_planes, g.b_plane_stride = b_planes.ptr, b_planes.stride
+            # a weight gradient's reduction may run to the next multiple of 16 when both buffers were allocated with zero pad rows
+            g.planes_k_padded = int(a_kmajor and b_kmajor and getattr(a_planes, "kpad", False) and getattr(b_planes, "kpad", False))
         elif b_planes is not None and a is not None:             # the weight operand alone (gemm_hyb.hip)
             g.b_planes, g.b_plane_stride = b_planes.ptr, b_planes.stride
         if c_planes is not None:

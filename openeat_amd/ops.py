@@ -1467,9 +1467,9 @@ class ConvSubsamplingFn(torch.autograd.Function):
         if _planes.available() and n > 0 and CONV1_PLANES_ONLY and geoms[0] == (3, 2) and CONV_DGRAD_IMPLICIT and CONV_WGRAD_PLANES \
                 and CONV_KORDER and C % 32 == 0 and C % 128 == 0 and T1 >= 3 and F1 >= 3:
             To0, Fo0 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
-            # (rows a multiple of the K-tile: the weight gradient reduces over them and has no other kernel to fall back to)
-            planes_only = (B * To0 * Fo0 >= CONV_KORDER_MIN_ROWS and B * (T1 // 2) * (F1 // 2) >= CONV_KORDER_MIN_ROWS and
-                           (B * To0 * Fo0) % 32 == 0)
+            # (the weight gradient reduces over the B To0 Fo0 output positions and has no other kernel to fall back to: any count
+            # goes since planes buffers carry zero pad rows to the next multiple of 16, oe_gemm_args.planes_k_padded)
+            planes_only = (B * To0 * Fo0 >= CONV_KORDER_MIN_ROWS and B * (T1 // 2) * (F1 // 2) >= CONV_KORDER_MIN_ROWS)
         if planes_only:
             y = None
             y_pl = _planes.alloc(B * T1 * F1, C, x.device)
@@ -1552,7 +1552,7 @@ class ConvSubsamplingFn(torch.autograd.Function):
             (dbk_buf, dbk) = grad_sink(bk)
             yin_pl = None
             if k == 0 and ctx.planes_only:          # acts[0] is the (3, rows, C) bf16 planes tensor: there is no fp32 copy
-                yin_pl = _planes.Planes(yin, yin.data_ptr(), yin.shape[1] * C, C, yin.shape[1], C)
+                yin_pl = _planes.Planes(yin, yin.data_ptr(), yin.shape[1] * C, C, yin.shape[1], C, kpad=True)     # (planes.alloc's buffer)
                 ap, bp = _planes.of(dy, make=True, force=True), yin_pl
                 assert ap is not None, "the conv stage's output gradient must be dense, 16-byte aligned fp32"
                 yin = None

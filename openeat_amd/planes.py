@@ -86,15 +86,23 @@ def split_activations() -> bool:
 
 class Planes:
     """Three bf16 planes of a (rows, cols) fp32 matrix: tensor `t` of shape (3, rows, cols) or a view into a larger buffer."""
-    __slots__ = ("t", "ptr", "stride", "ld", "rows", "cols")
+    __slots__ = ("t", "ptr", "stride", "ld", "rows", "cols", "kpad")
 
-    def __init__(self, t: torch.Tensor, ptr: int, stride: int, ld: int, rows: int, cols: int):
+    def __init__(self, t: torch.Tensor, ptr: int, stride: int, ld: int, rows: int, cols: int, kpad: bool = False):
         self.t, self.ptr, self.stride, self.ld, self.rows, self.cols = t, ptr, stride, ld, rows, cols
+        self.kpad = kpad            # the buffer holds ZERO rows from `rows` up to the next multiple of 16 (oe_gemm_args.planes_k_padded)
 
 
 def alloc(rows: int, cols: int, device) -> Planes:
-    t = torch.empty(3, rows, cols, dtype=torch.bfloat16, device=device)
-    return Planes(t, t.data_ptr(), rows * cols, cols, rows, cols)
+    """Planes buffer of a (rows, cols) matrix.  The row count of the ALLOCATION is rounded up to a multiple of 16 and the pad rows
+    are zero: as the k-major operand of a weight gradient the matrix can then be reduced over whole K-tiles whatever `rows` is
+    (ragged batches: rows = the step's valid positions; without it the pre-split kernel declines and configs[4]'s conv2 weight
+    gradient ran at 18 TFLOP/s)."""
+    rp = (rows + 15) // 16 * 16
+    t = torch.empty(3, rp, cols, dtype=torch.bfloat16, device=device)
+    if rp != rows:
+        t[:, rows:].zero_()
+    return Planes(t, t.data_ptr(), rp * cols, cols, rows, cols, kpad=True)
 
 
 # ---- activations: registry by device address ----------------------------------------------------------------------------

@@ -157,7 +157,11 @@ def test_layernorm_planes_outputs():
 
 
 @pytest.mark.parametrize("tile", [0, 24, 44])
-@pytest.mark.parametrize("B_,T1,F1,Cc", [(2, 21, 11, 32), (3, 40, 39, 64), (4, 30, 21, 128), (4, 37, 33, 256)])
+@pytest.mark.parametrize("B_,T1,F1,Cc", [(2, 21, 11, 32), (3, 40, 39, 64), (4, 30, 21, 128), (4, 37, 33, 256),
+                                         # ragged batches: B T2 F2 positions that are NOT a multiple of the K-tile (495 = 30 * 16 + 15,
+                                         # 1530 = 95 * 16 + 10): the weight gradient runs the padded length on zero pad rows of dY's
+                                         # planes and clamped gather positions (oe_gemm_args.planes_k_padded)
+                                         (3, 31, 23, 128), (5, 37, 35, 256)])
 def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
     """conv2 forward (im2col gather on a row-major A) and weight gradient (gather on a k-major B) on pre-split operands."""
     torch.manual_seed(5)
@@ -207,7 +211,7 @@ def test_planes_conv2_gathers(B_, T1, F1, Cc, tile):
         hip.gemm(dycd, x_nhwc, dwg, Cc, 9 * Cc, Mc, lda=Cc, ldb=0, ldc=9 * Cc, a_kmajor=True, b_kmajor=True, split_k=2, atomic_out=True,
                  conv=conv, conv_gather=hip.GATHER_B, a_planes=split(dycd), b_planes=xp)
         sync()
-        assert hip.lib().oe_gemm_pl_launches() - n0 == 2
+        assert hip.lib().oe_gemm_pl_launches() - n0 == 2                     # the pre-split kernel took it, whatever Mc % 16 is
         col = F.unfold(xc.double(), 3, stride=2).transpose(1, 2).reshape(Mc, Cc, 9)
         ref_dw = torch.einsum("mo,mck->okc", dyc.double(), col).reshape(Cc, 9 * Cc)
         assert float((dwg.cpu().double() - ref_dw).abs().max()) / math.sqrt(Mc) < 5e-6

@@ -34,6 +34,7 @@ ap.add_argument("--steps", type=int, default=40)
 ap.add_argument("--warmup", type=int, default=4)
 ap.add_argument("--mode", default="cached", choices=["cached", "eager"])
 ap.add_argument("--max-graphs", type=int, default=64)
+ap.add_argument("--gemm-table", action="store_true", help="log the per-problem GEMM timing table of the largest batch's step to stderr")
 ap.add_argument("--model", default="24L512", choices=["24L512", "12L256"],
                 help="12L256: the configs[1] model on the same ragged data (launch-bound when run eagerly)")
 args = ap.parse_args()
@@ -138,6 +139,16 @@ for _ in range(200):
 torch.cuda.synchronize()
 pair_ms = sorted(a.elapsed_time(b) for a, b in pairs)[100]
 g_secs = sum(max(r[0].elapsed_time(r[1]) - pair_ms, 0.0) for r in recs) * 1e-3
+if args.gemm_table:
+    by = {}
+    for r in recs:
+        c_ = by.setdefault(r[3], [0, 0.0, r[2]])
+        c_[0] += 1
+        c_[1] += max(r[0].elapsed_time(r[1]) - pair_ms, 0.0) * 1e3
+    print("[config5] GEMM problems of the largest batch's step (m, n, k, a_kmajor, b_kmajor, gather, split_k): launches, us each, ms total, TFLOP/s",
+          file=sys.stderr)
+    for key, (cnt, us, fl) in sorted(by.items(), key=lambda kv: -kv[1][1]):
+        print(f"[config5]   {str(key):48s} x{cnt:3d} {us / cnt:9.1f} us {us / 1e3:8.3f} ms {fl * cnt / max(us, 1e-9) / 1e6:7.1f}", file=sys.stderr)
 g_flops = sum(r[2] for r in recs)
 # bench.py's convention: the peak for ALGORITHMIC flops is the dense bf16 MFMA rate divided by the MFMAs a mode issues per product
 # (6 in the headline mode: 2500 / 6 = 416.7 TFLOP/s; 157.3 on the fp32-input MFMA), mfma_issue = algorithmic x that count
