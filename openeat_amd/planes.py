@@ -195,7 +195,10 @@ def lookup(t2d: torch.Tensor) -> Optional[Planes]:
     if src._version != ver or not _dense2d(t2d) or pl.rows * pl.cols != t2d.numel():
         return None
     if pl.rows != t2d.shape[0]:          # another dense 2-D view of the same memory: same planes, other row length
-        return Planes(pl.t, pl.ptr, pl.stride, t2d.shape[1], t2d.shape[0], t2d.shape[1])
+        r, c = t2d.shape
+        # the buffer's zero pad rows serve the view too if they cover ITS rows up to the next multiple of 16
+        kpad = pl.kpad and pl.stride - r * c >= ((r + 15) // 16 * 16 - r) * c
+        return Planes(pl.t, pl.ptr, pl.stride, c, r, c, kpad=kpad)
     return pl
 
 
