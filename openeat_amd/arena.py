@@ -148,6 +148,8 @@ class ParamArena:
         next reader splits again, under EVERY policy, and that launch is part of whatever graph the pass is captured into.
         planes.capture_scope() calls this on exit: a split that was only RECORDED has refreshed nothing."""
         self._planes_fresh = False
+        from . import planes as _planes
+        _planes.bump_generation()
 
     def step_planes(self):
         """Planes valid for the current pass: split on the pass's first use, reused until mark_step() or a torch write."""

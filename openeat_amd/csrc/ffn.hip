@@ -45,10 +45,8 @@ __device__ __forceinline__ int ffn_acc_row(int r, int lk) { return (r & 3) + 8 *
 // the second W1^T in W2's role (dX = dH W1): the same fragment layouts read through swapped strides - a lane's eight
 // elements are then strided in memory, but consecutive lanes (rows of the fragment) stay on consecutive addresses.
 template <bool TRANSPOSED>
-__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, int d, int ff,
-                                                       int planes, __bf16* __restrict__ w1p, __bf16* __restrict__ w2p) {
-    const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per (fragment, both planes)
-    const int lane = threadIdx.x & 63;
+__device__ __forceinline__ void ffn_pack_piece(const float* __restrict__ w1, const float* __restrict__ w2, int d, int ff, int planes,
+                                               __bf16* __restrict__ w1p, __bf16* __restrict__ w2p, long piece, int lane) {
     const int KS = d / 16, DT = d / 32, FT = ff / 32;
     const long n1 = (long)FT * KS, n2 = (long)FT * DT * 2;
     float x[8];
@@ -87,6 +85,26 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
     *reinterpret_cast<oe_bf16x8*>(dst) = pl[0];
     if (planes >= 2) *reinterpret_cast<oe_bf16x8*>(dst + 512) = pl[1];
     if (planes >= 3) *reinterpret_cast<oe_bf16x8*>(dst + 1024) = pl[2];
+}
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, int d, int ff,
+                                                       int planes, __bf16* __restrict__ w1p, __bf16* __restrict__ w2p) {
+    ffn_pack_piece<TRANSPOSED>(w1, w2, d, ff, planes, w1p, w2p, (long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);   // one wave per fragment
+}
+// Many feed-forwards' weights in ONE launch (oe_ffn_pack_weights_table): entry e = eight 64-bit words { W1, W2, packed W1, packed W2,
+// packed W2^T (backward stream 1), packed W1^T (backward stream 2), d, ff }; blockIdx.y = entry, blockIdx.z = orientation (0: forward
+// pair, 1: backward pair; a null destination skips it).  The table lives in device memory: a captured graph holds the launch.
+__global__ __launch_bounds__(256) void ffn_pack_table_kernel(const long long* __restrict__ table, int planes) {
+    const long long* e = table + (long)blockIdx.y * 8;
+    const float* w1 = reinterpret_cast<const float*>(e[0]);
+    const float* w2 = reinterpret_cast<const float*>(e[1]);
+    const int d = (int)e[6], ff = (int)e[7];
+    const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (blockIdx.z == 0) {
+        if (e[2] && e[3]) ffn_pack_piece<false>(w1, w2, d, ff, planes, reinterpret_cast<__bf16*>(e[2]), reinterpret_cast<__bf16*>(e[3]), piece, threadIdx.x & 63);
+    } else {
+        if (e[4] && e[5]) ffn_pack_piece<true>(w1, w2, d, ff, planes, reinterpret_cast<__bf16*>(e[4]), reinterpret_cast<__bf16*>(e[5]), piece, threadIdx.x & 63);
+    }
 }
 
 // ---- the fused kernel ------------------------------------------------------------------------------------------------------
@@ -363,6 +381,15 @@ static int ffn_pack(const float* w1, const float* w2, int d, int ff, int precisi
         hipLaunchKernelGGL(ffn_pack_kernel<false>, dim3(oe_cdiv(pieces, 4)), dim3(256), 0, (hipStream_t)stream, w1, w2, d, ff,
                            ffn_planes(precision), (__bf16*)w1p, (__bf16*)w2p);
     OE_LAUNCH_CHECK("oe_ffn_pack_weights");
+    return 0;
+}
+extern "C" int oe_ffn_pack_weights_table(const void* table, int n, int max_d, int max_ff, int precision, void* stream) {
+    OE_REQUIRE(table && n > 0, "oe_ffn_pack_weights_table: empty table");
+    OE_REQUIRE(oe_ffn_supported(max_d, max_ff, precision, 0), "oe_ffn_pack_weights_table: unsupported shape d=%d ff=%d precision=%d", max_d, max_ff, precision);
+    const long pieces = (long)(max_ff / 32) * (max_d / 16) + (long)(max_ff / 32) * (max_d / 32) * 2;       // the largest entry's count
+    hipLaunchKernelGGL(ffn_pack_table_kernel, dim3(oe_cdiv(pieces, 4), n, 2), dim3(256), 0, (hipStream_t)stream, (const long long*)table,
+                       ffn_planes(precision));
+    OE_LAUNCH_CHECK("oe_ffn_pack_weights_table");
     return 0;
 }
 extern "C" int oe_ffn_pack_weights(const float* w1, const float* w2, int d, int ff, int precision, void* w1p, void* w2p, void* stream) {

@@ -138,6 +138,7 @@ _SIGNATURES = {
     "oe_ffn_supported": (I, [I, I, I, I]),
     "oe_ffn_pack_weights": (I, [P, P, I, I, I, P, P, P]),
     "oe_ffn_pack_weights_bwd": (I, [P, P, I, I, I, P, P, P]),
+    "oe_ffn_pack_weights_table": (I, [P, I, I, I, I, P]),
     "oe_ffn_fwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_ffn_bwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_ffn6_config": (I, [I]),

@@ -936,13 +936,75 @@ def _ffn_fused_ok(x2, w1, w2, act, res2):
             (res2 is None or res2.stride(0) % 4 == 0) and w1.data_ptr() % 16 == 0 and w2.data_ptr() % 16 == 0)
 
 
-def _ffn_packed(w1, w2, d, ff):
+# The packed weights of every feed-forward that has been seen, refreshed by ONE table-driven launch (oe_ffn_pack_weights_table) the
+# first time any of them is needed after the weights may have changed (planes.weights_generation: a new forward pass, an optimizer
+# step, a graph replay; plus the tensors' own version counters for writes through torch) - 48 pack launches per step at config 2
+# otherwise (forward and backward orientation of 24 feed-forwards, 4.5 us each on the step's chain).
+import weakref
+
+_FFN_PACKS = {}            # (W1 address, W2 address, precision) -> entry dict
+_FFN_TABLE = {"dev": None, "n": 0, "max": (0, 0), "dirty": True}
+FFN_PACK_TABLE = os.environ.get("OE_FFN_PACK_TABLE", "1") == "1"
+
+
+def ffn_packs_clear():
+    _FFN_PACKS.clear()
+    _FFN_TABLE.update(dev=None, n=0, dirty=True)
+
+
+def _ffn_table_rebuild(prec):
+    dead = [k for k, e in _FFN_PACKS.items() if e["w1"]() is None or e["w2"]() is None or k[2] != prec]
+    for k in dead:
+        del _FFN_PACKS[k]
+    rows = []
+    for (p1, p2, _), e in _FFN_PACKS.items():
+        rows.append([p1, p2] + [b.data_ptr() for b in e["bufs"]] + [e["d"], e["ff"]])
+    if not rows:
+        _FFN_TABLE.update(dev=None, n=0, dirty=False)
+        return
+    dev = next(iter(_FFN_PACKS.values()))["bufs"][0].device
+    _FFN_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), dirty=False,
+                      max=(max(e["d"] for e in _FFN_PACKS.values()), max(e["ff"] for e in _FFN_PACKS.values())))
+
+
+def _ffn_packed(w1, w2, d, ff, bwd=False):
+    """Packed W1 / W2 (forward) or W2^T / W1^T (bwd) of one feed-forward, fresh for the weights' current values."""
     prec = hip.GEMM_PRECISION
     nbytes = hip.lib().oe_ffn_packed_bytes(d, ff, prec)
-    w1p = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
-    w2p = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
-    hip.call("oe_ffn_pack_weights", w1, w2, d, ff, prec, w1p, w2p)
-    return w1p, w2p
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (w1.data_ptr(), w2.data_ptr(), prec)
+    ent = _FFN_PACKS.get(key) if FFN_PACK_TABLE else None
+    if ent is not None and (ent["d"], ent["ff"]) != (d, ff):
+        del _FFN_PACKS[key]
+        _FFN_TABLE["dirty"] = True
+        ent = None
+    if ent is None and FFN_PACK_TABLE and not capturing and isinstance(w1, torch.nn.Parameter) and isinstance(w2, torch.nn.Parameter):
+        # first sight (outside a capture: these buffers outlive every graph): persistent buffers, a table entry, and this call's
+        # own pack launch below
+        bufs = [torch.empty(nbytes, dtype=torch.uint8, device=w1.device) for _ in range(4)]
+        ent = dict(w1=weakref.ref(w1), w2=weakref.ref(w2), bufs=bufs, d=d, ff=ff, gen=[-1, -1], ver=[None, None])
+        _FFN_PACKS[key] = ent
+        _ffn_table_rebuild(prec)
+    if ent is None:                                              # unregistered (inside a capture, plain tensors): a pack of its own
+        a = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+        b = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
+        hip.call("oe_ffn_pack_weights_bwd" if bwd else "oe_ffn_pack_weights", w1, w2, d, ff, prec, a, b)
+        return a, b
+    gen, ver, kind = _planes.weights_generation(), (w1._version, w2._version), int(bwd)
+    if ent["gen"][kind] != gen or ent["ver"][kind] != ver:
+        if _FFN_TABLE["dirty"] and not capturing:
+            _ffn_table_rebuild(prec)
+        if not _FFN_TABLE["dirty"] and _FFN_TABLE["n"] > 1 and ent["gen"][0] != gen and ent["gen"][1] != gen:
+            # nobody has refreshed anything in this generation yet: all feed-forwards, both orientations, one launch
+            hip.call("oe_ffn_pack_weights_table", _FFN_TABLE["dev"], _FFN_TABLE["n"], _FFN_TABLE["max"][0], _FFN_TABLE["max"][1], prec)
+            for e in _FFN_PACKS.values():
+                w1e, w2e = e["w1"](), e["w2"]()
+                v = (w1e._version, w2e._version) if (w1e is not None and w2e is not None) else None
+                e["gen"], e["ver"] = [gen, gen], [v, v]
+        else:
+            hip.call("oe_ffn_pack_weights_bwd" if bwd else "oe_ffn_pack_weights", w1, w2, d, ff, prec, ent["bufs"][2 * kind], ent["bufs"][2 * kind + 1])
+            ent["gen"][kind], ent["ver"][kind] = gen, ver
+    return ent["bufs"][2 * kind], ent["bufs"][2 * kind + 1]
 
 
 class FeedForwardFn(torch.autograd.Function):
@@ -1004,9 +1066,7 @@ class FeedForwardFn(torch.autograd.Function):
             M, d, ff = g2.shape[0], w2.shape[0], w1.shape[0]
             prec = hip.GEMM_PRECISION
             nbytes = hip.lib().oe_ffn_packed_bytes(d, ff, prec)
-            w2tp = torch.empty(nbytes, dtype=torch.uint8, device=g2.device)
-            w1tp = torch.empty(nbytes, dtype=torch.uint8, device=g2.device)
-            hip.call("oe_ffn_pack_weights_bwd", w1, w2, d, ff, prec, w2tp, w1tp)
+            w2tp, w1tp = _ffn_packed(w1, w2, d, ff, bwd=True)
             dh, dx = _new(M, ff, like=g2), _new(M, d, like=g2)
             hip.ffn_bwd(g2, w2tp, w1tp, M, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=_seed_dev, pre=pre, dh=dh, dx=dx)
             dw1, db1 = wgrad_bias(w1, b1, dh, x2)

@@ -128,6 +128,11 @@ def clear_all():
     that goes away must not leave planes of its weights behind under an address the next model may be given)."""
     _WCACHE.clear()
     clear()
+    try:
+        from . import ops as _ops
+        _ops.ffn_packs_clear()
+    except ImportError:                  # (planes is imported by ops: only a half-initialised package gets here)
+        pass
 
 
 @contextlib.contextmanager
@@ -163,13 +168,29 @@ def capture_scope():
     finally:
         _CAPTURE_DEPTH -= 1
         _REG = outer
-        if a is not None:
-            a.mark_step()                # a split that was only recorded has refreshed nothing
+        bump_generation()                # whatever the capture "refreshed" (weight planes, packed feed-forward weights) was only
+        if a is not None:                # recorded: the next eager reader refreshes for real
+            a.mark_step()
+
+
+_GEN = 0
+
+
+def weights_generation() -> int:
+    """Changes whenever weights may have moved without torch noticing (a new forward pass announces itself, FusedAdam steps, a captured
+    step is replayed): consumers of derived copies (ops' packed feed-forward weights) compare it with the value they packed at."""
+    return _GEN
+
+
+def bump_generation():
+    global _GEN
+    _GEN += 1
 
 
 def new_pass():
     """A forward pass starts (training step, decode, LM scoring): the arena's weight planes are split again by their first reader
     (whatever wrote the weights since - Adam's raw kernel, load_state_dict, a broadcast - is picked up)."""
+    bump_generation()
     from . import arena as _arena
     a = _arena.active()
     if a is not None:
