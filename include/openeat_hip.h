@@ -191,6 +191,28 @@ int oe_ffn_pack_weights_table(const void* table, int n, int max_d, int max_ff, i
  * Tuning / tests only: results are identical in every mode up to the order of the fp32 sums over the ff axis. */
 int oe_ffn6_config(int mode);
 
+/* One Linear with a short reduction as a ROW-BLOCK GEMM in precision 6 (csrc/ffn6.hip, the fused feed-forward's first half alone):
+ *     y[rows, n] = residual + beta * rowmask * dropout( x[rows, k] @ Wg[n, k]^T + bias ),   k in {256, 512}, n a multiple of 128
+ * (attention.py:56-58,97 linear_q / k / v / out, convolution.py:79-111 pointwise convs, and - with Wg = W^T - their input
+ * gradients).  wp: Wg as packed A-operand fragments (oe_rowgemm6_pack_table: 6 bytes per weight, refreshed whenever the weights
+ * change).  Dropout / rowmask / residual as oe_gemm_f32's epilogue (mask element index row * n + col, seed_dev mixed in the same way).
+ * All pointers 16-byte aligned, ldx / ldr / ldy multiples of 4. */
+typedef struct oe_rowgemm_args {
+    const float* x; long ldx;
+    const void* wp; const float* bias;          /* packed Wg; bias (n) or NULL */
+    int rows, k, n;
+    float drop_p; unsigned long long seed; const unsigned long long* seed_dev;
+    const unsigned char* rowmask;               /* (rows) or NULL: rows with 0 are zeroed before the residual is added */
+    const float* residual; long ldr; float beta;
+    float* y; long ldy;
+} oe_rowgemm_args;
+int oe_rowgemm6_supported(int k, int n);
+int oe_rowgemm6(const oe_rowgemm_args* args, void* stream);
+/* table: device array of n entries of six 64-bit words { W (device pointer), packed destination, R, Cc, row stride of W,
+ * transposed }: W (R, Cc) fp32 -> the fragments of Wg = W (transposed 0: an (R, Cc) operand, x W^T) or Wg = W^T (transposed 1: a
+ * (Cc, R) operand, dy W); max_pieces = the largest entry's (Wg rows / 32) * (Wg cols / 16).  One launch for every Linear of the model. */
+int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces, void* stream);
+
 /* Several weight gradients  C_i (+)= alpha_i * A_i^T B_i  (A_i (k_i, m_i), B_i (k_i, n_i), both k-major, fp32) in ONE launch
  * of the bf16-planes kernel, accumulated atomically into C_i (ops.flush_wgrads: the deferred weight gradients of a captured
  * step; autograd of torch.nn.Linear in the reference).  oe_gemm_tn_grouped_plan fills the launch geometry fields of a HOST

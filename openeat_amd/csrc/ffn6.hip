@@ -424,6 +424,210 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 
     F6_STAMP(3 + 5 * (nchunks / NG));
 }
 
+// ---- one Linear as a row-block GEMM (oe_rowgemm6): the first half of the kernel above on its own ------------------------------
+//   out[rows, NO] = residual + beta * rowmask * dropout( in[rows, D] @ Wg[NO, D]^T + bias )
+// for the K = d (256 / 512) Linears of an encoder layer (attention.py:56-58,97 linear_q/k/v/out, convolution.py:79-111 pointwise
+// convs) and their input gradients.  As tiled GEMM launches these 1-3 GFLOP problems are all ramp: a 128 x 128 block walks eight
+// K-tiles between a cold start and an epilogue (23-36 us in the step for 7936 rows, 45-88 TFLOP/s).  Here a block owns 32 rows for
+// the WHOLE reduction: the rows' three bf16 planes sit in LDS (split once), each wave computes 32 x 32 output tiles transposed
+// (Wg's packed fragments are the A operand, straight L2 -> registers through the four-set ring; the rows are the B operand), the
+// epilogue leaves through a wave-private patch as 128-byte row segments.  Eight waves in two groups take alternate 128-column
+// chunks: no barrier after the first, the waves drift apart and one's epilogue runs under another's MFMAs.
+struct Row6Params {
+    const float* x; long ldx;
+    const unsigned char* wp; const float* bias;
+    const float* residual; long ldr; float beta;
+    const unsigned char* rowmask;
+    float* y; long ldy;
+    int rows, no;
+    float p_out; unsigned long long seed_out;
+    const unsigned long long* seed_dev;
+};
+
+template <int D>
+__global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
+    constexpr int BM = 32, NG = 2;
+    constexpr int KS = D / 16;
+    constexpr int FR = 2, NSET = 4;
+    constexpr int NSTG = KS / FR;
+    static_assert(KS % FR == 0 && NSTG % NSET == 0, "stage split");
+    constexpr int XP = D + 8;
+    constexpr int X_BYTES = 3 * BM * XP * 2;
+    constexpr int PATCH = 32 * 36 * 4;
+    constexpr int PIECE = 3 * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[X_BYTES + 8 * PATCH];
+    unsigned char* xs = lds;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wv >> 2, wave = wv & 3;
+    const int lq = lane & 31, lk = lane >> 5;
+    const long m0 = (long)blockIdx.x * BM;
+    const int nchunks = p.no / 128;
+    const int rot = blockIdx.x % nchunks;
+    float* patch = reinterpret_cast<float*>(lds + X_BYTES + wv * PATCH);
+    {
+        constexpr int C4 = D / 4;
+        for (int i = threadIdx.x; i < BM * C4; i += 512) {
+            const int row = i / C4, c4 = (i - row * C4) * 4;
+            const long gr = min(m0 + row, (long)p.rows - 1);
+            const float4 v = *reinterpret_cast<const float4*>(p.x + gr * p.ldx + c4);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            oe_bf16x4v pl[3];
+            oe_split4<3>(xv, pl);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + c4) * 2) = pl[n];
+        }
+    }
+    const unsigned char* wl = p.wp + lane * 16 + (long)wave * KS * PIECE;
+    constexpr long W_CHUNK = 4L * KS * PIECE;
+    auto load_stage = [&](auto w_c, int c, F6 (&f)[FR]) {
+        constexpr int w = decltype(w_c)::value;
+        const unsigned char* b1p = wl + c * W_CHUNK;
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+            const unsigned char* src = b1p + (long)(w * FR + j) * PIECE;
+            f[j].p[0] = *reinterpret_cast<const bf16x8*>(src); f[j].p[1] = *reinterpret_cast<const bf16x8*>(src + 1024);
+            f[j].p[2] = *reinterpret_cast<const bf16x8*>(src + 2048);
+        }
+    };
+    auto chunk_at = [&](int ci) {
+        int c = min(ci, nchunks - 1) + rot;
+        return c >= nchunks ? c - nchunks : c;
+    };
+    F6 fr[NSET][FR];
+    {
+        const int c0 = chunk_at(grp);
+        static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, c0, fr[decltype(k_c)::value]); });
+    }
+    const unsigned long long seed_out = p.seed_out + (p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+    const DropParams dp_out = drop_params(p.p_out);
+    auto x_frag = [&](int ks, F6& f) {
+        const unsigned char* a = xs + ((size_t)lq * XP + 16 * ks + 8 * lk) * 2;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(a + (size_t)n * BM * XP * 2);
+    };
+    __syncthreads();                                                 // the rows' planes: the only block-wide barrier
+
+    for (int ci = grp; ci < nchunks; ci += NG) {
+        const int c = chunk_at(ci), c_next = chunk_at(ci + NG);
+        const int ft = 4 * c + wave;                                 // this wave's 32 output columns: 32 ft ..
+        float4 q0, q1, q2, q3;
+        q0 = q1 = q2 = q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            const float* bp = p.bias + ft * 32 + 4 * lk;
+            q0 = *reinterpret_cast<const float4*>(bp); q1 = *reinterpret_cast<const float4*>(bp + 8);
+            q2 = *reinterpret_cast<const float4*>(bp + 16); q3 = *reinterpret_cast<const float4*>(bp + 24);
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        F6 xf[2];
+        x_frag(0, xf[0]);
+        static_for<0, NSTG>([&](auto st_c) {
+            constexpr int st = decltype(st_c)::value;
+            constexpr int cu = st % NSET, pf = (st + NSET - 1) % NSET;
+            constexpr int ahead = st + NSET - 1;
+            load_stage(std::integral_constant<int, ahead % NSTG>{}, ahead < NSTG ? c : c_next, fr[pf]);
+            __builtin_amdgcn_sched_barrier(0);                      // (the prefetch stays here: ffn6_kernel)
+            static_for<0, FR>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value;
+                constexpr int ks = st * FR + j;
+                if constexpr (ks + 1 < KS) x_frag(ks + 1, xf[(ks + 1) & 1]);
+                acc = oe_mma_terms<6>(fr[cu][j], xf[ks & 1], acc);
+            });
+        });
+        // ---- epilogue: + bias on the accumulators (output column on the rows), then row segments through the patch
+        float hv[16];
+        hv[0] = acc[0] + q0.x; hv[1] = acc[1] + q0.y; hv[2] = acc[2] + q0.z; hv[3] = acc[3] + q0.w;
+        hv[4] = acc[4] + q1.x; hv[5] = acc[5] + q1.y; hv[6] = acc[6] + q1.z; hv[7] = acc[7] + q1.w;
+        hv[8] = acc[8] + q2.x; hv[9] = acc[9] + q2.y; hv[10] = acc[10] + q2.z; hv[11] = acc[11] + q2.w;
+        hv[12] = acc[12] + q3.x; hv[13] = acc[13] + q3.y; hv[14] = acc[14] + q3.z; hv[15] = acc[15] + q3.w;
+        f6_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[lq * 36 + f6_acc_row(r, lk)] = hv[r];
+        f6_wave_sync();
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+            const long gr = m0 + row;
+            if (gr >= p.rows) continue;
+            const int col = ft * 32 + c4;
+            float4 v = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+            if (p.p_out > 0.f) {
+                const uint2 h = drop_hash4(seed_out, ((unsigned long long)gr * p.no + col) >> 2);
+                v.x *= drop_field(h.x, 0, dp_out); v.y *= drop_field(h.x, 1, dp_out);
+                v.z *= drop_field(h.y, 0, dp_out); v.w *= drop_field(h.y, 1, dp_out);
+            }
+            if (p.rowmask && !p.rowmask[gr]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.residual || p.beta != 1.f) {
+                float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.residual) res = *reinterpret_cast<const float4*>(p.residual + gr * p.ldr + col);
+                v = make_float4(res.x + p.beta * v.x, res.y + p.beta * v.y, res.z + p.beta * v.z, res.w + p.beta * v.w);
+            }
+            *reinterpret_cast<float4*>(p.y + gr * p.ldy + col) = v;
+        }
+    }
+}
+
+// one matrix W (rows R, cols Cc, row-major) -> the A-operand fragments of Wg = W (transposed = 0: Wg is (R, Cc)) or of Wg = W^T
+// (transposed = 1: Wg is (Cc, R)): [tile of 32 Wg rows][k-step of 16][plane][lane][8], as ffn_pack_kernel's first stream
+__global__ __launch_bounds__(256) void row6_pack_table_kernel(const long long* __restrict__ table) {
+    const long long* e = table + (long)blockIdx.y * 6;
+    const float* w = reinterpret_cast<const float*>(e[0]);
+    __bf16* dst0 = reinterpret_cast<__bf16*>(e[1]);
+    const int R = (int)e[2], Cc = (int)e[3], ldw = (int)e[4], tr = (int)e[5];
+    const int NOg = tr ? Cc : R, Kg = tr ? R : Cc;                  // Wg is (NOg, Kg)
+    const int KSg = Kg / 16;
+    const long piece = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (piece >= (long)(NOg / 32) * KSg) return;
+    const int lane = threadIdx.x & 63;
+    const int ft = (int)(piece / KSg), ks = (int)(piece % KSg);
+    const int row = 32 * ft + (lane & 31), col = 16 * ks + 8 * (lane >> 5);     // Wg[row][col + e]
+    float x[8];
+    if (!tr) {
+        const float* src = w + (long)row * ldw + col;
+        const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) x[q] = w[(long)(col + q) * ldw + row];
+    }
+    oe_bf16x8 pl[3];
+    oe_split8<3>(x, pl);
+    __bf16* dst = dst0 + piece * 1536 + lane * 8;
+    *reinterpret_cast<oe_bf16x8*>(dst) = pl[0];
+    *reinterpret_cast<oe_bf16x8*>(dst + 512) = pl[1];
+    *reinterpret_cast<oe_bf16x8*>(dst + 1024) = pl[2];
+}
+
+extern "C" int oe_rowgemm6_supported(int k, int n) { return (k == 256 || k == 512) && n >= 128 && n % 128 == 0 && n <= 8192; }
+
+// table: device array of n entries of six 64-bit words { W, packed, R, Cc, ld, transposed }; max_pieces: the largest entry's
+// (Wg rows / 32) * (Wg cols / 16)
+extern "C" int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces, void* stream) {
+    OE_REQUIRE(table && n > 0 && max_pieces > 0, "oe_rowgemm6_pack_table: empty table");
+    hipLaunchKernelGGL(row6_pack_table_kernel, dim3(oe_cdiv(max_pieces, 4), n), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
+    OE_LAUNCH_CHECK("oe_rowgemm6_pack_table");
+    return 0;
+}
+
+extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
+    OE_REQUIRE(a && a->x && a->wp && a->y, "oe_rowgemm6: null pointer");
+    OE_REQUIRE(oe_rowgemm6_supported(a->k, a->n), "oe_rowgemm6: unsupported k=%d n=%d", a->k, a->n);
+    OE_REQUIRE(a->rows > 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && (!a->residual || a->ldr % 4 == 0), "oe_rowgemm6: bad rows / strides");
+    OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->residual) | ((uintptr_t)a->wp) | ((uintptr_t)a->bias)) & 15) == 0,
+               "oe_rowgemm6: 16-byte alignment required");
+    OE_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f, "oe_rowgemm6: dropout rate out of range");
+    Row6Params p{};
+    p.x = a->x; p.ldx = a->ldx; p.wp = (const unsigned char*)a->wp; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta;
+    p.rowmask = a->rowmask; p.y = a->y; p.ldy = a->ldy; p.rows = a->rows; p.no = a->n; p.p_out = a->drop_p; p.seed_out = a->seed; p.seed_dev = a->seed_dev;
+    const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
+    if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((rowgemm6_kernel<256>), grid, block, 0, (hipStream_t)stream, p);
+    OE_LAUNCH_CHECK("oe_rowgemm6");
+    return 0;
+}
+
 template <int D, int RT, int NG>
 static int ffn6_launch(const Ffn6Params& p, bool bwd, int nout, hipStream_t st) {
     const dim3 grid(oe_cdiv(p.rows, 32 * RT)), block(256 * NG);

@@ -91,6 +91,19 @@ class FfnArgs(C.Structure):
     ]
 
 
+class RowGemmArgs(C.Structure):
+    """oe_rowgemm_args (include/openeat_hip.h)."""
+    _fields_ = [
+        ("x", c_fp), ("ldx", C.c_long),
+        ("wp", c_fp), ("bias", c_fp),
+        ("rows", C.c_int), ("k", C.c_int), ("n", C.c_int),
+        ("drop_p", C.c_float), ("seed", C.c_ulonglong), ("seed_dev", c_fp),
+        ("rowmask", c_fp),
+        ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
+        ("y", c_fp), ("ldy", C.c_long),
+    ]
+
+
 class HipLibraryMissing(RuntimeError):
     pass
 
@@ -142,6 +155,9 @@ _SIGNATURES = {
     "oe_ffn_fwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_ffn_bwd": (I, [C.POINTER(FfnArgs), P]),
     "oe_ffn6_config": (I, [I]),
+    "oe_rowgemm6_supported": (I, [I, I]),
+    "oe_rowgemm6": (I, [C.POINTER(RowGemmArgs), P]),
+    "oe_rowgemm6_pack_table": (I, [P, I, L, P]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_fwd_pl": (I, [P, P, P, F, I, I, P, I, P, P, P, L, P]),
@@ -379,6 +395,25 @@ def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_d
         PROFILE.append((e0, e1, 4.0 * rows * d * ff, ("ffn_bwd", rows, d, ff, 0, 0, 1)))
         return
     check(lib().oe_ffn_bwd(C.byref(a), stream()), "oe_ffn_bwd")
+
+
+def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=None, rowmask=None, residual=None, ldr=0, beta=1.0):
+    """y = residual + beta * rowmask * dropout(x @ Wg^T + bias) on the row-block kernel (oe_rowgemm6; wp = packed Wg)."""
+    a = RowGemmArgs()
+    dp = lambda t: None if t is None else t.data_ptr()
+    a.x, a.ldx, a.wp, a.bias = x.data_ptr(), x.stride(0), wp.data_ptr(), dp(bias)
+    a.rows, a.k, a.n = rows, k, n
+    a.drop_p, a.seed, a.seed_dev, a.rowmask = drop_p, seed, dp(seed_dev), dp(rowmask)
+    a.residual, a.ldr, a.beta = dp(residual), ldr, beta
+    a.y, a.ldy = y.data_ptr(), y.stride(0)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(lib().oe_rowgemm6(C.byref(a), stream()), "oe_rowgemm6")
+        e1.record()
+        PROFILE.append((e0, e1, 2.0 * rows * k * n, ("rowgemm6", rows, n, k, 0, 0, 1)))
+        return
+    check(lib().oe_rowgemm6(C.byref(a), stream()), "oe_rowgemm6")
 
 
 def call(name, *args):

@@ -11,6 +11,7 @@ from __future__ import annotations
 import itertools
 import os
 import math
+import weakref
 from typing import Optional
 
 import torch
@@ -90,10 +91,103 @@ def _operand_planes(act2d, w2d):
     return (ap, bp) if bp is not None else (None, None)
 
 
+# ---- the short-reduction Linears as row-block GEMMs (csrc/ffn6.hip::rowgemm6_kernel) ---------------------------------------
+# x W^T and dy W with k in {256, 512} and an output width that is a multiple of 128, from ROWGEMM_MIN_ROWS rows on, in precision 6:
+# the weight is consumed as packed fragments, refreshed for EVERY registered matrix by one table-driven launch per weights
+# generation (as the feed-forwards' packs).  Anything the kernel's epilogue does not do stays on oe_gemm_f32.
+ROWGEMM = os.environ.get("OE_ROWGEMM", "1") == "1"
+ROWGEMM_MIN_ROWS = int(os.environ.get("OE_ROWGEMM_MIN_ROWS", "4096"))
+ROWGEMM_LAUNCHES = 0       # (tests: which path a call took)
+_ROW_PACKS = {}            # (address, rows, cols, row stride, transposed) -> entry
+_ROW_TABLE = {"dev": None, "n": 0, "max": 0, "dirty": True}
+_ROW_EPI_OK = {"drop_p", "seed", "seed_dev", "rowmask", "residual", "ldr", "beta"}
+
+
+def row_packs_clear():
+    _ROW_PACKS.clear()
+    _ROW_TABLE.update(dev=None, n=0, dirty=True)
+
+
+def _row_table_rebuild():
+    for k in [k for k, e in _ROW_PACKS.items() if e["owner"]() is None]:
+        del _ROW_PACKS[k]
+    rows = [[k[0], e["buf"].data_ptr(), k[1], k[2], k[3], k[4]] for k, e in _ROW_PACKS.items()]
+    if not rows:
+        _ROW_TABLE.update(dev=None, n=0, dirty=False)
+        return
+    dev = next(iter(_ROW_PACKS.values()))["buf"].device
+    _ROW_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), dirty=False,
+                      max=max((k[1] // 32) * (k[2] // 16) if not k[4] else (k[2] // 32) * (k[1] // 16) for k in _ROW_PACKS))
+
+
+def _row_packed(w, transposed):
+    """Packed fragments of Wg = w (x W^T) or w^T (dy W), fresh for the weight's current values; None if w cannot be registered."""
+    owner = w._base if w._base is not None else w
+    key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), int(transposed))
+    ent = _ROW_PACKS.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
+    if ent is None:
+        if capturing:
+            return None                                       # (its buffer would live in the graph's pool: stay on oe_gemm_f32)
+        ent = dict(owner=weakref.ref(owner), buf=torch.empty(w.shape[0] * w.shape[1] * 6, dtype=torch.uint8, device=w.device), gen=-1, ver=None)
+        _ROW_PACKS[key] = ent
+        _ROW_TABLE["dirty"] = True
+    gen, ver = _planes.weights_generation(), owner._version
+    if ent["gen"] != gen or ent["ver"] != ver:
+        if _ROW_TABLE["dirty"]:
+            if capturing:
+                return None
+            _row_table_rebuild()
+        # every registered matrix in one launch (all of them are stale together: the generation moved)
+        hip.call("oe_rowgemm6_pack_table", _ROW_TABLE["dev"], _ROW_TABLE["n"], _ROW_TABLE["max"])
+        for e in _ROW_PACKS.values():
+            o = e["owner"]()
+            e["gen"], e["ver"] = gen, (None if o is None else o._version)
+    return ent["buf"]
+
+
+def _rowgemm_try(x, w, transposed, bias, out, epi):
+    """x (M, k) @ Wg^T on the row-block kernel if the problem and its epilogue qualify; returns out or None."""
+    if not ROWGEMM or hip.GEMM_PRECISION != 6 or x.shape[0] < ROWGEMM_MIN_ROWS or not x.is_cuda:
+        return None
+    k = x.shape[1]
+    n = w.shape[1] if transposed else w.shape[0]
+    if (w.shape[0] if transposed else w.shape[1]) != k or not hip.lib().oe_rowgemm6_supported(k, n):
+        return None
+    for key, v in epi.items():                                 # an epilogue feature the kernel does not have: oe_gemm_f32
+        unset = v is None or (not isinstance(v, torch.Tensor) and (v is False or v == 0 or (key == "beta" and v == 1.0)))
+        if not unset and key not in _ROW_EPI_OK:
+            return None
+    if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
+        return None
+    res = epi.get("residual")
+    if res is not None and (res.stride(-1) != 1 or res.data_ptr() % 16 or epi.get("ldr", 0) % 4):
+        return None
+    if bias is not None and bias.data_ptr() % 16:
+        return None
+    wp = _row_packed(w, transposed)
+    if wp is None:
+        return None
+    M = x.shape[0]
+    if out is None:
+        out = _new(M, n, like=x)
+    elif out.stride(1) != 1 or out.stride(0) % 4 or out.data_ptr() % 16:
+        return None
+    global ROWGEMM_LAUNCHES
+    ROWGEMM_LAUNCHES += 1
+    hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0, seed_dev=epi.get("seed_dev"),
+                 rowmask=epi.get("rowmask"), residual=res, ldr=epi.get("ldr", 0) or 0, beta=epi.get("beta", 1.0))
+    return out
+
+
 def gemm_nt(x, w, bias=None, out=None, out_planes=False, **epi):
     """y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue).  out_planes: the output is a later GEMM's operand - write its bf16 planes too."""
     M, K = x.shape
     N = w.shape[0]
+    if not (out_planes and _planes.split_activations()):
+        y = _rowgemm_try(x, w, False, bias, out, epi)
+        if y is not None:
+            return y
     if out is None:
         out = _new(M, N, like=x)
     ap, bp = _operand_planes(x, w)
@@ -107,6 +201,10 @@ def gemm_nn(dy, w, out=None, out_planes=False, **epi):
     operands exist at all (the conv front end's policy)."""
     M, N = dy.shape
     K = w.shape[1]
+    if not out_planes:
+        y = _rowgemm_try(dy, w, True, None, out, epi)
+        if y is not None:
+            return y
     if out is None:
         out = _new(M, K, like=dy)
     ap, bp = _operand_planes(dy, w)
@@ -940,7 +1038,6 @@ def _ffn_fused_ok(x2, w1, w2, act, res2):
 # first time any of them is needed after the weights may have changed (planes.weights_generation: a new forward pass, an optimizer
 # step, a graph replay; plus the tensors' own version counters for writes through torch) - 48 pack launches per step at config 2
 # otherwise (forward and backward orientation of 24 feed-forwards, 4.5 us each on the step's chain).
-import weakref
 
 _FFN_PACKS = {}            # (W1 address, W2 address, precision) -> entry dict
 _FFN_TABLE = {"dev": None, "n": 0, "max": (0, 0), "dirty": True}
@@ -950,6 +1047,7 @@ FFN_PACK_TABLE = os.environ.get("OE_FFN_PACK_TABLE", "1") == "1"
 def ffn_packs_clear():
     _FFN_PACKS.clear()
     _FFN_TABLE.update(dev=None, n=0, dirty=True)
+    row_packs_clear()
 
 
 def _ffn_table_rebuild(prec):

@@ -21,7 +21,7 @@ def pytest_configure(config):
 # integration test must not hide the evidence for the kernels the bench line stands on.
 _GPU_FILE_ORDER = [
     "test_gpu_kernels.py", "test_gpu_kernels2.py", "test_gpu_gemm_dma.py", "test_gpu_planes.py", "test_gpu_fusions.py",
-    "test_gpu_ffn6.py", "test_gpu_width.py", "test_gpu_fullsize.py", "test_gpu_model.py", "test_gpu_capture_isolation.py",
+    "test_gpu_ffn6.py", "test_gpu_rowgemm6.py", "test_gpu_width.py", "test_gpu_fullsize.py", "test_gpu_model.py", "test_gpu_capture_isolation.py",
     "test_gpu_engine.py", "test_gpu_dataset.py", "test_gpu_decode_fullsize.py", "test_gpu_ddp.py", "test_gpu_bench.py",
 ]
 

@@ -1,0 +1,122 @@
+"""GPU: the short-reduction Linears as row-block GEMMs in precision 6 (csrc/ffn6.hip::rowgemm6_kernel through oe_rowgemm6 /
+oe_rowgemm6_pack_table) - attention.py:56-58,97 (linear_q / k / v / out), convolution.py:79-111 (pointwise convs) and their
+input gradients - against float64 and against oe_gemm_f32 on the fp32-input MFMA (precision 0) with the same epilogue."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from openeat_amd import hip, ops, planes  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def mode6():
+    old = hip.GEMM_PRECISION
+    hip.GEMM_PRECISION = 6
+    planes.clear_all()
+    yield
+    hip.GEMM_PRECISION = old
+    planes.clear_all()
+
+
+def _err(got, ref):
+    return float((got.cpu().double() - ref).abs().max())
+
+
+@pytest.mark.parametrize("rows,k,n,bias,p,res,mask,beta", [
+    (7936, 256, 768, True, 0.0, False, False, 1.0),        # fused q / k / v projection
+    (7936, 256, 256, True, 0.1, True, False, 1.0),         # linear_out: bias, dropout, residual
+    (7936, 256, 256, True, 0.1, True, True, 1.0),          # pointwise_conv2: + zeroed pad rows
+    (7936, 256, 512, True, 0.0, False, False, 1.0),        # pointwise_conv1
+    (4097, 256, 128, False, 0.0, True, False, 0.5),        # one chunk (the second wave group idles), ragged last block, scaled residual
+    (4500, 512, 1536, True, 0.2, False, False, 1.0),       # configs[4] width
+])
+def test_x_wT_matches_float64_and_the_fp32_kernel(rows, k, n, bias, p, res, mask, beta):
+    torch.manual_seed(71)
+    x = torch.randn(rows, k)
+    w = torch.nn.Parameter(torch.randn(n, k) / math.sqrt(k))
+    b = torch.randn(n) * 0.1 if bias else None
+    r = torch.randn(rows, n) if res else None
+    m = (torch.rand(rows) > 0.1).to(torch.uint8) if mask else None
+    xd, wd = x.to(DEV), torch.nn.Parameter(w.detach().to(DEV))
+    bd, rd, md = (None if t is None else t.to(DEV) for t in (b, r, m))
+    ctr = torch.tensor([7], dtype=torch.int64, device=DEV)
+    epi = dict(drop_p=p, seed=0x4444, seed_dev=ctr, rowmask=md, residual=rd, ldr=n if res else 0, beta=beta)
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        y = ops.gemm_nt(xd, wd, bd, **epi)
+    assert ops.ROWGEMM_LAUNCHES == n0 + 1                              # the row-block kernel took it
+    y0 = torch.empty(rows, n, device=DEV)
+    hip.gemm(xd, wd.detach(), y0, rows, n, k, lda=k, ldb=k, ldc=n, bias=bd, precision=0, **epi)
+    ones = torch.ones(rows, n, device=DEV)
+    dm = torch.empty_like(ones)
+    hip.call("oe_dropout_scale", ones, ones.numel(), n, 1.0, p, 0x4444, ctr, None, dm)
+    torch.cuda.synchronize()
+    want = x.double() @ w.detach().double().t()
+    if bias:
+        want = want + b.double()
+    want = want * dm.cpu().double()
+    if mask:
+        want = want * m.double().unsqueeze(1)
+    want = (r.double() if res else 0.0) + beta * want
+    e6, e0 = _err(y, want), _err(y0, want)
+    assert e6 <= 2.5 * e0 + 1e-6 * float(want.abs().max()), (e6, e0)
+    torch.testing.assert_close(y.cpu().double(), want, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("rows,n_fwd,k_fwd,mask", [(7936, 256, 256, False), (7936, 512, 256, True), (7936, 256, 512, False), (5000, 512, 1536, False)])
+def test_dy_w_matches_float64_and_the_fp32_kernel(rows, n_fwd, k_fwd, mask):
+    """The input gradient dx = dy W of a Linear with weight W (n_fwd, k_fwd): reduction over n_fwd (256 / 512), output k_fwd wide."""
+    torch.manual_seed(72)
+    dy = torch.randn(rows, n_fwd)
+    w = torch.randn(n_fwd, k_fwd) / math.sqrt(k_fwd)
+    m = (torch.rand(rows) > 0.1).to(torch.uint8) if mask else None
+    dyd, wd = dy.to(DEV), torch.nn.Parameter(w.to(DEV))
+    md = None if m is None else m.to(DEV)
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        dx = ops.gemm_nn(dyd, wd, rowmask=md)
+    assert ops.ROWGEMM_LAUNCHES == n0 + 1
+    dx0 = torch.empty(rows, k_fwd, device=DEV)
+    hip.gemm(dyd, wd.detach(), dx0, rows, k_fwd, n_fwd, lda=n_fwd, ldb=k_fwd, ldc=k_fwd, b_kmajor=True, rowmask=md, precision=0)
+    torch.cuda.synchronize()
+    want = dy.double() @ w.double()
+    if mask:
+        want = want * m.double().unsqueeze(1)
+    assert _err(dx, want) <= 2.5 * _err(dx0, want) + 1e-6 * float(want.abs().max())
+    torch.testing.assert_close(dx.cpu().double(), want, rtol=1e-4, atol=5e-5)
+
+
+def test_packed_weights_follow_the_weights():
+    """A weight written through torch (version counter) or behind torch's back (planes.bump_generation: what FusedAdam / a graph
+    replay / a new pass announce) is re-packed before its next use; an untouched one is not packed again."""
+    torch.manual_seed(73)
+    x = torch.randn(4096, 256, device=DEV)
+    w = torch.nn.Parameter(torch.randn(256, 256, device=DEV) / 16)
+    with torch.no_grad():
+        y1 = ops.gemm_nt(x, w)
+        w.mul_(2.0)                                                   # torch write: version counter
+        y2 = ops.gemm_nt(x, w)
+        w.data.view(-1)[:].copy_((w.data * 0.25).view(-1))            # (also a torch write)
+        planes.bump_generation()
+        y3 = ops.gemm_nt(x, w)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y2, 2.0 * y1, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y3, 0.5 * y1, rtol=1e-5, atol=1e-5)
+
+
+def test_unsupported_epilogues_and_shapes_stay_on_oe_gemm_f32():
+    x = torch.randn(4096, 256, device=DEV)
+    w = torch.nn.Parameter(torch.randn(384 + 6, 256, device=DEV) / 16)           # n = 390: not a multiple of 128
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        ops.gemm_nt(x, w)
+        w2 = torch.nn.Parameter(torch.randn(256, 256, device=DEV) / 16)
+        pre = torch.empty(4096, 256, device=DEV)
+        ops.gemm_nt(x, w2, None, act=ops.ACT_SWISH, preact_out=pre, ld_aux=256)   # an activation epilogue
+        ops.gemm_nt(x[:1000], w2)                                               # below ROWGEMM_MIN_ROWS
+    assert ops.ROWGEMM_LAUNCHES == n0
