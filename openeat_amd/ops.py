@@ -103,9 +103,23 @@ _ROW_TABLE = {"dev": None, "n": 0, "max": 0, "dirty": True}
 _ROW_EPI_OK = {"drop_p", "seed", "seed_dev", "rowmask", "residual", "ldr", "beta"}
 
 
+def _pack_done(tab):
+    """The refresh launch sits on the current stream: remember it, consumers on OTHER streams (the right-to-left decoder, the CTC
+    head) order themselves behind it."""
+    ev = torch.cuda.Event()
+    ev.record()
+    tab["event"], tab["stream"] = ev, torch.cuda.current_stream()
+
+
+def _pack_wait(tab):
+    ev = tab.get("event")
+    if ev is not None and tab.get("stream") != torch.cuda.current_stream():
+        torch.cuda.current_stream().wait_event(ev)
+
+
 def row_packs_clear():
     _ROW_PACKS.clear()
-    _ROW_TABLE.update(dev=None, n=0, dirty=True)
+    _ROW_TABLE.update(dev=None, n=0, dirty=True, event=None, stream=None)
 
 
 def _row_table_rebuild():
@@ -123,6 +137,12 @@ def _row_table_rebuild():
 def _row_packed(w, transposed):
     """Packed fragments of Wg = w (x W^T) or w^T (dy W), fresh for the weight's current values; None if w cannot be registered."""
     owner = w._base if w._base is not None else w
+    # only weights that OWN their memory for good: a Parameter (or a view of one), or a window of the parameter arena.  A temporary -
+    # q / k / v weights concatenated for the fused projection of a model without an arena - dies after the call and the next
+    # temporary lands on its address with other values and the same version: its cached pack would be taken for fresh
+    a = _arena.active()
+    if not (isinstance(owner, torch.nn.Parameter) or (a is not None and owner is a.flat)):
+        return None
     key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), int(transposed))
     ent = _ROW_PACKS.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
@@ -140,9 +160,12 @@ def _row_packed(w, transposed):
             _row_table_rebuild()
         # every registered matrix in one launch (all of them are stale together: the generation moved)
         hip.call("oe_rowgemm6_pack_table", _ROW_TABLE["dev"], _ROW_TABLE["n"], _ROW_TABLE["max"])
+        _pack_done(_ROW_TABLE)
         for e in _ROW_PACKS.values():
             o = e["owner"]()
             e["gen"], e["ver"] = gen, (None if o is None else o._version)
+    else:
+        _pack_wait(_ROW_TABLE)
     return ent["buf"]
 
 
@@ -1046,7 +1069,7 @@ FFN_PACK_TABLE = os.environ.get("OE_FFN_PACK_TABLE", "1") == "1"
 
 def ffn_packs_clear():
     _FFN_PACKS.clear()
-    _FFN_TABLE.update(dev=None, n=0, dirty=True)
+    _FFN_TABLE.update(dev=None, n=0, dirty=True, event=None, stream=None)
     row_packs_clear()
 
 
@@ -1095,6 +1118,7 @@ def _ffn_packed(w1, w2, d, ff, bwd=False):
         if not _FFN_TABLE["dirty"] and _FFN_TABLE["n"] > 1 and ent["gen"][0] != gen and ent["gen"][1] != gen:
             # nobody has refreshed anything in this generation yet: all feed-forwards, both orientations, one launch
             hip.call("oe_ffn_pack_weights_table", _FFN_TABLE["dev"], _FFN_TABLE["n"], _FFN_TABLE["max"][0], _FFN_TABLE["max"][1], prec)
+            _pack_done(_FFN_TABLE)
             for e in _FFN_PACKS.values():
                 w1e, w2e = e["w1"](), e["w2"]()
                 v = (w1e._version, w2e._version) if (w1e is not None and w2e is not None) else None
@@ -1102,6 +1126,8 @@ def _ffn_packed(w1, w2, d, ff, bwd=False):
         else:
             hip.call("oe_ffn_pack_weights_bwd" if bwd else "oe_ffn_pack_weights", w1, w2, d, ff, prec, ent["bufs"][2 * kind], ent["bufs"][2 * kind + 1])
             ent["gen"][kind], ent["ver"][kind] = gen, ver
+    else:
+        _pack_wait(_FFN_TABLE)
     return ent["bufs"][2 * kind], ent["bufs"][2 * kind + 1]
 
 

@@ -120,3 +120,27 @@ def test_unsupported_epilogues_and_shapes_stay_on_oe_gemm_f32():
         ops.gemm_nt(x, w2, None, act=ops.ACT_SWISH, preact_out=pre, ld_aux=256)   # an activation epilogue
         ops.gemm_nt(x[:1000], w2)                                               # below ROWGEMM_MIN_ROWS
     assert ops.ROWGEMM_LAUNCHES == n0
+
+
+def test_temporaries_are_never_cached():
+    """A model without a parameter arena concatenates q / k / v weights into a TEMPORARY for the fused projection (ops._fused_rows):
+    it dies after the call, and the next layer's temporary lands on the same address with other values and the same tensor version.
+    Such weights are not registered (their pack would be taken for fresh: the B = 32 whole-model parity test caught it as 2-9 % errors
+    in the decoders' gradient norms)."""
+    torch.manual_seed(74)
+    x = torch.randn(4096, 256, device=DEV)
+    wa, wb = torch.randn(256, 256, device=DEV) / 16, torch.randn(256, 256, device=DEV) / 16
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        ta = torch.cat([wa[:128], wa[128:]], 0)
+        pa = ta.data_ptr()
+        ya = ops.gemm_nt(x, ta)
+        del ta
+        tb = torch.cat([wb[:128], wb[128:]], 0)
+        same_address = tb.data_ptr() == pa
+        yb = ops.gemm_nt(x, tb)
+    torch.cuda.synchronize()
+    assert ops.ROWGEMM_LAUNCHES == n0                                  # temporaries stay on oe_gemm_f32
+    torch.testing.assert_close(ya, x @ wa.t(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(yb, x @ wb.t(), rtol=1e-4, atol=1e-4)
+    assert same_address or True                                        # (the hazard's precondition on this allocator; informational)
