@@ -465,19 +465,6 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     const int nchunks = p.no / 128;
     const int rot = blockIdx.x % nchunks;
     float* patch = reinterpret_cast<float*>(lds + X_BYTES + wv * PATCH);
-    {
-        constexpr int C4 = D / 4;
-        for (int i = threadIdx.x; i < BM * C4; i += 512) {
-            const int row = i / C4, c4 = (i - row * C4) * 4;
-            const long gr = min(m0 + row, (long)p.rows - 1);
-            const float4 v = *reinterpret_cast<const float4*>(p.x + gr * p.ldx + c4);
-            const float xv[4] = {v.x, v.y, v.z, v.w};
-            oe_bf16x4v pl[3];
-            oe_split4<3>(xv, pl);
-#pragma unroll
-            for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + c4) * 2) = pl[n];
-        }
-    }
     const unsigned char* wl = p.wp + lane * 16 + (long)wave * KS * PIECE;
     constexpr long W_CHUNK = 4L * KS * PIECE;
     auto load_stage = [&](auto w_c, int c, F6 (&f)[FR]) {
@@ -499,6 +486,20 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
         const int c0 = chunk_at(grp);
         static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, c0, fr[decltype(k_c)::value]); });
     }
+    // (the rows after the ring's first stages are on their way: both round trips overlap)
+    {
+        constexpr int C4 = D / 4;
+        for (int i = threadIdx.x; i < BM * C4; i += 512) {
+            const int row = i / C4, c4 = (i - row * C4) * 4;
+            const long gr = min(m0 + row, (long)p.rows - 1);
+            const float4 v = *reinterpret_cast<const float4*>(p.x + gr * p.ldx + c4);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+            oe_bf16x4v pl[3];
+            oe_split4<3>(xv, pl);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + c4) * 2) = pl[n];
+        }
+    }
     const unsigned long long seed_out = p.seed_out + (p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
     const DropParams dp_out = drop_params(p.p_out);
     auto x_frag = [&](int ks, F6& f) {
@@ -517,6 +518,16 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
             const float* bp = p.bias + ft * 32 + 4 * lk;
             q0 = *reinterpret_cast<const float4*>(bp); q1 = *reinterpret_cast<const float4*>(bp + 8);
             q2 = *reinterpret_cast<const float4*>(bp + 16); q3 = *reinterpret_cast<const float4*>(bp + 24);
+        }
+        // the residual's row segments of this tile, ahead of the product (their round trip would stand in front of the stores)
+        float4 r0, r1, r2, r3;
+        r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual) {
+            const long last = (long)p.rows - 1;
+            const float* rp = p.residual + ft * 32 + (lane & 7) * 4;
+            const long rr = m0 + (lane >> 3);
+            r0 = *reinterpret_cast<const float4*>(rp + min(rr, last) * p.ldr); r1 = *reinterpret_cast<const float4*>(rp + min(rr + 8, last) * p.ldr);
+            r2 = *reinterpret_cast<const float4*>(rp + min(rr + 16, last) * p.ldr); r3 = *reinterpret_cast<const float4*>(rp + min(rr + 24, last) * p.ldr);
         }
         f32x16 acc;
 #pragma unroll
@@ -560,8 +571,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
             }
             if (p.rowmask && !p.rowmask[gr]) v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.residual || p.beta != 1.f) {
-                float4 res = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.residual) res = *reinterpret_cast<const float4*>(p.residual + gr * p.ldr + col);
+                const float4 res = ps == 0 ? r0 : ps == 1 ? r1 : ps == 2 ? r2 : r3;
                 v = make_float4(res.x + p.beta * v.x, res.y + p.beta * v.y, res.z + p.beta * v.z, res.w + p.beta * v.w);
             }
             *reinterpret_cast<float4*>(p.y + gr * p.ldy + col) = v;
