@@ -34,8 +34,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 TERMS = {0: 1, 1: 1, 3: 3, 6: 6}     # bf16 MFMAs issued per algorithmic product in each arithmetic mode
 KERNEL_NAMES = {0: "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)",
-                6: "gemm_dma_kernel + gemm_pl_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel <terms=6> (the kernels behind oe_gemm_f32 / "
-                   "oe_gemm_tn_grouped precision 6: three exact bf16 pieces per operand, hh+hm+mh+mm+hl+lh on v_mfma_f32_32x32x16_bf16)",
+                6: "gemm_pl_kernel + gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn6_kernel + rowgemm6_kernel <terms=6> "
+                   "(the kernels behind oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd / oe_ffn_bwd / oe_rowgemm6 precision 6: three exact bf16 "
+                   "pieces per operand, hh+hm+mh+mm+hl+lh on v_mfma_f32_32x32x16_bf16)",
                 1: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=1> (the kernels behind "
                    "oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd precision 1, v_mfma_f32_32x32x16_bf16)",
                 3: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=3> (the kernels behind "
@@ -439,7 +440,7 @@ def main():
         # HBM bytes per launch: PMC counters cannot be read from inside this process - the figure is the one of the
         # committed rocprofv3 --pmc passes of this same command (tools/final_profiles.sh), and the line says so
         traffic, traffic_src = None, None
-        for name in ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
+        for name in ("r04_pmc_hbm_traffic.json", "r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     pmc = json.load(f)
