@@ -98,9 +98,61 @@ def _operand_planes(act2d, w2d):
 ROWGEMM = os.environ.get("OE_ROWGEMM", "1") == "1"
 ROWGEMM_MIN_ROWS = int(os.environ.get("OE_ROWGEMM_MIN_ROWS", "4096"))
 ROWGEMM_LAUNCHES = 0       # (tests: which path a call took)
-_ROW_PACKS = {}            # (address, rows, cols, row stride, transposed) -> entry
-_ROW_TABLE = {"dev": None, "n": 0, "max": 0, "dirty": True}
 _ROW_EPI_OK = {"drop_p", "seed", "seed_dev", "rowmask", "residual", "ldr", "beta"}
+
+
+class _PackTable:
+    """Device table of a table-driven pack launch (oe_rowgemm6_pack_table / oe_ffn_pack_weights_table) with the lifetime rules a
+    CAPTURED launch needs: the device tensor is allocated once and only ever updated in place, rows are append-only (a captured
+    launch bakes in the table's address and its row count: it keeps refreshing exactly the rows that existed when it was
+    captured), and a row whose weights died is NEUTRALISED (source pointer 0: the kernel skips it) instead of removed - its pack
+    buffer goes back to the allocator, and a replay must neither read the dead weights (their memory may be unmapped after
+    empty_cache: a GPU fault) nor write the buffer.  The first version rebuilt the table tensor at every registration: the decode
+    graphs of bench.py replayed a pack launch over a freed table (memory access fault at address 0x1e000, round 4)."""
+    CAP = 4096
+
+    def __init__(self, words):
+        self.words, self.host, self.dev, self.n, self.dirty = words, None, None, 0, False
+        self.event = self.stream = None
+        self.rows = {}                     # key -> row index
+        self.entries = {}                  # key -> entry dict (alive ones)
+
+    def add(self, key, row, entry, device):
+        if self.n >= self.CAP:
+            return False
+        if self.host is None:
+            self.host = torch.zeros(self.CAP, self.words, dtype=torch.int64)
+            self.dev = torch.zeros(self.CAP, self.words, dtype=torch.int64, device=device)
+        self.host[self.n] = torch.tensor(row, dtype=torch.int64)
+        self.rows[key], self.entries[key] = self.n, entry
+        self.n += 1
+        self.dirty = True
+        return True
+
+    def drop(self, key):
+        self.host[self.rows.pop(key)].zero_()
+        del self.entries[key]
+        self.dirty = True
+
+    def sweep(self, is_dead):
+        """Neutralise the rows of dead entries (called before every refresh launch outside a capture)."""
+        for k in [k for k, e in self.entries.items() if is_dead(k, e)]:
+            self.drop(k)
+
+    def upload(self):
+        if self.dirty and self.dev is not None:
+            self.dev.copy_(self.host, non_blocking=False)
+            self.dirty = False
+
+    def clear(self):
+        """Forget every entry (test teardown); the device tensor stays (an old graph may still hold its address)."""
+        for k in list(self.entries):
+            self.drop(k)
+        self.upload()
+        self.event = self.stream = None
+
+
+_ROW = _PackTable(6)        # rows: { W, packed, R, Cc, row stride, transposed }; key = (address, R, Cc, row stride, transposed)
 
 
 def _pack_done(tab):
@@ -108,30 +160,20 @@ def _pack_done(tab):
     head) order themselves behind it."""
     ev = torch.cuda.Event()
     ev.record()
-    tab["event"], tab["stream"] = ev, torch.cuda.current_stream()
+    tab.event, tab.stream = ev, torch.cuda.current_stream()
 
 
 def _pack_wait(tab):
-    ev = tab.get("event")
-    if ev is not None and tab.get("stream") != torch.cuda.current_stream():
-        torch.cuda.current_stream().wait_event(ev)
+    if tab.event is not None and tab.stream != torch.cuda.current_stream():
+        torch.cuda.current_stream().wait_event(tab.event)
 
 
 def row_packs_clear():
-    _ROW_PACKS.clear()
-    _ROW_TABLE.update(dev=None, n=0, dirty=True, event=None, stream=None)
+    _ROW.clear()
 
 
-def _row_table_rebuild():
-    for k in [k for k, e in _ROW_PACKS.items() if e["owner"]() is None]:
-        del _ROW_PACKS[k]
-    rows = [[k[0], e["buf"].data_ptr(), k[1], k[2], k[3], k[4]] for k, e in _ROW_PACKS.items()]
-    if not rows:
-        _ROW_TABLE.update(dev=None, n=0, dirty=False)
-        return
-    dev = next(iter(_ROW_PACKS.values()))["buf"].device
-    _ROW_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), dirty=False,
-                      max=max((k[1] // 32) * (k[2] // 16) if not k[4] else (k[2] // 32) * (k[1] // 16) for k in _ROW_PACKS))
+def _row_pieces(k):
+    return (k[1] // 32) * (k[2] // 16) if not k[4] else (k[2] // 32) * (k[1] // 16)
 
 
 def _row_packed(w, transposed):
@@ -144,28 +186,34 @@ def _row_packed(w, transposed):
     if not (isinstance(owner, torch.nn.Parameter) or (a is not None and owner is a.flat)):
         return None
     key = (w.data_ptr(), w.shape[0], w.shape[1], w.stride(0), int(transposed))
-    ent = _ROW_PACKS.get(key)
+    ent = _ROW.entries.get(key)
     capturing = torch.cuda.is_current_stream_capturing()
+    if ent is not None and ent["owner"]() is not owner:       # the address has a new tenant: the old row dies, a new one is appended
+        if capturing:
+            return None
+        _ROW.drop(key)
+        ent = None
     if ent is None:
         if capturing:
             return None                                       # (its buffer would live in the graph's pool: stay on oe_gemm_f32)
         ent = dict(owner=weakref.ref(owner), buf=torch.empty(w.shape[0] * w.shape[1] * 6, dtype=torch.uint8, device=w.device), gen=-1, ver=None)
-        _ROW_PACKS[key] = ent
-        _ROW_TABLE["dirty"] = True
+        if not _ROW.add(key, [key[0], ent["buf"].data_ptr(), key[1], key[2], key[3], key[4]], ent, w.device):
+            return None
     gen, ver = _planes.weights_generation(), owner._version
     if ent["gen"] != gen or ent["ver"] != ver:
-        if _ROW_TABLE["dirty"]:
-            if capturing:
-                return None
-            _row_table_rebuild()
+        if not capturing:
+            _ROW.sweep(lambda k, e: e["owner"]() is None)
+            _ROW.upload()
+        elif _ROW.dirty:
+            return None
         # every registered matrix in one launch (all of them are stale together: the generation moved)
-        hip.call("oe_rowgemm6_pack_table", _ROW_TABLE["dev"], _ROW_TABLE["n"], _ROW_TABLE["max"])
-        _pack_done(_ROW_TABLE)
-        for e in _ROW_PACKS.values():
+        hip.call("oe_rowgemm6_pack_table", _ROW.dev, _ROW.n, max(_row_pieces(k) for k in _ROW.entries))
+        _pack_done(_ROW)
+        for e in _ROW.entries.values():
             o = e["owner"]()
             e["gen"], e["ver"] = gen, (None if o is None else o._version)
     else:
-        _pack_wait(_ROW_TABLE)
+        _pack_wait(_ROW)
     return ent["buf"]
 
 
@@ -1062,30 +1110,13 @@ def _ffn_fused_ok(x2, w1, w2, act, res2):
 # step, a graph replay; plus the tensors' own version counters for writes through torch) - 48 pack launches per step at config 2
 # otherwise (forward and backward orientation of 24 feed-forwards, 4.5 us each on the step's chain).
 
-_FFN_PACKS = {}            # (W1 address, W2 address, precision) -> entry dict
-_FFN_TABLE = {"dev": None, "n": 0, "max": (0, 0), "dirty": True}
+_FFN = _PackTable(8)        # rows: { W1, W2, w1p, w2p, w2tp, w1tp, d, ff }; key = (W1 address, W2 address, precision)
 FFN_PACK_TABLE = os.environ.get("OE_FFN_PACK_TABLE", "1") == "1"
 
 
 def ffn_packs_clear():
-    _FFN_PACKS.clear()
-    _FFN_TABLE.update(dev=None, n=0, dirty=True, event=None, stream=None)
+    _FFN.clear()
     row_packs_clear()
-
-
-def _ffn_table_rebuild(prec):
-    dead = [k for k, e in _FFN_PACKS.items() if e["w1"]() is None or e["w2"]() is None or k[2] != prec]
-    for k in dead:
-        del _FFN_PACKS[k]
-    rows = []
-    for (p1, p2, _), e in _FFN_PACKS.items():
-        rows.append([p1, p2] + [b.data_ptr() for b in e["bufs"]] + [e["d"], e["ff"]])
-    if not rows:
-        _FFN_TABLE.update(dev=None, n=0, dirty=False)
-        return
-    dev = next(iter(_FFN_PACKS.values()))["bufs"][0].device
-    _FFN_TABLE.update(dev=torch.tensor(rows, dtype=torch.int64).to(dev), n=len(rows), dirty=False,
-                      max=(max(e["d"] for e in _FFN_PACKS.values()), max(e["ff"] for e in _FFN_PACKS.values())))
 
 
 def _ffn_packed(w1, w2, d, ff, bwd=False):
@@ -1094,32 +1125,35 @@ def _ffn_packed(w1, w2, d, ff, bwd=False):
     nbytes = hip.lib().oe_ffn_packed_bytes(d, ff, prec)
     capturing = torch.cuda.is_current_stream_capturing()
     key = (w1.data_ptr(), w2.data_ptr(), prec)
-    ent = _FFN_PACKS.get(key) if FFN_PACK_TABLE else None
-    if ent is not None and (ent["d"], ent["ff"]) != (d, ff):
-        del _FFN_PACKS[key]
-        _FFN_TABLE["dirty"] = True
-        ent = None
+    ent = _FFN.entries.get(key) if FFN_PACK_TABLE else None
+    if ent is not None and ((ent["d"], ent["ff"]) != (d, ff) or ent["w1"]() is not w1 or ent["w2"]() is not w2):
+        if capturing:
+            ent = False                                          # (no table surgery inside a capture: a pack of this call's own)
+        else:
+            _FFN.drop(key)
+            ent = None
     if ent is None and FFN_PACK_TABLE and not capturing and isinstance(w1, torch.nn.Parameter) and isinstance(w2, torch.nn.Parameter):
-        # first sight (outside a capture: these buffers outlive every graph): persistent buffers, a table entry, and this call's
-        # own pack launch below
+        # first sight (outside a capture: these buffers outlive every graph): persistent buffers, a table row
         bufs = [torch.empty(nbytes, dtype=torch.uint8, device=w1.device) for _ in range(4)]
         ent = dict(w1=weakref.ref(w1), w2=weakref.ref(w2), bufs=bufs, d=d, ff=ff, gen=[-1, -1], ver=[None, None])
-        _FFN_PACKS[key] = ent
-        _ffn_table_rebuild(prec)
-    if ent is None:                                              # unregistered (inside a capture, plain tensors): a pack of its own
+        if not _FFN.add(key, [key[0], key[1]] + [b.data_ptr() for b in bufs] + [d, ff], ent, w1.device):
+            ent = None
+    if not ent:                                                  # unregistered (inside a capture, plain tensors): a pack of its own
         a = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
         b = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)
         hip.call("oe_ffn_pack_weights_bwd" if bwd else "oe_ffn_pack_weights", w1, w2, d, ff, prec, a, b)
         return a, b
     gen, ver, kind = _planes.weights_generation(), (w1._version, w2._version), int(bwd)
     if ent["gen"][kind] != gen or ent["ver"][kind] != ver:
-        if _FFN_TABLE["dirty"] and not capturing:
-            _ffn_table_rebuild(prec)
-        if not _FFN_TABLE["dirty"] and _FFN_TABLE["n"] > 1 and ent["gen"][0] != gen and ent["gen"][1] != gen:
+        if not capturing:
+            _FFN.sweep(lambda k, e: e["w1"]() is None or e["w2"]() is None)
+            _FFN.upload()
+        if not _FFN.dirty and len(_FFN.entries) > 1 and ent["gen"][0] != gen and ent["gen"][1] != gen:
             # nobody has refreshed anything in this generation yet: all feed-forwards, both orientations, one launch
-            hip.call("oe_ffn_pack_weights_table", _FFN_TABLE["dev"], _FFN_TABLE["n"], _FFN_TABLE["max"][0], _FFN_TABLE["max"][1], prec)
-            _pack_done(_FFN_TABLE)
-            for e in _FFN_PACKS.values():
+            alive = _FFN.entries.values()
+            hip.call("oe_ffn_pack_weights_table", _FFN.dev, _FFN.n, max(e["d"] for e in alive), max(e["ff"] for e in alive), prec)
+            _pack_done(_FFN)
+            for e in alive:
                 w1e, w2e = e["w1"](), e["w2"]()
                 v = (w1e._version, w2e._version) if (w1e is not None and w2e is not None) else None
                 e["gen"], e["ver"] = [gen, gen], [v, v]
@@ -1127,7 +1161,7 @@ def _ffn_packed(w1, w2, d, ff, bwd=False):
             hip.call("oe_ffn_pack_weights_bwd" if bwd else "oe_ffn_pack_weights", w1, w2, d, ff, prec, ent["bufs"][2 * kind], ent["bufs"][2 * kind + 1])
             ent["gen"][kind], ent["ver"][kind] = gen, ver
     else:
-        _pack_wait(_FFN_TABLE)
+        _pack_wait(_FFN)
     return ent["bufs"][2 * kind], ent["bufs"][2 * kind + 1]
 
 

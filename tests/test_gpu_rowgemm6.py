@@ -144,3 +144,36 @@ def test_temporaries_are_never_cached():
     torch.testing.assert_close(ya, x @ wa.t(), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(yb, x @ wb.t(), rtol=1e-4, atol=1e-4)
     assert same_address or True                                        # (the hazard's precondition on this allocator; informational)
+
+
+def test_captured_refresh_survives_later_registrations():
+    """A captured graph bakes in the address of the pack table and of the packed buffers.  The table is therefore ONE persistent
+    tensor updated in place, append-only (the first version rebuilt it at every registration: bench.py's decode graphs replayed a
+    pack launch over a freed table and the GPU faulted at address 0x1e000).  Here: capture a pass, register more weights, let a
+    registered weight die, churn the allocator, change the captured weight - the replay must follow."""
+    import gc
+    torch.manual_seed(75)
+    x = torch.randn(4096, 256, device=DEV)
+    w = torch.nn.Parameter(torch.randn(256, 256, device=DEV) / 16)
+    with torch.no_grad():
+        y_ref = ops.gemm_nt(x, w).clone()                              # eager: registers w, uploads the table
+        xs = x.clone()
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        with planes.capture_scope(), torch.cuda.graph(g):
+            planes.new_pass()                                          # (what ASRModel.forward / _encode announce)
+            ys = ops.gemm_nt(xs, w)
+        table_ptr = ops._ROW.dev.data_ptr()
+        others = [torch.nn.Parameter(torch.randn(256, 256, device=DEV) / 16) for _ in range(6)]
+        for o in others:
+            ops.gemm_nt(x, o)                                          # later registrations
+        del others[2:]                                                 # ... and some of them die
+        gc.collect()
+        junk = [torch.full((n,), -1, dtype=torch.int64, device=DEV) for n in (6, 12, 48, 96, 384, 4096 * 6) for _ in range(4)]
+        planes.new_pass()
+        ops.gemm_nt(x, others[0])                                      # a refresh that sweeps the dead rows
+        w.mul_(2.0)
+        g.replay()
+        torch.cuda.synchronize()
+    assert ops._ROW.dev.data_ptr() == table_ptr and junk
+    torch.testing.assert_close(ys, 2.0 * y_ref, rtol=1e-5, atol=1e-5)
