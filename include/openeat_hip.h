@@ -181,9 +181,10 @@ int oe_ffn_fwd(const oe_ffn_args* args, void* stream);
 int oe_ffn_pack_weights_bwd(const float* w1, const float* w2, int d, int ff, int precision, void* w2t_packed, void* w1t_packed, void* stream);
 int oe_ffn_bwd(const oe_ffn_args* a, void* stream);
 /* The weights of n feed-forwards packed in ONE launch, both orientations (the optimizer moves every weight every step: 48 pack
- * launches per step at config 2 otherwise).  table: device array of n entries of eight 64-bit words { W1, W2, w1p, w2p, w2t_packed,
- * w1t_packed, d, ff } (device pointers as integers; a null destination pair skips that orientation); max_d / max_ff: the largest
- * entry's sizes (launch geometry).  The table lives in device memory, so a captured graph can hold the launch. */
+ * launches per step at config 2 otherwise).  table: device array of n entries of NINE 64-bit words { W1, W2, w1p, w2p, w2t_packed,
+ * w1t_packed, d, ff, planes } (device pointers as integers; planes = 1 / 2 / 3 for the precision the entry's buffers were sized for,
+ * oe_ffn_packed_bytes; a null destination pair skips that orientation, an all-zero entry is skipped); max_d / max_ff: the largest
+ * entry's sizes (launch geometry); precision: validated against max_d / max_ff only.  The table lives in device memory, so a captured graph can hold the launch. */
 int oe_ffn_pack_weights_table(const void* table, int n, int max_d, int max_ff, int precision, void* stream);
 /* precision 6 (csrc/ffn6.hip; d in {128, 256, 512}, three planes, oe_ffn_packed_bytes = 6 bytes per weight): block shape of the
  * fused kernel - 0 = automatic (32-row blocks of eight waves in two staggered groups wherever ff is a multiple of 256),

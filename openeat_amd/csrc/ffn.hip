@@ -91,11 +91,15 @@ __global__ __launch_bounds__(256) void ffn_pack_kernel(const float* __restrict__
                                                        int planes, __bf16* __restrict__ w1p, __bf16* __restrict__ w2p) {
     ffn_pack_piece<TRANSPOSED>(w1, w2, d, ff, planes, w1p, w2p, (long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);   // one wave per fragment
 }
-// Many feed-forwards' weights in ONE launch (oe_ffn_pack_weights_table): entry e = eight 64-bit words { W1, W2, packed W1, packed W2,
-// packed W2^T (backward stream 1), packed W1^T (backward stream 2), d, ff }; blockIdx.y = entry, blockIdx.z = orientation (0: forward
-// pair, 1: backward pair; a null destination skips it).  The table lives in device memory: a captured graph holds the launch.
-__global__ __launch_bounds__(256) void ffn_pack_table_kernel(const long long* __restrict__ table, int planes) {
-    const long long* e = table + (long)blockIdx.y * 8;
+// Many feed-forwards' weights in ONE launch (oe_ffn_pack_weights_table): entry e = nine 64-bit words { W1, W2, packed W1, packed W2,
+// packed W2^T (backward stream 1), packed W1^T (backward stream 2), d, ff, planes }; blockIdx.y = entry, blockIdx.z = orientation
+// (0: forward pair, 1: backward pair; a null destination skips it, an all-zero entry is skipped whole).  The plane count is the
+// ENTRY's (its buffers were sized for it: a table may hold feed-forwards registered under different precisions).  The table lives
+// in device memory: a captured graph holds the launch.
+__global__ __launch_bounds__(256) void ffn_pack_table_kernel(const long long* __restrict__ table) {
+    const long long* e = table + (long)blockIdx.y * 9;
+    const int planes = (int)e[8];
+    if (!e[0] || !e[1] || planes < 1) return;
     const float* w1 = reinterpret_cast<const float*>(e[0]);
     const float* w2 = reinterpret_cast<const float*>(e[1]);
     const int d = (int)e[6], ff = (int)e[7];
@@ -385,10 +389,10 @@ static int ffn_pack(const float* w1, const float* w2, int d, int ff, int precisi
 }
 extern "C" int oe_ffn_pack_weights_table(const void* table, int n, int max_d, int max_ff, int precision, void* stream) {
     OE_REQUIRE(table && n > 0, "oe_ffn_pack_weights_table: empty table");
-    OE_REQUIRE(oe_ffn_supported(max_d, max_ff, precision, 0), "oe_ffn_pack_weights_table: unsupported shape d=%d ff=%d precision=%d", max_d, max_ff, precision);
+    OE_REQUIRE(max_d >= 32 && max_d % 32 == 0 && max_ff >= 32 && max_ff % 32 == 0 && (precision == 1 || precision == 3 || precision == 6),
+               "oe_ffn_pack_weights_table: bad launch geometry d=%d ff=%d precision=%d", max_d, max_ff, precision);
     const long pieces = (long)(max_ff / 32) * (max_d / 16) + (long)(max_ff / 32) * (max_d / 32) * 2;       // the largest entry's count
-    hipLaunchKernelGGL(ffn_pack_table_kernel, dim3(oe_cdiv(pieces, 4), n, 2), dim3(256), 0, (hipStream_t)stream, (const long long*)table,
-                       ffn_planes(precision));
+    hipLaunchKernelGGL(ffn_pack_table_kernel, dim3(oe_cdiv(pieces, 4), n, 2), dim3(256), 0, (hipStream_t)stream, (const long long*)table);
     OE_LAUNCH_CHECK("oe_ffn_pack_weights_table");
     return 0;
 }

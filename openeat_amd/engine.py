@@ -409,6 +409,7 @@ class TrainEngine:
 
     def replay(self, batch: Optional[Dict[str, torch.Tensor]] = None, lr: Optional[float] = None):
         assert self._graph is not None
+        ops.pack_tables_sweep()                # (a replayed pack launch must not touch weights that have died since the capture)
         self.arena.mark_step()                 # the replayed optimizer moves the weights: eager readers of their planes split again
         if batch is not None:
             for k, v in batch.items():

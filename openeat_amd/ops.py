@@ -1110,13 +1110,23 @@ def _ffn_fused_ok(x2, w1, w2, act, res2):
 # step, a graph replay; plus the tensors' own version counters for writes through torch) - 48 pack launches per step at config 2
 # otherwise (forward and backward orientation of 24 feed-forwards, 4.5 us each on the step's chain).
 
-_FFN = _PackTable(8)        # rows: { W1, W2, w1p, w2p, w2tp, w1tp, d, ff }; key = (W1 address, W2 address, precision)
+_FFN = _PackTable(9)        # rows: { W1, W2, w1p, w2p, w2tp, w1tp, d, ff, planes }; key = (W1 address, W2 address, precision)
 FFN_PACK_TABLE = os.environ.get("OE_FFN_PACK_TABLE", "1") == "1"
 
 
 def ffn_packs_clear():
     _FFN.clear()
     row_packs_clear()
+
+
+def pack_tables_sweep():
+    """Neutralise the table rows of weights that have died since the last look (planes.new_pass, TrainEngine.replay: before anything
+    - a captured pack launch included - can touch them: their memory may be unmapped by now, torch.cuda.empty_cache)."""
+    if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        _FFN.sweep(lambda k, e: e["w1"]() is None or e["w2"]() is None)
+        _FFN.upload()
+        _ROW.sweep(lambda k, e: e["owner"]() is None)
+        _ROW.upload()
 
 
 def _ffn_packed(w1, w2, d, ff, bwd=False):
@@ -1136,7 +1146,9 @@ def _ffn_packed(w1, w2, d, ff, bwd=False):
         # first sight (outside a capture: these buffers outlive every graph): persistent buffers, a table row
         bufs = [torch.empty(nbytes, dtype=torch.uint8, device=w1.device) for _ in range(4)]
         ent = dict(w1=weakref.ref(w1), w2=weakref.ref(w2), bufs=bufs, d=d, ff=ff, gen=[-1, -1], ver=[None, None])
-        if not _FFN.add(key, [key[0], key[1]] + [b.data_ptr() for b in bufs] + [d, ff], ent, w1.device):
+        # (the row carries its own plane count: the table may hold feed-forwards registered under other precisions, whose
+        # buffers are smaller - bench.py's extra mode-3 / mode-1 legs; a refresh in THIS precision must not overrun them)
+        if not _FFN.add(key, [key[0], key[1]] + [b.data_ptr() for b in bufs] + [d, ff, {6: 3, 3: 2}.get(prec, 1)], ent, w1.device):
             ent = None
     if not ent:                                                  # unregistered (inside a capture, plain tensors): a pack of its own
         a = torch.empty(nbytes, dtype=torch.uint8, device=w1.device)

@@ -192,6 +192,8 @@ def new_pass():
     (whatever wrote the weights since - Adam's raw kernel, load_state_dict, a broadcast - is picked up)."""
     bump_generation()
     from . import arena as _arena
+    from . import ops as _ops
+    _ops.pack_tables_sweep()
     a = _arena.active()
     if a is not None:
         a.mark_step()

@@ -198,3 +198,39 @@ def test_feed_forward_op_fused_equals_unfused_in_precision6():
         planes.clear_all()
     for a, b, name in zip(out[True], out[False], ("y", "dx", "dw1", "db1", "dw2", "db2")):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * max(1.0, float(b.abs().max())), msg=lambda m, name=name: f"{name}: {m}")
+
+
+def test_pack_table_rows_keep_their_own_precision():
+    """bench.py runs the same process in precision 6, then 0, 3, 1 and back in 6 (decode): feed-forwards registered under
+    precision 3 / 1 have packed buffers of two / one plane.  A refresh launched in precision 6 walks ALL rows of the table - each
+    with the plane count it was registered with (a global count overran the smaller buffers: GPU memory fault in the r04 bundle)."""
+    from openeat_amd import planes
+    old = (hip.GEMM_PRECISION, ops.FUSED_FFN_MIN_ROWS)
+    ops.FUSED_FFN_MIN_ROWS = 0
+    torch.manual_seed(69)
+    rows, d, ff = 256, 256, 512
+    x = torch.randn(rows, d, device=DEV)
+
+    def params():
+        return (torch.nn.Parameter(torch.randn(ff, d, device=DEV) / 16), torch.nn.Parameter(torch.randn(ff, device=DEV) * 0.1),
+                torch.nn.Parameter(torch.randn(d, ff, device=DEV) / 22), torch.nn.Parameter(torch.randn(d, device=DEV) * 0.1))
+
+    def ref(p):
+        h = x.double() @ p[0].detach().double().t() + p[1].detach().double()
+        return (h * torch.sigmoid(h)) @ p[2].detach().double().t() + p[3].detach().double()
+    sets = {3: [params() for _ in range(2)], 1: [params() for _ in range(2)], 6: [params() for _ in range(2)]}
+    try:
+        with torch.no_grad():
+            for prec in (3, 1, 6, 3, 6):                                  # every switch is a new generation: a table refresh over all rows
+                hip.GEMM_PRECISION = prec
+                planes.new_pass()
+                for p in sets[prec]:
+                    y = ops.feed_forward(x, p[0], p[1], p[2], p[3], ops.ACT_SWISH)
+                    tol = dict(rtol=1e-4, atol=5e-5) if prec == 6 else dict(rtol=2e-4, atol=2e-4) if prec == 3 else dict(rtol=5e-2, atol=5e-2)
+                    torch.testing.assert_close(y.double().cpu(), ref(p).cpu(), **tol)
+        assert len(ops._FFN.entries) == 6
+        planes_of = {k[2]: int(ops._FFN.host[i, 8]) for k, i in ops._FFN.rows.items()}
+        assert planes_of == {3: 2, 1: 1, 6: 3}
+    finally:
+        hip.GEMM_PRECISION, ops.FUSED_FFN_MIN_ROWS = old
+        planes.clear_all()
