@@ -206,8 +206,15 @@ typedef struct oe_rowgemm_args {
     const unsigned char* rowmask;               /* (rows) or NULL: rows with 0 are zeroed before the residual is added */
     const float* residual; long ldr; float beta;
     float* y; long ldy;
+    /* tile form only (oe_rowgemm6_form = 2), oe_gemm_f32's activation epilogue: act = OE_ACT_NONE / RELU / SWISH applied after the bias
+     * (preact_out, optional: the value before it, row stride ld_aux), or - actgrad_in set - the product times act'(actgrad_in[row, col]) */
+    int act; float* preact_out; const float* actgrad_in; long ld_aux;
 } oe_rowgemm_args;
 int oe_rowgemm6_supported(int k, int n);
+/* Which kernel oe_rowgemm6 runs: 1 = the row-block form above (k in {256, 512}, n % 128 == 0: one 32-row block streams the whole packed
+ * matrix - for thousands of rows), 2 = the TILE form for few rows (rows <= 2048, k in {256, 512, 768, 1024}, n % 32 == 0: one block per
+ * 32 x 32 output tile, its eight waves split the reduction - the decoders' Linears, decoder_layer.py:82-106), 0 = neither. */
+int oe_rowgemm6_form(int rows, int k, int n);
 int oe_rowgemm6(const oe_rowgemm_args* args, void* stream);
 /* table: device array of n entries of six 64-bit words { W (device pointer), packed destination, R, Cc, row stride of W,
  * transposed }: W (R, Cc) fp32 -> the fragments of Wg = W (transposed 0: an (R, Cc) operand, x W^T) or Wg = W^T (transposed 1: a

@@ -58,8 +58,8 @@ __device__ __forceinline__ float f6_act_bwd(int act, float x) {
 }
 struct F6 { bf16x8 p[3]; };
 
-// Diagnostic build only (-DOE_GEMM_STAMPS, tools/ffn6_stamps.py): s_memtime stamps of block 0's waves at the phase boundaries,
-// written to a buffer nothing else reads.  No stamp exists in the shipped library.
+// Diagnostic build only (-DOE_GEMM_STAMPS, tools/ffn6_stamps.py, tools/rowgemm6_stamps.py): s_memtime stamps of the first and the last
+// block's waves at the phase boundaries, written to a (2 x 8 x 128)-word buffer nothing else reads.  No stamp exists in the shipped library.
 #ifdef OE_GEMM_STAMPS
 static __device__ unsigned long long* f6_stamp_buf = nullptr;
 extern "C" int oe_ffn6_set_stamps(void* buf) {
@@ -71,7 +71,8 @@ extern "C" int oe_ffn6_set_stamps(void* buf) {
         unsigned long long t_;                                                                                           \
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (f6_stamp_buf && blockIdx.x == 0 && (threadIdx.x & 63) == 0 && (slot) < 128) f6_stamp_buf[(threadIdx.x >> 6) * 128 + (slot)] = t_; \
+        if (f6_stamp_buf && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (threadIdx.x & 63) == 0 && (slot) < 128)     \
+            f6_stamp_buf[(blockIdx.x == 0 ? 0 : 1024) + (threadIdx.x >> 6) * 128 + (slot)] = t_;                        \
     } while (0)
 #else
 #define F6_STAMP(slot) do { } while (0)
@@ -442,6 +443,7 @@ struct Row6Params {
     int rows, no;
     float p_out; unsigned long long seed_out;
     const unsigned long long* seed_dev;
+    int k, act; float* preact_out; const float* actgrad_in; long ld_aux;     // (tile form only)
 };
 
 template <int D>
@@ -482,6 +484,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
         return c >= nchunks ? c - nchunks : c;
     };
     F6 fr[NSET][FR];
+    F6_STAMP(0);
     {
         const int c0 = chunk_at(grp);
         static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, c0, fr[decltype(k_c)::value]); });
@@ -507,7 +510,9 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
 #pragma unroll
         for (int n = 0; n < 3; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(a + (size_t)n * BM * XP * 2);
     };
+    F6_STAMP(1);
     __syncthreads();                                                 // the rows' planes: the only block-wide barrier
+    F6_STAMP(2);
 
     for (int ci = grp; ci < nchunks; ci += NG) {
         const int c = chunk_at(ci), c_next = chunk_at(ci + NG);
@@ -547,6 +552,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
                 acc = oe_mma_terms<6>(fr[cu][j], xf[ks & 1], acc);
             });
         });
+        F6_STAMP(3 + 3 * (ci / NG));
         // ---- epilogue: + bias on the accumulators (output column on the rows), then row segments through the patch
         float hv[16];
         hv[0] = acc[0] + q0.x; hv[1] = acc[1] + q0.y; hv[2] = acc[2] + q0.z; hv[3] = acc[3] + q0.w;
@@ -557,6 +563,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) patch[lq * 36 + f6_acc_row(r, lk)] = hv[r];
         f6_wave_sync();
+        F6_STAMP(4 + 3 * (ci / NG));
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
@@ -576,7 +583,96 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
             }
             *reinterpret_cast<float4*>(p.y + gr * p.ldy + col) = v;
         }
+        F6_STAMP(5 + 3 * (ci / NG));
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// TILE FORM of the same product for FEW rows (the decoders' Linears: 992 rows at config 2; the relative-position projection: 248).
+// There the row-block form is one latency chain per block - 31 blocks that each stream the whole packed matrix (393 KiB for
+// 256 x 256: 13.6 us, as long as for 7936 rows) - and a tiled launch is 16 blocks walking eight K-tiles (14 us).  Here a block owns
+// ONE 32 x 32 output tile and its eight waves split the REDUCTION: wave w takes k in [w k/8, (w+1) k/8) - its weight pieces
+// (k/128 of them, contiguous in the packed stream) and its x fragments (fp32 straight from global, 32 bytes per lane and step,
+// split in registers) are all requested at once, then k/128 six-term products, the eight partial tiles meet in LDS, every wave
+// finishes four rows.  One round trip of loads, one barrier: (rows/32) (n/32) blocks of ~5 us.  The epilogue is oe_gemm_f32's
+// element for element (bias -> pre-activation out -> activation, or times act'(aux) -> dropout -> dead rows -> residual + beta x),
+// so the feed-forward's first GEMM and the input gradient through it qualify too.
+template <int KSW>
+__global__ __launch_bounds__(512, 2) void rowtile6_kernel(Row6Params p) {
+    constexpr int PIECE = 3 * 1024;
+    __shared__ __attribute__((aligned(16))) float red[8][32 * 36];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, lk = lane >> 5;
+    const long m0 = (long)blockIdx.x * 32;
+    const int ft = blockIdx.y;
+    const long last = (long)p.rows - 1;
+    // this wave's weight pieces and x fragments: everything in flight at once
+    const unsigned char* wl = p.wp + ((long)ft * (8 * KSW) + wv * KSW) * PIECE + lane * 16;
+    const float* xr = p.x + min(m0 + lq, last) * p.ldx + wv * (16 * KSW) + 8 * lk;
+    F6 wf[KSW];
+    float4 xa[KSW], xb[KSW];
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        xa[j] = *reinterpret_cast<const float4*>(xr + 16 * j);
+        xb[j] = *reinterpret_cast<const float4*>(xr + 16 * j + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+#pragma unroll
+        for (int n = 0; n < 3; ++n) wf[j].p[n] = *reinterpret_cast<const bf16x8*>(wl + (long)j * PIECE + n * 1024);
+    }
+    // the two output elements this lane finishes: row 4 wv + (lane >> 4), columns 2 (lane & 15), + 1 of the tile
+    const int er = 4 * wv + (lane >> 4), ec = 2 * (lane & 15);
+    const long gr = m0 + er;
+    const long grc = min(gr, last);
+    const int col = ft * 32 + ec;
+    float2 bias2 = make_float2(0.f, 0.f), res2 = make_float2(0.f, 0.f), aux2 = make_float2(0.f, 0.f);
+    if (p.bias) bias2 = *reinterpret_cast<const float2*>(p.bias + col);
+    if (p.residual) res2 = *reinterpret_cast<const float2*>(p.residual + grc * p.ldr + col);
+    if (p.actgrad_in) aux2 = *reinterpret_cast<const float2*>(p.actgrad_in + grc * p.ld_aux + col);
+    const bool dead = p.rowmask && !p.rowmask[grc];
+    const unsigned long long seed_out = p.seed_out + (p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+    const DropParams dp_out = drop_params(p.p_out);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int j = 0; j < KSW; ++j) {
+        const float xv[8] = {xa[j].x, xa[j].y, xa[j].z, xa[j].w, xb[j].x, xb[j].y, xb[j].z, xb[j].w};
+        oe_bf16x8 pl[3];
+        oe_split8<3>(xv, pl);
+        F6 xf;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) xf.p[n] = pl[n];
+        acc = oe_mma_terms<6>(wf[j], xf, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wv][lq * 36 + f6_acc_row(r, lk)] = acc[r];
+    __syncthreads();
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) {
+        const float2 t = *reinterpret_cast<const float2*>(&red[w][er * 36 + ec]);
+        v0 += t.x; v1 += t.y;
+    }
+    if (gr > last) return;
+    float x0 = v0 + bias2.x, x1 = v1 + bias2.y;
+    if (p.preact_out) *reinterpret_cast<float2*>(p.preact_out + gr * p.ld_aux + col) = make_float2(x0, x1);
+    if (p.actgrad_in) {
+        x0 *= f6_act_bwd(p.act, aux2.x); x1 *= f6_act_bwd(p.act, aux2.y);
+    } else if (p.act == OE_ACT_RELU) {
+        x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f);
+    } else if (p.act == OE_ACT_SWISH) {
+        x0 *= sigmoidf_(x0); x1 *= sigmoidf_(x1);
+    }
+    if (p.p_out > 0.f) {
+        const uint2 h = drop_hash4(seed_out, ((unsigned long long)gr * p.no + col) >> 2);
+        const unsigned hw = (col & 2) ? h.y : h.x;
+        x0 *= drop_field(hw, 0, dp_out); x1 *= drop_field(hw, 1, dp_out);
+    }
+    if (dead) { x0 = 0.f; x1 = 0.f; }
+    *reinterpret_cast<float2*>(p.y + gr * p.ldy + col) = make_float2(res2.x + p.beta * x0, res2.y + p.beta * x1);
 }
 
 // one matrix W (rows R, cols Cc, row-major) -> the A-operand fragments of Wg = W (transposed = 0: Wg is (R, Cc)) or of Wg = W^T
@@ -611,6 +707,16 @@ __global__ __launch_bounds__(256) void row6_pack_table_kernel(const long long* _
 }
 
 extern "C" int oe_rowgemm6_supported(int k, int n) { return (k == 256 || k == 512) && n >= 128 && n % 128 == 0 && n <= 8192; }
+// which kernel oe_rowgemm6 runs for a problem: 2 = tile form (few rows: k a multiple of 128 up to 1024, n a multiple of 32),
+// 1 = row-block form, 0 = neither
+static int row6_tile_max_rows = getenv("OE_ROWTILE_MAX_ROWS") ? atoi(getenv("OE_ROWTILE_MAX_ROWS")) : 2048;
+extern "C" int oe_rowgemm6_form(int rows, int k, int n) {
+    const int ksw = k / 128;
+    if (rows > 0 && rows <= row6_tile_max_rows && k % 128 == 0 && (ksw == 2 || ksw == 4 || ksw == 6 || ksw == 8) && n >= 32 && n % 32 == 0 &&
+        n <= 32 * 65535)
+        return 2;
+    return oe_rowgemm6_supported(k, n) ? 1 : 0;
+}
 
 // table: device array of n entries of six 64-bit words { W, packed, R, Cc, ld, transposed }; max_pieces: the largest entry's
 // (Wg rows / 32) * (Wg cols / 16)
@@ -623,7 +729,13 @@ extern "C" int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces,
 
 extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     OE_REQUIRE(a && a->x && a->wp && a->y, "oe_rowgemm6: null pointer");
-    OE_REQUIRE(oe_rowgemm6_supported(a->k, a->n), "oe_rowgemm6: unsupported k=%d n=%d", a->k, a->n);
+    const int form = a->rows > 0 ? oe_rowgemm6_form(a->rows, a->k, a->n) : 0;
+    OE_REQUIRE(form != 0, "oe_rowgemm6: unsupported rows=%d k=%d n=%d", a->rows, a->k, a->n);
+    const bool has_act = a->act != OE_ACT_NONE || a->preact_out || a->actgrad_in;
+    OE_REQUIRE(form == 2 || !has_act, "oe_rowgemm6: activation / pre-activation epilogue only in the tile form (rows <= %d)", row6_tile_max_rows);
+    OE_REQUIRE(a->act == OE_ACT_NONE || a->act == OE_ACT_RELU || a->act == OE_ACT_SWISH, "oe_rowgemm6: activation %d is not fused", a->act);
+    OE_REQUIRE(!has_act || !(a->preact_out || a->actgrad_in) || (a->ld_aux % 2 == 0 && ((((uintptr_t)a->preact_out) | ((uintptr_t)a->actgrad_in)) & 7) == 0),
+               "oe_rowgemm6: pre-activation / act-grad source must be 8-byte aligned with an even row stride");
     OE_REQUIRE(a->rows > 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && (!a->residual || a->ldr % 4 == 0), "oe_rowgemm6: bad rows / strides");
     OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->residual) | ((uintptr_t)a->wp) | ((uintptr_t)a->bias)) & 15) == 0,
                "oe_rowgemm6: 16-byte alignment required");
@@ -631,6 +743,19 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     Row6Params p{};
     p.x = a->x; p.ldx = a->ldx; p.wp = (const unsigned char*)a->wp; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta;
     p.rowmask = a->rowmask; p.y = a->y; p.ldy = a->ldy; p.rows = a->rows; p.no = a->n; p.p_out = a->drop_p; p.seed_out = a->seed; p.seed_dev = a->seed_dev;
+    p.k = a->k; p.act = a->act; p.preact_out = a->preact_out; p.actgrad_in = a->actgrad_in; p.ld_aux = a->ld_aux;
+    if (form == 2) {
+        const dim3 tgrid(oe_cdiv(a->rows, 32), a->n / 32), tblock(512);
+        hipStream_t st = (hipStream_t)stream;
+        switch (a->k / 128) {
+            case 2: hipLaunchKernelGGL((rowtile6_kernel<2>), tgrid, tblock, 0, st, p); break;
+            case 4: hipLaunchKernelGGL((rowtile6_kernel<4>), tgrid, tblock, 0, st, p); break;
+            case 6: hipLaunchKernelGGL((rowtile6_kernel<6>), tgrid, tblock, 0, st, p); break;
+            default: hipLaunchKernelGGL((rowtile6_kernel<8>), tgrid, tblock, 0, st, p); break;
+        }
+        OE_LAUNCH_CHECK("oe_rowgemm6 (tile form)");
+        return 0;
+    }
     const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
     if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((rowgemm6_kernel<256>), grid, block, 0, (hipStream_t)stream, p);

@@ -101,6 +101,7 @@ class RowGemmArgs(C.Structure):
         ("rowmask", c_fp),
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
+        ("act", C.c_int), ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
     ]
 
 
@@ -158,6 +159,7 @@ _SIGNATURES = {
     "oe_rowgemm6_supported": (I, [I, I]),
     "oe_rowgemm6": (I, [C.POINTER(RowGemmArgs), P]),
     "oe_rowgemm6_pack_table": (I, [P, I, L, P]),
+    "oe_rowgemm6_form": (I, [I, I, I]),
     "oe_colsum_f32": (I, [P, L, I, I, F, P, P, I, P]),
     "oe_layernorm_fwd": (I, [P, P, P, F, I, I, P, I, P, P, P]),
     "oe_layernorm_fwd_pl": (I, [P, P, P, F, I, I, P, I, P, P, P, L, P]),
@@ -397,8 +399,9 @@ def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_d
     check(lib().oe_ffn_bwd(C.byref(a), stream()), "oe_ffn_bwd")
 
 
-def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=None, rowmask=None, residual=None, ldr=0, beta=1.0):
-    """y = residual + beta * rowmask * dropout(x @ Wg^T + bias) on the row-block kernel (oe_rowgemm6; wp = packed Wg)."""
+def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=None, rowmask=None, residual=None, ldr=0, beta=1.0,
+             act=0, preact_out=None, actgrad_in=None, ld_aux=0):
+    """y = residual + beta * rowmask * dropout(act(x @ Wg^T + bias)) on the row-block / tile kernels (oe_rowgemm6; wp = packed Wg)."""
     a = RowGemmArgs()
     dp = lambda t: None if t is None else t.data_ptr()
     a.x, a.ldx, a.wp, a.bias = x.data_ptr(), x.stride(0), wp.data_ptr(), dp(bias)
@@ -406,6 +409,7 @@ def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=No
     a.drop_p, a.seed, a.seed_dev, a.rowmask = drop_p, seed, dp(seed_dev), dp(rowmask)
     a.residual, a.ldr, a.beta = dp(residual), ldr, beta
     a.y, a.ldy = y.data_ptr(), y.stride(0)
+    a.act, a.preact_out, a.actgrad_in, a.ld_aux = act, dp(preact_out), dp(actgrad_in), ld_aux
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -99,6 +99,9 @@ ROWGEMM = os.environ.get("OE_ROWGEMM", "1") == "1"
 ROWGEMM_MIN_ROWS = int(os.environ.get("OE_ROWGEMM_MIN_ROWS", "4096"))
 ROWGEMM_LAUNCHES = 0       # (tests: which path a call took)
 _ROW_EPI_OK = {"drop_p", "seed", "seed_dev", "rowmask", "residual", "ldr", "beta"}
+# the tile form (few rows: oe_rowgemm6_form = 2, any k in {256, 512, 768, 1024}) also has oe_gemm_f32's activation epilogue
+_ROWTILE_EPI_OK = _ROW_EPI_OK | {"act", "preact_out", "actgrad_in", "ld_aux"}
+ROWTILE = os.environ.get("OE_ROWTILE", "1") == "1"
 
 
 class _PackTable:
@@ -219,15 +222,26 @@ def _row_packed(w, transposed):
 
 def _rowgemm_try(x, w, transposed, bias, out, epi):
     """x (M, k) @ Wg^T on the row-block kernel if the problem and its epilogue qualify; returns out or None."""
-    if not ROWGEMM or hip.GEMM_PRECISION != 6 or x.shape[0] < ROWGEMM_MIN_ROWS or not x.is_cuda:
+    if not ROWGEMM or hip.GEMM_PRECISION != 6 or not x.is_cuda:
         return None
     k = x.shape[1]
     n = w.shape[1] if transposed else w.shape[0]
-    if (w.shape[0] if transposed else w.shape[1]) != k or not hip.lib().oe_rowgemm6_supported(k, n):
+    if (w.shape[0] if transposed else w.shape[1]) != k:
         return None
+    form = hip.lib().oe_rowgemm6_form(x.shape[0], k, n)      # 2: tile form (few rows), 1: row-block form
+    if form == 0 or (form == 1 and x.shape[0] < ROWGEMM_MIN_ROWS) or (form == 2 and not ROWTILE):
+        return None
+    ok = _ROW_EPI_OK if form == 1 else _ROWTILE_EPI_OK
     for key, v in epi.items():                                 # an epilogue feature the kernel does not have: oe_gemm_f32
         unset = v is None or (not isinstance(v, torch.Tensor) and (v is False or v == 0 or (key == "beta" and v == 1.0)))
-        if not unset and key not in _ROW_EPI_OK:
+        if not unset and key not in ok:
+            return None
+    act = epi.get("act", 0) or 0
+    pre_out, aux_in, ld_aux = epi.get("preact_out"), epi.get("actgrad_in"), epi.get("ld_aux", 0) or 0
+    if act not in (0, ACT_RELU, ACT_SWISH) or (pre_out is not None and aux_in is not None):
+        return None
+    for t in (pre_out, aux_in):
+        if t is not None and (t.dtype != torch.float32 or t.data_ptr() % 8 or ld_aux % 2):
             return None
     if x.stride(1) != 1 or x.stride(0) % 4 or x.data_ptr() % 16 or w.stride(1) != 1 or w.stride(0) % 4 or w.data_ptr() % 16:
         return None
@@ -247,7 +261,8 @@ def _rowgemm_try(x, w, transposed, bias, out, epi):
     global ROWGEMM_LAUNCHES
     ROWGEMM_LAUNCHES += 1
     hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0, seed_dev=epi.get("seed_dev"),
-                 rowmask=epi.get("rowmask"), residual=res, ldr=epi.get("ldr", 0) or 0, beta=epi.get("beta", 1.0))
+                 rowmask=epi.get("rowmask"), residual=res, ldr=epi.get("ldr", 0) or 0, beta=epi.get("beta", 1.0),
+                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux)
     return out
 
 
@@ -272,7 +287,7 @@ def gemm_nn(dy, w, out=None, out_planes=False, **epi):
     operands exist at all (the conv front end's policy)."""
     M, N = dy.shape
     K = w.shape[1]
-    if not out_planes:
+    if not (out_planes and (_planes.available() if out_planes == "always" else _planes.split_activations())):
         y = _rowgemm_try(dy, w, True, None, out, epi)
         if y is not None:
             return y

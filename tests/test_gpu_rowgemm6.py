@@ -118,7 +118,7 @@ def test_unsupported_epilogues_and_shapes_stay_on_oe_gemm_f32():
         w2 = torch.nn.Parameter(torch.randn(256, 256, device=DEV) / 16)
         pre = torch.empty(4096, 256, device=DEV)
         ops.gemm_nt(x, w2, None, act=ops.ACT_SWISH, preact_out=pre, ld_aux=256)   # an activation epilogue
-        ops.gemm_nt(x[:1000], w2)                                               # below ROWGEMM_MIN_ROWS
+        ops.gemm_nt(x[:3000], w2)                                               # below ROWGEMM_MIN_ROWS, above the tile form's rows
     assert ops.ROWGEMM_LAUNCHES == n0
 
 
@@ -177,3 +177,115 @@ def test_captured_refresh_survives_later_registrations():
         torch.cuda.synchronize()
     assert ops._ROW.dev.data_ptr() == table_ptr and junk
     torch.testing.assert_close(ys, 2.0 * y_ref, rtol=1e-5, atol=1e-5)
+
+
+# --------------------------------------------------------------------------------------------------------------------------- #
+# tile form (oe_rowgemm6_form = 2): few rows, one 32 x 32 output tile per block, the eight waves split the reduction
+# --------------------------------------------------------------------------------------------------------------------------- #
+def test_form_table():
+    L = hip.lib()
+    assert L.oe_rowgemm6_form(992, 256, 256) == 2 and L.oe_rowgemm6_form(248, 256, 256) == 2 and L.oe_rowgemm6_form(5, 1024, 96) == 2
+    assert L.oe_rowgemm6_form(992, 768, 256) == 2 and L.oe_rowgemm6_form(992, 512, 1024) == 2
+    assert L.oe_rowgemm6_form(992, 384, 256) == 0 and L.oe_rowgemm6_form(992, 256, 3246) == 0 and L.oe_rowgemm6_form(992, 2048, 256) == 0
+    assert L.oe_rowgemm6_form(7936, 256, 256) == 1 and L.oe_rowgemm6_form(7936, 1024, 256) == 0 and L.oe_rowgemm6_form(7936, 256, 96) == 0
+    assert L.oe_rowgemm6_form(0, 256, 256) != 2
+
+
+@pytest.mark.parametrize("rows,k,n,bias,p,res,mask,beta,act", [
+    (992, 256, 768, True, 0.0, False, False, 1.0, 0),        # decoder self-attention q / k / v (decoder_layer.py:82-92)
+    (992, 256, 256, True, 0.1, True, False, 1.0, 0),         # attention output: bias, dropout, residual
+    (992, 1024, 256, True, 0.1, True, True, 0.5, 0),         # feed-forward w_2: k = 1024, scaled residual, dead rows
+    (992, 256, 1024, True, 0.1, False, False, 1.0, 1),       # feed-forward w_1 + relu + dropout, pre-activation kept
+    (992, 256, 1024, True, 0.0, False, False, 1.0, 2),       # ... + swish
+    (248, 256, 256, False, 0.0, False, False, 1.0, 0),       # linear_pos (attention.py:166-171): no bias
+    (37, 512, 96, True, 0.2, True, False, 1.0, 0),           # ragged single row block, n = 3 tiles
+    (2048, 768, 64, False, 0.0, False, False, 1.0, 0),       # k = 768
+])
+def test_tile_form_x_wT_matches_float64_and_the_fp32_kernel(rows, k, n, bias, p, res, mask, beta, act):
+    torch.manual_seed(81)
+    x = torch.randn(rows, k)
+    w = torch.randn(n, k) / math.sqrt(k)
+    b = torch.randn(n) * 0.1 if bias else None
+    r = torch.randn(rows, n) if res else None
+    m = (torch.rand(rows) > 0.1).to(torch.uint8) if mask else None
+    xd, wd = x.to(DEV), torch.nn.Parameter(w.to(DEV))
+    bd, rd, md = (None if t is None else t.to(DEV) for t in (b, r, m))
+    ctr = torch.tensor([9], dtype=torch.int64, device=DEV)
+    pre = torch.full((rows, n), float("nan"), device=DEV) if act else None
+    pre0 = torch.empty(rows, n, device=DEV) if act else None
+    epi = dict(drop_p=p, seed=0x5151, seed_dev=ctr, rowmask=md, residual=rd, ldr=n if res else 0, beta=beta, act=act, ld_aux=n if act else 0)
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        y = ops.gemm_nt(xd, wd, bd, preact_out=pre, **epi)
+    assert ops.ROWGEMM_LAUNCHES == n0 + 1
+    y0 = torch.empty(rows, n, device=DEV)
+    hip.gemm(xd, wd.detach(), y0, rows, n, k, lda=k, ldb=k, ldc=n, bias=bd, precision=0, preact_out=pre0, **epi)
+    ones = torch.ones(rows, n, device=DEV)
+    dm = torch.empty_like(ones)
+    hip.call("oe_dropout_scale", ones, ones.numel(), n, 1.0, p, 0x5151, ctr, None, dm)
+    torch.cuda.synchronize()
+    want = x.double() @ w.double().t()
+    if bias:
+        want = want + b.double()
+    want_pre = want
+    if act == 1:
+        want = want.clamp_min(0.0)
+    elif act == 2:
+        want = want * torch.sigmoid(want)
+    want = want * dm.cpu().double()
+    if mask:
+        want = want * m.double().unsqueeze(1)
+    want = (r.double() if res else 0.0) + beta * want
+    if act == 1:
+        # a pre-activation within rounding of zero may take the other branch: compare where it is clearly signed
+        sure = (want_pre.abs() > 1e-5)
+        assert float(((y.cpu().double() - want) * sure).abs().max()) < 5e-5
+    else:
+        e6, e0 = _err(y, want), _err(y0, want)
+        assert e6 <= 2.5 * e0 + 1e-6 * float(want.abs().max()), (e6, e0)
+        torch.testing.assert_close(y.cpu().double(), want, rtol=1e-4, atol=5e-5)
+    if act:
+        torch.testing.assert_close(pre.cpu().double(), want_pre, rtol=1e-4, atol=5e-5)
+
+
+@pytest.mark.parametrize("rows,n_fwd,k_fwd,act,p", [(992, 256, 256, 0, 0.0), (992, 1024, 256, 0, 0.0), (992, 256, 1024, 1, 0.1), (992, 256, 1024, 2, 0.1),
+                                                   (992, 768, 256, 0, 0.0), (61, 512, 256, 0, 0.0)])
+def test_tile_form_dy_w_matches_float64(rows, n_fwd, k_fwd, act, p):
+    """dx = dy W (reduction over n_fwd); with an activation: dH = (dy W2) * mask * act'(pre) - the feed-forward's backward
+    through w_2 (positionwise_feed_forward.py:36-43)."""
+    torch.manual_seed(82)
+    dy = torch.randn(rows, n_fwd)
+    w = torch.randn(n_fwd, k_fwd) / math.sqrt(k_fwd)
+    pre = torch.randn(rows, k_fwd) if act else None
+    dyd, wd = dy.to(DEV), torch.nn.Parameter(w.to(DEV))
+    pred = None if pre is None else pre.to(DEV)
+    ctr = torch.tensor([3], dtype=torch.int64, device=DEV)
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        dx = ops.gemm_nn(dyd, wd, act=act, actgrad_in=pred, ld_aux=k_fwd if act else 0, drop_p=p, seed=0x77, seed_dev=ctr, out_planes=True)
+    assert ops.ROWGEMM_LAUNCHES == n0 + 1
+    ones = torch.ones(rows, k_fwd, device=DEV)
+    dm = torch.empty_like(ones)
+    hip.call("oe_dropout_scale", ones, ones.numel(), k_fwd, 1.0, p, 0x77, ctr, None, dm)
+    torch.cuda.synchronize()
+    want = dy.double() @ w.double()
+    if act == 1:
+        want = want * (pre.double() > 0)
+    elif act == 2:
+        s = torch.sigmoid(pre.double())
+        want = want * (s * (1 + pre.double() * (1 - s)))
+    want = want * dm.cpu().double()
+    torch.testing.assert_close(dx.cpu().double(), want, rtol=1e-4, atol=5e-5)
+
+
+def test_tile_form_declines_what_it_cannot_do():
+    x = torch.randn(992, 256, device=DEV)
+    w = torch.nn.Parameter(torch.randn(3246, 256, device=DEV) / 16)              # n not a multiple of 32
+    w3 = torch.nn.Parameter(torch.randn(256, 384, device=DEV) / 16)              # k = 384
+    w4 = torch.nn.Parameter(torch.randn(256, 256, device=DEV) / 16)
+    n0 = ops.ROWGEMM_LAUNCHES
+    with torch.no_grad():
+        ops.gemm_nt(x, w)
+        ops.gemm_nt(torch.randn(992, 384, device=DEV), w3)
+        ops.gemm_nt(x, w4, alpha=0.5)                                            # an epilogue key the kernel does not have
+    assert ops.ROWGEMM_LAUNCHES == n0

@@ -22,7 +22,7 @@ nb = hip.lib().oe_ffn_packed_bytes(d, ff, 6)
 w1p, w2p = torch.empty(nb, dtype=torch.uint8, device=dev), torch.empty(nb, dtype=torch.uint8, device=dev)
 pre, a, y = torch.empty(rows, ff, device=dev), torch.empty(rows, ff, device=dev), torch.empty(rows, d, device=dev)
 hip.call("oe_ffn_pack_weights", w1, w2, d, ff, 6, w1p, w2p)
-stamps = torch.zeros(8 * 128, dtype=torch.int64, device=dev)
+stamps = torch.zeros(2 * 8 * 128, dtype=torch.int64, device=dev)
 mode = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 NG = 1 if mode in (1, 2) else 2
 L = hip.lib()
@@ -34,7 +34,7 @@ for _ in range(5):
     hip.ffn_fwd(x, w1p, b1, w2p, b2, rows, d, ff, 2, drop_in=0.1, seed_in=1, drop_out=0.1, seed_out=2, pre_out=pre, act_out=a, residual=res,
                 ldr=d, beta=0.5, y=y, precision=6)
 torch.cuda.synchronize()
-s = stamps.cpu().view(8, 128)
+s = stamps.cpu().view(2, 8, 128)[0]
 nch = ff // 128 // NG
 for w in range(4 * NG):
     t = s[w]
