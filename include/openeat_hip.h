@@ -193,7 +193,8 @@ int oe_ffn_pack_weights_table(const void* table, int n, int max_d, int max_ff, i
 int oe_ffn6_config(int mode);
 
 /* One Linear with a short reduction as a ROW-BLOCK GEMM in precision 6 (csrc/ffn6.hip, the fused feed-forward's first half alone):
- *     y[rows, n] = residual + beta * rowmask * dropout( x[rows, k] @ Wg[n, k]^T + bias ),   k in {256, 512}, n a multiple of 128
+ *     y[rows, n] = residual + beta * rowmask * dropout( x[rows, k] @ Wg[n, k]^T + bias ),   k in {256, 512}, n a multiple of 128;
+ *     also k in {768, 1024} with n in {128, 256} (K-phased kernel: the input gradient through the fused q / k / v projection)
  * (attention.py:56-58,97 linear_q / k / v / out, convolution.py:79-111 pointwise convs, and - with Wg = W^T - their input
  * gradients).  wp: Wg as packed A-operand fragments (oe_rowgemm6_pack_table: 6 bytes per weight, refreshed whenever the weights
  * change).  Dropout / rowmask / residual as oe_gemm_f32's epilogue (mask element index row * n + col, seed_dev mixed in the same way).

@@ -588,6 +588,152 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// K-PHASED form of the row-block GEMM: k = 256 nph (nph = 3, 4), n <= 256 - the input gradient through the fused q / k / v
+// projection (7936 x 256 <- 768: 36.6 us as 248 tiles of 128 x 64 walking 24 K-tiles, 85 TFLOP/s).  The rows of one phase (256
+// columns of x) sit in LDS as planes; the next phase's rows are already in registers while this phase's MFMAs run and replace
+// them behind a barrier pair; every wave keeps ONE accumulator tile through all phases (hence n <= 256: two groups x four waves);
+// the packed weight stream of a column tile is contiguous over the whole reduction, so the register ring runs straight through
+// the phase boundaries.
+__global__ __launch_bounds__(512, 2) void rowgemm6p_kernel(Row6Params p) {
+    constexpr int D = 256, BM = 32;
+    constexpr int KS = D / 16;
+    constexpr int FR = 2, NSET = 4;
+    constexpr int NSTG = KS / FR;
+    constexpr int XP = D + 8;
+    constexpr int X_BYTES = 3 * BM * XP * 2;
+    constexpr int PATCH = 32 * 36 * 4;
+    constexpr int PIECE = 3 * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[X_BYTES + 8 * PATCH];
+    unsigned char* xs = lds;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp = wv >> 2, wave = wv & 3;
+    const int lq = lane & 31, lk = lane >> 5;
+    const long m0 = (long)blockIdx.x * BM;
+    const long last = (long)p.rows - 1;
+    const int nchunks = p.no / 128;                                  // 1 or 2 (host check)
+    const int nph = p.k / D;
+    const int kst = p.k / 16;                                        // pieces per column tile
+    const bool active = grp < nchunks;                               // n = 128: the second group only helps with the rows
+    const int ft = 4 * (active ? grp : 0) + wave;
+    float* patch = reinterpret_cast<float*>(lds + X_BYTES + wv * PATCH);
+    const unsigned char* wl = p.wp + lane * 16 + (long)ft * kst * PIECE;
+    auto load_stage = [&](auto w_c, int ph, F6 (&f)[FR]) {
+        constexpr int w = decltype(w_c)::value;
+        const unsigned char* b1p = wl + (long)ph * KS * PIECE;
+#pragma unroll
+        for (int j = 0; j < FR; ++j) {
+            const unsigned char* src = b1p + (long)(w * FR + j) * PIECE;
+            f[j].p[0] = *reinterpret_cast<const bf16x8*>(src); f[j].p[1] = *reinterpret_cast<const bf16x8*>(src + 1024);
+            f[j].p[2] = *reinterpret_cast<const bf16x8*>(src + 2048);
+        }
+    };
+    F6 fr[NSET][FR];
+    static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, 0, fr[decltype(k_c)::value]); });
+    // this thread's four float4 of a phase's rows: element i = threadIdx.x + 512 q -> row i / 64, columns 4 (i % 64) ..
+    float4 xr[4];
+    auto load_x = [&](int ph) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + 512 * q;
+            xr[q] = *reinterpret_cast<const float4*>(p.x + min(m0 + (i >> 6), last) * p.ldx + ph * D + (i & 63) * 4);
+        }
+    };
+    auto store_x = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = threadIdx.x + 512 * q;
+            const int row = i >> 6, c4 = (i & 63) * 4;
+            const float xv[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w};
+            oe_bf16x4v pl[3];
+            oe_split4<3>(xv, pl);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + c4) * 2) = pl[n];
+        }
+    };
+    load_x(0);
+    const unsigned long long seed_out = p.seed_out + (p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+    const DropParams dp_out = drop_params(p.p_out);
+    float4 q0, q1, q2, q3;
+    q0 = q1 = q2 = q3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) {
+        const float* bp = p.bias + ft * 32 + 4 * lk;
+        q0 = *reinterpret_cast<const float4*>(bp); q1 = *reinterpret_cast<const float4*>(bp + 8);
+        q2 = *reinterpret_cast<const float4*>(bp + 16); q3 = *reinterpret_cast<const float4*>(bp + 24);
+    }
+    float4 r0, r1, r2, r3;
+    r0 = r1 = r2 = r3 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.residual) {
+        const float* rp = p.residual + ft * 32 + (lane & 7) * 4;
+        const long rr = m0 + (lane >> 3);
+        r0 = *reinterpret_cast<const float4*>(rp + min(rr, last) * p.ldr); r1 = *reinterpret_cast<const float4*>(rp + min(rr + 8, last) * p.ldr);
+        r2 = *reinterpret_cast<const float4*>(rp + min(rr + 16, last) * p.ldr); r3 = *reinterpret_cast<const float4*>(rp + min(rr + 24, last) * p.ldr);
+    }
+    auto x_frag = [&](int ks, F6& f) {
+        const unsigned char* a = xs + ((size_t)lq * XP + 16 * ks + 8 * lk) * 2;
+#pragma unroll
+        for (int n = 0; n < 3; ++n) f.p[n] = *reinterpret_cast<const bf16x8*>(a + (size_t)n * BM * XP * 2);
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int ph = 0; ph < nph; ++ph) {
+        if (ph > 0) __syncthreads();                                 // every wave is done with the previous phase's planes
+        store_x();
+        if (ph + 1 < nph) load_x(ph + 1);                            // in flight under this phase's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (active) {
+            const int ph_next = min(ph + 1, nph - 1);                // (past the end: the last phase's stages again, into sets nobody reads)
+            F6 xf[2];
+            x_frag(0, xf[0]);
+            static_for<0, NSTG>([&](auto st_c) {
+                constexpr int st = decltype(st_c)::value;
+                constexpr int cu = st % NSET, pf = (st + NSET - 1) % NSET;
+                constexpr int ahead = st + NSET - 1;
+                load_stage(std::integral_constant<int, ahead % NSTG>{}, ahead < NSTG ? ph : ph_next, fr[pf]);
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, FR>([&](auto j_c) {
+                    constexpr int j = decltype(j_c)::value;
+                    constexpr int ks = st * FR + j;
+                    if constexpr (ks + 1 < KS) x_frag(ks + 1, xf[(ks + 1) & 1]);
+                    acc = oe_mma_terms<6>(fr[cu][j], xf[ks & 1], acc);
+                });
+            });
+        }
+    }
+    if (!active) return;
+    float hv[16];
+    hv[0] = acc[0] + q0.x; hv[1] = acc[1] + q0.y; hv[2] = acc[2] + q0.z; hv[3] = acc[3] + q0.w;
+    hv[4] = acc[4] + q1.x; hv[5] = acc[5] + q1.y; hv[6] = acc[6] + q1.z; hv[7] = acc[7] + q1.w;
+    hv[8] = acc[8] + q2.x; hv[9] = acc[9] + q2.y; hv[10] = acc[10] + q2.z; hv[11] = acc[11] + q2.w;
+    hv[12] = acc[12] + q3.x; hv[13] = acc[13] + q3.y; hv[14] = acc[14] + q3.z; hv[15] = acc[15] + q3.w;
+    f6_wave_sync();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) patch[lq * 36 + f6_acc_row(r, lk)] = hv[r];
+    f6_wave_sync();
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
+        const long gr = m0 + row;
+        if (gr >= p.rows) continue;
+        const int col = ft * 32 + c4;
+        float4 v = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+        if (p.p_out > 0.f) {
+            const uint2 h = drop_hash4(seed_out, ((unsigned long long)gr * p.no + col) >> 2);
+            v.x *= drop_field(h.x, 0, dp_out); v.y *= drop_field(h.x, 1, dp_out);
+            v.z *= drop_field(h.y, 0, dp_out); v.w *= drop_field(h.y, 1, dp_out);
+        }
+        if (p.rowmask && !p.rowmask[gr]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.residual || p.beta != 1.f) {
+            const float4 res = ps == 0 ? r0 : ps == 1 ? r1 : ps == 2 ? r2 : r3;
+            v = make_float4(res.x + p.beta * v.x, res.y + p.beta * v.y, res.z + p.beta * v.z, res.w + p.beta * v.w);
+        }
+        *reinterpret_cast<float4*>(p.y + gr * p.ldy + col) = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // TILE FORM of the same product for FEW rows (the decoders' Linears: 992 rows at config 2; the relative-position projection: 248).
 // There the row-block form is one latency chain per block - 31 blocks that each stream the whole packed matrix (393 KiB for
 // 256 x 256: 13.6 us, as long as for 7936 rows) - and a tiled launch is 16 blocks walking eight K-tiles (14 us).  Here a block owns
@@ -706,7 +852,11 @@ __global__ __launch_bounds__(256) void row6_pack_table_kernel(const long long* _
     *reinterpret_cast<oe_bf16x8*>(dst + 1024) = pl[2];
 }
 
-extern "C" int oe_rowgemm6_supported(int k, int n) { return (k == 256 || k == 512) && n >= 128 && n % 128 == 0 && n <= 8192; }
+extern "C" int oe_rowgemm6_supported(int k, int n) {
+    static const int kphase = getenv("OE_ROWGEMM_KPHASE") ? atoi(getenv("OE_ROWGEMM_KPHASE")) : 1;      // tuning: 0 = off
+    if (kphase && (k == 768 || k == 1024) && (n == 128 || n == 256)) return 1;       // K-phased kernel: one accumulator tile per wave
+    return (k == 256 || k == 512) && n >= 128 && n % 128 == 0 && n <= 8192;
+}
 // which kernel oe_rowgemm6 runs for a problem: 2 = tile form (few rows: k a multiple of 128 up to 1024, n a multiple of 32),
 // 1 = row-block form, 0 = neither
 static int row6_tile_max_rows = getenv("OE_ROWTILE_MAX_ROWS") ? atoi(getenv("OE_ROWTILE_MAX_ROWS")) : 2048;
@@ -757,7 +907,8 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
         return 0;
     }
     const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
-    if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
+    if (a->k > 512) hipLaunchKernelGGL(rowgemm6p_kernel, grid, block, 0, (hipStream_t)stream, p);
+    else if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((rowgemm6_kernel<256>), grid, block, 0, (hipStream_t)stream, p);
     OE_LAUNCH_CHECK("oe_rowgemm6");
     return 0;

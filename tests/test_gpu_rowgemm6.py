@@ -34,6 +34,8 @@ def _err(got, ref):
     (7936, 256, 512, True, 0.0, False, False, 1.0),        # pointwise_conv1
     (4097, 256, 128, False, 0.0, True, False, 0.5),        # one chunk (the second wave group idles), ragged last block, scaled residual
     (4500, 512, 1536, True, 0.2, False, False, 1.0),       # configs[4] width
+    (4100, 768, 256, True, 0.1, True, True, 0.5),          # K-phased kernel: three phases of 256, both groups
+    (4097, 1024, 128, False, 0.0, False, False, 1.0),      # ... four phases, one chunk (the second group only stages rows), ragged
 ])
 def test_x_wT_matches_float64_and_the_fp32_kernel(rows, k, n, bias, p, res, mask, beta):
     torch.manual_seed(71)
@@ -68,7 +70,8 @@ def test_x_wT_matches_float64_and_the_fp32_kernel(rows, k, n, bias, p, res, mask
     torch.testing.assert_close(y.cpu().double(), want, rtol=1e-4, atol=5e-5)
 
 
-@pytest.mark.parametrize("rows,n_fwd,k_fwd,mask", [(7936, 256, 256, False), (7936, 512, 256, True), (7936, 256, 512, False), (5000, 512, 1536, False)])
+@pytest.mark.parametrize("rows,n_fwd,k_fwd,mask", [(7936, 256, 256, False), (7936, 512, 256, True), (7936, 256, 512, False), (5000, 512, 1536, False),
+                                                  (7936, 768, 256, False), (4999, 768, 256, True)])      # the fused q / k / v projection's input gradient
 def test_dy_w_matches_float64_and_the_fp32_kernel(rows, n_fwd, k_fwd, mask):
     """The input gradient dx = dy W of a Linear with weight W (n_fwd, k_fwd): reduction over n_fwd (256 / 512), output k_fwd wide."""
     torch.manual_seed(72)
@@ -187,7 +190,7 @@ def test_form_table():
     assert L.oe_rowgemm6_form(992, 256, 256) == 2 and L.oe_rowgemm6_form(248, 256, 256) == 2 and L.oe_rowgemm6_form(5, 1024, 96) == 2
     assert L.oe_rowgemm6_form(992, 768, 256) == 2 and L.oe_rowgemm6_form(992, 512, 1024) == 2
     assert L.oe_rowgemm6_form(992, 384, 256) == 0 and L.oe_rowgemm6_form(992, 256, 3246) == 0 and L.oe_rowgemm6_form(992, 2048, 256) == 0
-    assert L.oe_rowgemm6_form(7936, 256, 256) == 1 and L.oe_rowgemm6_form(7936, 1024, 256) == 0 and L.oe_rowgemm6_form(7936, 256, 96) == 0
+    assert L.oe_rowgemm6_form(7936, 256, 256) == 1 and L.oe_rowgemm6_form(7936, 1024, 256) == 1 and L.oe_rowgemm6_form(7936, 768, 512) == 0 and L.oe_rowgemm6_form(7936, 256, 96) == 0
     assert L.oe_rowgemm6_form(0, 256, 256) != 2
 
 
