@@ -34,7 +34,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md, dense bf16 MFMA (no sparsity)
 TERMS = {0: 1, 1: 1, 3: 3, 6: 6}     # bf16 MFMAs issued per algorithmic product in each arithmetic mode
 KERNEL_NAMES = {0: "gemm_f32_kernel (oe_gemm_f32, v_mfma_f32_32x32x2_f32)",
-                6: "gemm_pl_kernel + gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn6_kernel + rowgemm6_kernel <terms=6> "
+                6: "gemm_pl_kernel + gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn6_kernel + rowgemm6/rowgemm6p/rowtile6_kernel <terms=6> "
                    "(the kernels behind oe_gemm_f32 / oe_gemm_tn_grouped / oe_ffn_fwd / oe_ffn_bwd / oe_rowgemm6 precision 6: three exact bf16 "
                    "pieces per operand, hh+hm+mh+mm+hl+lh on v_mfma_f32_32x32x16_bf16)",
                 1: "gemm_dma_kernel + gemm_bf16_kernel + gemm_tn_planes/grouped_kernel + ffn_fwd_kernel <terms=1> (the kernels behind "

@@ -30,7 +30,7 @@ tot = sum(v["SQ_VALU_MFMA_BUSY_CYCLES"] for v in agg.values()) or 1.0
 cls = collections.defaultdict(lambda: [0.0, 0.0])
 for key, v in sorted(agg.items(), key=lambda kv: -kv[1]["SQ_VALU_MFMA_BUSY_CYCLES"]):
     busy, act = v["SQ_VALU_MFMA_BUSY_CYCLES"], v["GRBM_GUI_ACTIVE"]
-    c = "attention" if "attn_" in key[0] else "gemm" if ("gemm_" in key[0] or "ffn6_kernel" in key[0] or "rowgemm6_kernel" in key[0] or "ffn_fwd_kernel" in key[0]) else "other"
+    c = "attention" if "attn_" in key[0] else "gemm" if ("gemm_" in key[0] or "ffn6_kernel" in key[0] or ("rowgemm6" in key[0] or "rowtile6" in key[0]) or "ffn_fwd_kernel" in key[0]) else "other"
     cls[c][0] += busy
     cls[c][1] += act
     if busy <= 0:

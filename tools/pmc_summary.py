@@ -35,7 +35,7 @@ fetch, write = load("FETCH_SIZE"), load("WRITE_SIZE")
 adam = [v[0] for k, v in fetch.items() if "adam_kernel" in k]
 if adam:
     steps = float(adam[0])
-is_gemm = lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n or "ffn6_kernel" in n or "rowgemm6_kernel" in n
+is_gemm = lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n or "ffn6_kernel" in n or ("rowgemm6" in n or "rowtile6" in n)
 rows = []
 for name in sorted(set(fetch) | set(write)):
     n = max(fetch[name][0], write[name][0]) / steps

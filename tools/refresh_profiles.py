@@ -37,7 +37,7 @@ adam = [int(r["Calls"]) for r in rows if "adam_kernel" in r["Name"]]
 if adam:
     steps = float(adam[0])                       # the Adam kernel runs once per optimizer step
 tot = sum(int(r["TotalDurationNs"]) for r in rows)
-gem = [r for r in rows if "gemm_" in r["Name"] or "ffn_fwd_kernel" in r["Name"] or "ffn6_kernel" in r["Name"] or "rowgemm6_kernel" in r["Name"]]
+gem = [r for r in rows if "gemm_" in r["Name"] or "ffn_fwd_kernel" in r["Name"] or "ffn6_kernel" in r["Name"] or "rowgemm6" in r["Name"] or "rowtile6" in r["Name"]]
 gt, gc = sum(int(r["TotalDurationNs"]) for r in gem), sum(int(r["Calls"]) for r in gem)
 line = json.load(open(f"{src}/{tag}_bench_p{P}.json"))
 ro = line["roofline"]
@@ -47,7 +47,7 @@ with open(f"{dst}/{tag}_kernel_stats_p{P}.md", "w") as f:
             f"({steps:g} optimizer steps in the trace, counted by the Adam kernel's launches: first step + warm-up + timed + 2 event-bracketed; the `spin_kernel` launches that park the "
             f"GPU during the event-bracketed steps are left out).  Full table: `{tag}_kernel_stats_p{P}.csv`.\n\n")
     f.write(f"All kernels: {tot / 1e6 / steps:.2f} ms/step (serialised by the profiler; the un-profiled step is {line['ms_per_step']:.1f} ms).  "
-            f"**GEMM class (`gemm_pl_kernel` + `gemm_dma_kernel` + `gemm_bf16_kernel` + `gemm_tn_planes/grouped_kernel` + `ffn6_kernel` + `rowgemm6_kernel`, the kernels behind `oe_gemm_f32` / `oe_gemm_tn_grouped` / `oe_ffn_fwd` / `oe_ffn_bwd` / `oe_rowgemm6`): {gc / steps:.0f} launches/step, "
+            f"**GEMM class (`gemm_pl_kernel` + `gemm_dma_kernel` + `gemm_bf16_kernel` + `gemm_tn_planes/grouped_kernel` + `ffn6_kernel` + `rowgemm6_kernel` / `rowgemm6p_kernel` / `rowtile6_kernel`, the kernels behind `oe_gemm_f32` / `oe_gemm_tn_grouped` / `oe_ffn_fwd` / `oe_ffn_bwd` / `oe_rowgemm6`): {gc / steps:.0f} launches/step, "
             f"{gt / 1e6 / steps:.2f} ms/step, average launch {gt / gc / 1e3:.2f} us = {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TFLOP/s algorithmic** - "
             f"bench.py's live HIP-event figure (event-pair overhead calibrated out) is {ro['gemm_ms_per_step']:.2f} ms/step, "
             f"{ro['avg_launch_us']:.2f} us average, {ro['achieved']:.1f} TFLOP/s.\n\n")

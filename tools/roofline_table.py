@@ -36,7 +36,7 @@ ln_single = 12 * 3 + 1                                                  # norm_m
 ln_fwd_bytes = (ln_single * 2 + 11 * 3 + 1 * 2) * act + ln_dec * 2 * actd
 ln_bwd_bytes = (ln_single * 4 + 12 * 3 + 11 * 4 + 1 * 3) * act + ln_dec * 4 * actd
 classes = [
-    ("GEMM kernels (`gemm_pl_kernel`, `gemm_dma_kernel`, `gemm_bf16_kernel`, `gemm_tn_*`, `ffn6_kernel`, `rowgemm6_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n or "ffn6_kernel" in n or "rowgemm6_kernel" in n,   # gemm_tn_grouped_kernel included
+    ("GEMM kernels (`gemm_pl_kernel`, `gemm_dma_kernel`, `gemm_bf16_kernel`, `gemm_tn_*`, `ffn6_kernel`, `rowgemm6*_kernel`, `rowtile6_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n or "ffn6_kernel" in n or ("rowgemm6" in n or "rowtile6" in n),   # gemm_tn_grouped_kernel included
      f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
     ("attention (`attn_planes_q`, `attn_planes_k`; `attn_qtile`, `attn_ktile_bwd` for short axes)", "mfma", attn_enc + attn_dec, lambda n: n.startswith("void attn_") or n.startswith("attn_"),
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
