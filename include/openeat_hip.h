@@ -210,6 +210,15 @@ typedef struct oe_rowgemm_args {
     /* tile form only (oe_rowgemm6_form = 2), oe_gemm_f32's activation epilogue: act = OE_ACT_NONE / RELU / SWISH applied after the bias
      * (preact_out, optional: the value before it, row stride ld_aux), or - actgrad_in set - the product times act'(actgrad_in[row, col]) */
     int act; float* preact_out; const float* actgrad_in; long ld_aux;
+    /* LayerNorm-backward prologue (row-block form, k = 256; ln_dy != NULL; x is then ignored): the GEMM's input rows are MADE here as
+     *     dx = ln_add + LN'(ln_dy; ln_x, ln_stats (mean, rstd per row), ln_gamma),   g = g_alpha * dropmask(g_p, g_seed, seed_dev) * g_rowmask * dx
+     * i.e. oe_layernorm_bwd_dx_drop's two outputs (written to ln_dx / ln_g, both (rows, k) contiguous), g feeding the product; ln_ws
+     * receives the parameter-gradient partials in oe_layernorm_bwd_workspace_floats' layout for oe_layernorm_param_reduce(_table).
+     * (encoder_layer.py:79-95: the backward of `x = residual + dropout(f(norm(x)))` starts from this g.) */
+    const float* ln_dy; const float* ln_x; const float* ln_stats; const float* ln_gamma; const float* ln_add;
+    float* ln_dx; float* ln_g; float* ln_ws;
+    float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask;
+    const unsigned char* ln_rowmask;            /* the LayerNorm's own row mask (rows with 0: dx = ln_add, no parameter gradient) or NULL */
 } oe_rowgemm_args;
 int oe_rowgemm6_supported(int k, int n);
 /* Which kernel oe_rowgemm6 runs: 1 = the row-block form above (k in {256, 512}, n % 128 == 0: one 32-row block streams the whole packed

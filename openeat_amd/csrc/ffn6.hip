@@ -444,9 +444,22 @@ struct Row6Params {
     float p_out; unsigned long long seed_out;
     const unsigned long long* seed_dev;
     int k, act; float* preact_out; const float* actgrad_in; long ld_aux;     // (tile form only)
+    // LayerNorm-backward prologue (row-block form, LNP): the rows of x are not read but MADE - see rowgemm6_kernel
+    const float* ln_dy; const float* ln_x; const float* ln_stats; const float* ln_gamma; const float* ln_add;
+    float* ln_dx; float* ln_g; float* ln_ws;
+    float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask;
+    const unsigned char* ln_rowmask;
 };
 
-template <int D>
+// LNP (LayerNorm-backward prologue): the GEMM's input rows are the gradient a pre-norm residual block's backward STARTS from,
+//     g = g_alpha * dropmask(g_seed) * dx,   dx = ln_add + LN'(ln_dy; ln_x, ln_stats, ln_gamma)
+// (oe_layernorm_bwd_dx_drop's two outputs, element for element: same per-lane float4 order, same wave sums, same mask words).  A
+// block owns 32 whole rows and a wave owns four of them, exactly as in layernorm_bwd_kernel, so the LayerNorm backward that used
+// to be a launch of its own in front of this GEMM (10.8 us + a dependent-launch gap, 24 times per step at config 2) becomes the way
+// the rows reach LDS: dx and g are written (the residual stream and the weight gradient read them), g is split into the planes, and
+// the per-block partial sums of the LayerNorm's parameter gradients go to ln_ws in layernorm_bwd_kernel's layout (one slot per 16
+// rows: rows 0-15 and 16-31 of the block) for the same reduction launch.
+template <int D, bool LNP = false>
 __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     constexpr int BM = 32, NG = 2;
     constexpr int KS = D / 16;
@@ -490,7 +503,107 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
         static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, c0, fr[decltype(k_c)::value]); });
     }
     // (the rows after the ring's first stages are on their way: both round trips overlap)
-    {
+    if constexpr (LNP) {
+        static_assert(D == 256, "the prologue's partial sums reuse the patches: d = 256 only");
+        constexpr int NV = D / 256;
+        const float4* g4 = reinterpret_cast<const float4*>(p.ln_gamma);
+        float4 gam[NV], dg[2][NV], db[2][NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            gam[j] = g4[lane + 64 * j];
+            dg[0][j] = dg[1][j] = db[0][j] = db[1][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const DropParams g_dpar = drop_params(p.g_p);
+        const unsigned long long g_seed_eff = p.g_seed + (p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+        // this wave's four rows: wv, wv + 8 (slot 0 of the partial sums), wv + 16, wv + 24 (slot 1); all their loads first
+        float4 dyv[4][NV], xv[4][NV], av[4][NV];
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long rc = min(m0 + wv + 8 * k, (long)p.rows - 1);
+            mean[k] = p.ln_stats[rc * 2];
+            rstd[k] = p.ln_stats[rc * 2 + 1];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + 64 * j;
+                dyv[k][j] = reinterpret_cast<const float4*>(p.ln_dy + rc * D)[i];
+                xv[k][j] = reinterpret_cast<const float4*>(p.ln_x + rc * D)[i];
+                av[k][j] = p.ln_add ? reinterpret_cast<const float4*>(p.ln_add + rc * D)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = wv + 8 * k;
+            const long grow = m0 + row;
+            const bool valid = grow < p.rows;
+            const bool live = valid && !(p.ln_rowmask && !p.ln_rowmask[grow]);      // a masked row: dx = add, nothing for gamma / beta
+            float4 g[NV], xh[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float4 t = dyv[k][j];
+                const float4 v = xv[k][j];
+                xh[j] = make_float4((v.x - mean[k]) * rstd[k], (v.y - mean[k]) * rstd[k], (v.z - mean[k]) * rstd[k], (v.w - mean[k]) * rstd[k]);
+                if (!live) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = t; }
+                g[j] = make_float4(t.x * gam[j].x, t.y * gam[j].y, t.z * gam[j].z, t.w * gam[j].w);
+                s1 += g[j].x + g[j].y + g[j].z + g[j].w;
+                s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
+                float4& dgs = dg[k >> 1][j];
+                float4& dbs = db[k >> 1][j];
+                dgs.x += t.x * xh[j].x; dgs.y += t.y * xh[j].y; dgs.z += t.z * xh[j].z; dgs.w += t.w * xh[j].w;
+                dbs.x += t.x; dbs.y += t.y; dbs.z += t.z; dbs.w += t.w;
+            }
+            const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i = lane + 64 * j;
+                float4 o = av[k][j];
+                if (live) {
+                    o.x += rstd[k] * (g[j].x - c1 - xh[j].x * c2);
+                    o.y += rstd[k] * (g[j].y - c1 - xh[j].y * c2);
+                    o.z += rstd[k] * (g[j].z - c1 - xh[j].z * c2);
+                    o.w += rstd[k] * (g[j].w - c1 - xh[j].w * c2);
+                }
+                float4 gq = make_float4(o.x * p.g_alpha, o.y * p.g_alpha, o.z * p.g_alpha, o.w * p.g_alpha);
+                const unsigned long long e0 = (unsigned long long)grow * D + 4 * i;
+                if (p.g_p > 0.f) {
+                    const uint4 r = drop_words8(g_seed_eff, e0 >> 3);
+                    const bool hi = (e0 >> 2) & 1;                 // second half of the call's eight fields
+                    const unsigned wa = hi ? r.z : r.x, wb = hi ? r.w : r.y;
+                    gq.x *= drop_field(wa, 0, g_dpar); gq.y *= drop_field(wa, 1, g_dpar);
+                    gq.z *= drop_field(wb, 0, g_dpar); gq.w *= drop_field(wb, 1, g_dpar);
+                }
+                if (valid && p.g_rowmask && !p.g_rowmask[grow]) gq = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) {
+                    reinterpret_cast<float4*>(p.ln_dx + grow * D)[i] = o;
+                    reinterpret_cast<float4*>(p.ln_g + grow * D)[i] = gq;
+                }
+                const float xq[4] = {gq.x, gq.y, gq.z, gq.w};
+                oe_bf16x4v pl[3];
+                oe_split4<3>(xq, pl);
+#pragma unroll
+                for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + 4 * i) * 2) = pl[n];
+            }
+        }
+        // the parameter-gradient partials of the block's two 16-row slots: the waves' sums meet in the (still unused) patches
+        float* red = reinterpret_cast<float*>(lds + X_BYTES);                     // [8 waves][2 slots][2][D]
+        static_assert(8 * 2 * 2 * D * 4 <= 8 * PATCH, "partial sums fit the patches");
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 0) * D)[lane + 64 * j] = dg[sl][j];
+                reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 1) * D)[lane + 64 * j] = db[sl][j];
+            }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 4 * D; c += 512) {                           // c = (slot * 2 + which) * D + column
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[w * 4 * D + c];
+            const long slot = 2 * (long)blockIdx.x + c / (2 * D);
+            if (slot * 16 < p.rows) p.ln_ws[slot * 2 * D + (c % (2 * D))] = sum;
+        }
+    } else {
         constexpr int C4 = D / 4;
         for (int i = threadIdx.x; i < BM * C4; i += 512) {
             const int row = i / C4, c4 = (i - row * C4) * 4;
@@ -878,7 +991,7 @@ extern "C" int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces,
 }
 
 extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
-    OE_REQUIRE(a && a->x && a->wp && a->y, "oe_rowgemm6: null pointer");
+    OE_REQUIRE(a && (a->x || a->ln_dy) && a->wp && a->y, "oe_rowgemm6: null pointer");
     const int form = a->rows > 0 ? oe_rowgemm6_form(a->rows, a->k, a->n) : 0;
     OE_REQUIRE(form != 0, "oe_rowgemm6: unsupported rows=%d k=%d n=%d", a->rows, a->k, a->n);
     const bool has_act = a->act != OE_ACT_NONE || a->preact_out || a->actgrad_in;
@@ -887,6 +1000,13 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     OE_REQUIRE(!has_act || !(a->preact_out || a->actgrad_in) || (a->ld_aux % 2 == 0 && ((((uintptr_t)a->preact_out) | ((uintptr_t)a->actgrad_in)) & 7) == 0),
                "oe_rowgemm6: pre-activation / act-grad source must be 8-byte aligned with an even row stride");
     OE_REQUIRE(a->rows > 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && (!a->residual || a->ldr % 4 == 0), "oe_rowgemm6: bad rows / strides");
+    if (a->ln_dy) {
+        OE_REQUIRE(form == 1 && a->k == 256, "oe_rowgemm6: the LayerNorm-backward prologue exists in the row-block form at k = 256 only");
+        OE_REQUIRE(a->ln_x && a->ln_stats && a->ln_gamma && a->ln_dx && a->ln_g && a->ln_ws, "oe_rowgemm6: LayerNorm prologue: null pointer");
+        OE_REQUIRE(((((uintptr_t)a->ln_dy) | ((uintptr_t)a->ln_x) | ((uintptr_t)a->ln_gamma) | ((uintptr_t)a->ln_add) | ((uintptr_t)a->ln_dx) |
+                     ((uintptr_t)a->ln_g)) & 15) == 0, "oe_rowgemm6: LayerNorm prologue: 16-byte alignment required");
+        OE_REQUIRE(a->g_p >= 0.f && a->g_p < 1.f, "oe_rowgemm6: LayerNorm prologue: dropout rate out of range");
+    }
     OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->residual) | ((uintptr_t)a->wp) | ((uintptr_t)a->bias)) & 15) == 0,
                "oe_rowgemm6: 16-byte alignment required");
     OE_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f, "oe_rowgemm6: dropout rate out of range");
@@ -894,6 +1014,9 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     p.x = a->x; p.ldx = a->ldx; p.wp = (const unsigned char*)a->wp; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta;
     p.rowmask = a->rowmask; p.y = a->y; p.ldy = a->ldy; p.rows = a->rows; p.no = a->n; p.p_out = a->drop_p; p.seed_out = a->seed; p.seed_dev = a->seed_dev;
     p.k = a->k; p.act = a->act; p.preact_out = a->preact_out; p.actgrad_in = a->actgrad_in; p.ld_aux = a->ld_aux;
+    p.ln_dy = a->ln_dy; p.ln_x = a->ln_x; p.ln_stats = a->ln_stats; p.ln_gamma = a->ln_gamma; p.ln_add = a->ln_add;
+    p.ln_dx = a->ln_dx; p.ln_g = a->ln_g; p.ln_ws = a->ln_ws; p.g_alpha = a->g_alpha; p.g_p = a->g_p; p.g_seed = a->g_seed; p.g_rowmask = a->g_rowmask;
+    p.ln_rowmask = a->ln_rowmask;
     if (form == 2) {
         const dim3 tgrid(oe_cdiv(a->rows, 32), a->n / 32), tblock(512);
         hipStream_t st = (hipStream_t)stream;
@@ -908,6 +1031,7 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     }
     const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
     if (a->k > 512) hipLaunchKernelGGL(rowgemm6p_kernel, grid, block, 0, (hipStream_t)stream, p);
+    else if (a->ln_dy) hipLaunchKernelGGL((rowgemm6_kernel<256, true>), grid, block, 0, (hipStream_t)stream, p);
     else if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((rowgemm6_kernel<256>), grid, block, 0, (hipStream_t)stream, p);
     OE_LAUNCH_CHECK("oe_rowgemm6");

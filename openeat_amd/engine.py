@@ -93,6 +93,7 @@ class TrainEngine:
         loss = loss / self.accum_grad if self.accum_grad != 1 else loss
         ops.stamp("fwd: losses done")
         loss.backward()
+        ops.resolve_pending_ln()               # (a parked LayerNorm backward whose consumer never ran: none in a healthy step)
         ops.stamp("bwd: main chain done")
         ops.join_side_stream()                 # weight-gradient GEMMs running beside the backward chain
         ops.ln_table_flush()                   # captured graph: every LayerNorm's parameter-gradient partials in one launch

@@ -102,6 +102,10 @@ class RowGemmArgs(C.Structure):
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
         ("act", C.c_int), ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
+        ("ln_dy", c_fp), ("ln_x", c_fp), ("ln_stats", c_fp), ("ln_gamma", c_fp), ("ln_add", c_fp),
+        ("ln_dx", c_fp), ("ln_g", c_fp), ("ln_ws", c_fp),
+        ("g_alpha", C.c_float), ("g_p", C.c_float), ("g_seed", C.c_ulonglong), ("g_rowmask", c_fp),
+        ("ln_rowmask", c_fp),
     ]
 
 
@@ -400,16 +404,21 @@ def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_d
 
 
 def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=None, rowmask=None, residual=None, ldr=0, beta=1.0,
-             act=0, preact_out=None, actgrad_in=None, ld_aux=0):
+             act=0, preact_out=None, actgrad_in=None, ld_aux=0, ln=None):
     """y = residual + beta * rowmask * dropout(act(x @ Wg^T + bias)) on the row-block / tile kernels (oe_rowgemm6; wp = packed Wg)."""
     a = RowGemmArgs()
     dp = lambda t: None if t is None else t.data_ptr()
-    a.x, a.ldx, a.wp, a.bias = x.data_ptr(), x.stride(0), wp.data_ptr(), dp(bias)
+    a.x, a.ldx, a.wp, a.bias = (0 if x is None else x.data_ptr()), (k if x is None else x.stride(0)), wp.data_ptr(), dp(bias)
     a.rows, a.k, a.n = rows, k, n
     a.drop_p, a.seed, a.seed_dev, a.rowmask = drop_p, seed, dp(seed_dev), dp(rowmask)
     a.residual, a.ldr, a.beta = dp(residual), ldr, beta
     a.y, a.ldy = y.data_ptr(), y.stride(0)
     a.act, a.preact_out, a.actgrad_in, a.ld_aux = act, dp(preact_out), dp(actgrad_in), ld_aux
+    if ln is not None:        # LayerNorm-backward prologue: dict(dy, x, stats, gamma, add, dx, g, ws, alpha, p, seed, rowmask)
+        a.ln_dy, a.ln_x, a.ln_stats, a.ln_gamma, a.ln_add = dp(ln["dy"]), dp(ln["x"]), dp(ln["stats"]), dp(ln["gamma"]), dp(ln.get("add"))
+        a.ln_dx, a.ln_g, a.ln_ws = dp(ln["dx"]), dp(ln["g"]), dp(ln["ws"])
+        a.g_alpha, a.g_p, a.g_seed, a.g_rowmask = ln["alpha"], ln["p"], ln["seed"], dp(ln.get("rowmask"))
+        a.ln_rowmask = dp(ln.get("ln_rowmask"))
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

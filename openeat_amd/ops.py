@@ -220,8 +220,18 @@ def _row_packed(w, transposed):
     return ent["buf"]
 
 
-def _rowgemm_try(x, w, transposed, bias, out, epi):
-    """x (M, k) @ Wg^T on the row-block kernel if the problem and its epilogue qualify; returns out or None."""
+def _rowgemm_try(x, w, transposed, bias, out, epi, ln_pending=None):
+    """x (M, k) @ Wg^T on the row-block / tile kernels if the problem and its epilogue qualify; returns out or None.
+    ln_pending: x is the `g` of a parked LayerNorm backward (_PENDING_LN) - launched as the kernel's prologue when this is the
+    k = 256 row-block kernel, and on its own BEFORE anything reads x in every other case (also when None is returned)."""
+    try:
+        return _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending)
+    finally:
+        if ln_pending is not None:
+            _resolve_ln(ln_pending)              # (no-op when the fused launch has happened)
+
+
+def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending):
     if not ROWGEMM or hip.GEMM_PRECISION != 6 or not x.is_cuda:
         return None
     k = x.shape[1]
@@ -258,11 +268,27 @@ def _rowgemm_try(x, w, transposed, bias, out, epi):
         out = _new(M, n, like=x)
     elif out.stride(1) != 1 or out.stride(0) % 4 or out.data_ptr() % 16:
         return None
-    global ROWGEMM_LAUNCHES
+    global ROWGEMM_LAUNCHES, LN_BWD_FUSED_LAUNCHES
     ROWGEMM_LAUNCHES += 1
-    hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0, seed_dev=epi.get("seed_dev"),
+    ln = None
+    if ln_pending is not None and not ln_pending.get("done"):
+        pd = ln_pending
+        sd = epi.get("seed_dev")
+        if (form == 1 and k == 256 and x.is_contiguous() and x.data_ptr() == pd["g"].data_ptr() and M == pd["rows"] and
+                (sd is None or _seed_dev is None or sd.data_ptr() == _seed_dev.data_ptr()) and (epi.get("drop_p", 0.0) or 0.0) == 0.0):
+            alpha, p, seed, gmask = pd["spec"]
+            ln = dict(dy=pd["dy"], x=pd["x"], stats=pd["stats"], gamma=pd["gamma"], add=pd["add"], dx=pd["dx"], g=pd["g"], ws=pd["ws"],
+                      alpha=alpha, p=p, seed=seed, rowmask=gmask, ln_rowmask=pd.get("rowmask"))
+        else:
+            _resolve_ln(pd)                     # this launch reads x: the LayerNorm backward first, on its own
+    hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0,
+                 seed_dev=(_seed_dev if ln is not None else epi.get("seed_dev")),
                  rowmask=epi.get("rowmask"), residual=res, ldr=epi.get("ldr", 0) or 0, beta=epi.get("beta", 1.0),
-                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux)
+                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux, ln=ln)
+    if ln is not None:
+        ln_pending["done"] = True
+        LN_BWD_FUSED_LAUNCHES += 1
+        _ln_reduce(ln_pending)
     return out
 
 
@@ -287,10 +313,13 @@ def gemm_nn(dy, w, out=None, out_planes=False, **epi):
     operands exist at all (the conv front end's policy)."""
     M, N = dy.shape
     K = w.shape[1]
+    pend = _PENDING_LN.pop(dy.data_ptr(), None) if _PENDING_LN else None         # dy is the g of a parked LayerNorm backward
     if not (out_planes and (_planes.available() if out_planes == "always" else _planes.split_activations())):
-        y = _rowgemm_try(dy, w, True, None, out, epi)
+        y = _rowgemm_try(dy, w, True, None, out, epi, ln_pending=pend)             # (launches or resolves it on every path)
         if y is not None:
             return y
+    elif pend is not None:
+        _resolve_ln(pend)
     if out is None:
         out = _new(M, K, like=dy)
     ap, bp = _operand_planes(dy, w)
@@ -753,14 +782,64 @@ _PREDROP = {}
 def predrop_clear():
     """Called where a new step starts (ASRModel.forward / LanguageModel.forward / TrainEngine): drops the previous step's
     leftovers - dropped-gradient copies and the registry of pre-split GEMM operands."""
+    if _PENDING_LN:
+        resolve_pending_ln()
     _PREDROP.clear()
     _planes.clear()
 
 
-def _tag_out_drop(out, out_scale, p_out, s_out, rowmask=None):
+def _tag_out_drop(out, out_scale, p_out, s_out, rowmask=None, ln_fuse=False):
     if FUSE_OUT_DROP and (p_out > 0 or out_scale != 1.0 or rowmask is not None):
         out._oe_outdrop = (float(out_scale), float(p_out), int(s_out), rowmask)
+        if ln_fuse:
+            out._oe_lnfuse = True          # this block's backward can take the next LayerNorm's backward into its first GEMM (_ln_bwd)
     return out
+
+
+# The LayerNorm backward in front of a block's backward as the PROLOGUE of that block's first input-gradient GEMM (oe_rowgemm6's
+# ln_* arguments): the block (attention: linear_out; conv module: pointwise_conv2) says at forward time that its backward starts with
+# `g = _out_drop_grad(dy)` followed by `gemm_nn(g, w)` on the row-block kernel (_ln_fuse_ok); the pre-norm fork that consumes the
+# block's output then does NOT launch its backward kernel but parks its arguments here, keyed by the address of g; gemm_nn finds
+# them and launches the fused kernel, which writes dx and g before anything else can read them.  Every other path out of
+# _out_drop_grad / gemm_nn resolves a parked entry by launching the LayerNorm backward on its own (_resolve_ln), and TrainEngine
+# checks that none is left behind.  24 launches per step at config 2 (10.8 us + a dependent-launch gap each).
+LN_BWD_FUSE = os.environ.get("OE_LN_BWD_FUSE", "1") == "1"
+LN_BWD_FUSED_LAUNCHES = 0       # (tests)
+_PENDING_LN = {}
+
+
+def _ln_fuse_ok(rows, d, w):
+    """Forward-time promise of a block whose backward starts with gemm_nn(g, w), w (d, d): will that be the k = 256 row-block kernel?"""
+    return (LN_BWD_FUSE and ROWGEMM and FUSE_OUT_DROP and hip.GEMM_PRECISION == 6 and d == 256 and rows >= ROWGEMM_MIN_ROWS and
+            w.shape[0] == 256 and w.shape[1] == 256 and not _planes.active())
+
+
+def _ln_reduce(pend):
+    if pend["table"]:
+        return                                   # (a captured step: the entry is in LN_TABLE, one launch at the end of backward)
+    hip.call("oe_layernorm_param_reduce", pend["ws"], pend["rows"], pend["d"], pend["dg"], pend["db"])
+
+
+def _resolve_ln(pend):
+    """The parked LayerNorm backward as a launch of its own (exactly what _ln_bwd would have launched)."""
+    if pend.get("done"):
+        return
+    alpha, p, seed, gmask = pend["spec"]
+    hip.call("oe_layernorm_bwd_dx_drop", pend["dy"], pend["x"], pend["gamma"], pend["beta"], 0, pend["stats"], pend["rows"], pend["d"],
+             pend.get("rowmask"), pend["add"], pend["dx"], pend["g"], alpha, p, seed, _seed_dev, gmask, pend["ws"])
+    pend["done"] = True
+    _ln_reduce(pend)
+
+
+def resolve_pending_ln():
+    """Safety net (TrainEngine after backward, predrop_clear): a parked LayerNorm backward nobody picked up.  Returns the count."""
+    n = 0
+    for pend in list(_PENDING_LN.values()):
+        if not pend.get("done"):
+            _resolve_ln(pend)
+            n += 1
+    _PENDING_LN.clear()
+    return n
 
 
 def _out_drop_grad(dy2, out_scale, p_out, s_out, rowmask=None):
@@ -770,18 +849,40 @@ def _out_drop_grad(dy2, out_scale, p_out, s_out, rowmask=None):
         # the entry keeps the producing dx alive, so no other tensor can have been given this address meanwhile; an
         # in-place change of dx since (autograd summing a second consumer's gradient into it) shows in its version
         g, spec, dx, version = hit
+        pend = _PENDING_LN.get(g.data_ptr()) if _PENDING_LN else None
         if dx._version != version or dx.numel() != dy2.numel():
+            if pend is not None:
+                _resolve_ln(_PENDING_LN.pop(g.data_ptr()))
             return dropout_scale(dy2, out_scale, p_out, s_out, rowmask)
         same_mask = (spec[3] is None and rowmask is None) or (spec[3] is not None and rowmask is not None and
                                                                spec[3].data_ptr() == rowmask.data_ptr())
         if spec[:3] == (float(out_scale), float(p_out), int(s_out)) and same_mask and g.numel() == dy2.numel():
-            return g.view(dy2.shape)
+            return g.view(dy2.shape)              # (possibly still parked: the caller's gemm_nn comes next and launches it)
+        if pend is not None:
+            _resolve_ln(_PENDING_LN.pop(g.data_ptr()))
     return dropout_scale(dy2, out_scale, p_out, s_out, rowmask)
 
 
-def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, to_arena, prev_drop=None):
+def _ln_bwd(dy, x, gamma, beta, act, stats, rows, d, rowmask, add, dx, dg, db, to_arena, prev_drop=None, fuse=False):
     ws = _ln_ws(x, rows, d)
     g = None
+    # (to_arena: the parameter gradients are written later than this function returns - fine for arena slices, which autograd never
+    # sees, wrong for fresh tensors that PreNormFn.backward hands back to autograd right away)
+    if (fuse and to_arena and prev_drop is not None and LN_BWD_FUSE and FUSE_OUT_DROP and act == ACT_NONE and d == 256 and
+            hip.GEMM_PRECISION == 6 and rows >= ROWGEMM_MIN_ROWS and not _planes.active() and dy.is_contiguous() and x.is_contiguous() and
+            (add is None or add.is_contiguous())):
+        # parked: the consuming block's first input-gradient GEMM launches it as its prologue (see _PENDING_LN)
+        g = torch.empty_like(dx)
+        t = LN_TABLE
+        table = t is not None and to_arena
+        _PENDING_LN[g.data_ptr()] = dict(dy=dy, x=x, gamma=gamma, beta=beta, stats=stats, add=add, dx=dx, g=g, ws=ws, spec=prev_drop,
+                                         rows=rows, d=d, dg=dg, db=db, table=table, done=False, rowmask=rowmask)
+        _PREDROP[dx.data_ptr()] = (g, prev_drop, dx, dx._version)
+        if table:
+            t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
+            t["keep"].append(ws)
+            t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
+        return
     if prev_drop is not None and FUSE_OUT_DROP and d % 8 == 0:
         g = torch.empty_like(dx)
         alpha, p, seed, gmask = prev_drop
@@ -853,6 +954,7 @@ class PreNormFn(torch.autograd.Function):
         _ln_fwd(x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
         ctx.save_for_backward(x, gamma, beta, stats, rowmask)
         ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
+        ctx.ln_fuse = bool(sole_consumer and getattr(x, "_oe_lnfuse", False))
         return x.view_as(x), y
 
     @staticmethod
@@ -866,7 +968,7 @@ class PreNormFn(torch.autograd.Function):
         (dg, rg), (db, rb) = grad_sink(gamma), grad_sink(beta)
         add = None if dres is None else dres.contiguous()
         _ln_bwd(dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db, rg is None and rb is None,
-                ctx.prev_drop)
+                ctx.prev_drop, fuse=ctx.ln_fuse)
         return dx, rg, rb, None, None, None
 
 
@@ -1366,7 +1468,7 @@ class AttentionFn(torch.autograd.Function):
         ctx.cfg = (self_attn, rel, B, T1, T2, d, H, D, scale, p_attn, s_att, p_out, s_out, residual is not None, mstr)
         ctx.biases = (bq, bk, bv, bo)
         ctx.pp_external = pp_in is not None
-        return _tag_out_drop(y.view(B, T1, d), 1.0, p_out, s_out)
+        return _tag_out_drop(y.view(B, T1, d), 1.0, p_out, s_out, ln_fuse=_ln_fuse_ok(B * T1, d, wo))
 
     @staticmethod
     def backward(ctx, dy):
@@ -1377,8 +1479,8 @@ class AttentionFn(torch.autograd.Function):
         g = dy2 if p_out == 0 else _out_drop_grad(dy2, 1.0, p_out, s_out)
         att2 = att.view(-1, d)
         bq, bk, bv, bo = ctx.biases
+        datt = gemm_nn(g, wo)                    # FIRST: g may be a parked LayerNorm backward that this launch makes (_PENDING_LN)
         dwo, dbo = wgrad_bias(wo, bo, g, att2)
-        datt = gemm_nn(g, wo)
         delta = _new(B, H, T1, like=dy)
         if self_attn:
             dqkv = _new(B * T1, 3 * d, like=dy)
@@ -1568,7 +1670,7 @@ class ConvModuleFn(torch.autograd.Function):
         ctx.save_for_backward(xm, rowmask, w1, wd, g, b, w2, a, yc, stats, z, gpad)
         ctx.biases = (b1, bd, b2)
         ctx.cfg = (B, T, d, K, causal, act, p_out, s_out, residual is not None)
-        return _tag_out_drop(y.view(B, T, d), 1.0, p_out, s_out, rowmask)
+        return _tag_out_drop(y.view(B, T, d), 1.0, p_out, s_out, rowmask, ln_fuse=_ln_fuse_ok(B * T, d, w2m))
 
     @staticmethod
     def backward(ctx, dy):
@@ -1579,8 +1681,8 @@ class ConvModuleFn(torch.autograd.Function):
         dy2 = dy.view(-1, d)
         w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
         gq = dy2 if (p_out == 0 and rowmask is None) else _out_drop_grad(dy2, 1.0, p_out, s_out, rowmask)
+        dz = gemm_nn(gq, w2m)                    # FIRST: gq may be a parked LayerNorm backward that this launch makes (_PENDING_LN)
         dw2, db2 = wgrad_bias(w2, b2, gq, z)
-        dz = gemm_nn(gq, w2m)
         dyc = torch.empty_like(yc)
         (dg, rg), (dbeta, rbeta) = grad_sink(g), grad_sink(b)
         _ln_bwd(dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta, rg is None and rbeta is None)

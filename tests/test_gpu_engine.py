@@ -717,3 +717,43 @@ def test_weight_planes_follow_an_optimizer_loop_outside_the_engine(policy):
         planes.clear_all()
     assert losses["0"][0] > losses["0"][-1]                                   # the loop does train
     np.testing.assert_allclose(losses[policy], losses["0"], rtol=5e-4)
+
+
+def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
+    """ops._PENDING_LN: at d = 256 and >= 4096 rows in precision 6 the backward of the pre-norm fork behind an attention / conv-module
+    block runs as the prologue of that block's first input-gradient GEMM (oe_rowgemm6's ln_* arguments).  Same model, same batch, same
+    dropout masks with the switch off and on: the gradient arena must agree to rounding (the two kernels contract a*b+c differently:
+    one unit in the last place per element), the fused launches are counted, nothing stays parked."""
+    from openeat_amd import hip
+    old = (hip.GEMM_PRECISION, ops.LN_BWD_FUSE)
+    hip.GEMM_PRECISION = 6
+    grads, losses, launches = [], [], []
+    B, T = 11, 1530                                              # T' = 381: 11 x 381 = 4191 encoder rows
+    try:
+        for fuse in (False, True):
+            ops.LN_BWD_FUSE = fuse
+            torch.manual_seed(5)
+            ops.manual_seed(17)                                  # the same dropout streams in both runs
+            m = ASRModel(80, 40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=256, attention_heads=4,
+                         linear_units=512, dropout_rate=0.1, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3).to(DEV).train()
+            e = TrainEngine(m, lr=1e-3, grad_clip=5.0, static_shapes=True)
+            try:
+                b = batch_of(B=B, T=T, L=9, seed=4)
+                n0 = ops.LN_BWD_FUSED_LAUNCHES
+                e.arena.zero_grad()
+                loss, _ = e._fwd_bwd(b)
+                torch.cuda.synchronize()
+                assert not ops._PENDING_LN
+                launches.append(ops.LN_BWD_FUSED_LAUNCHES - n0)
+                grads.append(e.arena.grad.detach().clone())
+                losses.append(float(loss))
+            finally:
+                e.arena.deactivate()
+                ops.set_seed_device_counter(None)
+    finally:
+        hip.GEMM_PRECISION, ops.LN_BWD_FUSE = old
+    assert launches == [0, 4]                                    # two encoder layers x (attention, conv module)
+    assert losses[0] == losses[1]                                # the forward pass is untouched
+    scale = float(grads[0].abs().max())
+    assert float((grads[1] - grads[0]).abs().max()) <= 2e-5 * scale
+    assert float((grads[1] - grads[0]).norm()) <= 1e-5 * float(grads[0].norm())

@@ -292,3 +292,91 @@ def test_tile_form_declines_what_it_cannot_do():
         ops.gemm_nt(torch.randn(992, 384, device=DEV), w3)
         ops.gemm_nt(x, w4, alpha=0.5)                                            # an epilogue key the kernel does not have
     assert ops.ROWGEMM_LAUNCHES == n0
+
+
+# --------------------------------------------------------------------------------------------------------------------------- #
+# LayerNorm-backward prologue (oe_rowgemm_args.ln_*): the rows of the GEMM are made by the LayerNorm backward that preceded it
+# --------------------------------------------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("rows,p,with_add,with_mask,ln_mask", [(7936, 0.1, True, False, False), (4101, 0.0, False, False, False),
+                                                               (7936, 0.1, True, True, False), (5000, 0.1, True, True, True)])
+def test_ln_backward_prologue_equals_the_two_launches(rows, p, with_add, with_mask, ln_mask):
+    """oe_layernorm_bwd_dx_drop followed by oe_rowgemm6 against ONE oe_rowgemm6 with the ln_* arguments: dx, g and the product to one
+    unit in the last place, the same mask, the parameter-gradient partials to rounding (other grouping of the same sums)."""
+    torch.manual_seed(91)
+    d = 256
+    x = torch.randn(rows, d, device=DEV) * 1.7 + 0.3
+    dy = torch.randn(rows, d, device=DEV)
+    add = torch.randn(rows, d, device=DEV) if with_add else None
+    gamma, beta = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    gmask = (torch.rand(rows, device=DEV) > 0.1).to(torch.uint8) if with_mask else None
+    lmask = (torch.rand(rows, device=DEV) > 0.15).to(torch.uint8) if ln_mask else None      # the LayerNorm's own row mask
+    w = torch.nn.Parameter(torch.randn(d, d, device=DEV) / 16)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    mean = x.mean(1)
+    rstd = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    stats = torch.stack([mean, rstd], 1).contiguous()
+    nws = hip.lib().oe_layernorm_bwd_workspace_floats(rows, d)
+    # two launches
+    dx0, g0, ws0 = torch.empty_like(x), torch.empty_like(x), torch.zeros(nws, device=DEV)
+    old = ops._seed_dev
+    ops._seed_dev = ctr
+    try:
+        hip.call("oe_layernorm_bwd_dx_drop", dy, x, gamma, beta, 0, stats, rows, d, lmask, add, dx0, g0, 0.5, p, 0x1234, ctr, gmask, ws0)
+        with torch.no_grad():
+            ops.LN_BWD_FUSE, keep = False, ops.LN_BWD_FUSE
+            y0 = ops.gemm_nn(g0, w)
+            ops.LN_BWD_FUSE = keep
+            # one launch
+            dx1, g1, ws1 = torch.full_like(x, float("nan")), torch.full_like(x, float("nan")), torch.zeros(nws, device=DEV)
+            dg, db = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+            pend = dict(dy=dy, x=x, gamma=gamma, beta=beta, stats=stats, add=add, dx=dx1, g=g1, ws=ws1, spec=(0.5, p, 0x1234, gmask), rows=rows, d=d,
+                        dg=dg, db=db, table=False, done=False, rowmask=lmask)
+            ops._PENDING_LN[g1.data_ptr()] = pend
+            n0 = ops.LN_BWD_FUSED_LAUNCHES
+            y1 = ops.gemm_nn(g1, w)
+            assert ops.LN_BWD_FUSED_LAUNCHES == n0 + 1 and pend["done"] and not ops._PENDING_LN
+    finally:
+        ops._seed_dev = old
+    dg0, db0 = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    hip.call("oe_layernorm_param_reduce", ws0, rows, d, dg0, db0)
+    torch.cuda.synchronize()
+    # (the same formulas in another kernel: hipcc contracts a*b+c differently here and there - one unit in the last place)
+    torch.testing.assert_close(dx1, dx0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(g1, g0, rtol=2e-6, atol=1e-6)
+    assert torch.equal(g1 == 0, g0 == 0)                              # the same dropout mask / dead rows
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dg, dg0, rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(db, db0, rtol=2e-5, atol=2e-4)
+
+
+def test_a_parked_layernorm_backward_is_resolved_on_every_other_path():
+    """gemm_nn on a kernel that cannot take the prologue (k = 512 here; the tile form; oe_gemm_f32) launches the LayerNorm backward on
+    its own first; so does a miss in _out_drop_grad; resolve_pending_ln() sweeps what nobody picked up."""
+    torch.manual_seed(92)
+    rows, d = 4096, 256
+    x, dy = torch.randn(rows, d, device=DEV), torch.randn(rows, d, device=DEV)
+    gamma, beta = torch.ones(d, device=DEV), torch.zeros(d, device=DEV)
+    stats = torch.stack([x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    nws = hip.lib().oe_layernorm_bwd_workspace_floats(rows, d)
+
+    def park():
+        dx, g = torch.full_like(x, float("nan")), torch.full_like(x, float("nan"))
+        pend = dict(dy=dy, x=x, gamma=gamma, beta=beta, stats=stats, add=None, dx=dx, g=g, ws=torch.zeros(nws, device=DEV), spec=(1.0, 0.0, 0, None),
+                    rows=rows, d=d, dg=torch.zeros(d, device=DEV), db=torch.zeros(d, device=DEV), table=False, done=False)
+        ops._PENDING_LN[g.data_ptr()] = pend
+        return pend
+
+    want = torch.empty_like(x)
+    hip.call("oe_layernorm_bwd_dx", dy, x, gamma, beta, 0, stats, rows, d, None, None, want, torch.zeros(nws, device=DEV))
+    with torch.no_grad():
+        w_wide = torch.nn.Parameter(torch.randn(256, 320, device=DEV) / 16)            # output 320 wide (not a multiple of 128): oe_gemm_f32
+        pend = park()
+        n0 = ops.LN_BWD_FUSED_LAUNCHES
+        y = ops.gemm_nn(pend["g"], w_wide)
+        assert pend["done"] and ops.LN_BWD_FUSED_LAUNCHES == n0 and not ops._PENDING_LN
+        torch.cuda.synchronize()
+        assert torch.equal(pend["dx"], want) and torch.equal(pend["g"], want) and bool(torch.isfinite(y).all())      # (the same kernel: exact)
+        pend = park()
+        assert ops.resolve_pending_ln() == 1 and pend["done"] and not ops._PENDING_LN
+        torch.cuda.synchronize()
+        assert torch.equal(pend["dx"], want)
