@@ -156,6 +156,20 @@ int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves);
  * seed_dev mixed in the same way), so oe_gemm_f32 / oe_dropout_scale regenerate them in backward.
  * All pointers 16-byte aligned, ldx / ldr / ldy multiples of 4.
  * ------------------------------------------------------------------------- */
+/* LayerNorm-backward PROLOGUE of a row-block kernel (oe_rowgemm6 at k = 256, oe_ffn_bwd at d = 256, precision 6): when dy != NULL the
+ * kernel's input rows are not read but MADE, as
+ *     dx = add + LN'(dy; x, stats (mean, rstd per row), gamma),   g = g_alpha * dropmask(g_p, g_seed, seed_dev) * g_rowmask * dx
+ * i.e. oe_layernorm_bwd_dx_drop's two outputs (written to dx / g, both (rows, 256) contiguous), g feeding the kernel's product; ws
+ * receives the parameter-gradient partials in oe_layernorm_bwd_workspace_floats' layout for oe_layernorm_param_reduce(_table).
+ * (encoder_layer.py:79-106: the backward of every `x = residual + dropout(f(norm(x)))` starts from this g, and the LayerNorm
+ * backward that makes it used to be a launch of its own.)  ln_rowmask: the LayerNorm's own row mask (rows with 0: dx = add, no
+ * parameter gradient) or NULL.  The seed_dev of the enclosing argument block is the one mixed into g_seed. */
+typedef struct oe_ln_prologue {
+    const float* dy; const float* x; const float* stats; const float* gamma; const float* add;
+    float* dx; float* g; float* ws;
+    float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask; const unsigned char* ln_rowmask;
+} oe_ln_prologue;
+
 typedef struct oe_ffn_args {
     const float* x; long ldx;                  /* (rows, d) */
     const void* w1p; const float* b1;          /* packed W1, bias (ff) or NULL */
@@ -167,6 +181,7 @@ typedef struct oe_ffn_args {
     float* pre_out; float* act_out;
     const float* residual; long ldr; float beta;
     float* y; long ldy;
+    oe_ln_prologue ln;                          /* oe_ffn_bwd only (precision 6, d = 256): ln.dy != NULL makes the rows of dY (x is then ignored) */
 } oe_ffn_args;
 size_t oe_ffn_packed_bytes(int d, int ff, int precision);
 int oe_ffn_supported(int d, int ff, int precision, int act);
@@ -210,15 +225,7 @@ typedef struct oe_rowgemm_args {
     /* tile form only (oe_rowgemm6_form = 2), oe_gemm_f32's activation epilogue: act = OE_ACT_NONE / RELU / SWISH applied after the bias
      * (preact_out, optional: the value before it, row stride ld_aux), or - actgrad_in set - the product times act'(actgrad_in[row, col]) */
     int act; float* preact_out; const float* actgrad_in; long ld_aux;
-    /* LayerNorm-backward prologue (row-block form, k = 256; ln_dy != NULL; x is then ignored): the GEMM's input rows are MADE here as
-     *     dx = ln_add + LN'(ln_dy; ln_x, ln_stats (mean, rstd per row), ln_gamma),   g = g_alpha * dropmask(g_p, g_seed, seed_dev) * g_rowmask * dx
-     * i.e. oe_layernorm_bwd_dx_drop's two outputs (written to ln_dx / ln_g, both (rows, k) contiguous), g feeding the product; ln_ws
-     * receives the parameter-gradient partials in oe_layernorm_bwd_workspace_floats' layout for oe_layernorm_param_reduce(_table).
-     * (encoder_layer.py:79-95: the backward of `x = residual + dropout(f(norm(x)))` starts from this g.) */
-    const float* ln_dy; const float* ln_x; const float* ln_stats; const float* ln_gamma; const float* ln_add;
-    float* ln_dx; float* ln_g; float* ln_ws;
-    float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask;
-    const unsigned char* ln_rowmask;            /* the LayerNorm's own row mask (rows with 0: dx = ln_add, no parameter gradient) or NULL */
+    oe_ln_prologue ln;                          /* row-block form at k = 256: ln.dy != NULL makes the input rows (x is then ignored) */
 } oe_rowgemm_args;
 int oe_rowgemm6_supported(int k, int n);
 /* Which kernel oe_rowgemm6 runs: 1 = the row-block form above (k in {256, 512}, n % 128 == 0: one 32-row block streams the whole packed

@@ -441,7 +441,8 @@ extern "C" int oe_ffn_fwd(const oe_ffn_args* a, void* stream) {
 // forward's pre-activation (rows, ff) - an INPUT -, act_out = dH (rows, ff) output, y = dX (rows, d); b1, b2, residual,
 // drop_out must be unset.
 extern "C" int oe_ffn_bwd(const oe_ffn_args* a, void* stream) {
-    OE_REQUIRE(a && a->x && a->w1p && a->w2p && a->y && a->pre_out && a->act_out, "oe_ffn_bwd: null pointer");
+    OE_REQUIRE(a && (a->x || a->ln.dy) && a->w1p && a->w2p && a->y && a->pre_out && a->act_out, "oe_ffn_bwd: null pointer");
+    OE_REQUIRE(!a->ln.dy || a->precision == 6, "oe_ffn_bwd: the LayerNorm-backward prologue exists in precision 6 only");
     OE_REQUIRE(oe_ffn_supported(a->d, a->ff, a->precision, a->act), "oe_ffn_bwd: unsupported d=%d ff=%d precision=%d act=%d", a->d, a->ff,
                a->precision, a->act);
     OE_REQUIRE(!a->b1 && !a->b2 && !a->residual && a->drop_out == 0.f && a->beta == 1.f, "oe_ffn_bwd: bias / residual / output dropout do not apply");

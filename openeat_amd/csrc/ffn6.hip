@@ -36,6 +36,25 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// LayerNorm-backward prologue (oe_ln_prologue of the header): see ln_bwd_rows_to_planes
+struct LnPro {
+    const float* dy; const float* x; const float* stats; const float* gamma; const float* add;
+    float* dx; float* g; float* ws;
+    float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask; const unsigned char* ln_rowmask;
+};
+static LnPro ln_pro_of(const oe_ln_prologue& a) {
+    LnPro q;
+    q.dy = a.dy; q.x = a.x; q.stats = a.stats; q.gamma = a.gamma; q.add = a.add; q.dx = a.dx; q.g = a.g; q.ws = a.ws;
+    q.g_alpha = a.g_alpha; q.g_p = a.g_p; q.g_seed = a.g_seed; q.g_rowmask = a.g_rowmask; q.ln_rowmask = a.ln_rowmask;
+    return q;
+}
+static const char* ln_pro_check(const oe_ln_prologue& a) {
+    if (!(a.x && a.stats && a.gamma && a.dx && a.g && a.ws)) return "null pointer";
+    if (((((uintptr_t)a.dy) | ((uintptr_t)a.x) | ((uintptr_t)a.gamma) | ((uintptr_t)a.add) | ((uintptr_t)a.dx) | ((uintptr_t)a.g)) & 15) != 0) return "16-byte alignment required";
+    if (!(a.g_p >= 0.f && a.g_p < 1.f)) return "dropout rate out of range";
+    return nullptr;
+}
+
 struct Ffn6Params {
     const float* x; long ldx;
     const unsigned char* w1p; const float* b1;
@@ -47,6 +66,7 @@ struct Ffn6Params {
     float p_in; unsigned long long seed_in;
     float p_out; unsigned long long seed_out;
     const unsigned long long* seed_dev;
+    LnPro ln;                                    // BWD with LNP: the rows of x (= dY) are made by a LayerNorm backward
 };
 
 // derivative of the three activations the kernel admits (oe_ffn_supported): none, relu, swish - act_bwd's full table (tanh, erf, ...)
@@ -162,9 +182,121 @@ __device__ __forceinline__ void f6_write_planes(const float (&hv)[16], unsigned 
 // (GEMM 2 of a chunk + GEMM 1 of its next) while the other is in its vector phase (epilogue 1): with one wave per SIMD the
 // epilogues (a quarter of the block's cycles, tools/ffn6_stamps.py) and every wait on the weight stream stand in front of the
 // matrix pipe; with two co-resident waves of opposite phase the hardware interleaves them.  The groups' partial y^T meet in LDS.
-template <int D, int RT, bool BWD, int NOUT, int NG>
+// The LayerNorm backward in front of a row-block kernel as the way its 32 rows reach LDS (eight waves, D = 256):
+//     dx = add + LN'(dy; x, stats, gamma),   g = g_alpha * dropmask(g_seed) * g_rowmask * dx
+// are oe_layernorm_bwd_dx_drop's two outputs, element for element (same per-lane float4 order, same wave sums, same mask words); a
+// wave owns rows wv, wv + 8, wv + 16, wv + 24 of the block exactly as a wave of layernorm_bwd_kernel owns whole rows.  dx and g
+// are written (the residual stream and the weight gradient read them), g is split into the block's three planes at xs, and the
+// per-block partial sums of the LayerNorm's parameter gradients go to q.ws in layernorm_bwd_kernel's layout (one slot per 16
+// rows) for the same reduction launch.  `red`: 32 KiB of LDS nothing else uses yet ([8 waves][2 slots][2][D] floats).  Contains
+// one __syncthreads(); the caller's own barrier behind the planes must follow.
+template <int D>
+__device__ __forceinline__ void ln_bwd_rows_to_planes(const LnPro& q, const unsigned long long* seed_dev, int rows, long m0, int wv, int lane,
+                                                      unsigned char* xs, float* red) {
+    static_assert(D == 256, "one float4 per lane and row");
+    constexpr int BM = 32, XP = D + 8;
+    constexpr int NV = D / 256;
+    const float4* g4 = reinterpret_cast<const float4*>(q.gamma);
+    float4 gam[NV], dg[2][NV], db[2][NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        gam[j] = g4[lane + 64 * j];
+        dg[0][j] = dg[1][j] = db[0][j] = db[1][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const DropParams g_dpar = drop_params(q.g_p);
+    const unsigned long long g_seed_eff = q.g_seed + (seed_dev ? *seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
+    // this wave's four rows: wv, wv + 8 (slot 0 of the partial sums), wv + 16, wv + 24 (slot 1); all their loads first
+    float4 dyv[4][NV], xv[4][NV], av[4][NV];
+    float mean[4], rstd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long rc = min(m0 + wv + 8 * k, (long)rows - 1);
+        mean[k] = q.stats[rc * 2];
+        rstd[k] = q.stats[rc * 2 + 1];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            dyv[k][j] = reinterpret_cast<const float4*>(q.dy + rc * D)[i];
+            xv[k][j] = reinterpret_cast<const float4*>(q.x + rc * D)[i];
+            av[k][j] = q.add ? reinterpret_cast<const float4*>(q.add + rc * D)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = wv + 8 * k;
+        const long grow = m0 + row;
+        const bool valid = grow < rows;
+        const bool live = valid && !(q.ln_rowmask && !q.ln_rowmask[grow]);      // a masked row: dx = add, nothing for gamma / beta
+        float4 g[NV], xh[NV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            float4 t = dyv[k][j];
+            const float4 v = xv[k][j];
+            xh[j] = make_float4((v.x - mean[k]) * rstd[k], (v.y - mean[k]) * rstd[k], (v.z - mean[k]) * rstd[k], (v.w - mean[k]) * rstd[k]);
+            if (!live) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = t; }
+            g[j] = make_float4(t.x * gam[j].x, t.y * gam[j].y, t.z * gam[j].z, t.w * gam[j].w);
+            s1 += g[j].x + g[j].y + g[j].z + g[j].w;
+            s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
+            float4& dgs = dg[k >> 1][j];
+            float4& dbs = db[k >> 1][j];
+            dgs.x += t.x * xh[j].x; dgs.y += t.y * xh[j].y; dgs.z += t.z * xh[j].z; dgs.w += t.w * xh[j].w;
+            dbs.x += t.x; dbs.y += t.y; dbs.z += t.z; dbs.w += t.w;
+        }
+        const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i = lane + 64 * j;
+            float4 o = av[k][j];
+            if (live) {
+                o.x += rstd[k] * (g[j].x - c1 - xh[j].x * c2);
+                o.y += rstd[k] * (g[j].y - c1 - xh[j].y * c2);
+                o.z += rstd[k] * (g[j].z - c1 - xh[j].z * c2);
+                o.w += rstd[k] * (g[j].w - c1 - xh[j].w * c2);
+            }
+            float4 gq = make_float4(o.x * q.g_alpha, o.y * q.g_alpha, o.z * q.g_alpha, o.w * q.g_alpha);
+            const unsigned long long e0 = (unsigned long long)grow * D + 4 * i;
+            if (q.g_p > 0.f) {
+                const uint4 r = drop_words8(g_seed_eff, e0 >> 3);
+                const bool hi = (e0 >> 2) & 1;                 // second half of the call's eight fields
+                const unsigned wa = hi ? r.z : r.x, wb = hi ? r.w : r.y;
+                gq.x *= drop_field(wa, 0, g_dpar); gq.y *= drop_field(wa, 1, g_dpar);
+                gq.z *= drop_field(wb, 0, g_dpar); gq.w *= drop_field(wb, 1, g_dpar);
+            }
+            if (valid && q.g_rowmask && !q.g_rowmask[grow]) gq = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                reinterpret_cast<float4*>(q.dx + grow * D)[i] = o;
+                reinterpret_cast<float4*>(q.g + grow * D)[i] = gq;
+            }
+            const float xq[4] = {gq.x, gq.y, gq.z, gq.w};
+            oe_bf16x4v pl[3];
+            oe_split4<3>(xq, pl);
+#pragma unroll
+            for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + 4 * i) * 2) = pl[n];
+        }
+    }
+    // the parameter-gradient partials of the block's two 16-row slots: the waves' sums meet in the (still unused) patches
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 0) * D)[lane + 64 * j] = dg[sl][j];
+            reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 1) * D)[lane + 64 * j] = db[sl][j];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 4 * D; c += 512) {                           // c = (slot * 2 + which) * D + column
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sum += red[w * 4 * D + c];
+        const long slot = 2 * (long)blockIdx.x + c / (2 * D);
+        if (slot * 16 < rows) q.ws[slot * 2 * D + (c % (2 * D))] = sum;
+    }
+}
+
+template <int D, int RT, bool BWD, int NOUT, int NG, bool LNP = false>
 __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 1) void ffn6_kernel(Ffn6Params p) {
     static_assert(NG == 1 || (NG == 2 && RT == 1), "two wave groups: 32-row blocks");
+    static_assert(!LNP || (BWD && D == 256 && RT == 1 && NG == 2), "LayerNorm-backward prologue: the eight-wave 32-row backward at d = 256");
     constexpr int BM = 32 * RT;
     constexpr int KS = D / 16, DT = D / 32, DPW = DT / 4;            // k-steps of GEMM 1, output tiles, output tiles per wave
     constexpr int FR = 2, NSET = 4;
@@ -192,7 +324,12 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 
     const int rot = blockIdx.x % nchunks;                            // blocks start their walk over the weights at different chunks
 
     // ---- the block's rows -> three bf16 planes in LDS (rows past the end re-read the last one; never stored)
-    {
+    if constexpr (LNP) {
+        // ... made by the LayerNorm backward that precedes this feed-forward's backward (ln_bwd_rows_to_planes); the partial sums
+        // meet in the h regions, which nothing uses before the first chunk's epilogue
+        static_assert(!LNP || 8 * 2 * 2 * D * 4 <= NG * H_BYTES, "the prologue's partial sums reuse the h regions");
+        ln_bwd_rows_to_planes<D>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
+    } else {
         constexpr int C4 = D / 4;
         for (int i = threadIdx.x; i < BM * C4; i += 256 * NG) {
             const int row = i / C4, c4 = (i - row * C4) * 4;
@@ -444,11 +581,7 @@ struct Row6Params {
     float p_out; unsigned long long seed_out;
     const unsigned long long* seed_dev;
     int k, act; float* preact_out; const float* actgrad_in; long ld_aux;     // (tile form only)
-    // LayerNorm-backward prologue (row-block form, LNP): the rows of x are not read but MADE - see rowgemm6_kernel
-    const float* ln_dy; const float* ln_x; const float* ln_stats; const float* ln_gamma; const float* ln_add;
-    float* ln_dx; float* ln_g; float* ln_ws;
-    float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask;
-    const unsigned char* ln_rowmask;
+    LnPro ln;                                    // LayerNorm-backward prologue (row-block form, LNP): the rows of x are MADE
 };
 
 // LNP (LayerNorm-backward prologue): the GEMM's input rows are the gradient a pre-norm residual block's backward STARTS from,
@@ -504,105 +637,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     }
     // (the rows after the ring's first stages are on their way: both round trips overlap)
     if constexpr (LNP) {
-        static_assert(D == 256, "the prologue's partial sums reuse the patches: d = 256 only");
-        constexpr int NV = D / 256;
-        const float4* g4 = reinterpret_cast<const float4*>(p.ln_gamma);
-        float4 gam[NV], dg[2][NV], db[2][NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            gam[j] = g4[lane + 64 * j];
-            dg[0][j] = dg[1][j] = db[0][j] = db[1][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const DropParams g_dpar = drop_params(p.g_p);
-        const unsigned long long g_seed_eff = p.g_seed + (p.seed_dev ? *p.seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
-        // this wave's four rows: wv, wv + 8 (slot 0 of the partial sums), wv + 16, wv + 24 (slot 1); all their loads first
-        float4 dyv[4][NV], xv[4][NV], av[4][NV];
-        float mean[4], rstd[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const long rc = min(m0 + wv + 8 * k, (long)p.rows - 1);
-            mean[k] = p.ln_stats[rc * 2];
-            rstd[k] = p.ln_stats[rc * 2 + 1];
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = lane + 64 * j;
-                dyv[k][j] = reinterpret_cast<const float4*>(p.ln_dy + rc * D)[i];
-                xv[k][j] = reinterpret_cast<const float4*>(p.ln_x + rc * D)[i];
-                av[k][j] = p.ln_add ? reinterpret_cast<const float4*>(p.ln_add + rc * D)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int row = wv + 8 * k;
-            const long grow = m0 + row;
-            const bool valid = grow < p.rows;
-            const bool live = valid && !(p.ln_rowmask && !p.ln_rowmask[grow]);      // a masked row: dx = add, nothing for gamma / beta
-            float4 g[NV], xh[NV];
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                float4 t = dyv[k][j];
-                const float4 v = xv[k][j];
-                xh[j] = make_float4((v.x - mean[k]) * rstd[k], (v.y - mean[k]) * rstd[k], (v.z - mean[k]) * rstd[k], (v.w - mean[k]) * rstd[k]);
-                if (!live) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh[j] = t; }
-                g[j] = make_float4(t.x * gam[j].x, t.y * gam[j].y, t.z * gam[j].z, t.w * gam[j].w);
-                s1 += g[j].x + g[j].y + g[j].z + g[j].w;
-                s2 += g[j].x * xh[j].x + g[j].y * xh[j].y + g[j].z * xh[j].z + g[j].w * xh[j].w;
-                float4& dgs = dg[k >> 1][j];
-                float4& dbs = db[k >> 1][j];
-                dgs.x += t.x * xh[j].x; dgs.y += t.y * xh[j].y; dgs.z += t.z * xh[j].z; dgs.w += t.w * xh[j].w;
-                dbs.x += t.x; dbs.y += t.y; dbs.z += t.z; dbs.w += t.w;
-            }
-            const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i = lane + 64 * j;
-                float4 o = av[k][j];
-                if (live) {
-                    o.x += rstd[k] * (g[j].x - c1 - xh[j].x * c2);
-                    o.y += rstd[k] * (g[j].y - c1 - xh[j].y * c2);
-                    o.z += rstd[k] * (g[j].z - c1 - xh[j].z * c2);
-                    o.w += rstd[k] * (g[j].w - c1 - xh[j].w * c2);
-                }
-                float4 gq = make_float4(o.x * p.g_alpha, o.y * p.g_alpha, o.z * p.g_alpha, o.w * p.g_alpha);
-                const unsigned long long e0 = (unsigned long long)grow * D + 4 * i;
-                if (p.g_p > 0.f) {
-                    const uint4 r = drop_words8(g_seed_eff, e0 >> 3);
-                    const bool hi = (e0 >> 2) & 1;                 // second half of the call's eight fields
-                    const unsigned wa = hi ? r.z : r.x, wb = hi ? r.w : r.y;
-                    gq.x *= drop_field(wa, 0, g_dpar); gq.y *= drop_field(wa, 1, g_dpar);
-                    gq.z *= drop_field(wb, 0, g_dpar); gq.w *= drop_field(wb, 1, g_dpar);
-                }
-                if (valid && p.g_rowmask && !p.g_rowmask[grow]) gq = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) {
-                    reinterpret_cast<float4*>(p.ln_dx + grow * D)[i] = o;
-                    reinterpret_cast<float4*>(p.ln_g + grow * D)[i] = gq;
-                }
-                const float xq[4] = {gq.x, gq.y, gq.z, gq.w};
-                oe_bf16x4v pl[3];
-                oe_split4<3>(xq, pl);
-#pragma unroll
-                for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + 4 * i) * 2) = pl[n];
-            }
-        }
-        // the parameter-gradient partials of the block's two 16-row slots: the waves' sums meet in the (still unused) patches
-        float* red = reinterpret_cast<float*>(lds + X_BYTES);                     // [8 waves][2 slots][2][D]
-        static_assert(8 * 2 * 2 * D * 4 <= 8 * PATCH, "partial sums fit the patches");
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 0) * D)[lane + 64 * j] = dg[sl][j];
-                reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 1) * D)[lane + 64 * j] = db[sl][j];
-            }
-        __syncthreads();
-        for (int c = threadIdx.x; c < 4 * D; c += 512) {                           // c = (slot * 2 + which) * D + column
-            float sum = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) sum += red[w * 4 * D + c];
-            const long slot = 2 * (long)blockIdx.x + c / (2 * D);
-            if (slot * 16 < p.rows) p.ln_ws[slot * 2 * D + (c % (2 * D))] = sum;
-        }
+        static_assert(8 * 2 * 2 * D * 4 <= 8 * PATCH, "the prologue's partial sums reuse the (still unused) patches");
+        ln_bwd_rows_to_planes<D>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
     } else {
         constexpr int C4 = D / 4;
         for (int i = threadIdx.x; i < BM * C4; i += 512) {
@@ -991,7 +1027,7 @@ extern "C" int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces,
 }
 
 extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
-    OE_REQUIRE(a && (a->x || a->ln_dy) && a->wp && a->y, "oe_rowgemm6: null pointer");
+    OE_REQUIRE(a && (a->x || a->ln.dy) && a->wp && a->y, "oe_rowgemm6: null pointer");
     const int form = a->rows > 0 ? oe_rowgemm6_form(a->rows, a->k, a->n) : 0;
     OE_REQUIRE(form != 0, "oe_rowgemm6: unsupported rows=%d k=%d n=%d", a->rows, a->k, a->n);
     const bool has_act = a->act != OE_ACT_NONE || a->preact_out || a->actgrad_in;
@@ -1000,12 +1036,10 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     OE_REQUIRE(!has_act || !(a->preact_out || a->actgrad_in) || (a->ld_aux % 2 == 0 && ((((uintptr_t)a->preact_out) | ((uintptr_t)a->actgrad_in)) & 7) == 0),
                "oe_rowgemm6: pre-activation / act-grad source must be 8-byte aligned with an even row stride");
     OE_REQUIRE(a->rows > 0 && a->ldx % 4 == 0 && a->ldy % 4 == 0 && (!a->residual || a->ldr % 4 == 0), "oe_rowgemm6: bad rows / strides");
-    if (a->ln_dy) {
+    if (a->ln.dy) {
         OE_REQUIRE(form == 1 && a->k == 256, "oe_rowgemm6: the LayerNorm-backward prologue exists in the row-block form at k = 256 only");
-        OE_REQUIRE(a->ln_x && a->ln_stats && a->ln_gamma && a->ln_dx && a->ln_g && a->ln_ws, "oe_rowgemm6: LayerNorm prologue: null pointer");
-        OE_REQUIRE(((((uintptr_t)a->ln_dy) | ((uintptr_t)a->ln_x) | ((uintptr_t)a->ln_gamma) | ((uintptr_t)a->ln_add) | ((uintptr_t)a->ln_dx) |
-                     ((uintptr_t)a->ln_g)) & 15) == 0, "oe_rowgemm6: LayerNorm prologue: 16-byte alignment required");
-        OE_REQUIRE(a->g_p >= 0.f && a->g_p < 1.f, "oe_rowgemm6: LayerNorm prologue: dropout rate out of range");
+        const char* why = ln_pro_check(a->ln);
+        OE_REQUIRE(why == nullptr, "oe_rowgemm6: LayerNorm prologue: %s", why);
     }
     OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->residual) | ((uintptr_t)a->wp) | ((uintptr_t)a->bias)) & 15) == 0,
                "oe_rowgemm6: 16-byte alignment required");
@@ -1014,9 +1048,7 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     p.x = a->x; p.ldx = a->ldx; p.wp = (const unsigned char*)a->wp; p.bias = a->bias; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta;
     p.rowmask = a->rowmask; p.y = a->y; p.ldy = a->ldy; p.rows = a->rows; p.no = a->n; p.p_out = a->drop_p; p.seed_out = a->seed; p.seed_dev = a->seed_dev;
     p.k = a->k; p.act = a->act; p.preact_out = a->preact_out; p.actgrad_in = a->actgrad_in; p.ld_aux = a->ld_aux;
-    p.ln_dy = a->ln_dy; p.ln_x = a->ln_x; p.ln_stats = a->ln_stats; p.ln_gamma = a->ln_gamma; p.ln_add = a->ln_add;
-    p.ln_dx = a->ln_dx; p.ln_g = a->ln_g; p.ln_ws = a->ln_ws; p.g_alpha = a->g_alpha; p.g_p = a->g_p; p.g_seed = a->g_seed; p.g_rowmask = a->g_rowmask;
-    p.ln_rowmask = a->ln_rowmask;
+    p.ln = ln_pro_of(a->ln);
     if (form == 2) {
         const dim3 tgrid(oe_cdiv(a->rows, 32), a->n / 32), tblock(512);
         hipStream_t st = (hipStream_t)stream;
@@ -1031,7 +1063,7 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     }
     const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
     if (a->k > 512) hipLaunchKernelGGL(rowgemm6p_kernel, grid, block, 0, (hipStream_t)stream, p);
-    else if (a->ln_dy) hipLaunchKernelGGL((rowgemm6_kernel<256, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (a->ln.dy) hipLaunchKernelGGL((rowgemm6_kernel<256, true>), grid, block, 0, (hipStream_t)stream, p);
     else if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((rowgemm6_kernel<256>), grid, block, 0, (hipStream_t)stream, p);
     OE_LAUNCH_CHECK("oe_rowgemm6");
@@ -1041,6 +1073,14 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
 template <int D, int RT, int NG>
 static int ffn6_launch(const Ffn6Params& p, bool bwd, int nout, hipStream_t st) {
     const dim3 grid(oe_cdiv(p.rows, 32 * RT)), block(256 * NG);
+    if constexpr (D == 256 && RT == 1 && NG == 2) {
+        if (bwd && p.ln.dy) {
+            hipLaunchKernelGGL((ffn6_kernel<D, RT, true, 1, NG, true>), grid, block, 0, st, p);
+            OE_LAUNCH_CHECK("oe_ffn_bwd (precision 6, LayerNorm-backward prologue)");
+            return 0;
+        }
+    }
+    OE_REQUIRE(!p.ln.dy, "oe_ffn: the LayerNorm-backward prologue exists for the backward at d = 256 in the two-group block shape only");
     if (bwd) hipLaunchKernelGGL((ffn6_kernel<D, RT, true, 1, NG>), grid, block, 0, st, p);
     else if (nout == 2) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 2, NG>), grid, block, 0, st, p);
     else if (nout == 1) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 1, NG>), grid, block, 0, st, p);
@@ -1068,6 +1108,11 @@ int oe_ffn6_run(const oe_ffn_args* a, bool bwd, void* stream) {
     p.pre = a->pre_out; p.act_out = a->act_out; p.residual = a->residual; p.ldr = a->ldr; p.beta = a->beta; p.y = a->y; p.ldy = a->ldy;
     p.rows = a->rows; p.ff = a->ff; p.act = a->act; p.p_in = a->drop_in; p.seed_in = a->seed_in; p.p_out = a->drop_out; p.seed_out = a->seed_out;
     p.seed_dev = a->seed_dev;
+    if (a->ln.dy) {
+        const char* why = ln_pro_check(a->ln);
+        OE_REQUIRE(bwd && why == nullptr, "oe_ffn: LayerNorm prologue: %s", bwd ? why : "backward only");
+        p.ln = ln_pro_of(a->ln);
+    }
     const int nout = a->act_out ? 2 : a->pre_out ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;
     const int mode = ffn6_mode();

@@ -78,6 +78,23 @@ class AttnArgs(C.Structure):
     ]
 
 
+class LnPrologue(C.Structure):
+    """oe_ln_prologue (include/openeat_hip.h)."""
+    _fields_ = [
+        ("dy", c_fp), ("x", c_fp), ("stats", c_fp), ("gamma", c_fp), ("add", c_fp),
+        ("dx", c_fp), ("g", c_fp), ("ws", c_fp),
+        ("g_alpha", C.c_float), ("g_p", C.c_float), ("g_seed", C.c_ulonglong), ("g_rowmask", c_fp), ("ln_rowmask", c_fp),
+    ]
+
+    def fill(self, ln):
+        """ln: dict(dy, x, stats, gamma, add, dx, g, ws, alpha, p, seed, rowmask, ln_rowmask)."""
+        dp = lambda t: None if t is None else t.data_ptr()
+        self.dy, self.x, self.stats, self.gamma, self.add = dp(ln["dy"]), dp(ln["x"]), dp(ln["stats"]), dp(ln["gamma"]), dp(ln.get("add"))
+        self.dx, self.g, self.ws = dp(ln["dx"]), dp(ln["g"]), dp(ln["ws"])
+        self.g_alpha, self.g_p, self.g_seed = ln["alpha"], ln["p"], ln["seed"]
+        self.g_rowmask, self.ln_rowmask = dp(ln.get("rowmask")), dp(ln.get("ln_rowmask"))
+
+
 class FfnArgs(C.Structure):
     _fields_ = [
         ("x", c_fp), ("ldx", C.c_long),
@@ -88,6 +105,7 @@ class FfnArgs(C.Structure):
         ("pre_out", c_fp), ("act_out", c_fp),
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
+        ("ln", LnPrologue),
     ]
 
 
@@ -102,10 +120,7 @@ class RowGemmArgs(C.Structure):
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
         ("act", C.c_int), ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
-        ("ln_dy", c_fp), ("ln_x", c_fp), ("ln_stats", c_fp), ("ln_gamma", c_fp), ("ln_add", c_fp),
-        ("ln_dx", c_fp), ("ln_g", c_fp), ("ln_ws", c_fp),
-        ("g_alpha", C.c_float), ("g_p", C.c_float), ("g_seed", C.c_ulonglong), ("g_rowmask", c_fp),
-        ("ln_rowmask", c_fp),
+        ("ln", LnPrologue),
     ]
 
 
@@ -382,11 +397,14 @@ def ffn_fwd(x2, w1p, b1, w2p, b2, rows, d, ff, act, *, drop_in=0.0, seed_in=0, d
     check(lib().oe_ffn_fwd(C.byref(a), stream()), "oe_ffn_fwd")
 
 
-def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_dev=None, pre=None, dh=None, dx=None, precision=None):
-    """dH = (dY W2) * mask * act'(pre), dX = dH W1 in one launch (oe_ffn_bwd)."""
+def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_dev=None, pre=None, dh=None, dx=None, precision=None, ln=None):
+    """dH = (dY W2) * mask * act'(pre), dX = dH W1 in one launch (oe_ffn_bwd).  ln: LayerNorm-backward prologue (LnPrologue.fill) -
+    the rows of dY are then made by the kernel (dy2 is where they are ALSO written: ln["g"])."""
     a = FfnArgs()
     dp = lambda t: None if t is None else t.data_ptr()
     a.x, a.ldx = dy2.data_ptr(), dy2.stride(0)
+    if ln is not None:
+        a.ln.fill(ln)
     a.w1p, a.b1, a.w2p, a.b2 = w2tp.data_ptr(), None, w1tp.data_ptr(), None
     a.rows, a.d, a.ff, a.act = rows, d, ff, act
     a.precision = GEMM_PRECISION if precision is None else precision
@@ -414,11 +432,8 @@ def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=No
     a.residual, a.ldr, a.beta = dp(residual), ldr, beta
     a.y, a.ldy = y.data_ptr(), y.stride(0)
     a.act, a.preact_out, a.actgrad_in, a.ld_aux = act, dp(preact_out), dp(actgrad_in), ld_aux
-    if ln is not None:        # LayerNorm-backward prologue: dict(dy, x, stats, gamma, add, dx, g, ws, alpha, p, seed, rowmask)
-        a.ln_dy, a.ln_x, a.ln_stats, a.ln_gamma, a.ln_add = dp(ln["dy"]), dp(ln["x"]), dp(ln["stats"]), dp(ln["gamma"]), dp(ln.get("add"))
-        a.ln_dx, a.ln_g, a.ln_ws = dp(ln["dx"]), dp(ln["g"]), dp(ln["ws"])
-        a.g_alpha, a.g_p, a.g_seed, a.g_rowmask = ln["alpha"], ln["p"], ln["seed"], dp(ln.get("rowmask"))
-        a.ln_rowmask = dp(ln.get("ln_rowmask"))
+    if ln is not None:        # LayerNorm-backward prologue (LnPrologue.fill)
+        a.ln.fill(ln)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -1321,7 +1321,10 @@ class FeedForwardFn(torch.autograd.Function):
             ctx.biases = (b1, b2)
             ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
             ctx.fused = True
-            return _tag_out_drop(y.view(*x.shape[:-1], w2.shape[0]), out_scale, p_out, s_out)
+            # (the backward's fused kernel can take the next LayerNorm's backward as its prologue: _PENDING_LN)
+            lnf = (LN_BWD_FUSE and FUSE_OUT_DROP and hip.GEMM_PRECISION == 6 and d == 256 and M >= ROWGEMM_MIN_ROWS and ff % 256 == 0 and
+                   _ffn_bwd_fused() and hip.lib().oe_ffn6_config(-1) in (0, 3) and not _planes.active())
+            return _tag_out_drop(y.view(*x.shape[:-1], w2.shape[0]), out_scale, p_out, s_out, ln_fuse=lnf)
         ctx.fused = False
         pre = _new(M, ff, like=x)
         if act in GEMM_FUSED_ACTS:
@@ -1347,7 +1350,7 @@ class FeedForwardFn(torch.autograd.Function):
         dy2 = dy.view(-1, w2.shape[0])
         g2 = dy2 if (p_out == 0 and out_scale == 1.0) else _out_drop_grad(dy2, out_scale, p_out, s_out)
         b1, b2 = ctx.biases
-        dw2, db2 = wgrad_bias(w2, b2, g2, a)
+        pend = _PENDING_LN.pop(g2.data_ptr(), None) if _PENDING_LN else None     # g2 may be a parked LayerNorm backward
         if ctx.fused and _ffn_bwd_fused() and g2.stride(0) % 4 == 0:
             # both input-gradient GEMMs in one launch (csrc/ffn.hip, oe_ffn_bwd): dH is written once and never re-read here
             M, d, ff = g2.shape[0], w2.shape[0], w1.shape[0]
@@ -1355,9 +1358,28 @@ class FeedForwardFn(torch.autograd.Function):
             nbytes = hip.lib().oe_ffn_packed_bytes(d, ff, prec)
             w2tp, w1tp = _ffn_packed(w1, w2, d, ff, bwd=True)
             dh, dx = _new(M, ff, like=g2), _new(M, d, like=g2)
-            hip.ffn_bwd(g2, w2tp, w1tp, M, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=_seed_dev, pre=pre, dh=dh, dx=dx)
+            ln = None
+            if pend is not None and not pend.get("done"):
+                if (prec == 6 and d == 256 and ff % 256 == 0 and hip.lib().oe_ffn6_config(-1) in (0, 3) and g2.is_contiguous() and
+                        g2.data_ptr() == pend["g"].data_ptr() and M == pend["rows"]):
+                    alpha, p_g, seed_g, gmask = pend["spec"]
+                    ln = dict(dy=pend["dy"], x=pend["x"], stats=pend["stats"], gamma=pend["gamma"], add=pend["add"], dx=pend["dx"], g=pend["g"],
+                              ws=pend["ws"], alpha=alpha, p=p_g, seed=seed_g, rowmask=gmask, ln_rowmask=pend.get("rowmask"))
+                else:
+                    _resolve_ln(pend)
+            # FIRST launch of this backward: it makes g2 when that is a parked LayerNorm backward (the weight gradient reads it after)
+            hip.ffn_bwd(g2, w2tp, w1tp, M, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=_seed_dev, pre=pre, dh=dh, dx=dx, ln=ln)
+            if ln is not None:
+                global LN_BWD_FUSED_LAUNCHES
+                pend["done"] = True
+                LN_BWD_FUSED_LAUNCHES += 1
+                _ln_reduce(pend)
+            dw2, db2 = wgrad_bias(w2, b2, g2, a)
             dw1, db1 = wgrad_bias(w1, b1, dh, x2)
             return dx.view(in_shape), dw1, db1, dw2, db2, None, None, (dy if has_res else None), None, None
+        if pend is not None:
+            _resolve_ln(pend)
+        dw2, db2 = wgrad_bias(w2, b2, g2, a)
         if act in GEMM_FUSED_ACTS:
             dh = gemm_nn(g2, w2, act=act, actgrad_in=pre, ld_aux=pre.stride(0), drop_p=p_in, seed=s_in, seed_dev=_seed_dev, out_planes=True)
         else:

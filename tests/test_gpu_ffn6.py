@@ -234,3 +234,55 @@ def test_pack_table_rows_keep_their_own_precision():
     finally:
         hip.GEMM_PRECISION, ops.FUSED_FFN_MIN_ROWS = old
         planes.clear_all()
+
+
+@pytest.mark.parametrize("rows,p,ln_mask", [(7936, 0.1, False), (4103, 0.0, True)])
+def test_input_gradient_with_the_layernorm_backward_as_its_prologue(rows, p, ln_mask):
+    """oe_ffn_bwd with oe_ffn_args.ln set (precision 6, d = 256, the two-group block shape): the rows of dY are made by the LayerNorm
+    backward that used to be a launch in front of it - dx_ln and g as oe_layernorm_bwd_dx_drop writes them (to one unit in the last
+    place: another kernel, another contraction of a*b+c), dH / dX as the plain oe_ffn_bwd gives on that g."""
+    torch.manual_seed(68)
+    d, ff, act, p_in, s_in = 256, 1024, 2, 0.1, 0x3333
+    x = torch.randn(rows, d, device=DEV) * 1.3 - 0.2
+    dy_ln = torch.randn(rows, d, device=DEV)
+    add = torch.randn(rows, d, device=DEV)
+    gamma, beta = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    lmask = (torch.rand(rows, device=DEV) > 0.15).to(torch.uint8) if ln_mask else None
+    stats = torch.stack([x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    w1, w2 = torch.randn(ff, d, device=DEV) / math.sqrt(d), torch.randn(d, ff, device=DEV) / math.sqrt(ff)
+    pre = torch.randn(rows, ff, device=DEV) * 1.5
+    L = hip.lib()
+    nb = L.oe_ffn_packed_bytes(d, ff, 6)
+    w2tp, w1tp = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hip.call("oe_ffn_pack_weights_bwd", w1, w2, d, ff, 6, w2tp, w1tp)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    nws = L.oe_layernorm_bwd_workspace_floats(rows, d)
+    # two launches
+    dxl0, g0, ws0 = torch.empty_like(x), torch.empty_like(x), torch.zeros(nws, device=DEV)
+    hip.call("oe_layernorm_bwd_dx_drop", dy_ln, x, gamma, beta, 0, stats, rows, d, lmask, add, dxl0, g0, 0.5, p, 0x77, ctr, None, ws0)
+    dh0, dx0 = torch.empty(rows, ff, device=DEV), torch.empty(rows, d, device=DEV)
+    hip.ffn_bwd(g0, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pre, dh=dh0, dx=dx0, precision=6)
+    # one launch
+    nan = float("nan")
+    dxl1, g1, ws1 = torch.full_like(x, nan), torch.full_like(x, nan), torch.zeros(nws, device=DEV)
+    dh1, dx1 = torch.full((rows, ff), nan, device=DEV), torch.full((rows, d), nan, device=DEV)
+    ln = dict(dy=dy_ln, x=x, stats=stats, gamma=gamma, add=add, dx=dxl1, g=g1, ws=ws1, alpha=0.5, p=p, seed=0x77, rowmask=None, ln_rowmask=lmask)
+    hip.ffn_bwd(g1, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pre, dh=dh1, dx=dx1, precision=6, ln=ln)
+    dg0, db0, dg1, db1 = (torch.zeros(d, device=DEV) for _ in range(4))
+    hip.call("oe_layernorm_param_reduce", ws0, rows, d, dg0, db0)
+    hip.call("oe_layernorm_param_reduce", ws1, rows, d, dg1, db1)
+    sync()
+    torch.testing.assert_close(dxl1, dxl0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(g1, g0, rtol=2e-6, atol=1e-6)
+    assert torch.equal(g1 == 0, g0 == 0)
+    torch.testing.assert_close(dh1, dh0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx1, dx0, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(dg1, dg0, rtol=2e-5, atol=2e-4)
+    torch.testing.assert_close(db1, db0, rtol=2e-5, atol=2e-4)
+    # the prologue exists for this block shape only: any other is refused, not silently run without it
+    L.oe_ffn6_config(1)
+    try:
+        with pytest.raises(RuntimeError, match="prologue"):
+            hip.ffn_bwd(g1, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pre, dh=dh1, dx=dx1, precision=6, ln=ln)
+    finally:
+        L.oe_ffn6_config(0)
