@@ -168,6 +168,10 @@ typedef struct oe_ln_prologue {
     const float* dy; const float* x; const float* stats; const float* gamma; const float* add;
     float* dx; float* g; float* ws;
     float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask; const unsigned char* ln_rowmask;
+    /* PAIR (gamma2 != NULL): two norms back to back, y2 = LN2(u), u = LN1(x) (oe_layernorm_pair_bwd_dx_drop: encoder_layer.py:109-110
+     * followed by the next layer's :79-80) - dy is then the gradient of y2, add the gradient that reaches u on its other path, x /
+     * stats / gamma / beta belong to LN1 (u is recomputed), gamma2 / stats2 to LN2, ws2 receives LN2's parameter partials; no row mask. */
+    const float* beta; const float* gamma2; const float* stats2; float* ws2;
 } oe_ln_prologue;
 
 typedef struct oe_ffn_args {

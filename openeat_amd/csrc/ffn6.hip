@@ -41,17 +41,21 @@ struct LnPro {
     const float* dy; const float* x; const float* stats; const float* gamma; const float* add;
     float* dx; float* g; float* ws;
     float g_alpha, g_p; unsigned long long g_seed; const unsigned char* g_rowmask; const unsigned char* ln_rowmask;
+    const float* beta; const float* gamma2; const float* stats2; float* ws2;     // pair (gamma2 != nullptr): see ln_bwd_rows_to_planes
 };
 static LnPro ln_pro_of(const oe_ln_prologue& a) {
     LnPro q;
     q.dy = a.dy; q.x = a.x; q.stats = a.stats; q.gamma = a.gamma; q.add = a.add; q.dx = a.dx; q.g = a.g; q.ws = a.ws;
     q.g_alpha = a.g_alpha; q.g_p = a.g_p; q.g_seed = a.g_seed; q.g_rowmask = a.g_rowmask; q.ln_rowmask = a.ln_rowmask;
+    q.beta = a.beta; q.gamma2 = a.gamma2; q.stats2 = a.stats2; q.ws2 = a.ws2;
     return q;
 }
 static const char* ln_pro_check(const oe_ln_prologue& a) {
     if (!(a.x && a.stats && a.gamma && a.dx && a.g && a.ws)) return "null pointer";
     if (((((uintptr_t)a.dy) | ((uintptr_t)a.x) | ((uintptr_t)a.gamma) | ((uintptr_t)a.add) | ((uintptr_t)a.dx) | ((uintptr_t)a.g)) & 15) != 0) return "16-byte alignment required";
     if (!(a.g_p >= 0.f && a.g_p < 1.f)) return "dropout rate out of range";
+    if (a.gamma2 && !(a.beta && a.stats2 && a.ws2 && !a.ln_rowmask)) return "pair: beta / stats2 / ws2 missing (and no row mask)";
+    if (((((uintptr_t)a.beta) | ((uintptr_t)a.gamma2)) & 15) != 0) return "16-byte alignment required";
     return nullptr;
 }
 
@@ -190,7 +194,10 @@ __device__ __forceinline__ void f6_write_planes(const float (&hv)[16], unsigned 
 // per-block partial sums of the LayerNorm's parameter gradients go to q.ws in layernorm_bwd_kernel's layout (one slot per 16
 // rows) for the same reduction launch.  `red`: 32 KiB of LDS nothing else uses yet ([8 waves][2 slots][2][D] floats).  Contains
 // one __syncthreads(); the caller's own barrier behind the planes must follow.
-template <int D>
+// PAIR (layernorm_bwd_kernel's PAIR): two norms back to back, y2 = LN2(u), u = LN1(x) - dy is the gradient of y2, `add` the gradient
+// that reaches u on its other path, u is recomputed from x and LN1's statistics (q.stats, q.gamma, q.beta); the row first goes
+// through LN2's backward (q.gamma2, q.stats2; its parameter partials to q.ws2), the result through LN1's.
+template <int D, bool PAIR>
 __device__ __forceinline__ void ln_bwd_rows_to_planes(const LnPro& q, const unsigned long long* seed_dev, int rows, long m0, int wv, int lane,
                                                       unsigned char* xs, float* red) {
     static_assert(D == 256, "one float4 per lane and row");
@@ -198,10 +205,16 @@ __device__ __forceinline__ void ln_bwd_rows_to_planes(const LnPro& q, const unsi
     constexpr int NV = D / 256;
     const float4* g4 = reinterpret_cast<const float4*>(q.gamma);
     float4 gam[NV], dg[2][NV], db[2][NV];
+    float4 bet[PAIR ? NV : 1], gam2[PAIR ? NV : 1], dg2[2][PAIR ? NV : 1], db2[2][PAIR ? NV : 1];
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         gam[j] = g4[lane + 64 * j];
         dg[0][j] = dg[1][j] = db[0][j] = db[1][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (PAIR) {
+            bet[j] = reinterpret_cast<const float4*>(q.beta)[lane + 64 * j];
+            gam2[j] = reinterpret_cast<const float4*>(q.gamma2)[lane + 64 * j];
+            dg2[0][j] = dg2[1][j] = db2[0][j] = db2[1][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     const DropParams g_dpar = drop_params(q.g_p);
     const unsigned long long g_seed_eff = q.g_seed + (seed_dev ? *seed_dev * 0x9E3779B97F4A7C15ull : 0ull);
@@ -227,6 +240,40 @@ __device__ __forceinline__ void ln_bwd_rows_to_planes(const LnPro& q, const unsi
         const long grow = m0 + row;
         const bool valid = grow < rows;
         const bool live = valid && !(q.ln_rowmask && !q.ln_rowmask[grow]);      // a masked row: dx = add, nothing for gamma / beta
+        if (PAIR) {
+            // LN2's backward on this row first: u = LN1(x) recomputed, dyv <- add + LN2'(dy); `add` is used up
+            const long rc = min(grow, (long)rows - 1);
+            const float mean2 = q.stats2[rc * 2], rstd2 = q.stats2[rc * 2 + 1];
+            float4 g2[NV], xh2[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float4 v = xv[k][j];
+                const float4 u = make_float4((v.x - mean[k]) * rstd[k] * gam[j].x + bet[j].x, (v.y - mean[k]) * rstd[k] * gam[j].y + bet[j].y,
+                                             (v.z - mean[k]) * rstd[k] * gam[j].z + bet[j].z, (v.w - mean[k]) * rstd[k] * gam[j].w + bet[j].w);
+                xh2[j] = make_float4((u.x - mean2) * rstd2, (u.y - mean2) * rstd2, (u.z - mean2) * rstd2, (u.w - mean2) * rstd2);
+                float4 t = dyv[k][j];
+                if (!live) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh2[j] = t; }
+                g2[j] = make_float4(t.x * gam2[j].x, t.y * gam2[j].y, t.z * gam2[j].z, t.w * gam2[j].w);
+                s1 += g2[j].x + g2[j].y + g2[j].z + g2[j].w;
+                s2 += g2[j].x * xh2[j].x + g2[j].y * xh2[j].y + g2[j].z * xh2[j].z + g2[j].w * xh2[j].w;
+                float4& dgs = dg2[k >> 1][j];
+                float4& dbs = db2[k >> 1][j];
+                dgs.x += t.x * xh2[j].x; dgs.y += t.y * xh2[j].y; dgs.z += t.z * xh2[j].z; dgs.w += t.w * xh2[j].w;
+                dbs.x += t.x; dbs.y += t.y; dbs.z += t.z; dbs.w += t.w;
+            }
+            const float c1 = wave_sum(s1) / D, c2 = wave_sum(s2) / D;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float4 o = av[k][j];
+                o.x += rstd2 * (g2[j].x - c1 - xh2[j].x * c2);
+                o.y += rstd2 * (g2[j].y - c1 - xh2[j].y * c2);
+                o.z += rstd2 * (g2[j].z - c1 - xh2[j].z * c2);
+                o.w += rstd2 * (g2[j].w - c1 - xh2[j].w * c2);
+                dyv[k][j] = o;
+                av[k][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
         float4 g[NV], xh[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -291,6 +338,24 @@ __device__ __forceinline__ void ln_bwd_rows_to_planes(const LnPro& q, const unsi
         const long slot = 2 * (long)blockIdx.x + c / (2 * D);
         if (slot * 16 < rows) q.ws[slot * 2 * D + (c % (2 * D))] = sum;
     }
+    if (PAIR) {
+        __syncthreads();                                                        // everyone has read the first norm's sums
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 0) * D)[lane + 64 * j] = dg2[sl][j];
+                reinterpret_cast<float4*>(red + ((wv * 2 + sl) * 2 + 1) * D)[lane + 64 * j] = db2[sl][j];
+            }
+        __syncthreads();
+        for (int c = threadIdx.x; c < 4 * D; c += 512) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) sum += red[w * 4 * D + c];
+            const long slot = 2 * (long)blockIdx.x + c / (2 * D);
+            if (slot * 16 < rows) q.ws2[slot * 2 * D + (c % (2 * D))] = sum;
+        }
+    }
 }
 
 template <int D, int RT, bool BWD, int NOUT, int NG, bool LNP = false>
@@ -328,7 +393,8 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 
         // ... made by the LayerNorm backward that precedes this feed-forward's backward (ln_bwd_rows_to_planes); the partial sums
         // meet in the h regions, which nothing uses before the first chunk's epilogue
         static_assert(!LNP || 8 * 2 * 2 * D * 4 <= NG * H_BYTES, "the prologue's partial sums reuse the h regions");
-        ln_bwd_rows_to_planes<D>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
+        if (p.ln.gamma2) ln_bwd_rows_to_planes<D, true>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
+        else ln_bwd_rows_to_planes<D, false>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
     } else {
         constexpr int C4 = D / 4;
         for (int i = threadIdx.x; i < BM * C4; i += 256 * NG) {
@@ -638,7 +704,8 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     // (the rows after the ring's first stages are on their way: both round trips overlap)
     if constexpr (LNP) {
         static_assert(8 * 2 * 2 * D * 4 <= 8 * PATCH, "the prologue's partial sums reuse the (still unused) patches");
-        ln_bwd_rows_to_planes<D>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
+        if (p.ln.gamma2) ln_bwd_rows_to_planes<D, true>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
+        else ln_bwd_rows_to_planes<D, false>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
     } else {
         constexpr int C4 = D / 4;
         for (int i = threadIdx.x; i < BM * C4; i += 512) {

@@ -84,15 +84,17 @@ class LnPrologue(C.Structure):
         ("dy", c_fp), ("x", c_fp), ("stats", c_fp), ("gamma", c_fp), ("add", c_fp),
         ("dx", c_fp), ("g", c_fp), ("ws", c_fp),
         ("g_alpha", C.c_float), ("g_p", C.c_float), ("g_seed", C.c_ulonglong), ("g_rowmask", c_fp), ("ln_rowmask", c_fp),
+        ("beta", c_fp), ("gamma2", c_fp), ("stats2", c_fp), ("ws2", c_fp),
     ]
 
     def fill(self, ln):
-        """ln: dict(dy, x, stats, gamma, add, dx, g, ws, alpha, p, seed, rowmask, ln_rowmask)."""
+        """ln: dict(dy, x, stats, gamma, add, dx, g, ws, alpha, p, seed, rowmask, ln_rowmask [, beta, gamma2, stats2, ws2: a pair])."""
         dp = lambda t: None if t is None else t.data_ptr()
         self.dy, self.x, self.stats, self.gamma, self.add = dp(ln["dy"]), dp(ln["x"]), dp(ln["stats"]), dp(ln["gamma"]), dp(ln.get("add"))
         self.dx, self.g, self.ws = dp(ln["dx"]), dp(ln["g"]), dp(ln["ws"])
         self.g_alpha, self.g_p, self.g_seed = ln["alpha"], ln["p"], ln["seed"]
         self.g_rowmask, self.ln_rowmask = dp(ln.get("rowmask")), dp(ln.get("ln_rowmask"))
+        self.beta, self.gamma2, self.stats2, self.ws2 = dp(ln.get("beta")), dp(ln.get("gamma2")), dp(ln.get("stats2")), dp(ln.get("ws2"))
 
 
 class FfnArgs(C.Structure):

@@ -276,9 +276,7 @@ def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending):
         sd = epi.get("seed_dev")
         if (form == 1 and k == 256 and x.is_contiguous() and x.data_ptr() == pd["g"].data_ptr() and M == pd["rows"] and
                 (sd is None or _seed_dev is None or sd.data_ptr() == _seed_dev.data_ptr()) and (epi.get("drop_p", 0.0) or 0.0) == 0.0):
-            alpha, p, seed, gmask = pd["spec"]
-            ln = dict(dy=pd["dy"], x=pd["x"], stats=pd["stats"], gamma=pd["gamma"], add=pd["add"], dx=pd["dx"], g=pd["g"], ws=pd["ws"],
-                      alpha=alpha, p=p, seed=seed, rowmask=gmask, ln_rowmask=pd.get("rowmask"))
+            ln = _ln_dict(pd)
         else:
             _resolve_ln(pd)                     # this launch reads x: the LayerNorm backward first, on its own
     hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0,
@@ -816,17 +814,31 @@ def _ln_fuse_ok(rows, d, w):
 
 def _ln_reduce(pend):
     if pend["table"]:
-        return                                   # (a captured step: the entry is in LN_TABLE, one launch at the end of backward)
+        return                                   # (a captured step: the entries are in LN_TABLE, one launch at the end of backward)
     hip.call("oe_layernorm_param_reduce", pend["ws"], pend["rows"], pend["d"], pend["dg"], pend["db"])
+    if pend.get("gamma2") is not None:
+        hip.call("oe_layernorm_param_reduce", pend["ws2"], pend["rows"], pend["d"], pend["dg2"], pend["db2"])
+
+
+def _ln_dict(pend):
+    """A parked LayerNorm backward as the `ln` argument of hip.rowgemm6 / hip.ffn_bwd (LnPrologue.fill)."""
+    alpha, p, seed, gmask = pend["spec"]
+    return dict(dy=pend["dy"], x=pend["x"], stats=pend["stats"], gamma=pend["gamma"], add=pend["add"], dx=pend["dx"], g=pend["g"], ws=pend["ws"],
+                alpha=alpha, p=p, seed=seed, rowmask=gmask, ln_rowmask=pend.get("rowmask"), beta=pend["beta"] if pend.get("gamma2") is not None else None,
+                gamma2=pend.get("gamma2"), stats2=pend.get("stats2"), ws2=pend.get("ws2"))
 
 
 def _resolve_ln(pend):
-    """The parked LayerNorm backward as a launch of its own (exactly what _ln_bwd would have launched)."""
+    """The parked LayerNorm backward as a launch of its own (exactly what _ln_bwd / NormPairFn.backward would have launched)."""
     if pend.get("done"):
         return
     alpha, p, seed, gmask = pend["spec"]
-    hip.call("oe_layernorm_bwd_dx_drop", pend["dy"], pend["x"], pend["gamma"], pend["beta"], 0, pend["stats"], pend["rows"], pend["d"],
-             pend.get("rowmask"), pend["add"], pend["dx"], pend["g"], alpha, p, seed, _seed_dev, gmask, pend["ws"])
+    if pend.get("gamma2") is not None:
+        hip.call("oe_layernorm_pair_bwd_dx_drop", pend["dy"], pend["x"], pend["gamma"], pend["beta"], pend["stats"], pend["gamma2"], pend["stats2"],
+                 pend["rows"], pend["d"], pend["add"], pend["dx"], pend["g"], alpha, p, seed, _seed_dev, gmask, pend["ws"], pend["ws2"])
+    else:
+        hip.call("oe_layernorm_bwd_dx_drop", pend["dy"], pend["x"], pend["gamma"], pend["beta"], 0, pend["stats"], pend["rows"], pend["d"],
+                 pend.get("rowmask"), pend["add"], pend["dx"], pend["g"], alpha, p, seed, _seed_dev, gmask, pend["ws"])
     pend["done"] = True
     _ln_reduce(pend)
 
@@ -1002,6 +1014,7 @@ class NormPairFn(torch.autograd.Function):
         hip.call("oe_layernorm_pair_fwd", x, g1, b1, eps1, g2, b2, eps2, rows, d, u, st1, y, st2)
         ctx.save_for_backward(x, g1, b1, st1, g2, b2, st2)
         ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
+        ctx.ln_fuse = bool(sole_consumer and getattr(x, "_oe_lnfuse", False))
         ctx.want_first = want_first
         if want_first:
             return u, y
@@ -1022,6 +1035,22 @@ class NormPairFn(torch.autograd.Function):
         (dg2, rg2), (db2, rb2) = grad_sink(g2), grad_sink(b2)
         ws1, ws2 = _ln_ws(x, rows, d), _ln_ws(x, rows, d)
         gout, alpha, p, seed, gmask = None, 1.0, 0.0, 0, None
+        arena_all = rg1 is None and rb1 is None and rg2 is None and rb2 is None
+        if (ctx.ln_fuse and arena_all and ctx.prev_drop is not None and LN_BWD_FUSE and FUSE_OUT_DROP and d == 256 and hip.GEMM_PRECISION == 6 and
+                rows >= ROWGEMM_MIN_ROWS and not _planes.active() and x.is_contiguous() and (add is None or add.is_contiguous())):
+            # parked: the previous block's backward (the second feed-forward's oe_ffn_bwd) launches it as its prologue (_PENDING_LN)
+            gout = torch.empty_like(dx)
+            t = LN_TABLE
+            _PENDING_LN[gout.data_ptr()] = dict(dy=dy, x=x, gamma=g1, beta=b1, stats=st1, gamma2=g2, stats2=st2, add=add, dx=dx, g=gout, ws=ws1,
+                                                ws2=ws2, spec=ctx.prev_drop, rows=rows, d=d, dg=dg1, db=db1, dg2=dg2, db2=db2, table=t is not None,
+                                                done=False)
+            _PREDROP[dx.data_ptr()] = (gout, ctx.prev_drop, dx, dx._version)
+            if t is not None:
+                for ws, dg, db in ((ws1, dg1, db1), (ws2, dg2, db2)):
+                    t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
+                    t["keep"].append(ws)
+                t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
+            return dx, rg1, rb1, None, rg2, rb2, None, None, None
         if ctx.prev_drop is not None and FUSE_OUT_DROP and d % 8 == 0:
             gout = torch.empty_like(dx)
             alpha, p, seed, gmask = ctx.prev_drop
@@ -1362,9 +1391,7 @@ class FeedForwardFn(torch.autograd.Function):
             if pend is not None and not pend.get("done"):
                 if (prec == 6 and d == 256 and ff % 256 == 0 and hip.lib().oe_ffn6_config(-1) in (0, 3) and g2.is_contiguous() and
                         g2.data_ptr() == pend["g"].data_ptr() and M == pend["rows"]):
-                    alpha, p_g, seed_g, gmask = pend["spec"]
-                    ln = dict(dy=pend["dy"], x=pend["x"], stats=pend["stats"], gamma=pend["gamma"], add=pend["add"], dx=pend["dx"], g=pend["g"],
-                              ws=pend["ws"], alpha=alpha, p=p_g, seed=seed_g, rowmask=gmask, ln_rowmask=pend.get("rowmask"))
+                    ln = _ln_dict(pend)
                 else:
                     _resolve_ln(pend)
             # FIRST launch of this backward: it makes g2 when that is a parked LayerNorm backward (the weight gradient reads it after)

@@ -752,7 +752,7 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
                 ops.set_seed_device_counter(None)
     finally:
         hip.GEMM_PRECISION, ops.LN_BWD_FUSE = old
-    assert launches == [0, 6]                                    # two encoder layers x (attention, conv module, first feed-forward)
+    assert launches == [0, 8]                                    # two encoder layers x (attention, conv module, both feed-forwards)
     assert losses[0] == losses[1]                                # the forward pass is untouched
     scale = float(grads[0].abs().max())
     assert float((grads[1] - grads[0]).abs().max()) <= 2e-5 * scale

@@ -286,3 +286,51 @@ def test_input_gradient_with_the_layernorm_backward_as_its_prologue(rows, p, ln_
             hip.ffn_bwd(g1, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pre, dh=dh1, dx=dx1, precision=6, ln=ln)
     finally:
         L.oe_ffn6_config(0)
+
+
+def test_input_gradient_with_a_pair_of_layernorm_backwards_as_its_prologue():
+    """The PAIR form of the prologue (oe_ln_prologue.gamma2): norm_final of an encoder layer and the norm behind it, whose joint
+    backward (oe_layernorm_pair_bwd_dx_drop) precedes the second feed-forward's backward."""
+    torch.manual_seed(69)
+    rows, d, ff, act, p_in, s_in, p = 4999, 256, 512, 2, 0.0, 0, 0.1
+    x = torch.randn(rows, d, device=DEV) * 1.3 - 0.2
+    g1, b1 = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    g2, b2 = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    u, y2 = torch.empty_like(x), torch.empty_like(x)
+    st1, st2 = torch.empty(rows, 2, device=DEV), torch.empty(rows, 2, device=DEV)
+    hip.call("oe_layernorm_pair_fwd", x, g1, b1, 1e-5, g2, b2, 1e-5, rows, d, u, st1, y2, st2)
+    dy, du = torch.randn(rows, d, device=DEV), torch.randn(rows, d, device=DEV)
+    w1, w2 = torch.randn(ff, d, device=DEV) / math.sqrt(d), torch.randn(d, ff, device=DEV) / math.sqrt(ff)
+    pre = torch.randn(rows, ff, device=DEV) * 1.5
+    L = hip.lib()
+    nb = L.oe_ffn_packed_bytes(d, ff, 6)
+    w2tp, w1tp = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hip.call("oe_ffn_pack_weights_bwd", w1, w2, d, ff, 6, w2tp, w1tp)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    nws = L.oe_layernorm_bwd_workspace_floats(rows, d)
+    dxl0, gq0 = torch.empty_like(x), torch.empty_like(x)
+    wsa0, wsb0 = torch.zeros(nws, device=DEV), torch.zeros(nws, device=DEV)
+    hip.call("oe_layernorm_pair_bwd_dx_drop", dy, x, g1, b1, st1, g2, st2, rows, d, du, dxl0, gq0, 0.5, p, 0x99, ctr, None, wsa0, wsb0)
+    dh0, dx0 = torch.empty(rows, ff, device=DEV), torch.empty(rows, d, device=DEV)
+    hip.ffn_bwd(gq0, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pre, dh=dh0, dx=dx0, precision=6)
+    nan = float("nan")
+    dxl1, gq1 = torch.full_like(x, nan), torch.full_like(x, nan)
+    wsa1, wsb1 = torch.zeros(nws, device=DEV), torch.zeros(nws, device=DEV)
+    dh1, dx1 = torch.full((rows, ff), nan, device=DEV), torch.full((rows, d), nan, device=DEV)
+    ln = dict(dy=dy, x=x, stats=st1, gamma=g1, beta=b1, gamma2=g2, stats2=st2, add=du, dx=dxl1, g=gq1, ws=wsa1, ws2=wsb1, alpha=0.5, p=p, seed=0x99,
+              rowmask=None, ln_rowmask=None)
+    hip.ffn_bwd(gq1, w2tp, w1tp, rows, d, ff, act, drop_in=p_in, seed_in=s_in, seed_dev=ctr, pre=pre, dh=dh1, dx=dx1, precision=6, ln=ln)
+    outs = []
+    for wsa, wsb in ((wsa0, wsb0), (wsa1, wsb1)):
+        r = [torch.zeros(d, device=DEV) for _ in range(4)]
+        hip.call("oe_layernorm_param_reduce", wsa, rows, d, r[0], r[1])
+        hip.call("oe_layernorm_param_reduce", wsb, rows, d, r[2], r[3])
+        outs.append(r)
+    sync()
+    torch.testing.assert_close(dxl1, dxl0, rtol=3e-6, atol=2e-6)
+    torch.testing.assert_close(gq1, gq0, rtol=3e-6, atol=2e-6)
+    assert torch.equal(gq1 == 0, gq0 == 0)
+    torch.testing.assert_close(dh1, dh0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dx1, dx0, rtol=1e-5, atol=2e-5)
+    for a, b in zip(outs[1], outs[0]):
+        torch.testing.assert_close(a, b, rtol=2e-5, atol=3e-4)
