@@ -174,6 +174,15 @@ typedef struct oe_ln_prologue {
     const float* beta; const float* gamma2; const float* stats2; float* ws2;
 } oe_ln_prologue;
 
+/* LayerNorm-FORWARD prologue of a row-block kernel (oe_rowgemm6 at k = 256, oe_ffn_fwd at d = 256, precision 6): when x != NULL the
+ * kernel's input rows are MADE as y = LayerNorm(x; gamma, beta, eps) (rows with rowmask 0: y = 0), written to y with the (mean, rstd)
+ * pairs to stats - oe_layernorm_fwd's outputs - and fed to the product: the pre-norm of a residual block (encoder_layer.py:79-80,
+ * 86-87, 92-93, 103-104) without a launch of its own. */
+typedef struct oe_lnf_prologue {
+    const float* x; const float* gamma; const float* beta; float eps;
+    float* y; float* stats; const unsigned char* rowmask;
+} oe_lnf_prologue;
+
 typedef struct oe_ffn_args {
     const float* x; long ldx;                  /* (rows, d) */
     const void* w1p; const float* b1;          /* packed W1, bias (ff) or NULL */
@@ -186,6 +195,7 @@ typedef struct oe_ffn_args {
     const float* residual; long ldr; float beta;
     float* y; long ldy;
     oe_ln_prologue ln;                          /* oe_ffn_bwd only (precision 6, d = 256): ln.dy != NULL makes the rows of dY (x is then ignored) */
+    oe_lnf_prologue lnf;                        /* oe_ffn_fwd only (precision 6, d = 256): lnf.x != NULL makes the rows of x (x is then ignored) */
 } oe_ffn_args;
 size_t oe_ffn_packed_bytes(int d, int ff, int precision);
 int oe_ffn_supported(int d, int ff, int precision, int act);
@@ -230,6 +240,7 @@ typedef struct oe_rowgemm_args {
      * (preact_out, optional: the value before it, row stride ld_aux), or - actgrad_in set - the product times act'(actgrad_in[row, col]) */
     int act; float* preact_out; const float* actgrad_in; long ld_aux;
     oe_ln_prologue ln;                          /* row-block form at k = 256: ln.dy != NULL makes the input rows (x is then ignored) */
+    oe_lnf_prologue lnf;                        /* ... or lnf.x != NULL: a LayerNorm forward makes them */
 } oe_rowgemm_args;
 int oe_rowgemm6_supported(int k, int n);
 /* Which kernel oe_rowgemm6 runs: 1 = the row-block form above (k in {256, 512}, n % 128 == 0: one 32-row block streams the whole packed

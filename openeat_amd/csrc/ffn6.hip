@@ -59,6 +59,19 @@ static const char* ln_pro_check(const oe_ln_prologue& a) {
     return nullptr;
 }
 
+// LayerNorm-FORWARD prologue (oe_lnf_prologue of the header): see ln_fwd_rows_to_planes
+struct LnfPro { const float* x; const float* gamma; const float* beta; float eps; float* y; float* stats; const unsigned char* rowmask; };
+static LnfPro lnf_pro_of(const oe_lnf_prologue& a) {
+    LnfPro q;
+    q.x = a.x; q.gamma = a.gamma; q.beta = a.beta; q.eps = a.eps; q.y = a.y; q.stats = a.stats; q.rowmask = a.rowmask;
+    return q;
+}
+static const char* lnf_pro_check(const oe_lnf_prologue& a) {
+    if (!(a.gamma && a.beta && a.y && a.stats)) return "null pointer";
+    if (((((uintptr_t)a.x) | ((uintptr_t)a.gamma) | ((uintptr_t)a.beta) | ((uintptr_t)a.y)) & 15) != 0) return "16-byte alignment required";
+    return nullptr;
+}
+
 struct Ffn6Params {
     const float* x; long ldx;
     const unsigned char* w1p; const float* b1;
@@ -70,7 +83,8 @@ struct Ffn6Params {
     float p_in; unsigned long long seed_in;
     float p_out; unsigned long long seed_out;
     const unsigned long long* seed_dev;
-    LnPro ln;                                    // BWD with LNP: the rows of x (= dY) are made by a LayerNorm backward
+    LnPro ln;                                    // BWD with LNP = 1: the rows of x (= dY) are made by a LayerNorm backward
+    LnfPro lnf;                                  // forward with LNP = 2: the rows of x are made by a LayerNorm forward
 };
 
 // derivative of the three activations the kernel admits (oe_ffn_supported): none, relu, swish - act_bwd's full table (tanh, erf, ...)
@@ -194,6 +208,42 @@ __device__ __forceinline__ void f6_write_planes(const float (&hv)[16], unsigned 
 // per-block partial sums of the LayerNorm's parameter gradients go to q.ws in layernorm_bwd_kernel's layout (one slot per 16
 // rows) for the same reduction launch.  `red`: 32 KiB of LDS nothing else uses yet ([8 waves][2 slots][2][D] floats).  Contains
 // one __syncthreads(); the caller's own barrier behind the planes must follow.
+// The LayerNorm FORWARD in front of a row-block kernel (the pre-norm of a residual block, encoder_layer.py:79-80, 86-87, 92-93, 103-104)
+// as the way its 32 rows reach LDS: y = (x - mean) rstd gamma + beta per row, a wave per row exactly as layernorm_fwd_kernel (same
+// two-pass statistics, same per-lane order); y and the (mean, rstd) pairs are written (the weight gradient and the LayerNorm's backward
+// read them), y is split into the block's planes.  rowmask: rows with 0 give y = 0 (convolution.py:88-89).  No barrier of its own.
+template <int D>
+__device__ __forceinline__ void ln_fwd_rows_to_planes(const LnfPro& q, int rows, long m0, int wv, int lane, unsigned char* xs) {
+    static_assert(D == 256, "one float4 per lane and row");
+    constexpr int BM = 32, XP = D + 8;
+    const float4 g = reinterpret_cast<const float4*>(q.gamma)[lane], bb = reinterpret_cast<const float4*>(q.beta)[lane];
+    float4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(q.x + min(m0 + wv + 8 * k, (long)rows - 1) * D)[lane];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = wv + 8 * k;
+        const long grow = m0 + row;
+        const bool valid = grow < rows;
+        const float mean = wave_sum(v[k].x + v[k].y + v[k].z + v[k].w) / D;
+        const float a = v[k].x - mean, b = v[k].y - mean, c = v[k].z - mean, e = v[k].w - mean;
+        const float rstd = rsqrtf(wave_sum(a * a + b * b + c * c + e * e) / D + q.eps);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(valid && q.rowmask && !q.rowmask[grow]))
+            o = make_float4((v[k].x - mean) * rstd * g.x + bb.x, (v[k].y - mean) * rstd * g.y + bb.y,
+                            (v[k].z - mean) * rstd * g.z + bb.z, (v[k].w - mean) * rstd * g.w + bb.w);
+        if (valid) {
+            if (lane == 0) { q.stats[grow * 2] = mean; q.stats[grow * 2 + 1] = rstd; }
+            reinterpret_cast<float4*>(q.y + grow * D)[lane] = o;
+        }
+        const float xq[4] = {o.x, o.y, o.z, o.w};
+        oe_bf16x4v pl[3];
+        oe_split4<3>(xq, pl);
+#pragma unroll
+        for (int n = 0; n < 3; ++n) *reinterpret_cast<oe_bf16x4v*>(xs + ((size_t)(n * BM + row) * XP + 4 * lane) * 2) = pl[n];
+    }
+}
+
 // PAIR (layernorm_bwd_kernel's PAIR): two norms back to back, y2 = LN2(u), u = LN1(x) - dy is the gradient of y2, `add` the gradient
 // that reaches u on its other path, u is recomputed from x and LN1's statistics (q.stats, q.gamma, q.beta); the row first goes
 // through LN2's backward (q.gamma2, q.stats2; its parameter partials to q.ws2), the result through LN1's.
@@ -358,10 +408,10 @@ __device__ __forceinline__ void ln_bwd_rows_to_planes(const LnPro& q, const unsi
     }
 }
 
-template <int D, int RT, bool BWD, int NOUT, int NG, bool LNP = false>
+template <int D, int RT, bool BWD, int NOUT, int NG, int LNP = 0>
 __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 1) void ffn6_kernel(Ffn6Params p) {
     static_assert(NG == 1 || (NG == 2 && RT == 1), "two wave groups: 32-row blocks");
-    static_assert(!LNP || (BWD && D == 256 && RT == 1 && NG == 2), "LayerNorm-backward prologue: the eight-wave 32-row backward at d = 256");
+    static_assert(LNP == 0 || (D == 256 && RT == 1 && NG == 2 && BWD == (LNP == 1)), "LayerNorm prologues: the eight-wave 32-row kernels at d = 256");
     constexpr int BM = 32 * RT;
     constexpr int KS = D / 16, DT = D / 32, DPW = DT / 4;            // k-steps of GEMM 1, output tiles, output tiles per wave
     constexpr int FR = 2, NSET = 4;
@@ -389,10 +439,12 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 
     const int rot = blockIdx.x % nchunks;                            // blocks start their walk over the weights at different chunks
 
     // ---- the block's rows -> three bf16 planes in LDS (rows past the end re-read the last one; never stored)
-    if constexpr (LNP) {
+    if constexpr (LNP == 2) {
+        ln_fwd_rows_to_planes<D>(p.lnf, p.rows, m0, wv, lane, xs);           // ... made by the pre-norm in front of this feed-forward
+    } else if constexpr (LNP == 1) {
         // ... made by the LayerNorm backward that precedes this feed-forward's backward (ln_bwd_rows_to_planes); the partial sums
         // meet in the h regions, which nothing uses before the first chunk's epilogue
-        static_assert(!LNP || 8 * 2 * 2 * D * 4 <= NG * H_BYTES, "the prologue's partial sums reuse the h regions");
+        static_assert(LNP != 1 || 8 * 2 * 2 * D * 4 <= NG * H_BYTES, "the prologue's partial sums reuse the h regions");
         if (p.ln.gamma2) ln_bwd_rows_to_planes<D, true>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
         else ln_bwd_rows_to_planes<D, false>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
     } else {
@@ -647,7 +699,8 @@ struct Row6Params {
     float p_out; unsigned long long seed_out;
     const unsigned long long* seed_dev;
     int k, act; float* preact_out; const float* actgrad_in; long ld_aux;     // (tile form only)
-    LnPro ln;                                    // LayerNorm-backward prologue (row-block form, LNP): the rows of x are MADE
+    LnPro ln;                                    // LayerNorm-backward prologue (row-block form, LNP = 1): the rows of x are MADE
+    LnfPro lnf;                                  // LayerNorm-forward prologue (LNP = 2)
 };
 
 // LNP (LayerNorm-backward prologue): the GEMM's input rows are the gradient a pre-norm residual block's backward STARTS from,
@@ -658,7 +711,7 @@ struct Row6Params {
 // the rows reach LDS: dx and g are written (the residual stream and the weight gradient read them), g is split into the planes, and
 // the per-block partial sums of the LayerNorm's parameter gradients go to ln_ws in layernorm_bwd_kernel's layout (one slot per 16
 // rows: rows 0-15 and 16-31 of the block) for the same reduction launch.
-template <int D, bool LNP = false>
+template <int D, int LNP = 0>
 __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     constexpr int BM = 32, NG = 2;
     constexpr int KS = D / 16;
@@ -702,7 +755,9 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
         static_for<0, NSET - 1>([&](auto k_c) { load_stage(k_c, c0, fr[decltype(k_c)::value]); });
     }
     // (the rows after the ring's first stages are on their way: both round trips overlap)
-    if constexpr (LNP) {
+    if constexpr (LNP == 2) {
+        ln_fwd_rows_to_planes<D>(p.lnf, p.rows, m0, wv, lane, xs);
+    } else if constexpr (LNP == 1) {
         static_assert(8 * 2 * 2 * D * 4 <= 8 * PATCH, "the prologue's partial sums reuse the (still unused) patches");
         if (p.ln.gamma2) ln_bwd_rows_to_planes<D, true>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
         else ln_bwd_rows_to_planes<D, false>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
@@ -1094,7 +1149,7 @@ extern "C" int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces,
 }
 
 extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
-    OE_REQUIRE(a && (a->x || a->ln.dy) && a->wp && a->y, "oe_rowgemm6: null pointer");
+    OE_REQUIRE(a && (a->x || a->ln.dy || a->lnf.x) && a->wp && a->y, "oe_rowgemm6: null pointer");
     const int form = a->rows > 0 ? oe_rowgemm6_form(a->rows, a->k, a->n) : 0;
     OE_REQUIRE(form != 0, "oe_rowgemm6: unsupported rows=%d k=%d n=%d", a->rows, a->k, a->n);
     const bool has_act = a->act != OE_ACT_NONE || a->preact_out || a->actgrad_in;
@@ -1108,6 +1163,11 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
         const char* why = ln_pro_check(a->ln);
         OE_REQUIRE(why == nullptr, "oe_rowgemm6: LayerNorm prologue: %s", why);
     }
+    if (a->lnf.x) {
+        OE_REQUIRE(form == 1 && a->k == 256 && !a->ln.dy, "oe_rowgemm6: the LayerNorm-forward prologue exists in the row-block form at k = 256 only");
+        const char* why = lnf_pro_check(a->lnf);
+        OE_REQUIRE(why == nullptr, "oe_rowgemm6: LayerNorm-forward prologue: %s", why);
+    }
     OE_REQUIRE(((((uintptr_t)a->x) | ((uintptr_t)a->y) | ((uintptr_t)a->residual) | ((uintptr_t)a->wp) | ((uintptr_t)a->bias)) & 15) == 0,
                "oe_rowgemm6: 16-byte alignment required");
     OE_REQUIRE(a->drop_p >= 0.f && a->drop_p < 1.f, "oe_rowgemm6: dropout rate out of range");
@@ -1116,6 +1176,7 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     p.rowmask = a->rowmask; p.y = a->y; p.ldy = a->ldy; p.rows = a->rows; p.no = a->n; p.p_out = a->drop_p; p.seed_out = a->seed; p.seed_dev = a->seed_dev;
     p.k = a->k; p.act = a->act; p.preact_out = a->preact_out; p.actgrad_in = a->actgrad_in; p.ld_aux = a->ld_aux;
     p.ln = ln_pro_of(a->ln);
+    p.lnf = lnf_pro_of(a->lnf);
     if (form == 2) {
         const dim3 tgrid(oe_cdiv(a->rows, 32), a->n / 32), tblock(512);
         hipStream_t st = (hipStream_t)stream;
@@ -1130,7 +1191,8 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     }
     const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
     if (a->k > 512) hipLaunchKernelGGL(rowgemm6p_kernel, grid, block, 0, (hipStream_t)stream, p);
-    else if (a->ln.dy) hipLaunchKernelGGL((rowgemm6_kernel<256, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (a->ln.dy) hipLaunchKernelGGL((rowgemm6_kernel<256, 1>), grid, block, 0, (hipStream_t)stream, p);
+    else if (a->lnf.x) hipLaunchKernelGGL((rowgemm6_kernel<256, 2>), grid, block, 0, (hipStream_t)stream, p);
     else if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((rowgemm6_kernel<256>), grid, block, 0, (hipStream_t)stream, p);
     OE_LAUNCH_CHECK("oe_rowgemm6");
@@ -1142,12 +1204,19 @@ static int ffn6_launch(const Ffn6Params& p, bool bwd, int nout, hipStream_t st) 
     const dim3 grid(oe_cdiv(p.rows, 32 * RT)), block(256 * NG);
     if constexpr (D == 256 && RT == 1 && NG == 2) {
         if (bwd && p.ln.dy) {
-            hipLaunchKernelGGL((ffn6_kernel<D, RT, true, 1, NG, true>), grid, block, 0, st, p);
+            hipLaunchKernelGGL((ffn6_kernel<D, RT, true, 1, NG, 1>), grid, block, 0, st, p);
             OE_LAUNCH_CHECK("oe_ffn_bwd (precision 6, LayerNorm-backward prologue)");
             return 0;
         }
+        if (!bwd && p.lnf.x) {
+            if (nout == 2) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 2, NG, 2>), grid, block, 0, st, p);
+            else if (nout == 1) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 1, NG, 2>), grid, block, 0, st, p);
+            else hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 0, NG, 2>), grid, block, 0, st, p);
+            OE_LAUNCH_CHECK("oe_ffn_fwd (precision 6, LayerNorm prologue)");
+            return 0;
+        }
     }
-    OE_REQUIRE(!p.ln.dy, "oe_ffn: the LayerNorm-backward prologue exists for the backward at d = 256 in the two-group block shape only");
+    OE_REQUIRE(!p.ln.dy && !p.lnf.x, "oe_ffn: the LayerNorm prologues exist at d = 256 in the two-group block shape only");
     if (bwd) hipLaunchKernelGGL((ffn6_kernel<D, RT, true, 1, NG>), grid, block, 0, st, p);
     else if (nout == 2) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 2, NG>), grid, block, 0, st, p);
     else if (nout == 1) hipLaunchKernelGGL((ffn6_kernel<D, RT, false, 1, NG>), grid, block, 0, st, p);
@@ -1179,6 +1248,11 @@ int oe_ffn6_run(const oe_ffn_args* a, bool bwd, void* stream) {
         const char* why = ln_pro_check(a->ln);
         OE_REQUIRE(bwd && why == nullptr, "oe_ffn: LayerNorm prologue: %s", bwd ? why : "backward only");
         p.ln = ln_pro_of(a->ln);
+    }
+    if (a->lnf.x) {
+        const char* why = lnf_pro_check(a->lnf);
+        OE_REQUIRE(!bwd && why == nullptr, "oe_ffn: LayerNorm-forward prologue: %s", bwd ? "forward only" : why);
+        p.lnf = lnf_pro_of(a->lnf);
     }
     const int nout = a->act_out ? 2 : a->pre_out ? 1 : 0;
     hipStream_t st = (hipStream_t)stream;

@@ -97,6 +97,17 @@ class LnPrologue(C.Structure):
         self.beta, self.gamma2, self.stats2, self.ws2 = dp(ln.get("beta")), dp(ln.get("gamma2")), dp(ln.get("stats2")), dp(ln.get("ws2"))
 
 
+class LnfPrologue(C.Structure):
+    """oe_lnf_prologue (include/openeat_hip.h)."""
+    _fields_ = [("x", c_fp), ("gamma", c_fp), ("beta", c_fp), ("eps", C.c_float), ("y", c_fp), ("stats", c_fp), ("rowmask", c_fp)]
+
+    def fill(self, q):
+        """q: dict(x, gamma, beta, eps, y, stats, rowmask)."""
+        dp = lambda t: None if t is None else t.data_ptr()
+        self.x, self.gamma, self.beta, self.eps = dp(q["x"]), dp(q["gamma"]), dp(q["beta"]), float(q["eps"])
+        self.y, self.stats, self.rowmask = dp(q["y"]), dp(q["stats"]), dp(q.get("rowmask"))
+
+
 class FfnArgs(C.Structure):
     _fields_ = [
         ("x", c_fp), ("ldx", C.c_long),
@@ -107,7 +118,7 @@ class FfnArgs(C.Structure):
         ("pre_out", c_fp), ("act_out", c_fp),
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
-        ("ln", LnPrologue),
+        ("ln", LnPrologue), ("lnf", LnfPrologue),
     ]
 
 
@@ -122,7 +133,7 @@ class RowGemmArgs(C.Structure):
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
         ("act", C.c_int), ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
-        ("ln", LnPrologue),
+        ("ln", LnPrologue), ("lnf", LnfPrologue),
     ]
 
 
@@ -379,10 +390,13 @@ def tn_grouped_launch(table_dev: torch.Tensor, n: int, total_blocks: int, precis
 
 
 def ffn_fwd(x2, w1p, b1, w2p, b2, rows, d, ff, act, *, drop_in=0.0, seed_in=0, drop_out=0.0, seed_out=0, seed_dev=None, pre_out=None,
-            act_out=None, residual=None, ldr=0, beta=1.0, y=None, precision=None):
+            act_out=None, residual=None, ldr=0, beta=1.0, y=None, precision=None, lnf=None):
+    """lnf: LayerNorm-forward prologue (LnfPrologue.fill) - the rows of x2 are then made by the kernel (x2 = lnf["y"], written too)."""
     a = FfnArgs()
     dp = lambda t: None if t is None else t.data_ptr()
     a.x, a.ldx = x2.data_ptr(), x2.stride(0)
+    if lnf is not None:
+        a.lnf.fill(lnf)
     a.w1p, a.b1, a.w2p, a.b2 = w1p.data_ptr(), dp(b1), w2p.data_ptr(), dp(b2)
     a.rows, a.d, a.ff, a.act = rows, d, ff, act
     a.precision = GEMM_PRECISION if precision is None else precision
@@ -424,7 +438,7 @@ def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_d
 
 
 def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=None, rowmask=None, residual=None, ldr=0, beta=1.0,
-             act=0, preact_out=None, actgrad_in=None, ld_aux=0, ln=None):
+             act=0, preact_out=None, actgrad_in=None, ld_aux=0, ln=None, lnf=None):
     """y = residual + beta * rowmask * dropout(act(x @ Wg^T + bias)) on the row-block / tile kernels (oe_rowgemm6; wp = packed Wg)."""
     a = RowGemmArgs()
     dp = lambda t: None if t is None else t.data_ptr()
@@ -436,6 +450,8 @@ def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=No
     a.act, a.preact_out, a.actgrad_in, a.ld_aux = act, dp(preact_out), dp(actgrad_in), ld_aux
     if ln is not None:        # LayerNorm-backward prologue (LnPrologue.fill)
         a.ln.fill(ln)
+    if lnf is not None:       # LayerNorm-forward prologue (LnfPrologue.fill)
+        a.lnf.fill(lnf)
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

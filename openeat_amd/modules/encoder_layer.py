@@ -39,8 +39,10 @@ class EncoderLayer(nn.Module):
     @staticmethod
     def _fork(norm: nn.LayerNorm, x, rowmask=None, sole=True):
         """(residual, LN(x)): the two branches of a pre-norm block from one op (their gradients meet in one kernel).
-        sole: x feeds nothing but this fork (true everywhere in this layer except where the adapter also reads x)."""
-        return ops.pre_norm(x, norm.weight, norm.bias, norm.eps, rowmask, sole_consumer=sole)
+        sole: x feeds nothing but this fork (true everywhere in this layer except where the adapter also reads x).
+        fuse_fwd: every caller below hands the normed branch to ONE op of openeat_amd.ops and to nothing else - that op's first kernel
+        may compute the norm on its way in (ops._PENDING_LNF)."""
+        return ops.pre_norm(x, norm.weight, norm.bias, norm.eps, rowmask, sole_consumer=sole, fuse_fwd=True)
 
     def forward(self, x: torch.Tensor, masks: torch.Tensor, pos_emb: torch.Tensor, pre=None, defer_final: bool = False):
         """pre: (residual, norm_ff_macaron(residual)) already computed by the caller - the previous layer's norm_final and this

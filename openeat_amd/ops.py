@@ -51,11 +51,49 @@ def manual_seed(seed: int):
     _seed_counter = itertools.count(0x5EED0001 + (seed & 0xFFFFFFF) * 7919)
 
 
-def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+def _chk(t: torch.Tensor, name: str, keep_pending: bool = False) -> torch.Tensor:
     if not t.is_cuda or t.dtype != torch.float32:
         raise TypeError(f"{name}: openeat_amd ops need float32 CUDA tensors (got {t.dtype} on {t.device}); "
                         "there is no CPU fallback")
+    if _PENDING_LNF and not keep_pending:
+        # the output of a parked LayerNorm forward (PreNormFn) reaching an op that does not make it itself: launch it now
+        pend = _PENDING_LNF.pop(t.data_ptr(), None)
+        if pend is not None:
+            _resolve_lnf(pend)
     return t.contiguous()
+
+
+# The LayerNorm FORWARD of a pre-norm fork as the prologue of the GEMM that consumes it (oe_rowgemm6 / oe_ffn_fwd's lnf arguments):
+# EncoderLayer promises (fuse_fwd) that the normed branch goes straight into an op of this module; PreNormFn.forward then parks the
+# launch here, keyed by the address of its (still unwritten) output; the consumer's first kernel - the feed-forward, the fused
+# q / k / v projection, the conv module's pointwise_conv1 - makes the rows on its way to LDS and writes y and the statistics for the
+# backward.  Any other op of this module that receives a parked tensor launches the LayerNorm on its own first (_chk); leftovers are
+# launched where the step's bookkeeping is reset (predrop_clear).  36 launches per step at config 2.
+LN_FWD_FUSE = os.environ.get("OE_LN_FWD_FUSE", "1") == "1"
+LN_FWD_FUSED_LAUNCHES = 0       # (tests)
+_PENDING_LNF = {}
+
+
+def _resolve_lnf(pend):
+    if pend.get("done"):
+        return
+    pend["done"] = True
+    _ln_fwd(pend["x"], pend["gamma"], pend["beta"], pend["eps"], pend["rows"], pend["d"], pend["rowmask"], ACT_NONE, pend["y"], pend["stats"])
+
+
+def resolve_pending_lnf():
+    n = 0
+    for pend in list(_PENDING_LNF.values()):
+        if not pend.get("done"):
+            _resolve_lnf(pend)
+            n += 1
+    _PENDING_LNF.clear()
+    return n
+
+
+def _lnf_take(t):
+    """The parked LayerNorm forward whose output is t (removed from the registry), or None."""
+    return _PENDING_LNF.pop(t.data_ptr(), None) if _PENDING_LNF else None
 
 
 def _new(*shape, like: torch.Tensor, zero=False):
@@ -220,18 +258,20 @@ def _row_packed(w, transposed):
     return ent["buf"]
 
 
-def _rowgemm_try(x, w, transposed, bias, out, epi, ln_pending=None):
+def _rowgemm_try(x, w, transposed, bias, out, epi, ln_pending=None, lnf_pending=None):
     """x (M, k) @ Wg^T on the row-block / tile kernels if the problem and its epilogue qualify; returns out or None.
     ln_pending: x is the `g` of a parked LayerNorm backward (_PENDING_LN) - launched as the kernel's prologue when this is the
     k = 256 row-block kernel, and on its own BEFORE anything reads x in every other case (also when None is returned)."""
     try:
-        return _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending)
+        return _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending)
     finally:
         if ln_pending is not None:
             _resolve_ln(ln_pending)              # (no-op when the fused launch has happened)
+        if lnf_pending is not None:
+            _resolve_lnf(lnf_pending)
 
 
-def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending):
+def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending=None):
     if not ROWGEMM or hip.GEMM_PRECISION != 6 or not x.is_cuda:
         return None
     k = x.shape[1]
@@ -279,14 +319,25 @@ def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending):
             ln = _ln_dict(pd)
         else:
             _resolve_ln(pd)                     # this launch reads x: the LayerNorm backward first, on its own
+    lnf = None
+    if lnf_pending is not None and not lnf_pending.get("done"):
+        q = lnf_pending
+        if form == 1 and k == 256 and ln is None and x.is_contiguous() and x.data_ptr() == q["y"].data_ptr() and M == q["rows"]:
+            lnf = dict(x=q["x"], gamma=q["gamma"], beta=q["beta"], eps=q["eps"], y=q["y"], stats=q["stats"], rowmask=q["rowmask"])
+        else:
+            _resolve_lnf(q)                     # this launch reads x: the LayerNorm first, on its own
     hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0,
                  seed_dev=(_seed_dev if ln is not None else epi.get("seed_dev")),
                  rowmask=epi.get("rowmask"), residual=res, ldr=epi.get("ldr", 0) or 0, beta=epi.get("beta", 1.0),
-                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux, ln=ln)
+                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux, ln=ln, lnf=lnf)
     if ln is not None:
         ln_pending["done"] = True
         LN_BWD_FUSED_LAUNCHES += 1
         _ln_reduce(ln_pending)
+    if lnf is not None:
+        global LN_FWD_FUSED_LAUNCHES
+        lnf_pending["done"] = True
+        LN_FWD_FUSED_LAUNCHES += 1
     return out
 
 
@@ -294,10 +345,13 @@ def gemm_nt(x, w, bias=None, out=None, out_planes=False, **epi):
     """y[M,N] = x[M,K] @ w[N,K]^T (+ epilogue).  out_planes: the output is a later GEMM's operand - write its bf16 planes too."""
     M, K = x.shape
     N = w.shape[0]
+    lnf = _lnf_take(x)                                                            # x may be the output of a parked LayerNorm forward
     if not (out_planes and _planes.split_activations()):
-        y = _rowgemm_try(x, w, False, bias, out, epi)
+        y = _rowgemm_try(x, w, False, bias, out, epi, lnf_pending=lnf)             # (launches or resolves it on every path)
         if y is not None:
             return y
+    elif lnf is not None:
+        _resolve_lnf(lnf)
     if out is None:
         out = _new(M, N, like=x)
     ap, bp = _operand_planes(x, w)
@@ -782,6 +836,8 @@ def predrop_clear():
     leftovers - dropped-gradient copies and the registry of pre-split GEMM operands."""
     if _PENDING_LN:
         resolve_pending_ln()
+    if _PENDING_LNF:
+        resolve_pending_lnf()
     _PREDROP.clear()
     _planes.clear()
 
@@ -957,13 +1013,18 @@ class PreNormFn(torch.autograd.Function):
     backward kernel itself (its `add` input) instead of a separate elementwise add by autograd."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, rowmask, sole_consumer=False):
+    def forward(ctx, x, gamma, beta, eps, rowmask, sole_consumer=False, fuse_fwd=False):
         x = _chk(x, "pre_norm")
         d = x.shape[-1]
         rows = x.numel() // d
         y = torch.empty_like(x)
         stats = _new(rows, 2, like=x)
-        _ln_fwd(x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
+        if (fuse_fwd and LN_FWD_FUSE and ROWGEMM and hip.GEMM_PRECISION == 6 and d == 256 and rows >= ROWGEMM_MIN_ROWS and not _planes.active() and
+                gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0):
+            # parked: the consumer's first kernel makes y (see _PENDING_LNF)
+            _PENDING_LNF[y.data_ptr()] = dict(x=x, gamma=gamma, beta=beta, eps=eps, rows=rows, d=d, rowmask=rowmask, y=y, stats=stats, done=False)
+        else:
+            _ln_fwd(x, gamma, beta, eps, rows, d, rowmask, ACT_NONE, y, stats)
         ctx.save_for_backward(x, gamma, beta, stats, rowmask)
         ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
         ctx.ln_fuse = bool(sole_consumer and getattr(x, "_oe_lnfuse", False))
@@ -973,7 +1034,7 @@ class PreNormFn(torch.autograd.Function):
     def backward(ctx, dres, dy):
         x, gamma, beta, stats, rowmask = ctx.saved_tensors
         if dy is None:
-            return dres, None, None, None, None, None
+            return dres, None, None, None, None, None, None
         d = x.shape[-1]
         rows = x.numel() // d
         dx = torch.empty_like(x)
@@ -981,12 +1042,14 @@ class PreNormFn(torch.autograd.Function):
         add = None if dres is None else dres.contiguous()
         _ln_bwd(dy.contiguous(), x, gamma, beta, ACT_NONE, stats, rows, d, rowmask, add, dx, dg, db, rg is None and rb is None,
                 ctx.prev_drop, fuse=ctx.ln_fuse)
-        return dx, rg, rb, None, None, None
+        return dx, rg, rb, None, None, None, None
 
 
-def pre_norm(x, gamma, beta, eps, rowmask=None, sole_consumer=False):
-    """-> (residual, normed): use `residual` for the skip connection of the block.  sole_consumer: see layer_norm."""
-    return PreNormFn.apply(x, gamma, beta, eps, rowmask, sole_consumer)
+def pre_norm(x, gamma, beta, eps, rowmask=None, sole_consumer=False, fuse_fwd=False):
+    """-> (residual, normed): use `residual` for the skip connection of the block.  sole_consumer: see layer_norm.
+    fuse_fwd: the caller hands `normed` straight to an op of this module and to nothing else (EncoderLayer) - its first kernel may
+    then make it (_PENDING_LNF)."""
+    return PreNormFn.apply(x, gamma, beta, eps, rowmask, sole_consumer, fuse_fwd)
 
 
 # Two LayerNorms back to back - an encoder layer's norm_final followed by the next layer's first pre-norm fork, or by the
@@ -1329,13 +1392,23 @@ class FeedForwardFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, act, p_in, residual, out_scale, p_out):
-        x = _chk(x, "feed_forward")
+        x = _chk(x, "feed_forward", keep_pending=True)
         d = x.shape[-1]
         x2 = x.reshape(-1, d)
         M, ff = x2.shape[0], w1.shape[0]
         s_in, s_out = (next_seed() if p_in > 0 else 0), (next_seed() if p_out > 0 else 0)
         res2 = None if residual is None else _chk(residual, "residual").reshape(-1, w2.shape[0])
-        if FUSED_FFN and _ffn_fused_ok(x2, w1, w2, act, res2):
+        lnf_p = _lnf_take(x2)                     # x may be the output of a parked LayerNorm forward (_PENDING_LNF)
+        fused_now = FUSED_FFN and _ffn_fused_ok(x2, w1, w2, act, res2)
+        lnf = None
+        if lnf_p is not None:
+            if (fused_now and hip.GEMM_PRECISION == 6 and d == 256 and ff % 256 == 0 and hip.lib().oe_ffn6_config(-1) in (0, 3) and
+                    x2.is_contiguous() and M == lnf_p["rows"]):
+                lnf = dict(x=lnf_p["x"], gamma=lnf_p["gamma"], beta=lnf_p["beta"], eps=lnf_p["eps"], y=lnf_p["y"], stats=lnf_p["stats"],
+                           rowmask=lnf_p["rowmask"])
+            else:
+                _resolve_lnf(lnf_p)
+        if fused_now:
             # one kernel (csrc/ffn.hip): the (M, ff) intermediate stays in registers; pre / a are written only when a
             # backward will read them
             need = any(ctx.needs_input_grad)
@@ -1345,7 +1418,11 @@ class FeedForwardFn(torch.autograd.Function):
             y = _new(M, d, like=x)
             hip.ffn_fwd(x2, w1p, b1, w2p, b2, M, d, ff, act, drop_in=p_in, seed_in=s_in, drop_out=p_out, seed_out=s_out,
                         seed_dev=_seed_dev, pre_out=pre, act_out=a, residual=res2, ldr=0 if res2 is None else res2.stride(0),
-                        beta=out_scale, y=y)
+                        beta=out_scale, y=y, lnf=lnf)
+            if lnf is not None:
+                global LN_FWD_FUSED_LAUNCHES
+                lnf_p["done"] = True
+                LN_FWD_FUSED_LAUNCHES += 1
             ctx.save_for_backward(x2, w1, w2, pre, a)
             ctx.biases = (b1, b2)
             ctx.cfg = (act, p_in, s_in, out_scale, p_out, s_out, residual is not None, x.shape)
@@ -1465,7 +1542,7 @@ class AttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xq, xkv, wq, bq, wk, bk, wv, bv, wo, bo, mask, pos_emb, wpos, pu, pv, H, p_attn, residual, p_out, pp_in=None):
-        xq = _chk(xq, "attention query")
+        xq = _chk(xq, "attention query", keep_pending=True)        # (a parked LayerNorm forward: the q / k / v projection below makes it)
         self_attn = xkv is None
         B, T1, d = xq.shape
         D = d // H
@@ -1693,7 +1770,7 @@ class ConvModuleFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, rowmask, w1, b1, wd, bd, g, b, w2, b2, K, causal, act, residual, p_out, input_masked):
-        x = _chk(x, "conv_module")
+        x = _chk(x, "conv_module", keep_pending=not (rowmask is not None and not input_masked))    # (pointwise_conv1 below makes a parked LayerNorm)
         B, T, d = x.shape
         x2 = x.view(-1, d)
         xm = x2 if (rowmask is None or input_masked) else dropout_scale(x2, 1.0, 0.0, 0, rowmask)

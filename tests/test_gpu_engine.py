@@ -720,18 +720,19 @@ def test_weight_planes_follow_an_optimizer_loop_outside_the_engine(policy):
 
 
 def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
-    """ops._PENDING_LN: at d = 256 and >= 4096 rows in precision 6 the backward of the pre-norm fork behind an attention / conv-module
-    block runs as the prologue of that block's first input-gradient GEMM (oe_rowgemm6's ln_* arguments).  Same model, same batch, same
+    """ops._PENDING_LN / _PENDING_LNF: at d = 256 and >= 4096 rows in precision 6 the pre-norm forks of an encoder layer run as prologues
+    of the row-block kernels next to them - forward in front of the consuming feed-forward / q-k-v projection / pointwise_conv1, backward
+    in front of the previous block's first input-gradient kernel (oe_rowgemm6's and oe_ffn_fwd / _bwd's ln / lnf arguments).  Same model, same batch, same
     dropout masks with the switch off and on: the gradient arena must agree to rounding (the two kernels contract a*b+c differently:
     one unit in the last place per element), the fused launches are counted, nothing stays parked."""
     from openeat_amd import hip
-    old = (hip.GEMM_PRECISION, ops.LN_BWD_FUSE)
+    old = (hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE)
     hip.GEMM_PRECISION = 6
-    grads, losses, launches = [], [], []
+    grads, losses, launches, fwd_launches = [], [], [], []
     B, T = 11, 1530                                              # T' = 381: 11 x 381 = 4191 encoder rows
     try:
         for fuse in (False, True):
-            ops.LN_BWD_FUSE = fuse
+            ops.LN_BWD_FUSE = ops.LN_FWD_FUSE = fuse
             torch.manual_seed(5)
             ops.manual_seed(17)                                  # the same dropout streams in both runs
             m = ASRModel(80, 40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=256, attention_heads=4,
@@ -739,21 +740,24 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
             e = TrainEngine(m, lr=1e-3, grad_clip=5.0, static_shapes=True)
             try:
                 b = batch_of(B=B, T=T, L=9, seed=4)
-                n0 = ops.LN_BWD_FUSED_LAUNCHES
+                n0, f0 = ops.LN_BWD_FUSED_LAUNCHES, ops.LN_FWD_FUSED_LAUNCHES
                 e.arena.zero_grad()
                 loss, _ = e._fwd_bwd(b)
                 torch.cuda.synchronize()
                 assert not ops._PENDING_LN
+                assert not ops._PENDING_LNF
                 launches.append(ops.LN_BWD_FUSED_LAUNCHES - n0)
+                fwd_launches.append(ops.LN_FWD_FUSED_LAUNCHES - f0)
                 grads.append(e.arena.grad.detach().clone())
                 losses.append(float(loss))
             finally:
                 e.arena.deactivate()
                 ops.set_seed_device_counter(None)
     finally:
-        hip.GEMM_PRECISION, ops.LN_BWD_FUSE = old
+        hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE = old
+    assert fwd_launches == [0, 7]                                # the first layer's macaron norm + per layer: norm_mha, norm_conv, norm_ff
     assert launches == [0, 8]                                    # two encoder layers x (attention, conv module, both feed-forwards)
-    assert losses[0] == losses[1]                                # the forward pass is untouched
+    assert abs(losses[0] - losses[1]) <= 2e-6 * abs(losses[0])    # (forward: the same norms computed in other kernels)
     scale = float(grads[0].abs().max())
     assert float((grads[1] - grads[0]).abs().max()) <= 2e-5 * scale
     assert float((grads[1] - grads[0]).norm()) <= 1e-5 * float(grads[0].norm())

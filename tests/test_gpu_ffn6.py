@@ -334,3 +334,41 @@ def test_input_gradient_with_a_pair_of_layernorm_backwards_as_its_prologue():
     torch.testing.assert_close(dx1, dx0, rtol=1e-5, atol=2e-5)
     for a, b in zip(outs[1], outs[0]):
         torch.testing.assert_close(a, b, rtol=2e-5, atol=3e-4)
+
+
+def test_forward_with_the_layernorm_as_its_prologue():
+    """oe_ffn_fwd with oe_ffn_args.lnf set: the pre-norm in front of the feed-forward (encoder_layer.py:79-83, 103-106) computed on the
+    way into the kernel - y_ln, the statistics and every output as oe_layernorm_fwd + oe_ffn_fwd give them (one unit in the last place)."""
+    torch.manual_seed(70)
+    rows, d, ff, act = 4133, 256, 1024, 2
+    x = torch.randn(rows, d, device=DEV) * 1.4 + 0.2
+    gamma, beta = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    w1, b1 = torch.randn(ff, d, device=DEV) / math.sqrt(d), torch.randn(ff, device=DEV) * 0.1
+    w2, b2 = torch.randn(d, ff, device=DEV) / math.sqrt(ff), torch.randn(d, device=DEV) * 0.1
+    L = hip.lib()
+    nb = L.oe_ffn_packed_bytes(d, ff, 6)
+    w1p, w2p = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hip.call("oe_ffn_pack_weights", w1, w2, d, ff, 6, w1p, w2p)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    kw = dict(drop_in=0.1, seed_in=11, drop_out=0.1, seed_out=12, seed_dev=ctr, residual=x, ldr=d, beta=0.5, precision=6)
+    yl0, st0 = torch.empty_like(x), torch.empty(rows, 2, device=DEV)
+    hip.call("oe_layernorm_fwd", x, gamma, beta, 1e-5, rows, d, None, 0, yl0, st0)
+    pre0, a0, y0 = torch.empty(rows, ff, device=DEV), torch.empty(rows, ff, device=DEV), torch.empty(rows, d, device=DEV)
+    hip.ffn_fwd(yl0, w1p, b1, w2p, b2, rows, d, ff, act, pre_out=pre0, act_out=a0, y=y0, **kw)
+    nan = float("nan")
+    yl1, st1 = torch.full_like(x, nan), torch.full((rows, 2), nan, device=DEV)
+    pre1, a1, y1 = torch.full((rows, ff), nan, device=DEV), torch.full((rows, ff), nan, device=DEV), torch.full((rows, d), nan, device=DEV)
+    lnf = dict(x=x, gamma=gamma, beta=beta, eps=1e-5, y=yl1, stats=st1, rowmask=None)
+    hip.ffn_fwd(yl1, w1p, b1, w2p, b2, rows, d, ff, act, pre_out=pre1, act_out=a1, y=y1, lnf=lnf, **kw)
+    sync()
+    torch.testing.assert_close(yl1, yl0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(st1, st0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(pre1, pre0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(a1, a0, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(y1, y0, rtol=1e-5, atol=2e-5)
+    L.oe_ffn6_config(1)                                                  # another block shape: refused, not run without the norm
+    try:
+        with pytest.raises(RuntimeError, match="prologue"):
+            hip.ffn_fwd(yl1, w1p, b1, w2p, b2, rows, d, ff, act, pre_out=pre1, act_out=a1, y=y1, lnf=lnf, **kw)
+    finally:
+        L.oe_ffn6_config(0)

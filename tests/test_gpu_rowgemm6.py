@@ -380,3 +380,37 @@ def test_a_parked_layernorm_backward_is_resolved_on_every_other_path():
         assert ops.resolve_pending_ln() == 1 and pend["done"] and not ops._PENDING_LN
         torch.cuda.synchronize()
         assert torch.equal(pend["dx"], want)
+
+
+@pytest.mark.parametrize("rows,n,with_mask", [(7936, 768, False), (4099, 512, True)])
+def test_ln_forward_prologue_equals_the_two_launches(rows, n, with_mask):
+    """oe_layernorm_fwd followed by oe_rowgemm6 against ONE oe_rowgemm6 with the lnf arguments (the pre-norm in front of the fused
+    q / k / v projection and of pointwise_conv1): y, the statistics and the product to one unit in the last place."""
+    torch.manual_seed(95)
+    d = 256
+    x = torch.randn(rows, d, device=DEV) * 1.7 + 0.3
+    gamma, beta = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    mask = (torch.rand(rows, device=DEV) > 0.1).to(torch.uint8) if with_mask else None
+    w = torch.nn.Parameter(torch.randn(n, d, device=DEV) / 16)
+    b = torch.randn(n, device=DEV) * 0.1
+    y0, st0 = torch.empty_like(x), torch.empty(rows, 2, device=DEV)
+    hip.call("oe_layernorm_fwd", x, gamma, beta, 1e-5, rows, d, mask, 0, y0, st0)
+    with torch.no_grad():
+        out0 = ops.gemm_nt(y0, w, b)
+        y1, st1 = torch.full_like(x, float("nan")), torch.full((rows, 2), float("nan"), device=DEV)
+        pend = dict(x=x, gamma=gamma, beta=beta, eps=1e-5, rows=rows, d=d, rowmask=mask, y=y1, stats=st1, done=False)
+        ops._PENDING_LNF[y1.data_ptr()] = pend
+        n0 = ops.LN_FWD_FUSED_LAUNCHES
+        out1 = ops.gemm_nt(y1, w, b)
+        assert ops.LN_FWD_FUSED_LAUNCHES == n0 + 1 and pend["done"] and not ops._PENDING_LNF
+        # any other op of the module that receives a parked tensor launches the LayerNorm on its own first
+        y2, st2 = torch.full_like(x, float("nan")), torch.full((rows, 2), float("nan"), device=DEV)
+        ops._PENDING_LNF[y2.data_ptr()] = dict(x=x, gamma=gamma, beta=beta, eps=1e-5, rows=rows, d=d, rowmask=mask, y=y2, stats=st2, done=False)
+        z = ops.add(y2, y2) if hasattr(ops, "add") else None
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y1, y0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(st1, st0, rtol=2e-6, atol=1e-6)
+    torch.testing.assert_close(out1, out0, rtol=1e-5, atol=1e-5)
+    assert not ops._PENDING_LNF and torch.equal(y2, y0) and torch.equal(st2, st0)
+    if z is not None:
+        assert torch.equal(z, y0 + y0)
