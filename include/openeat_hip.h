@@ -183,6 +183,16 @@ typedef struct oe_lnf_prologue {
     float* y; float* stats; const unsigned char* rowmask;
 } oe_lnf_prologue;
 
+/* LayerNorm-backward EPILOGUE of oe_rowgemm6 (row-block form, 256 <- 256): dx != NULL sends the product's rows dz through the backward of
+ * z = act(LayerNorm(x; gamma, beta)) (act in OE_ACT_NONE / RELU / SWISH) with the forward's statistics - the conv module's norm +
+ * activation between the depthwise convolution and pointwise_conv2 (convolution.py:107-111), whose input gradient the launch computes:
+ * dx (rows, 256) receives the gradient of x, ws the parameter-gradient partials (oe_layernorm_bwd_workspace_floats' layout); y is not
+ * written and no other epilogue feature applies. */
+typedef struct oe_ln_epilogue {
+    const float* x; const float* stats; const float* gamma; const float* beta; int act;
+    float* dx; float* ws;
+} oe_ln_epilogue;
+
 typedef struct oe_ffn_args {
     const float* x; long ldx;                  /* (rows, d) */
     const void* w1p; const float* b1;          /* packed W1, bias (ff) or NULL */
@@ -241,6 +251,7 @@ typedef struct oe_rowgemm_args {
     int act; float* preact_out; const float* actgrad_in; long ld_aux;
     oe_ln_prologue ln;                          /* row-block form at k = 256: ln.dy != NULL makes the input rows (x is then ignored) */
     oe_lnf_prologue lnf;                        /* ... or lnf.x != NULL: a LayerNorm forward makes them */
+    oe_ln_epilogue lne;                         /* lne.dx != NULL: the product leaves through a LayerNorm backward */
 } oe_rowgemm_args;
 int oe_rowgemm6_supported(int k, int n);
 /* Which kernel oe_rowgemm6 runs: 1 = the row-block form above (k in {256, 512}, n % 128 == 0: one 32-row block streams the whole packed

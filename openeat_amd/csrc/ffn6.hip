@@ -701,6 +701,9 @@ struct Row6Params {
     int k, act; float* preact_out; const float* actgrad_in; long ld_aux;     // (tile form only)
     LnPro ln;                                    // LayerNorm-backward prologue (row-block form, LNP = 1): the rows of x are MADE
     LnfPro lnf;                                  // LayerNorm-forward prologue (LNP = 2)
+    // LayerNorm-backward EPILOGUE (LNE): the product's rows go through the backward of a LayerNorm (+ activation) whose output the
+    // forward GEMM consumed; le_dx receives the result instead of y
+    const float* le_x; const float* le_stats; const float* le_gamma; const float* le_beta; int le_act; float* le_dx; float* le_ws;
 };
 
 // LNP (LayerNorm-backward prologue): the GEMM's input rows are the gradient a pre-norm residual block's backward STARTS from,
@@ -711,7 +714,13 @@ struct Row6Params {
 // the rows reach LDS: dx and g are written (the residual stream and the weight gradient read them), g is split into the planes, and
 // the per-block partial sums of the LayerNorm's parameter gradients go to ln_ws in layernorm_bwd_kernel's layout (one slot per 16
 // rows: rows 0-15 and 16-31 of the block) for the same reduction launch.
-template <int D, int LNP = 0>
+// LNE (LayerNorm-backward epilogue, n = 256): the product is the gradient of z = act(LN(yc)) - the conv module's norm + activation
+// between the depthwise convolution and pointwise_conv2 (convolution.py:107-111), whose input gradient this launch computes - and
+// what the next kernel wants is the gradient of yc: the block owns its 32 rows whole (eight waves x 32 columns), so the LayerNorm
+// backward runs on the accumulators' way out: t = dz act'(xh gamma + beta), g = t gamma, row sums of g and g xh across the eight
+// waves through LDS (one barrier), dx = rstd (g - c1 - xh c2); the parameter-gradient partials go to le_ws in layernorm_bwd_kernel's
+// layout.  dz itself is never written.
+template <int D, int LNP = 0, bool LNE = false>
 __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     constexpr int BM = 32, NG = 2;
     constexpr int KS = D / 16;
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     constexpr int X_BYTES = 3 * BM * XP * 2;
     constexpr int PATCH = 32 * 36 * 4;
     constexpr int PIECE = 3 * 1024;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[X_BYTES + 8 * PATCH];
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[X_BYTES + 8 * PATCH + (LNE ? 8 * 32 * 2 * 4 : 0)];
     unsigned char* xs = lds;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -835,6 +844,81 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
         for (int r = 0; r < 16; ++r) patch[lq * 36 + f6_acc_row(r, lk)] = hv[r];
         f6_wave_sync();
         F6_STAMP(4 + 3 * (ci / NG));
+        if constexpr (LNE) {
+            static_assert(D == 256, "row sums over eight waves x 32 columns");
+            // Every wave of the block is past its MFMA loop before any of them re-reads its patch.  Without this barrier the row sums of
+            // rows 6 and 7 of ONE wave came out wrong in ~10 % of the blocks, different ones from run to run (the plain store epilogue
+            // above reads the same patch the same way and never showed it; waiting for all outstanding global loads or rewriting the
+            // patch did not help, the barrier does: tools/probes/dbg_lne.py, profiles/r04_experiments.md) - cause not understood.
+            __syncthreads();
+            float (*rowsum)[32][2] = reinterpret_cast<float (*)[32][2]>(lds + X_BYTES + 8 * PATCH);     // [8 waves][32 rows][2]
+            const int c4 = (lane & 7) * 4, col = ft * 32 + c4;
+            const float4 gm = *reinterpret_cast<const float4*>(p.le_gamma + col), bt = *reinterpret_cast<const float4*>(p.le_beta + col);
+            float4 tt[4], xh[4], gg[4];
+            float rs[4];
+            float4 dgs[2], dbs[2];
+            dgs[0] = dgs[1] = dbs[0] = dbs[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const long gr = m0 + row;
+                const bool valid = gr < p.rows;
+                const long rc = min(gr, (long)p.rows - 1);
+                const float4 v = *reinterpret_cast<const float4*>(&patch[row * 36 + c4]);
+                const float4 xv = *reinterpret_cast<const float4*>(p.le_x + rc * D + col);
+                const float mean = p.le_stats[rc * 2], rstd = p.le_stats[rc * 2 + 1];
+                rs[ps] = rstd;
+                xh[ps] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+                float4 t = v;
+                if (p.le_act) {
+                    t.x *= f6_act_bwd(p.le_act, xh[ps].x * gm.x + bt.x); t.y *= f6_act_bwd(p.le_act, xh[ps].y * gm.y + bt.y);
+                    t.z *= f6_act_bwd(p.le_act, xh[ps].z * gm.z + bt.z); t.w *= f6_act_bwd(p.le_act, xh[ps].w * gm.w + bt.w);
+                }
+                if (!valid) { t = make_float4(0.f, 0.f, 0.f, 0.f); xh[ps] = t; }
+                tt[ps] = t;
+                gg[ps] = make_float4(t.x * gm.x, t.y * gm.y, t.z * gm.z, t.w * gm.w);
+                float s1 = gg[ps].x + gg[ps].y + gg[ps].z + gg[ps].w;
+                float s2 = gg[ps].x * xh[ps].x + gg[ps].y * xh[ps].y + gg[ps].z * xh[ps].z + gg[ps].w * xh[ps].w;
+                s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+                s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+                s1 += __shfl_xor(s1, 4, 64); s2 += __shfl_xor(s2, 4, 64);
+                if ((lane & 7) == 0) { rowsum[wv][row][0] = s1; rowsum[wv][row][1] = s2; }
+                float4& dgq = dgs[ps >> 1];
+                float4& dbq = dbs[ps >> 1];
+                dgq.x += t.x * xh[ps].x; dgq.y += t.y * xh[ps].y; dgq.z += t.z * xh[ps].z; dgq.w += t.w * xh[ps].w;
+                dbq.x += t.x; dbq.y += t.y; dbq.z += t.z; dbq.w += t.w;
+            }
+            __syncthreads();                                         // (n = 256: every wave runs this body exactly once)
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const int row = ps * 8 + (lane >> 3);
+                const long gr = m0 + row;
+                float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { c1 += rowsum[w][row][0]; c2 += rowsum[w][row][1]; }
+                c1 /= D; c2 /= D;
+                const float4 o = make_float4(rs[ps] * (gg[ps].x - c1 - xh[ps].x * c2), rs[ps] * (gg[ps].y - c1 - xh[ps].y * c2),
+                                             rs[ps] * (gg[ps].z - c1 - xh[ps].z * c2), rs[ps] * (gg[ps].w - c1 - xh[ps].w * c2));
+                if (gr < p.rows) *reinterpret_cast<float4*>(p.le_dx + gr * D + col) = o;
+            }
+            // parameter-gradient partials: this wave's 32 columns over the block's two 16-row slots
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                float4 a = dgs[sl], b = dbs[sl];
+#pragma unroll
+                for (int o = 8; o < 64; o <<= 1) {
+                    a.x += __shfl_xor(a.x, o, 64); a.y += __shfl_xor(a.y, o, 64); a.z += __shfl_xor(a.z, o, 64); a.w += __shfl_xor(a.w, o, 64);
+                    b.x += __shfl_xor(b.x, o, 64); b.y += __shfl_xor(b.y, o, 64); b.z += __shfl_xor(b.z, o, 64); b.w += __shfl_xor(b.w, o, 64);
+                }
+                const long slot = 2 * (long)blockIdx.x + sl;
+                if (lane < 8 && slot * 16 < p.rows) {
+                    *reinterpret_cast<float4*>(p.le_ws + slot * 2 * D + col) = a;
+                    *reinterpret_cast<float4*>(p.le_ws + slot * 2 * D + D + col) = b;
+                }
+            }
+            F6_STAMP(5 + 3 * (ci / NG));
+            continue;
+        }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps) {
             const int row = ps * 8 + (lane >> 3), c4 = (lane & 7) * 4;
@@ -1149,7 +1233,7 @@ extern "C" int oe_rowgemm6_pack_table(const void* table, int n, long max_pieces,
 }
 
 extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
-    OE_REQUIRE(a && (a->x || a->ln.dy || a->lnf.x) && a->wp && a->y, "oe_rowgemm6: null pointer");
+    OE_REQUIRE(a && (a->x || a->ln.dy || a->lnf.x) && a->wp && (a->y || a->lne.dx), "oe_rowgemm6: null pointer");
     const int form = a->rows > 0 ? oe_rowgemm6_form(a->rows, a->k, a->n) : 0;
     OE_REQUIRE(form != 0, "oe_rowgemm6: unsupported rows=%d k=%d n=%d", a->rows, a->k, a->n);
     const bool has_act = a->act != OE_ACT_NONE || a->preact_out || a->actgrad_in;
@@ -1177,6 +1261,16 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     p.k = a->k; p.act = a->act; p.preact_out = a->preact_out; p.actgrad_in = a->actgrad_in; p.ld_aux = a->ld_aux;
     p.ln = ln_pro_of(a->ln);
     p.lnf = lnf_pro_of(a->lnf);
+    if (a->lne.dx) {
+        OE_REQUIRE(form == 1 && a->k == 256 && a->n == 256 && !a->lnf.x, "oe_rowgemm6: the LayerNorm-backward epilogue exists for 256 <- 256 in the row-block form only");
+        OE_REQUIRE(a->lne.x && a->lne.stats && a->lne.gamma && a->lne.beta && a->lne.ws, "oe_rowgemm6: LayerNorm epilogue: null pointer");
+        OE_REQUIRE(!a->bias && a->drop_p == 0.f && !a->rowmask && !a->residual && a->beta == 1.f, "oe_rowgemm6: LayerNorm epilogue: no other epilogue feature applies");
+        OE_REQUIRE(a->lne.act == OE_ACT_NONE || a->lne.act == OE_ACT_RELU || a->lne.act == OE_ACT_SWISH, "oe_rowgemm6: LayerNorm epilogue: activation %d", a->lne.act);
+        OE_REQUIRE(((((uintptr_t)a->lne.x) | ((uintptr_t)a->lne.gamma) | ((uintptr_t)a->lne.beta) | ((uintptr_t)a->lne.dx) | ((uintptr_t)a->lne.ws)) & 15) == 0,
+                   "oe_rowgemm6: LayerNorm epilogue: 16-byte alignment required");
+        p.le_x = a->lne.x; p.le_stats = a->lne.stats; p.le_gamma = a->lne.gamma; p.le_beta = a->lne.beta; p.le_act = a->lne.act;
+        p.le_dx = a->lne.dx; p.le_ws = a->lne.ws;
+    }
     if (form == 2) {
         const dim3 tgrid(oe_cdiv(a->rows, 32), a->n / 32), tblock(512);
         hipStream_t st = (hipStream_t)stream;
@@ -1191,6 +1285,8 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
     }
     const dim3 grid(oe_cdiv(a->rows, 32)), block(512);
     if (a->k > 512) hipLaunchKernelGGL(rowgemm6p_kernel, grid, block, 0, (hipStream_t)stream, p);
+    else if (a->lne.dx && a->ln.dy) hipLaunchKernelGGL((rowgemm6_kernel<256, 1, true>), grid, block, 0, (hipStream_t)stream, p);
+    else if (a->lne.dx) hipLaunchKernelGGL((rowgemm6_kernel<256, 0, true>), grid, block, 0, (hipStream_t)stream, p);
     else if (a->ln.dy) hipLaunchKernelGGL((rowgemm6_kernel<256, 1>), grid, block, 0, (hipStream_t)stream, p);
     else if (a->lnf.x) hipLaunchKernelGGL((rowgemm6_kernel<256, 2>), grid, block, 0, (hipStream_t)stream, p);
     else if (a->k == 512) hipLaunchKernelGGL((rowgemm6_kernel<512>), grid, block, 0, (hipStream_t)stream, p);

@@ -108,6 +108,11 @@ class LnfPrologue(C.Structure):
         self.y, self.stats, self.rowmask = dp(q["y"]), dp(q["stats"]), dp(q.get("rowmask"))
 
 
+class LnEpilogue(C.Structure):
+    """oe_ln_epilogue (include/openeat_hip.h)."""
+    _fields_ = [("x", c_fp), ("stats", c_fp), ("gamma", c_fp), ("beta", c_fp), ("act", C.c_int), ("dx", c_fp), ("ws", c_fp)]
+
+
 class FfnArgs(C.Structure):
     _fields_ = [
         ("x", c_fp), ("ldx", C.c_long),
@@ -133,7 +138,7 @@ class RowGemmArgs(C.Structure):
         ("residual", c_fp), ("ldr", C.c_long), ("beta", C.c_float),
         ("y", c_fp), ("ldy", C.c_long),
         ("act", C.c_int), ("preact_out", c_fp), ("actgrad_in", c_fp), ("ld_aux", C.c_long),
-        ("ln", LnPrologue), ("lnf", LnfPrologue),
+        ("ln", LnPrologue), ("lnf", LnfPrologue), ("lne", LnEpilogue),
     ]
 
 
@@ -438,7 +443,7 @@ def ffn_bwd(dy2, w2tp, w1tp, rows, d, ff, act, *, drop_in=0.0, seed_in=0, seed_d
 
 
 def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=None, rowmask=None, residual=None, ldr=0, beta=1.0,
-             act=0, preact_out=None, actgrad_in=None, ld_aux=0, ln=None, lnf=None):
+             act=0, preact_out=None, actgrad_in=None, ld_aux=0, ln=None, lnf=None, lne=None):
     """y = residual + beta * rowmask * dropout(act(x @ Wg^T + bias)) on the row-block / tile kernels (oe_rowgemm6; wp = packed Wg)."""
     a = RowGemmArgs()
     dp = lambda t: None if t is None else t.data_ptr()
@@ -452,6 +457,9 @@ def rowgemm6(x, wp, y, rows, k, n, *, bias=None, drop_p=0.0, seed=0, seed_dev=No
         a.ln.fill(ln)
     if lnf is not None:       # LayerNorm-forward prologue (LnfPrologue.fill)
         a.lnf.fill(lnf)
+    if lne is not None:       # LayerNorm-backward epilogue: dict(x, stats, gamma, beta, act, dx, ws)
+        a.lne.x, a.lne.stats, a.lne.gamma, a.lne.beta = dp(lne["x"]), dp(lne["stats"]), dp(lne["gamma"]), dp(lne["beta"])
+        a.lne.act, a.lne.dx, a.lne.ws = int(lne["act"]), dp(lne["dx"]), dp(lne["ws"])
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -258,12 +258,12 @@ def _row_packed(w, transposed):
     return ent["buf"]
 
 
-def _rowgemm_try(x, w, transposed, bias, out, epi, ln_pending=None, lnf_pending=None):
+def _rowgemm_try(x, w, transposed, bias, out, epi, ln_pending=None, lnf_pending=None, ln_epi=None):
     """x (M, k) @ Wg^T on the row-block / tile kernels if the problem and its epilogue qualify; returns out or None.
     ln_pending: x is the `g` of a parked LayerNorm backward (_PENDING_LN) - launched as the kernel's prologue when this is the
     k = 256 row-block kernel, and on its own BEFORE anything reads x in every other case (also when None is returned)."""
     try:
-        return _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending)
+        return _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending, ln_epi)
     finally:
         if ln_pending is not None:
             _resolve_ln(ln_pending)              # (no-op when the fused launch has happened)
@@ -271,7 +271,7 @@ def _rowgemm_try(x, w, transposed, bias, out, epi, ln_pending=None, lnf_pending=
             _resolve_lnf(lnf_pending)
 
 
-def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending=None):
+def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending=None, ln_epi=None):
     if not ROWGEMM or hip.GEMM_PRECISION != 6 or not x.is_cuda:
         return None
     k = x.shape[1]
@@ -326,10 +326,16 @@ def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending=
             lnf = dict(x=q["x"], gamma=q["gamma"], beta=q["beta"], eps=q["eps"], y=q["y"], stats=q["stats"], rowmask=q["rowmask"])
         else:
             _resolve_lnf(q)                     # this launch reads x: the LayerNorm first, on its own
+    lne = None
+    if (ln_epi is not None and form == 1 and k == 256 and n == 256 and lnf is None and bias is None and not epi and
+            M == ln_epi["dx"].shape[0] and ln_epi["dx"].is_contiguous() and ln_epi["x"].is_contiguous()):
+        lne = ln_epi                            # the product leaves through a LayerNorm backward: `out` is not written, ln_epi["dx"] is
     hip.rowgemm6(x, wp, out, M, k, n, bias=bias, drop_p=epi.get("drop_p", 0.0) or 0.0, seed=epi.get("seed", 0) or 0,
                  seed_dev=(_seed_dev if ln is not None else epi.get("seed_dev")),
                  rowmask=epi.get("rowmask"), residual=res, ldr=epi.get("ldr", 0) or 0, beta=epi.get("beta", 1.0),
-                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux, ln=ln, lnf=lnf)
+                 act=act, preact_out=pre_out, actgrad_in=aux_in, ld_aux=ld_aux, ln=ln, lnf=lnf, lne=lne)
+    if lne is not None:
+        ln_epi["done"] = True
     if ln is not None:
         ln_pending["done"] = True
         LN_BWD_FUSED_LAUNCHES += 1
@@ -360,14 +366,14 @@ def gemm_nt(x, w, bias=None, out=None, out_planes=False, **epi):
     return out
 
 
-def gemm_nn(dy, w, out=None, out_planes=False, **epi):
+def gemm_nn(dy, w, out=None, out_planes=False, ln_epi=None, **epi):
     """dx[M,K] = dy[M,N] @ w[N,K].  out_planes: True = with the general pre-split policy, "always" = whenever pre-split
     operands exist at all (the conv front end's policy)."""
     M, N = dy.shape
     K = w.shape[1]
     pend = _PENDING_LN.pop(dy.data_ptr(), None) if _PENDING_LN else None         # dy is the g of a parked LayerNorm backward
     if not (out_planes and (_planes.available() if out_planes == "always" else _planes.split_activations())):
-        y = _rowgemm_try(dy, w, True, None, out, epi, ln_pending=pend)             # (launches or resolves it on every path)
+        y = _rowgemm_try(dy, w, True, None, out, epi, ln_pending=pend, ln_epi=ln_epi)      # (launches or resolves it on every path)
         if y is not None:
             return y
     elif pend is not None:
@@ -859,6 +865,8 @@ def _tag_out_drop(out, out_scale, p_out, s_out, rowmask=None, ln_fuse=False):
 # checks that none is left behind.  24 launches per step at config 2 (10.8 us + a dependent-launch gap each).
 LN_BWD_FUSE = os.environ.get("OE_LN_BWD_FUSE", "1") == "1"
 LN_BWD_FUSED_LAUNCHES = 0       # (tests)
+LN_EPI_FUSE = os.environ.get("OE_LN_EPI_FUSE", "1") == "1"      # the conv module's norm backward as an epilogue (ConvModuleFn.backward)
+LN_EPI_FUSED_LAUNCHES = 0
 _PENDING_LN = {}
 
 
@@ -1807,11 +1815,29 @@ class ConvModuleFn(torch.autograd.Function):
         dy2 = dy.view(-1, d)
         w1m, w2m = w1.view(2 * d, d), w2.view(d, d)
         gq = dy2 if (p_out == 0 and rowmask is None) else _out_drop_grad(dy2, 1.0, p_out, s_out, rowmask)
-        dz = gemm_nn(gq, w2m)                    # FIRST: gq may be a parked LayerNorm backward that this launch makes (_PENDING_LN)
-        dw2, db2 = wgrad_bias(w2, b2, gq, z)
         dyc = torch.empty_like(yc)
         (dg, rg), (dbeta, rbeta) = grad_sink(g), grad_sink(b)
-        _ln_bwd(dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta, rg is None and rbeta is None)
+        to_arena = rg is None and rbeta is None
+        # the norm + activation behind the depthwise convolution: its backward as the EPILOGUE of pointwise_conv2's input gradient
+        # (oe_rowgemm6's lne arguments: the block owns whole rows), when that launch is the 256 <- 256 row-block kernel
+        epi_ln = None
+        if (LN_EPI_FUSE and ROWGEMM and hip.GEMM_PRECISION == 6 and d == 256 and B * T >= ROWGEMM_MIN_ROWS and act in GEMM_FUSED_ACTS and
+                not _planes.active() and to_arena):
+            epi_ln = dict(x=yc, stats=stats, gamma=g, beta=b, act=act, dx=dyc, ws=_ln_ws(yc, B * T, d), done=False)
+        dz = gemm_nn(gq, w2m, ln_epi=epi_ln)     # FIRST: gq may be a parked LayerNorm backward that this launch makes (_PENDING_LN)
+        dw2, db2 = wgrad_bias(w2, b2, gq, z)
+        if epi_ln is not None and epi_ln["done"]:
+            global LN_EPI_FUSED_LAUNCHES
+            LN_EPI_FUSED_LAUNCHES += 1
+            t = LN_TABLE
+            if t is None:
+                hip.call("oe_layernorm_param_reduce", epi_ln["ws"], B * T, d, dg, dbeta)
+            else:
+                t["entries"].append((epi_ln["ws"].data_ptr(), B * T, d, dg.data_ptr(), dbeta.data_ptr()))
+                t["keep"].append(epi_ln["ws"])
+                t["max_rows"], t["max_d"] = max(t["max_rows"], B * T), max(t["max_d"], d)
+        else:
+            _ln_bwd(dz, yc, g, b, act, stats, B * T, d, None, None, dyc, dg, dbeta, to_arena)
         da = torch.empty_like(a)
         (dwd, rwd), (dbd, rbd) = grad_sink(wd), grad_sink(bd)
         dgpad = torch.zeros(d, device=dy.device) if causal else None

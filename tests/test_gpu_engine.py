@@ -726,13 +726,13 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
     dropout masks with the switch off and on: the gradient arena must agree to rounding (the two kernels contract a*b+c differently:
     one unit in the last place per element), the fused launches are counted, nothing stays parked."""
     from openeat_amd import hip
-    old = (hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE)
+    old = (hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE, ops.LN_EPI_FUSE)
     hip.GEMM_PRECISION = 6
-    grads, losses, launches, fwd_launches = [], [], [], []
+    grads, losses, launches, fwd_launches, epi_launches = [], [], [], [], []
     B, T = 11, 1530                                              # T' = 381: 11 x 381 = 4191 encoder rows
     try:
         for fuse in (False, True):
-            ops.LN_BWD_FUSE = ops.LN_FWD_FUSE = fuse
+            ops.LN_BWD_FUSE = ops.LN_FWD_FUSE = ops.LN_EPI_FUSE = fuse
             torch.manual_seed(5)
             ops.manual_seed(17)                                  # the same dropout streams in both runs
             m = ASRModel(80, 40, encoder_num_blocks=2, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=256, attention_heads=4,
@@ -740,7 +740,7 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
             e = TrainEngine(m, lr=1e-3, grad_clip=5.0, static_shapes=True)
             try:
                 b = batch_of(B=B, T=T, L=9, seed=4)
-                n0, f0 = ops.LN_BWD_FUSED_LAUNCHES, ops.LN_FWD_FUSED_LAUNCHES
+                n0, f0, e0 = ops.LN_BWD_FUSED_LAUNCHES, ops.LN_FWD_FUSED_LAUNCHES, ops.LN_EPI_FUSED_LAUNCHES
                 e.arena.zero_grad()
                 loss, _ = e._fwd_bwd(b)
                 torch.cuda.synchronize()
@@ -748,14 +748,16 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
                 assert not ops._PENDING_LNF
                 launches.append(ops.LN_BWD_FUSED_LAUNCHES - n0)
                 fwd_launches.append(ops.LN_FWD_FUSED_LAUNCHES - f0)
+                epi_launches.append(ops.LN_EPI_FUSED_LAUNCHES - e0)
                 grads.append(e.arena.grad.detach().clone())
                 losses.append(float(loss))
             finally:
                 e.arena.deactivate()
                 ops.set_seed_device_counter(None)
     finally:
-        hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE = old
+        hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE, ops.LN_EPI_FUSE = old
     assert fwd_launches == [0, 7]                                # the first layer's macaron norm + per layer: norm_mha, norm_conv, norm_ff
+    assert epi_launches == [0, 2]                                # the conv module's own norm, behind pointwise_conv2's input gradient
     assert launches == [0, 8]                                    # two encoder layers x (attention, conv module, both feed-forwards)
     assert abs(losses[0] - losses[1]) <= 2e-6 * abs(losses[0])    # (forward: the same norms computed in other kernels)
     scale = float(grads[0].abs().max())

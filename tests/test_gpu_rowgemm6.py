@@ -414,3 +414,61 @@ def test_ln_forward_prologue_equals_the_two_launches(rows, n, with_mask):
     assert not ops._PENDING_LNF and torch.equal(y2, y0) and torch.equal(st2, st0)
     if z is not None:
         assert torch.equal(z, y0 + y0)
+
+
+@pytest.mark.parametrize("rows,act", [(7936, 2), (4107, 1), (5000, 0)])
+def test_ln_backward_epilogue_equals_the_two_launches(rows, act):
+    """oe_rowgemm6 with the lne arguments (the conv module's norm + activation between the depthwise convolution and pointwise_conv2,
+    convolution.py:107-111): dz = g W2 followed by oe_layernorm_bwd_dx against ONE launch whose product leaves through that backward."""
+    torch.manual_seed(97)
+    d = 256
+    gq = torch.randn(rows, d, device=DEV)
+    w = torch.nn.Parameter(torch.randn(d, d, device=DEV) / 16)
+    yc = torch.randn(rows, d, device=DEV) * 1.5 + 0.4
+    gamma, beta = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    stats = torch.stack([yc.mean(1), 1.0 / torch.sqrt(yc.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    nws = hip.lib().oe_layernorm_bwd_workspace_floats(rows, d)
+    with torch.no_grad():
+        dz = ops.gemm_nn(gq, w)
+        dx0, ws0 = torch.empty_like(yc), torch.zeros(nws, device=DEV)
+        hip.call("oe_layernorm_bwd_dx", dz, yc, gamma, beta, act, stats, rows, d, None, None, dx0, ws0)
+        dx1, ws1 = torch.full_like(yc, float("nan")), torch.zeros(nws, device=DEV)
+        epi = dict(x=yc, stats=stats, gamma=gamma, beta=beta, act=act, dx=dx1, ws=ws1, done=False)
+        ops.gemm_nn(gq, w, ln_epi=epi)
+        assert epi["done"]
+        epi2 = dict(epi, dx=torch.empty_like(yc), done=False)
+        ops.gemm_nn(gq, torch.nn.Parameter(torch.randn(d, 320, device=DEV)), ln_epi=epi2)      # not 256 <- 256: plain product, nothing fused
+        assert not epi2["done"]
+    r = [torch.zeros(d, device=DEV) for _ in range(4)]
+    hip.call("oe_layernorm_param_reduce", ws0, rows, d, r[0], r[1])
+    hip.call("oe_layernorm_param_reduce", ws1, rows, d, r[2], r[3])
+    torch.cuda.synchronize()
+    scale = float(dx0.abs().max())
+    assert float((dx1 - dx0).abs().max()) <= 3e-6 * scale + 1e-6
+    torch.testing.assert_close(r[2], r[0], rtol=3e-5, atol=3e-4)
+    torch.testing.assert_close(r[3], r[1], rtol=3e-5, atol=3e-4)
+
+
+def test_ln_backward_epilogue_is_stable_over_many_launches():
+    """Regression: before a block-wide barrier was put between the waves' matrix loops and the re-read of their patches, the row sums
+    of two rows of one wave came out wrong in ~10 % of the blocks, other blocks at every launch (tools/probes/dbg_lne.py)."""
+    torch.manual_seed(98)
+    rows, d = 7936, 256
+    gq = torch.randn(rows, d, device=DEV)
+    w = torch.nn.Parameter(torch.randn(d, d, device=DEV) / 16)
+    yc = torch.randn(rows, d, device=DEV) * 1.5 + 0.4
+    gamma, beta = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    stats = torch.stack([yc.mean(1), 1.0 / torch.sqrt(yc.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+    nws = hip.lib().oe_layernorm_bwd_workspace_floats(rows, d)
+    with torch.no_grad():
+        dz = ops.gemm_nn(gq, w)
+        dx0 = torch.empty_like(yc)
+        hip.call("oe_layernorm_bwd_dx", dz, yc, gamma, beta, 2, stats, rows, d, None, None, dx0, torch.zeros(nws, device=DEV))
+        worst = 0.0
+        for _ in range(60):
+            dx1 = torch.full_like(yc, float("nan"))
+            epi = dict(x=yc, stats=stats, gamma=gamma, beta=beta, act=2, dx=dx1, ws=torch.zeros(nws, device=DEV), done=False)
+            ops.gemm_nn(gq, w, ln_epi=epi)
+            assert epi["done"]
+            worst = max(worst, float((dx1 - dx0).abs().max()))
+    assert worst <= 3e-6 * float(dx0.abs().max()) + 1e-6, worst
