@@ -70,6 +70,7 @@ class TrainEngine:
                 if self._capturing or self._hooks_off:   # a HIP-graph capture holds no collectives: all of it goes after the graph
                     return
                 ops.join_side_stream()          # weight-gradient GEMMs of the finished units run on the side stream
+                ops.ln_table_flush()            # ... and their LayerNorms' parameter gradients are still per-block partials (eager table)
                 self.reducer.reduce_tail(us[unit])
             return cb
 
@@ -89,6 +90,17 @@ class TrainEngine:
     def _fwd_bwd(self, batch):
         ops.predrop_clear()
         ops.stamp("step starts")
+        # eager steps use the LayerNorm parameter-gradient table too (one reduce launch per step instead of one per norm)
+        own_table = ops.LN_EAGER_TABLE and ops.LN_TABLE is None and not self._capturing and self.arena.flat.is_cuda
+        if own_table:
+            ops.ln_table_begin(self.arena.flat.device, eager=True)
+        try:
+            return self._fwd_bwd_body(batch)
+        finally:
+            if own_table:
+                ops.LN_TABLE = None
+
+    def _fwd_bwd_body(self, batch):
         loss, acc = self.model(**batch)
         loss = loss / self.accum_grad if self.accum_grad != 1 else loss
         ops.stamp("fwd: losses done")

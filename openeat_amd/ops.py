@@ -633,7 +633,7 @@ def _group_wgrads(descs):
         return set()
     host, total = plan
     table = torch.empty(len(host), dtype=torch.uint8, device=descs[idx[0]]["dy"].device)
-    if LN_TABLE is not None:
+    if LN_TABLE is not None and not LN_TABLE.get("eager"):
         LN_TABLE.setdefault("uploads", []).append((table, host))       # inside a capture: filled by ln_table_end, kept with the graph
     else:
         # stream-ordered upload from pinned memory: the host never waits for the stream (bench.py's bracketed steps park the GPU
@@ -792,10 +792,22 @@ LN_TABLE = None
 LN_TABLE_CAPACITY = 512
 
 
-def ln_table_begin(device):
+LN_EAGER_TABLE = os.environ.get("OE_LN_EAGER_TABLE", "1") == "1"
+_LN_EAGER_DEV = {}          # device -> the eager table's device tensor (allocated once)
+_LN_EAGER_PINNED = []       # pinned host tables of the last flushes (alive until their stream-ordered uploads have surely run)
+
+
+def ln_table_begin(device, eager=False):
+    """eager: table mode for an eager step too (TrainEngine) - the table is uploaded stream-ordered right before the launch that reads it
+    (a captured step fills it once after the capture, ln_table_end)."""
     global LN_TABLE
-    LN_TABLE = {"dev": torch.zeros(LN_TABLE_CAPACITY, 5, dtype=torch.int64, device=device), "entries": [], "keep": [],
-                "max_rows": 1, "max_d": 4, "launched": 0}
+    if eager:
+        dev = _LN_EAGER_DEV.get(device)
+        if dev is None:
+            dev = _LN_EAGER_DEV[device] = torch.zeros(LN_TABLE_CAPACITY, 5, dtype=torch.int64, device=device)
+    else:
+        dev = torch.zeros(LN_TABLE_CAPACITY, 5, dtype=torch.int64, device=device)
+    LN_TABLE = {"dev": dev, "entries": [], "keep": [], "max_rows": 1, "max_d": 4, "launched": 0, "eager": eager}
     return LN_TABLE
 
 
@@ -807,6 +819,14 @@ def ln_table_flush():
         return
     first, n = t["launched"], len(t["entries"]) - t["launched"]
     assert len(t["entries"]) <= LN_TABLE_CAPACITY, "LN_TABLE_CAPACITY exceeded"
+    if t.get("eager"):
+        host = torch.tensor(t["entries"][first:], dtype=torch.int64).pin_memory()
+        t["dev"][first:first + n].copy_(host, non_blocking=True)
+        _LN_EAGER_PINNED.append(host)
+        del _LN_EAGER_PINNED[:-8]
+        cur = torch.cuda.current_stream()
+        for ws in t["keep"]:
+            ws.record_stream(cur)               # (workspaces of norms that ran on the decoders' streams)
     hip.call("oe_layernorm_param_reduce_table", t["dev"][first:], n, t["max_rows"], t["max_d"])
     t["launched"] = len(t["entries"])
     t["keep"] = []                      # later allocations may reuse the workspaces: they come after this launch in stream order

@@ -32,9 +32,13 @@ attn_dec = 6 * (4 + 14) * B * H * (L1 * L1 + L1 * Tp) * (d // H)         # self 
 ln_enc, ln_dec = 12 * 6 + 1, 6 * 3 + 2                                   # 5 block norms + conv-module norm per layer, after_norm
 # round 3, second session: a layer's norm_final + the norm behind it are ONE launch (11 pairs that write both outputs, one - in
 # front of after_norm - that writes the second only), the conv module's norm rides in the depthwise-conv forward
-ln_single = 12 * 3 + 1                                                  # norm_mha, norm_conv, norm_ff per layer + layer 0's macaron norm
-ln_fwd_bytes = (ln_single * 2 + 11 * 3 + 1 * 2) * act + ln_dec * 2 * actd
-ln_bwd_bytes = (ln_single * 4 + 12 * 3 + 11 * 4 + 1 * 3) * act + ln_dec * 4 * actd
+# round 4: most encoder norms run as prologues / epilogues of the row-block GEMM kernels (their time is in the GEMM class): only the
+# launches that still exist are counted here - by their call counts in the trace (decoder norms: ln_dec of them, 992 rows each)
+calls = lambda pred: sum(int(r["Calls"]) for r in rows if pred(r["Name"])) / steps
+n_fs, n_fp = calls(lambda n: "layernorm_fwd_kernel" in n and "false>" in n), calls(lambda n: "layernorm_fwd_kernel" in n and "true>" in n)
+n_bs, n_bp = calls(lambda n: "layernorm_bwd_kernel" in n and "false>" in n), calls(lambda n: "layernorm_bwd_kernel" in n and "true>" in n)
+ln_fwd_bytes = max(0.0, n_fs - ln_dec) * 2 * act + max(0.0, n_fp - 1) * 3 * act + min(n_fp, 1) * 2 * act + min(n_fs, ln_dec) * 2 * actd
+ln_bwd_bytes = max(0.0, n_bs - ln_dec) * 4 * act + n_bp * 4 * act + min(n_bs, ln_dec) * 4 * actd
 classes = [
     ("GEMM kernels (`gemm_pl_kernel`, `gemm_dma_kernel`, `gemm_bf16_kernel`, `gemm_tn_*`, `ffn6_kernel`, `rowgemm6*_kernel`, `rowtile6_kernel`)", "mfma", GEMM_FLOP, lambda n: ("gemm_" in n and "kernel" in n) or "ffn_fwd_kernel" in n or "ffn6_kernel" in n or ("rowgemm6" in n or "rowtile6" in n),   # gemm_tn_grouped_kernel included
      f"2*m*n*k of the step's {GEMM_LAUNCHES} launches (counted live by bench.py; conv2 forward / input / weight gradients included)"),
@@ -42,9 +46,9 @@ classes = [
      "(4 fwd + 14 bwd) * B*H*T1*T2*dk, encoder self-attention + decoder self/source attention"),
     ("CTC (`ctc_rows`, `ctc_alphabeta`, `ctc_labels`)", "hbm", 2 * M * V * f4 + 4 * M * (2 * 30 + 1) * f4, lambda n: "ctc_" in n and "greedy" not in n,
      "logits read once + gradient written once + alpha/beta"),
-    ("LayerNorm forward (single norms and norm pairs)", "hbm", ln_fwd_bytes, lambda n: "layernorm_fwd" in n, "read x + write y (a pair: + its first norm's output)"),
-    ("LayerNorm backward (+ parameter reduce)", "hbm", ln_bwd_bytes, lambda n: "layernorm_bwd" in n or "ln_param_reduce" in n,
-     "read dy, x, residual gradient + write dx"),
+    ("LayerNorm forward (the launches that exist: norm pairs, decoder norms; the other encoder norms are prologues of GEMM-class kernels)", "hbm", ln_fwd_bytes, lambda n: "layernorm_fwd" in n, f"{n_fs:.0f} single + {n_fp:.0f} pair launches per step: read x + write y (a pair: + its first norm's output)"),
+    ("LayerNorm backward (+ parameter reduce; the launches that exist)", "hbm", ln_bwd_bytes, lambda n: "layernorm_bwd" in n or "ln_param_reduce" in n,
+     f"{n_bs:.0f} single + {n_bp:.0f} pair launches per step: read dy, x, residual gradient + write dx"),
     ("depthwise conv + GLU + its LayerNorm, forward", "hbm", 12 * 4 * act, lambda n: "dwconv_glu_fwd" in n, "read (B*T', 2d) + write (B*T', d) twice (conv output, normalised + activated)"),
     ("depthwise conv + GLU backward (+ reduce)", "hbm", 12 * 5 * act, lambda n: "dwconv_glu_bwd" in n or "dwconv_param_reduce" in n, "read a, dy + write da"),
     ("conv1 forward (`conv1_fwd`)", "hbm", y1 * 3 // 2 + B * T * 80 * f4, lambda n: "conv1_fwd" in n, "write the NHWC activation as three bf16 planes (6 bytes per element; no fp32 copy)"),
