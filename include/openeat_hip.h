@@ -181,6 +181,10 @@ typedef struct oe_ln_prologue {
 typedef struct oe_lnf_prologue {
     const float* x; const float* gamma; const float* beta; float eps;
     float* y; float* stats; const unsigned char* rowmask;
+    /* PAIR (oe_ffn_fwd only; gamma2 != NULL): y = LN2(u; gamma2, beta2, eps2) with u = LN1(x; gamma, beta, eps) - norm_final of an encoder
+     * layer and the next layer's first pre-norm (oe_layernorm_pair_fwd); u (optional output, the feed-forward's residual) and stats2 are
+     * written too; no row mask. */
+    const float* gamma2; const float* beta2; float eps2; float* u; float* stats2;
 } oe_lnf_prologue;
 
 /* LayerNorm-backward EPILOGUE of oe_rowgemm6 (row-block form, 256 <- 256): dx != NULL sends the product's rows dz through the backward of

@@ -60,15 +60,21 @@ static const char* ln_pro_check(const oe_ln_prologue& a) {
 }
 
 // LayerNorm-FORWARD prologue (oe_lnf_prologue of the header): see ln_fwd_rows_to_planes
-struct LnfPro { const float* x; const float* gamma; const float* beta; float eps; float* y; float* stats; const unsigned char* rowmask; };
+struct LnfPro {
+    const float* x; const float* gamma; const float* beta; float eps; float* y; float* stats; const unsigned char* rowmask;
+    const float* gamma2; const float* beta2; float eps2; float* u; float* stats2;      // pair (gamma2 != nullptr): y = LN2(u), u = LN1(x)
+};
 static LnfPro lnf_pro_of(const oe_lnf_prologue& a) {
     LnfPro q;
     q.x = a.x; q.gamma = a.gamma; q.beta = a.beta; q.eps = a.eps; q.y = a.y; q.stats = a.stats; q.rowmask = a.rowmask;
+    q.gamma2 = a.gamma2; q.beta2 = a.beta2; q.eps2 = a.eps2; q.u = a.u; q.stats2 = a.stats2;
     return q;
 }
 static const char* lnf_pro_check(const oe_lnf_prologue& a) {
     if (!(a.gamma && a.beta && a.y && a.stats)) return "null pointer";
     if (((((uintptr_t)a.x) | ((uintptr_t)a.gamma) | ((uintptr_t)a.beta) | ((uintptr_t)a.y)) & 15) != 0) return "16-byte alignment required";
+    if (a.gamma2 && !(a.beta2 && a.stats2 && !a.rowmask)) return "pair: beta2 / stats2 missing (and no row mask)";
+    if (((((uintptr_t)a.gamma2) | ((uintptr_t)a.beta2) | ((uintptr_t)a.u)) & 15) != 0) return "16-byte alignment required";
     return nullptr;
 }
 
@@ -212,11 +218,13 @@ __device__ __forceinline__ void f6_write_planes(const float (&hv)[16], unsigned 
 // as the way its 32 rows reach LDS: y = (x - mean) rstd gamma + beta per row, a wave per row exactly as layernorm_fwd_kernel (same
 // two-pass statistics, same per-lane order); y and the (mean, rstd) pairs are written (the weight gradient and the LayerNorm's backward
 // read them), y is split into the block's planes.  rowmask: rows with 0 give y = 0 (convolution.py:88-89).  No barrier of its own.
-template <int D>
+template <int D, bool PAIR>
 __device__ __forceinline__ void ln_fwd_rows_to_planes(const LnfPro& q, int rows, long m0, int wv, int lane, unsigned char* xs) {
     static_assert(D == 256, "one float4 per lane and row");
     constexpr int BM = 32, XP = D + 8;
     const float4 g = reinterpret_cast<const float4*>(q.gamma)[lane], bb = reinterpret_cast<const float4*>(q.beta)[lane];
+    float4 g2 = g, bb2 = bb;
+    if (PAIR) { g2 = reinterpret_cast<const float4*>(q.gamma2)[lane]; bb2 = reinterpret_cast<const float4*>(q.beta2)[lane]; }
     float4 v[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) v[k] = reinterpret_cast<const float4*>(q.x + min(m0 + wv + 8 * k, (long)rows - 1) * D)[lane];
@@ -232,10 +240,18 @@ __device__ __forceinline__ void ln_fwd_rows_to_planes(const LnfPro& q, int rows,
         if (!(valid && q.rowmask && !q.rowmask[grow]))
             o = make_float4((v[k].x - mean) * rstd * g.x + bb.x, (v[k].y - mean) * rstd * g.y + bb.y,
                             (v[k].z - mean) * rstd * g.z + bb.z, (v[k].w - mean) * rstd * g.w + bb.w);
-        if (valid) {
-            if (lane == 0) { q.stats[grow * 2] = mean; q.stats[grow * 2 + 1] = rstd; }
-            reinterpret_cast<float4*>(q.y + grow * D)[lane] = o;
+        if (valid && lane == 0) { q.stats[grow * 2] = mean; q.stats[grow * 2 + 1] = rstd; }
+        if (PAIR) {
+            // the second norm on the first one's output (layernorm_fwd_kernel's PAIR): o = LN2(u); u itself leaves too when wanted
+            if (valid && q.u) reinterpret_cast<float4*>(q.u + grow * D)[lane] = o;
+            const float mean2 = wave_sum(o.x + o.y + o.z + o.w) / D;
+            const float a2 = o.x - mean2, b2 = o.y - mean2, c2 = o.z - mean2, e2 = o.w - mean2;
+            const float rstd2 = rsqrtf(wave_sum(a2 * a2 + b2 * b2 + c2 * c2 + e2 * e2) / D + q.eps2);
+            if (valid && lane == 0) { q.stats2[grow * 2] = mean2; q.stats2[grow * 2 + 1] = rstd2; }
+            o = make_float4((o.x - mean2) * rstd2 * g2.x + bb2.x, (o.y - mean2) * rstd2 * g2.y + bb2.y,
+                            (o.z - mean2) * rstd2 * g2.z + bb2.z, (o.w - mean2) * rstd2 * g2.w + bb2.w);
         }
+        if (valid) reinterpret_cast<float4*>(q.y + grow * D)[lane] = o;
         const float xq[4] = {o.x, o.y, o.z, o.w};
         oe_bf16x4v pl[3];
         oe_split4<3>(xq, pl);
@@ -440,7 +456,10 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 
 
     // ---- the block's rows -> three bf16 planes in LDS (rows past the end re-read the last one; never stored)
     if constexpr (LNP == 2) {
-        ln_fwd_rows_to_planes<D>(p.lnf, p.rows, m0, wv, lane, xs);           // ... made by the pre-norm in front of this feed-forward
+        // ... made by the pre-norm in front of this feed-forward (or by norm_final + that pre-norm: the pair form writes u, the
+        // residual this kernel's epilogue 2 reads back from global memory - same block, behind the barriers below)
+        if (p.lnf.gamma2) ln_fwd_rows_to_planes<D, true>(p.lnf, p.rows, m0, wv, lane, xs);
+        else ln_fwd_rows_to_planes<D, false>(p.lnf, p.rows, m0, wv, lane, xs);
     } else if constexpr (LNP == 1) {
         // ... made by the LayerNorm backward that precedes this feed-forward's backward (ln_bwd_rows_to_planes); the partial sums
         // meet in the h regions, which nothing uses before the first chunk's epilogue
@@ -765,7 +784,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     }
     // (the rows after the ring's first stages are on their way: both round trips overlap)
     if constexpr (LNP == 2) {
-        ln_fwd_rows_to_planes<D>(p.lnf, p.rows, m0, wv, lane, xs);
+        ln_fwd_rows_to_planes<D, false>(p.lnf, p.rows, m0, wv, lane, xs);
     } else if constexpr (LNP == 1) {
         static_assert(8 * 2 * 2 * D * 4 <= 8 * PATCH, "the prologue's partial sums reuse the (still unused) patches");
         if (p.ln.gamma2) ln_bwd_rows_to_planes<D, true>(p.ln, p.seed_dev, p.rows, m0, wv, lane, xs, reinterpret_cast<float*>(lds + X_BYTES));
@@ -1248,7 +1267,7 @@ extern "C" int oe_rowgemm6(const oe_rowgemm_args* a, void* stream) {
         OE_REQUIRE(why == nullptr, "oe_rowgemm6: LayerNorm prologue: %s", why);
     }
     if (a->lnf.x) {
-        OE_REQUIRE(form == 1 && a->k == 256 && !a->ln.dy, "oe_rowgemm6: the LayerNorm-forward prologue exists in the row-block form at k = 256 only");
+        OE_REQUIRE(form == 1 && a->k == 256 && !a->ln.dy && !a->lnf.gamma2, "oe_rowgemm6: the (single) LayerNorm-forward prologue exists in the row-block form at k = 256 only");
         const char* why = lnf_pro_check(a->lnf);
         OE_REQUIRE(why == nullptr, "oe_rowgemm6: LayerNorm-forward prologue: %s", why);
     }

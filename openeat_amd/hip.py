@@ -99,13 +99,16 @@ class LnPrologue(C.Structure):
 
 class LnfPrologue(C.Structure):
     """oe_lnf_prologue (include/openeat_hip.h)."""
-    _fields_ = [("x", c_fp), ("gamma", c_fp), ("beta", c_fp), ("eps", C.c_float), ("y", c_fp), ("stats", c_fp), ("rowmask", c_fp)]
+    _fields_ = [("x", c_fp), ("gamma", c_fp), ("beta", c_fp), ("eps", C.c_float), ("y", c_fp), ("stats", c_fp), ("rowmask", c_fp),
+                ("gamma2", c_fp), ("beta2", c_fp), ("eps2", C.c_float), ("u", c_fp), ("stats2", c_fp)]
 
     def fill(self, q):
         """q: dict(x, gamma, beta, eps, y, stats, rowmask)."""
         dp = lambda t: None if t is None else t.data_ptr()
         self.x, self.gamma, self.beta, self.eps = dp(q["x"]), dp(q["gamma"]), dp(q["beta"]), float(q["eps"])
         self.y, self.stats, self.rowmask = dp(q["y"]), dp(q["stats"]), dp(q.get("rowmask"))
+        self.gamma2, self.beta2, self.eps2 = dp(q.get("gamma2")), dp(q.get("beta2")), float(q.get("eps2") or 0.0)
+        self.u, self.stats2 = dp(q.get("u")), dp(q.get("stats2"))
 
 
 class LnEpilogue(C.Structure):

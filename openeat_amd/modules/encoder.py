@@ -137,7 +137,9 @@ class TransformerEncoder(torch.nn.Module):
                     normed_out = True
                 else:
                     nm = nxt.norm_ff_macaron
-                    pre = ops.layer_norm_pair(xs, nf.weight, nf.bias, nf.eps, nm.weight, nm.bias, nm.eps, want_first=True, sole_consumer=True)
+                    # (fuse_fwd: `pre` goes to the next layer's first feed-forward as (residual, input) and nowhere else)
+                    pre = ops.layer_norm_pair(xs, nf.weight, nf.bias, nf.eps, nm.weight, nm.bias, nm.eps, want_first=True, sole_consumer=True,
+                                              fuse_fwd=True)
                     xs = pre[0]
         finally:
             for att in ahead:

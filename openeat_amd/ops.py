@@ -78,6 +78,10 @@ def _resolve_lnf(pend):
     if pend.get("done"):
         return
     pend["done"] = True
+    if pend.get("gamma2") is not None:
+        hip.call("oe_layernorm_pair_fwd", pend["x"], pend["gamma"], pend["beta"], pend["eps"], pend["gamma2"], pend["beta2"], pend["eps2"], pend["rows"],
+                 pend["d"], pend["u"], pend["stats"], pend["y"], pend["stats2"])
+        return
     _ln_fwd(pend["x"], pend["gamma"], pend["beta"], pend["eps"], pend["rows"], pend["d"], pend["rowmask"], ACT_NONE, pend["y"], pend["stats"])
 
 
@@ -322,7 +326,8 @@ def _rowgemm_try_impl(x, w, transposed, bias, out, epi, ln_pending, lnf_pending=
     lnf = None
     if lnf_pending is not None and not lnf_pending.get("done"):
         q = lnf_pending
-        if form == 1 and k == 256 and ln is None and x.is_contiguous() and x.data_ptr() == q["y"].data_ptr() and M == q["rows"]:
+        if (form == 1 and k == 256 and ln is None and x.is_contiguous() and x.data_ptr() == q["y"].data_ptr() and M == q["rows"] and
+                q.get("gamma2") is None):
             lnf = dict(x=q["x"], gamma=q["gamma"], beta=q["beta"], eps=q["eps"], y=q["y"], stats=q["stats"], rowmask=q["rowmask"])
         else:
             _resolve_lnf(q)                     # this launch reads x: the LayerNorm first, on its own
@@ -1095,14 +1100,20 @@ class NormPairFn(torch.autograd.Function):
     Backward: d x = LN1'(d u + LN2'(d y)) in one kernel, u recomputed from x."""
 
     @staticmethod
-    def forward(ctx, x, g1, b1, eps1, g2, b2, eps2, want_first, sole_consumer):
+    def forward(ctx, x, g1, b1, eps1, g2, b2, eps2, want_first, sole_consumer, fuse_fwd=False):
         x = _chk(x, "layer_norm_pair")
         d = x.shape[-1]
         rows = x.numel() // d
         u = torch.empty_like(x) if want_first else None
         y = torch.empty_like(x)
         st1, st2 = _new(rows, 2, like=x), _new(rows, 2, like=x)
-        hip.call("oe_layernorm_pair_fwd", x, g1, b1, eps1, g2, b2, eps2, rows, d, u, st1, y, st2)
+        if (fuse_fwd and want_first and LN_FWD_FUSE and FUSED_FFN and hip.GEMM_PRECISION == 6 and d == 256 and rows >= ROWGEMM_MIN_ROWS and
+                not _planes.active() and all(t.data_ptr() % 16 == 0 for t in (g1, b1, g2, b2))):
+            # parked: the next layer's first feed-forward makes u and y on its rows' way in (_PENDING_LNF, pair form)
+            _PENDING_LNF[y.data_ptr()] = dict(x=x, gamma=g1, beta=b1, eps=eps1, gamma2=g2, beta2=b2, eps2=eps2, rows=rows, d=d, rowmask=None,
+                                              u=u, y=y, stats=st1, stats2=st2, done=False)
+        else:
+            hip.call("oe_layernorm_pair_fwd", x, g1, b1, eps1, g2, b2, eps2, rows, d, u, st1, y, st2)
         ctx.save_for_backward(x, g1, b1, st1, g2, b2, st2)
         ctx.prev_drop = getattr(x, "_oe_outdrop", None) if sole_consumer else None
         ctx.ln_fuse = bool(sole_consumer and getattr(x, "_oe_lnfuse", False))
@@ -1141,7 +1152,7 @@ class NormPairFn(torch.autograd.Function):
                     t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
                     t["keep"].append(ws)
                 t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
-            return dx, rg1, rb1, None, rg2, rb2, None, None, None
+            return dx, rg1, rb1, None, rg2, rb2, None, None, None, None
         if ctx.prev_drop is not None and FUSE_OUT_DROP and d % 8 == 0:
             gout = torch.empty_like(dx)
             alpha, p, seed, gmask = ctx.prev_drop
@@ -1156,12 +1167,13 @@ class NormPairFn(torch.autograd.Function):
                 t["entries"].append((ws.data_ptr(), rows, d, dg.data_ptr(), db.data_ptr()))
                 t["keep"].append(ws)
                 t["max_rows"], t["max_d"] = max(t["max_rows"], rows), max(t["max_d"], d)
-        return dx, rg1, rb1, None, rg2, rb2, None, None, None
+        return dx, rg1, rb1, None, rg2, rb2, None, None, None, None
 
 
-def layer_norm_pair(x, g1, b1, eps1, g2, b2, eps2, want_first=True, sole_consumer=False):
-    """(LN1(x), LN2(LN1(x))) - or only the second with want_first=False.  sole_consumer: as layer_norm's."""
-    return NormPairFn.apply(x, g1, b1, eps1, g2, b2, eps2, want_first, sole_consumer)
+def layer_norm_pair(x, g1, b1, eps1, g2, b2, eps2, want_first=True, sole_consumer=False, fuse_fwd=False):
+    """(LN1(x), LN2(LN1(x))) - or only the second with want_first=False.  sole_consumer: as layer_norm's.  fuse_fwd (with
+    want_first): the caller hands the pair to a feed-forward as (residual, input) and to nothing else (pre_norm's fuse_fwd)."""
+    return NormPairFn.apply(x, g1, b1, eps1, g2, b2, eps2, want_first, sole_consumer, fuse_fwd)
 
 
 # --------------------------------------------------------------------------- #
@@ -1433,7 +1445,11 @@ class FeedForwardFn(torch.autograd.Function):
             if (fused_now and hip.GEMM_PRECISION == 6 and d == 256 and ff % 256 == 0 and hip.lib().oe_ffn6_config(-1) in (0, 3) and
                     x2.is_contiguous() and M == lnf_p["rows"]):
                 lnf = dict(x=lnf_p["x"], gamma=lnf_p["gamma"], beta=lnf_p["beta"], eps=lnf_p["eps"], y=lnf_p["y"], stats=lnf_p["stats"],
-                           rowmask=lnf_p["rowmask"])
+                           rowmask=lnf_p["rowmask"], gamma2=lnf_p.get("gamma2"), beta2=lnf_p.get("beta2"), eps2=lnf_p.get("eps2"),
+                           u=lnf_p.get("u"), stats2=lnf_p.get("stats2"))
+                if lnf["gamma2"] is not None and (res2 is None or lnf["u"] is None or res2.data_ptr() != lnf["u"].data_ptr()):
+                    lnf = None                    # the pair form is for `residual = u` (EncoderLayer's pre): anything else, the plain way
+                    _resolve_lnf(lnf_p)
             else:
                 _resolve_lnf(lnf_p)
         if fused_now:

@@ -756,7 +756,7 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
                 ops.set_seed_device_counter(None)
     finally:
         hip.GEMM_PRECISION, ops.LN_BWD_FUSE, ops.LN_FWD_FUSE, ops.LN_EPI_FUSE = old
-    assert fwd_launches == [0, 7]                                # the first layer's macaron norm + per layer: norm_mha, norm_conv, norm_ff
+    assert fwd_launches == [0, 8]                                # layer 0's macaron norm, the pair in front of layer 1's, per layer: norm_mha, norm_conv, norm_ff
     assert epi_launches == [0, 2]                                # the conv module's own norm, behind pointwise_conv2's input gradient
     assert launches == [0, 8]                                    # two encoder layers x (attention, conv module, both feed-forwards)
     assert abs(losses[0] - losses[1]) <= 2e-6 * abs(losses[0])    # (forward: the same norms computed in other kernels)

@@ -372,3 +372,41 @@ def test_forward_with_the_layernorm_as_its_prologue():
             hip.ffn_fwd(yl1, w1p, b1, w2p, b2, rows, d, ff, act, pre_out=pre1, act_out=a1, y=y1, lnf=lnf, **kw)
     finally:
         L.oe_ffn6_config(0)
+
+
+def test_forward_with_a_pair_of_layernorms_as_its_prologue():
+    """The PAIR form of oe_ffn_args.lnf: norm_final of an encoder layer and the next layer's first pre-norm (oe_layernorm_pair_fwd) in
+    front of that layer's first feed-forward, whose residual IS the first norm's output - written by the kernel's prologue and read
+    back by its own epilogue."""
+    torch.manual_seed(71)
+    rows, d, ff, act = 4157, 256, 1024, 2
+    x = torch.randn(rows, d, device=DEV) * 1.4 + 0.2
+    g1, b1n = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    g2, b2n = torch.randn(d, device=DEV) * 0.2 + 1.0, torch.randn(d, device=DEV) * 0.1
+    w1, b1 = torch.randn(ff, d, device=DEV) / math.sqrt(d), torch.randn(ff, device=DEV) * 0.1
+    w2, b2 = torch.randn(d, ff, device=DEV) / math.sqrt(ff), torch.randn(d, device=DEV) * 0.1
+    L = hip.lib()
+    nb = L.oe_ffn_packed_bytes(d, ff, 6)
+    w1p, w2p = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.empty(nb, dtype=torch.uint8, device=DEV)
+    hip.call("oe_ffn_pack_weights", w1, w2, d, ff, 6, w1p, w2p)
+    ctr = torch.tensor([5], dtype=torch.int64, device=DEV)
+    u0, y20 = torch.empty_like(x), torch.empty_like(x)
+    sa0, sb0 = torch.empty(rows, 2, device=DEV), torch.empty(rows, 2, device=DEV)
+    hip.call("oe_layernorm_pair_fwd", x, g1, b1n, 1e-5, g2, b2n, 1e-5, rows, d, u0, sa0, y20, sb0)
+    kw = dict(drop_in=0.1, seed_in=11, drop_out=0.1, seed_out=12, seed_dev=ctr, ldr=d, beta=0.5, precision=6)
+    pre0, a0, out0 = torch.empty(rows, ff, device=DEV), torch.empty(rows, ff, device=DEV), torch.empty(rows, d, device=DEV)
+    hip.ffn_fwd(y20, w1p, b1, w2p, b2, rows, d, ff, act, pre_out=pre0, act_out=a0, y=out0, residual=u0, **kw)
+    nan = float("nan")
+    u1, y21 = torch.full_like(x, nan), torch.full_like(x, nan)
+    sa1, sb1 = torch.full((rows, 2), nan, device=DEV), torch.full((rows, 2), nan, device=DEV)
+    pre1, a1, out1 = torch.full((rows, ff), nan, device=DEV), torch.full((rows, ff), nan, device=DEV), torch.full((rows, d), nan, device=DEV)
+    lnf = dict(x=x, gamma=g1, beta=b1n, eps=1e-5, gamma2=g2, beta2=b2n, eps2=1e-5, u=u1, y=y21, stats=sa1, stats2=sb1, rowmask=None)
+    for _ in range(3):                                   # (the residual read-back: stable over launches)
+        hip.ffn_fwd(y21, w1p, b1, w2p, b2, rows, d, ff, act, pre_out=pre1, act_out=a1, y=out1, residual=u1, lnf=lnf, **kw)
+        sync()
+        torch.testing.assert_close(u1, u0, rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(y21, y20, rtol=3e-6, atol=2e-6)
+        torch.testing.assert_close(sa1, sa0, rtol=2e-6, atol=1e-6)
+        torch.testing.assert_close(sb1, sb0, rtol=3e-6, atol=2e-6)
+        torch.testing.assert_close(pre1, pre0, rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(out1, out0, rtol=1e-5, atol=3e-5)
