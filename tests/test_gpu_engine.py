@@ -763,3 +763,52 @@ def test_layernorm_backward_as_a_gemm_prologue_equals_the_separate_launches():
     scale = float(grads[0].abs().max())
     assert float((grads[1] - grads[0]).abs().max()) <= 2e-5 * scale
     assert float((grads[1] - grads[0]).norm()) <= 1e-5 * float(grads[0].norm())
+
+
+def test_inference_with_the_layernorm_prologues_equals_the_separate_launches():
+    """The decode entry points run the same fused forward (no_grad, eval): encoder output and CTC greedy ids with ops.LN_FWD_FUSE on
+    and off at a size where the prologues are active (>= 4096 encoder rows, d = 256, precision 6), eagerly and from a captured graph."""
+    from openeat_amd import hip
+    old = (hip.GEMM_PRECISION, ops.LN_FWD_FUSE)
+    hip.GEMM_PRECISION = 6
+    torch.manual_seed(6)
+    m = ASRModel(80, 40, encoder_num_blocks=3, decoder_num_blocks=1, r_decoder_num_blocks=1, d_model=256, attention_heads=4,
+                 linear_units=512, dropout_rate=0.1, ctc_weight=0.3, lsm_weight=0.1, reverse_weight=0.3).to(DEV).eval()
+    g = torch.Generator().manual_seed(3)
+    B, T = 11, 1530
+    feats = torch.randn(B, T, 80, generator=g).to(DEV)
+    nfr = torch.tensor([T, T - 40, T, T - 200, T, T, T - 8, T, T, T - 333, T], dtype=torch.int32, device=DEV)
+    outs, ids, fused = [], [], []
+    try:
+        with torch.no_grad():
+            for fuse in (False, True):
+                ops.LN_FWD_FUSE = fuse
+                f0 = ops.LN_FWD_FUSED_LAUNCHES
+                enc, mask, _ = m._encode(feats, nfr)
+                torch.cuda.synchronize()
+                assert not ops._PENDING_LNF
+                fused.append(ops.LN_FWD_FUSED_LAUNCHES - f0)
+                outs.append(enc.clone())
+                ids.append(m.ctc_greedy_search(feats, nfr))
+            # ... and from a captured graph (what the batched decode paths replay)
+            ops.LN_FWD_FUSE = True
+            static = feats.clone()
+            gph = torch.cuda.CUDAGraph()
+            from openeat_amd import planes
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                m._encode(static, nfr)
+                torch.cuda.synchronize()
+                with planes.capture_scope(), torch.cuda.graph(gph, stream=s):
+                    enc_g, _, _ = m._encode(static, nfr)
+            torch.cuda.synchronize()
+            enc_g.fill_(float("nan"))
+            gph.replay()
+            torch.cuda.synchronize()
+    finally:
+        hip.GEMM_PRECISION, ops.LN_FWD_FUSE = old
+    assert fused[0] == 0 and fused[1] >= 3 * 3
+    scale = float(outs[0].abs().max())
+    assert float((outs[1] - outs[0]).abs().max()) <= 2e-5 * scale
+    assert ids[0] == ids[1]
+    assert float((enc_g - outs[1]).abs().max()) <= 2e-5 * scale
