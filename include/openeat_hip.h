@@ -141,6 +141,10 @@ long oe_gemm_hyb_launches(void);
  * (default 96 blocks: below that the splitting kernels' smaller tiles / split-K fill the chip better), a forced tile (22 =
  * 128 x 128, 11 = 64 x 64, 0 = automatic), a forced K-tile (16 / 32, 0 = automatic), waves per 128 x 128 block (8 / 4) */
 int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves);
+/* 1 (default, OE_PL_HYBRID): a row-major x row-major problem that runs on 128 x 256 tiles takes whole rounds of the chip on 256 x 256
+ * tiles first (rows [0, m1)) and the rest on 128 x 256 (two launches, same operands) where that is fewer tile-rounds: the conv2 forward
+ * and input-gradient GEMMs of subsampling.py:88-93.  -1 only reads.  Returns the previous setting. */
+int oe_gemm_pl_hybrid(int on);
 
 /* ------------------------------------------------------------------------- *
  * Position-wise feed forward as one kernel (positionwise_feed_forward.py:36-43 with the caller's residual / dropout of

@@ -115,7 +115,7 @@ __device__ __forceinline__ int pl_div_small(int k, int d, float rd, int& rem) { 
 template <int TM, int TN, int WM, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
 __global__ __launch_bounds__(WM * 128, (WM == 2 && NST * 3 * (32 * TM * WM + 64 * TN) * BK * 2 <= 80 * 1024) ? 2 : (WM == 4 ? 2 : 1))
 void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, int M, int N, int K, int k_chunk, int gx, int gy, EpiParams ep,
-                    int k_valid) {
+                    int k_valid, int m_base) {
     int tile_x, tile_y, tile_z;
     {   // XCD-aware tile order (gemm_bf16.hip)
         const int nblk = gridDim.x, id = blockIdx.x;
@@ -141,7 +141,7 @@ void gemm_pl_kernel(PlOperand A, PlOperand B, float* __restrict__ C, long ldc, i
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const long m0 = (long)tile_y * BM, n0 = (long)tile_x * BN;
+    const long m0 = (long)m_base + (long)tile_y * BM, n0 = (long)tile_x * BN;      // m_base: first row of this launch (a row range of the problem)
     const int k_begin = tile_z * k_chunk;
     const int k_end = min(K, k_begin + k_chunk);
     const int nk = (k_end - k_begin) / BK;
@@ -334,7 +334,7 @@ extern "C" long oe_gemm_pl_launches(void) { return pl_launches; }
 // forced tile (22 / 11, 0 = automatic), bk = forced K-tile of the 128 x 128 tiles (16 / 32, 0 = automatic), waves = 8 or 4
 static int pl_env(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static int pl_min_blocks = pl_env("OE_PL_MIN_BLOCKS", 96), pl_forced_tile = pl_env("OE_PL_TILE", 0), pl_forced_bk = pl_env("OE_PL_BK", 0),
-           pl_waves = pl_env("OE_PL_WAVES", 8), pl_t44_min = pl_env("OE_PL_T44_MIN", 1024);
+           pl_waves = pl_env("OE_PL_WAVES", 8), pl_t44_min = pl_env("OE_PL_T44_MIN", 1024), pl_hybrid = pl_env("OE_PL_HYBRID", 1);
 extern "C" int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves) {
     if (min_blocks >= 0) pl_min_blocks = min_blocks;
     if (tile >= 0) pl_forced_tile = tile;
@@ -343,15 +343,26 @@ extern "C" int oe_gemm_pl_config(int min_blocks, int tile, int bk, int waves) {
     return 0;
 }
 
+// whole rounds of 256 x 256 tiles in front of the 128 x 256 ones (tests / A-B runs): returns the previous setting
+extern "C" int oe_gemm_pl_hybrid(int on) {
+    const int was = pl_hybrid;
+    if (on >= 0) pl_hybrid = on;
+    return was;
+}
+
 static int pl_k_valid = 0;          // set by oe_gemm_pl_try around a launch whose K was padded (host-side, same thread as the launch)
 template <int TM, int TN, int WM, bool AK, bool BKM, int BK, int NST, bool GA, bool GB>
-static int launch_pl(const PlOperand& A, const PlOperand& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep, hipStream_t st) {
+static int launch_pl(const PlOperand& A_, const PlOperand& B, float* C, long ldc, int M, int N, int K, int sk, const EpiParams& ep, hipStream_t st,
+                     int m_base = 0) {
+    // rows m_base .. M - 1 of the problem (m_base a multiple of the tile height; A's rows stop at M for this launch)
+    PlOperand A = A_;
+    if (!AK) A.rows_total = M;
     int kc = oe_cdiv(oe_cdiv(K, sk), BK) * BK;
     if (kc <= 0) kc = BK;
     const int nz = oe_cdiv(K, kc);
-    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M, 32 * TM * WM);
+    const int gx = oe_cdiv(N, 64 * TN), gy = oe_cdiv(M - m_base, 32 * TM * WM);
     hipLaunchKernelGGL((gemm_pl_kernel<TM, TN, WM, AK, BKM, BK, NST, GA, GB>), dim3(gx * gy * nz), dim3(WM * 128), 0, st, A, B, C, ldc, M, N, K, kc, gx, gy, ep,
-                       pl_k_valid > 0 ? pl_k_valid : K);
+                       pl_k_valid > 0 ? pl_k_valid : K, m_base);
     OE_LAUNCH_CHECK("oe_gemm (bf16x6 planes)");
     ++pl_launches;
     return 0;
@@ -453,8 +464,31 @@ static int pl_try_impl(const OperandDesc& A, const OperandDesc& B, const void* A
         // once instead of once per column tile and a K-tile moves 72 KiB for 96 MFMAs per wave instead of 48 KiB for 48.
         // Worth it where the grid still fills the chip (the conv2 forward / input-gradient GEMMs: ~1200 blocks)
         if (tile == 24 && K % 32 == 0) {
-            if (ga) return launch_pl<1, 4, 4, false, false, 32, 2, true, false>(a, b, C, ldc, M, N, K, sk, ep, st);
-            return launch_pl<1, 4, 4, false, false, 32, 2, false, false>(a, b, C, ldc, M, N, K, sk, ep, st);
+            // Whole rounds of 256 x 256 tiles first, the rest on 128 x 256: the big tile moves half the LDS-DMA bytes per MFMA (52-59 % matrix-
+            // pipe busy against 45-50) but its grid is coarse - conv2 forward is 589 of them = 2.3 rounds of the chip, which as THREE
+            // rounds lost to the five rounds of 128 x 256 tiles.  Two full rounds of the big tile + one round of the small one take
+            // 2 x 1.84 + 1 = 4.7 small-tile rounds (measured: conv2 forward 1068 -> 1001 us, the input gradient's K = 1024 / 512 classes
+            // 547 -> 507, 342 -> 327, 333 -> 324; its K = 256 class is 6 us SLOWER - sixteen K-tiles of 16 do not amortise the big tile's
+            // epilogue - hence K >= 512).  (Rows [0, m1) and [m1, M) of the same problem: two launches, same operands.)
+            int m1 = 0;
+            if (pl_hybrid && sk == 1 && !forced_tile && K % 16 == 0 && K >= 512 && M >= 256) {
+                const int gxn = N / 256;
+                const long t44 = (long)(M / 256) * gxn;                       // whole big tiles
+                const long full = t44 / 256;                                   // whole rounds of them
+                if (full >= 1 && (full * 256) % gxn == 0) {
+                    const long rows1 = full * 256 / gxn * 256;
+                    const long rest24 = (long)oe_cdiv(M - rows1, 128) * gxn;
+                    const double cost_a = (double)oe_cdiv((long)oe_cdiv(M, 128) * gxn, 256L);
+                    const double cost_b = 1.85 * full + (double)oe_cdiv(rest24, 256L);
+                    if (rows1 < M && cost_b < cost_a) m1 = (int)rows1;
+                }
+            }
+            if (m1 > 0) {
+                if (ga) launch_pl<2, 4, 4, false, false, 16, 3, true, false>(a, b, C, ldc, m1, N, K, 1, ep, st);
+                else launch_pl<2, 4, 4, false, false, 16, 3, false, false>(a, b, C, ldc, m1, N, K, 1, ep, st);
+            }
+            if (ga) return launch_pl<1, 4, 4, false, false, 32, 2, true, false>(a, b, C, ldc, M, N, K, sk, ep, st, m1);
+            return launch_pl<1, 4, 4, false, false, 32, 2, false, false>(a, b, C, ldc, M, N, K, sk, ep, st, m1);
         }
         if (ga) OE_PL(false, false, true, false); else OE_PL(false, false, false, false);
     }

@@ -186,6 +186,7 @@ _SIGNATURES = {
     "oe_gemm_pl_launches": (L, []),
     "oe_gemm_hyb_launches": (L, []),
     "oe_gemm_pl_config": (I, [I, I, I, I]),
+    "oe_gemm_pl_hybrid": (I, [I]),
     "oe_gemm_tn_grouped_plan": (I, [C.POINTER(TnProblem), I, I]),
     "oe_gemm_tn_grouped": (I, [P, I, I, I, P]),
     "oe_ffn_packed_bytes": (SZ, [I, I, I]),

@@ -270,3 +270,57 @@ def test_weight_planes_gemm_epilogues_match_the_plain_kernels():
     for t0, t1 in zip(outs[False], outs[True]):
         torch.testing.assert_close(t1, t0, rtol=1e-5, atol=1e-5)
         assert torch.equal(t0 == 0, t1 == 0)
+
+
+def test_whole_rounds_of_big_tiles_in_front_of_the_small_ones_give_the_same_product():
+    """gemm_pl.hip's hybrid dispatch (oe_gemm_pl_hybrid): rows [0, m1) of a 128 x 256-tile problem on 256 x 256 tiles, the rest on
+    128 x 256 - two launches over row ranges of the same operands.  A plain x W^T with bias and planes output, and the conv2 forward
+    gather in channel-chunk order, at row counts where the split pays (>= one round of big tiles, a ragged last tile): equal to the
+    one-launch result element for element (both tiles walk the reduction in the same order), which the tests above hold to float64."""
+    from openeat_amd.ops import _korder_cols
+    lib = hip.lib()
+    torch.manual_seed(9)
+    was = lib.oe_gemm_pl_hybrid(-1)
+    lib.oe_gemm_pl_config(96, 0, 0, 8)
+    try:
+        # (a) x W^T + b, 70003 x 256 over K = 512, planes output
+        M, N, K = 70003, 256, 512
+        x, w, b = cu(torch.randn(M, K)), cu(torch.randn(N, K) * 0.1), cu(torch.randn(N))
+        xp, wp = split(x), split(w)
+        res = []
+        for on in (0, 1):
+            lib.oe_gemm_pl_hybrid(on)
+            y = torch.full((M, N), float("nan"), device=DEV)
+            yp = planes.alloc(M, N, DEV)
+            n0 = lib.oe_gemm_pl_launches()
+            hip.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, precision=6, a_planes=xp, b_planes=wp, c_planes=yp)
+            sync()
+            assert lib.oe_gemm_pl_launches() - n0 == 1 + on
+            res.append((y.clone(), yp.t[:, :M].clone()))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        rows = torch.randint(0, M, (512,))
+        ref = x[rows].double().cpu() @ w.double().cpu().T + b.double().cpu()
+        assert float((res[1][0][rows].cpu().double() - ref).abs().max()) / math.sqrt(K) < 1.5e-6
+        # (b) conv2 forward gather: B = 16, (T1, F1) = (161, 115) -> (80, 57): 72960 output positions, C = 256, K = 2304
+        B_, T1, F1, Cc = 16, 161, 115, 256
+        T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
+        Mc = B_ * T2 * F2
+        x_nhwc = cu(torch.randn(B_, T1, F1, Cc))
+        w_g = cu(torch.randn(Cc, 9 * Cc) * 0.05)
+        bias = cu(torch.randn(Cc))
+        ap, bp = split(x_nhwc.view(-1, Cc)), split(_korder_cols(w_g, 9, Cc))
+        outs = []
+        for on in (0, 1):
+            lib.oe_gemm_pl_hybrid(on)
+            out = torch.full((Mc, Cc), float("nan"), device=DEV)
+            n0 = lib.oe_gemm_pl_launches()
+            hip.gemm(None, w_g, out, Mc, Cc, 9 * Cc, lda=0, ldb=9 * Cc, ldc=Cc, bias=bias, act=1, conv=(T1, F1, T2, F2, Cc), conv_gather=hip.GATHER_A,
+                     a_planes=ap, b_planes=bp, conv_korder=1, precision=6)
+            sync()
+            assert lib.oe_gemm_pl_launches() - n0 == 1 + on
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1])
+        assert bool(torch.isfinite(outs[1]).all())
+    finally:
+        lib.oe_gemm_pl_hybrid(was)
+        planes.clear()
