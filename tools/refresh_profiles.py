@@ -71,6 +71,15 @@ if os.path.exists(f"{src}/c5_cached.json"):
                "12L d=256 model on the same ragged data, per-shape graph cache": c5.get("c5s_cached"),
                "12L d=256 model on the same ragged data, eager steps": c5.get("c5s_eager")}, open(f"{dst}/{tag}_config5_1gpu.json", "w"), indent=1)
 pm = json.load(open(f"{dst}/{tag}_pmc_hbm_traffic.json"))
+# the bench line quotes the PMC figure that was committed when it ran: make the committed line quote THIS bundle's passes
+_lines = open(f"{dst}/{tag}_bench_p{P}.json").read().rstrip("\n").splitlines()
+_d = json.loads(_lines[-1])
+if _d.get("roofline") and pm.get("precision") == int(P):
+    _d["roofline"]["traffic"] = pm["gemm"]["hbm_bytes_per_launch"]
+    _lines[-1] = json.dumps(_d)
+    open(f"{dst}/{tag}_bench_p{P}.json", "w").write("\n".join(_lines) + "\n")
+with open(f"{dst}/{tag}_roofline_by_class.md", "w") as _f:
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "roofline_table.py"), f"{dst}/{tag}_kernel_stats_p{P}.csv", str(steps), P], stdout=_f)
 print(f"bench {line['ms_per_step']:.2f} ms/step {line['value']:.0f} frames/s graph={line['config']['hip_graph']}")
 print(f"roofline live {ro['achieved']:.1f} TF/s {ro['gemm_ms_per_step']:.2f} ms {ro['avg_launch_us']:.2f} us | rocprof {line['roofline']['algorithmic_gflop_per_step'] / (gt / 1e6 / steps):.1f} TF/s "
       f"{gt / 1e6 / steps:.2f} ms {gt / gc / 1e3:.2f} us | all kernels {tot / 1e6 / steps:.2f} ms")
