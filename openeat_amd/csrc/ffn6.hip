@@ -865,11 +865,12 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
         F6_STAMP(4 + 3 * (ci / NG));
         if constexpr (LNE) {
             static_assert(D == 256, "row sums over eight waves x 32 columns");
-            // Every wave of the block is past its MFMA loop before any of them re-reads its patch.  Without this barrier the row sums of
-            // rows 6 and 7 of ONE wave came out wrong in ~10 % of the blocks, different ones from run to run (the plain store epilogue
-            // above reads the same patch the same way and never showed it; waiting for all outstanding global loads or rewriting the
-            // patch did not help, the barrier does: tools/probes/dbg_lne.py, profiles/r04_experiments.md) - cause not understood.
+            // Every wave of the block is past its MFMA loop before any of them starts this epilogue: a second line of defence against the
+            // packed-fp32 hazard described at `xh` below (the barrier alone also hides it - that is how it was first worked around - and
+            // costs nothing measurable; which other v_pk_* pairs could be hit next to another wave's MFMAs is not characterised).
+#ifndef OE_LNE_REPRO
             __syncthreads();
+#endif
             float (*rowsum)[32][2] = reinterpret_cast<float (*)[32][2]>(lds + X_BYTES + 8 * PATCH);     // [8 waves][32 rows][2]
             const int c4 = (lane & 7) * 4, col = ft * 32 + c4;
             const float4 gm = *reinterpret_cast<const float4*>(p.le_gamma + col), bt = *reinterpret_cast<const float4*>(p.le_beta + col);
@@ -887,7 +888,24 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
                 const float4 xv = *reinterpret_cast<const float4*>(p.le_x + rc * D + col);
                 const float mean = p.le_stats[rc * 2], rstd = p.le_stats[rc * 2 + 1];
                 rs[ps] = rstd;
+#ifndef OE_LNE_REPRO
+                // (x - mean) rstd on ONE-FLOAT instructions.  What hipcc makes of the plain expression - v_pk_add_f32 (x.xy - mean, op_sel_hi /
+                // neg) and, two instructions later, v_pk_mul_f32 (.. x rstd, op_sel:[0,1]) on the register pair the statistics were loaded
+                // into - returned +-0 in the LOW half (.x, .z) for lanes 48-63 of the first pass whenever the other wave of the SIMD was
+                // still issuing MFMAs: rows 6 and 7 of a block wrong in ~10 % of the blocks, different ones every launch; inputs verified
+                // right in the same run, the high halves always right (tools/probes/dbg_lne.py with -DOE_LNE_REPRO, profiles/r04_experiments.md).
+                {
+                    float e[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        asm("v_sub_f32 %0, %1, %2" : "=v"(e[q]) : "v"(e[q]), "v"(mean));
+                        asm("v_mul_f32 %0, %1, %2" : "=v"(e[q]) : "v"(e[q]), "v"(rstd));
+                    }
+                    xh[ps] = make_float4(e[0], e[1], e[2], e[3]);
+                }
+#else
                 xh[ps] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+#endif
                 float4 t = v;
                 if (p.le_act) {
                     t.x *= f6_act_bwd(p.le_act, xh[ps].x * gm.x + bt.x); t.y *= f6_act_bwd(p.le_act, xh[ps].y * gm.y + bt.y);

@@ -450,8 +450,10 @@ def test_ln_backward_epilogue_equals_the_two_launches(rows, act):
 
 
 def test_ln_backward_epilogue_is_stable_over_many_launches():
-    """Regression: before a block-wide barrier was put between the waves' matrix loops and the re-read of their patches, the row sums
-    of two rows of one wave came out wrong in ~10 % of the blocks, other blocks at every launch (tools/probes/dbg_lne.py)."""
+    """Regression: with (x - mean) rstd compiled to packed-fp32 instructions (v_pk_add_f32 ... v_pk_mul_f32 op_sel:[0,1]) the low halves came
+    out zero for lanes 48-63 while the SIMD's other wave issued MFMAs: rows 6 / 7 of ~10 % of the blocks wrong, other blocks at every launch.
+    The kernel writes it as single-float instructions and starts the epilogue behind a block barrier (profiles/r04_experiments.md, Findings;
+    reproducer: -DOE_LNE_REPRO, tools/probes/lne_variants.sh)."""
     torch.manual_seed(98)
     rows, d = 7936, 256
     gq = torch.randn(rows, d, device=DEV)

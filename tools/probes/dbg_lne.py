@@ -6,7 +6,7 @@ from openeat_amd import hip, ops
 DEV = "cuda"
 hip.GEMM_PRECISION = 6
 torch.manual_seed(97)
-rows, d, act = 7936, 256, 2
+rows, d, act = 7936, 256, int(os.environ.get("LNE_ACT", "2"))
 gq = torch.randn(rows, d, device=DEV)
 w = torch.nn.Parameter(torch.randn(d, d, device=DEV) / 16)
 yc = torch.randn(rows, d, device=DEV) * 1.5 + 0.4
