@@ -301,6 +301,24 @@ def test_whole_rounds_of_big_tiles_in_front_of_the_small_ones_give_the_same_prod
         rows = torch.randint(0, M, (512,))
         ref = x[rows].double().cpu() @ w.double().cpu().T + b.double().cpu()
         assert float((res[1][0][rows].cpu().double() - ref).abs().max()) / math.sqrt(K) < 1.5e-6
+        # (a') two column tiles (N = 512): whole rounds count tiles of both columns, the row split stays a multiple of 256
+        M2, N2, K2 = 40003, 512, 512
+        x2, w2 = cu(torch.randn(M2, K2)), cu(torch.randn(N2, K2) * 0.1)
+        xp2, wp2 = split(x2), split(w2)
+        res2 = []
+        for on in (0, 1):
+            lib.oe_gemm_pl_hybrid(on)
+            y2 = torch.full((M2, N2), float("nan"), device=DEV)
+            n0 = lib.oe_gemm_pl_launches()
+            hip.gemm(x2, w2, y2, M2, N2, K2, lda=K2, ldb=K2, ldc=N2, precision=6, a_planes=xp2, b_planes=wp2)
+            sync()
+            assert lib.oe_gemm_pl_launches() - n0 == 1 + on
+            res2.append(y2)
+        assert torch.equal(res2[0], res2[1])
+        rows2 = torch.randint(0, M2, (256,))
+        ref2 = x2[rows2].double().cpu() @ w2.double().cpu().T
+        assert float((res2[1][rows2].cpu().double() - ref2).abs().max()) / math.sqrt(K2) < 1.5e-6
+        del x2, w2, xp2, wp2, res2
         # (b) conv2 forward gather: B = 16, (T1, F1) = (161, 115) -> (80, 57): 72960 output positions, C = 256, K = 2304
         B_, T1, F1, Cc = 16, 161, 115, 256
         T2, F2 = (T1 - 3) // 2 + 1, (F1 - 3) // 2 + 1
