@@ -33,6 +33,18 @@
 #include "gemm_common.h"
 #include "../../include/openeat_hip.h"
 
+// Shape of the weight ring: NSET register sets of FR pieces (3 KiB each), NSET - 1 stages in flight per wave.  Measured on MI355X
+// (tools/probes/ring_depth.py + the step, same box, profiles/r04_experiments.md): (FR, NSET) = (2, 4) - 144 KiB per block in flight, the
+// round's first choice - 15.94-15.96 ms/step, (2, 2) 15.85-15.89, (4, 2) 15.97, (1, 8) 15.86-15.88, (1, 2) slower feed-forward,
+// (2, 8) spills; **(1, 4)** - 72 KiB in flight, 48 ring registers instead of 96 - 15.70-15.77, and faster at every shape tried (d = 512:
+// 332 -> 310 us backward; 25 472 rows: 214 -> 203 us).  The kernels' intake is a rate, not a latency: more bytes in flight buy nothing.
+#ifndef OE_F6_NSET
+#define OE_F6_NSET 4
+#endif
+#ifndef OE_F6_FR
+#define OE_F6_FR 1
+#endif
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256 * NG, (NG == 2 || (RT == 1 && D <= 256)) ? 2 : 
     static_assert(LNP == 0 || (D == 256 && RT == 1 && NG == 2 && BWD == (LNP == 1)), "LayerNorm prologues: the eight-wave 32-row kernels at d = 256");
     constexpr int BM = 32 * RT;
     constexpr int KS = D / 16, DT = D / 32, DPW = DT / 4;            // k-steps of GEMM 1, output tiles, output tiles per wave
-    constexpr int FR = 2, NSET = 4;
+    constexpr int FR = OE_F6_FR, NSET = OE_F6_NSET;
     constexpr int NS1 = KS / FR, NS2 = DPW * 8 / FR, NSTG = NS1 + NS2;
     static_assert(DT % 4 == 0 && KS % FR == 0 && NSTG % NSET == 0, "stage split");
     constexpr int XP = D + 8;                                        // bf16 elements per x row in LDS
@@ -743,7 +755,7 @@ template <int D, int LNP = 0, bool LNE = false>
 __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
     constexpr int BM = 32, NG = 2;
     constexpr int KS = D / 16;
-    constexpr int FR = 2, NSET = 4;
+    constexpr int FR = OE_F6_FR, NSET = OE_F6_NSET;
     constexpr int NSTG = KS / FR;
     static_assert(KS % FR == 0 && NSTG % NSET == 0, "stage split");
     constexpr int XP = D + 8;
@@ -989,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void rowgemm6_kernel(Row6Params p) {
 __global__ __launch_bounds__(512, 2) void rowgemm6p_kernel(Row6Params p) {
     constexpr int D = 256, BM = 32;
     constexpr int KS = D / 16;
-    constexpr int FR = 2, NSET = 4;
+    constexpr int FR = OE_F6_FR, NSET = OE_F6_NSET;
     constexpr int NSTG = KS / FR;
     constexpr int XP = D + 8;
     constexpr int X_BYTES = 3 * BM * XP * 2;
