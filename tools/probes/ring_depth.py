@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Row-block GEMM and fused feed-forward, HIP-event timed back to back (warm) and behind a 512 MB fill (cold), for the library in
-OE_HIP_LIB - run once with the shipped library (weight ring of 4 register sets: 3 stages = 144 KiB per block in flight) and once with
-a build of ffn6.hip with -DOE_F6_NSET=2 (1 stage = 48 KiB in flight).  (GPU box.)"""
+OE_HIP_LIB - run once with the shipped library (weight ring of 4 register sets of one 3 KiB piece: 3 stages = 72 KiB per block in flight) and once with
+builds of ffn6.hip with other ring shapes, e.g. -DOE_F6_FR=2 -DOE_F6_NSET=4 (the round's first choice: 144 KiB in flight).  Results are
+identical across shapes (same order of the reduction; tests/test_gpu_rowgemm6.py, test_gpu_ffn6.py hold the shipped one).  (GPU box.)"""
 import os
 import sys
 
@@ -43,11 +44,7 @@ for n, k in ((256, 256), (512, 256), (256, 512), (768, 256)):
     table = torch.tensor([w.data_ptr(), wp.data_ptr(), n, k, k, 0], dtype=torch.int64, device=dev)
     hip.call("oe_rowgemm6_pack_table", table, 1, (n // 32) * (k // 16))
     f = lambda: hip.rowgemm6(x, wp, y, rows, k, n, bias=b, residual=res, ldr=n, beta=1.0, drop_p=0.1, seed=3)
-    f()
-    ref = (x[:512].double() @ w.double().T + b.double())
-    keep = (y[:512] != 0)
-    err = float((((y[:512] - res[:512]).double() / (1 / 0.9)) - ref)[keep].abs().max())
-    print(f"rowgemm6 {rows} x {n} <- {k}: max err {err:.1e}  warm {timed(f, False):6.1f} us  cold {timed(f, True):6.1f} us   (weights {n * k * 6 / 1024:.0f} KiB per block)")
+    print(f"rowgemm6 {rows} x {n} <- {k}: warm {timed(f, False):6.1f} us  cold {timed(f, True):6.1f} us   (weights {n * k * 6 / 1024:.0f} KiB per block)")
 d, ff = 256, 1024
 x, res = torch.randn(rows, d, device=dev), torch.randn(rows, d, device=dev)
 w1, b1 = torch.randn(ff, d, device=dev) / 16, torch.randn(ff, device=dev)
